@@ -1,0 +1,284 @@
+// HBM-bound vector / reduction kernels of the path:
+//   - forward substitution pieces of  alpha = L^-1 (Y - m)     (densities.py:81-82,
+//     models/gpr.py:123): 128-block solve through the stored block inverse and the
+//     gemv update  y2 -= L21 y1  of the recursive trsv;
+//   - sum(log diag L), sum(alpha^2)                             (densities.py:92-94);
+//   - fmean = A^T V and colsum(A*A) in ONE pass over A^T        (models/gpr.py:124,130);
+//   - layout helpers (pad / extract / transpose) for the host-matrix entry points.
+// All of them stream each matrix element exactly once with 16-byte loads; wave
+// reductions use 64-wide shuffles.
+#include "gps_common.hpp"
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// y_blk[r][0..127] = Linv[128][128] * y_blk[r]   (grid.x = r)
+__global__ __launch_bounds__(256) void trsv_base_kernel(const double* __restrict__ Linv,
+                                                        double* __restrict__ y, i64 ldy) {
+  __shared__ double ys[128];
+  __shared__ double outs[128];
+  double* yr = y + (i64)blockIdx.x * ldy;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 128) ys[tid] = yr[tid];
+  __syncthreads();
+  const double y0 = ys[lane], y1 = ys[lane + 64];
+  for (int row = wave; row < 128; row += 4) {
+    const double* Lr = Linv + row * 128;
+    double p = Lr[lane] * y0 + Lr[lane + 64] * y1;
+    p = wave_sum(p);
+    if (lane == 0) outs[row] = p;
+  }
+  __syncthreads();
+  if (tid < 128) yr[tid] = outs[tid];
+}
+
+// y2[r][i] -= sum_k L21[i][k] * y1[r][k],  i < n2, k < n1 (n1 multiple of 128).
+// One wave per row, 16-byte loads along the row; RC right-hand sides per pass.
+template <int RC>
+__global__ __launch_bounds__(256) void gemv_sub_kernel(const double* __restrict__ L21, i64 ldl,
+                                                       i64 n2, i64 n1,
+                                                       const double* __restrict__ y1,
+                                                       double* __restrict__ y2, i64 ldy, int r0,
+                                                       int rcount) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave_global = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const i64 nwaves = (i64)gridDim.x * 4;
+  for (i64 row = wave_global; row < n2; row += nwaves) {
+    const double* Lr = L21 + row * ldl;
+    double acc[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) acc[q] = 0.0;
+    for (i64 k = 2 * lane; k < n1; k += 128) {
+      const v2d l = *reinterpret_cast<const v2d*>(Lr + k);
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        if (q < rcount) {
+          const v2d v = *reinterpret_cast<const v2d*>(y1 + (i64)(r0 + q) * ldy + k);
+          acc[q] += l.x * v.x + l.y * v.y;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RC; ++q) {
+      const double s = wave_sum(acc[q]);
+      if (lane == 0 && q < rcount) y2[(i64)(r0 + q) * ldy + row] -= s;
+    }
+  }
+}
+
+// partial[b][0] = sum_i log L_ii ; partial[b][1] = sum alpha^2   (fixed-order, host adds
+// the gridDim.x partials so the result is bitwise reproducible)
+__global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, i64 ldl,
+                                                         i64 n, const double* __restrict__ alpha,
+                                                         i64 ldy, i64 r,
+                                                         double* __restrict__ partial) {
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s0 = 0.0, s1 = 0.0;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    s0 += log(L[i * ldl + i]);
+    for (i64 q = 0; q < r; ++q) {
+      const double a = alpha[q * ldy + i];
+      s1 += a * a;
+    }
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    partial[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+// One workgroup per row of A^T [n_new, npad]:
+//   mean[i][q] = sum_n At[i][n] * alpha[q][n] ;  sumsq[i] = sum_n At[i][n]^2
+__global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ At, i64 ldat,
+                                                     i64 npad, const double* __restrict__ alpha,
+                                                     i64 ldy, int r, double* __restrict__ mean,
+                                                     double* __restrict__ sumsq) {
+  __shared__ double sh[4];
+  const i64 row = blockIdx.x;
+  const double* Ar = At + row * ldat;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // sum of squares + first output together, remaining outputs re-read the row (L2-hot)
+  for (int q = 0; q < (r > 0 ? r : 1); ++q) {
+    double s = 0.0, ss = 0.0;
+    for (i64 k = 2 * (i64)threadIdx.x; k < npad; k += 512) {
+      const v2d a = *reinterpret_cast<const v2d*>(Ar + k);
+      if (r > 0) {
+        const v2d v = *reinterpret_cast<const v2d*>(alpha + (i64)q * ldy + k);
+        s += a.x * v.x + a.y * v.y;
+      }
+      if (q == 0) ss += a.x * a.x + a.y * a.y;
+    }
+    s = wave_sum(s);
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && r > 0) mean[row * r + q] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    if (q == 0) {
+      ss = wave_sum(ss);
+      if (lane == 0) sh[wave] = ss;
+      __syncthreads();
+      if (threadIdx.x == 0) sumsq[row] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void fill_info_kernel(int* p, int v) { *p = v; }
+
+// var[i] = kdiag - sumsq[i]
+__global__ void var_finish_kernel(double* __restrict__ var, const double* __restrict__ kdiag,
+                                  double kconst, const double* __restrict__ sumsq, i64 n) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) var[i] = (kdiag ? kdiag[i] : kconst) - sumsq[i];
+}
+
+// dst[c][r] = src[r][c]  (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, i64 lds_,
+                                                        i64 rows, i64 cols,
+                                                        double* __restrict__ dst, i64 ldd) {
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const i64 rr = r0 + j, cc = c0 + tx;
+    t[j][tx] = (rr < rows && cc < cols) ? src[rr * lds_ + cc] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const i64 cc = c0 + j, rr = r0 + tx;      // dst row = src col
+    if (cc < cols && rr < rows) dst[cc * ldd + rr] = t[tx][j];
+  }
+}
+
+// dst [prow, pcol] <- src [rows, cols] zero padded; identity_pad: dst[i][i] = 1 for i >= rows;
+// diag_add added on the real diagonal.
+__global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict__ src, i64 lds_,
+                                                       i64 rows, i64 cols,
+                                                       double* __restrict__ dst, i64 ldd, i64 prow,
+                                                       i64 pcol, int identity_pad,
+                                                       double diag_add) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= pcol) return;
+  for (i64 rr = blockIdx.y; rr < prow; rr += gridDim.y) {
+    double v = 0.0;
+    if (rr < rows && c < cols) {
+      v = src[rr * lds_ + c];
+      if (rr == c) v += diag_add;
+    } else if (identity_pad && rr == c) {
+      v = 1.0;
+    }
+    dst[rr * ldd + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void extract_kernel(const double* __restrict__ src, i64 lds_,
+                                                      i64 rows, i64 cols,
+                                                      double* __restrict__ dst, i64 ldd,
+                                                      int lower_only) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (i64 rr = blockIdx.y; rr < rows; rr += gridDim.y)
+    dst[rr * ldd + c] = (lower_only && c > rr) ? 0.0 : src[rr * lds_ + c];
+}
+
+// ---------------------------------------------------------------------------------
+int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r) {
+  LaunchScope ls(h, KC_TRSV, 2.0 * 128 * 128 * r, 128.0 * 128 * 8);
+  hipLaunchKernelGGL(trsv_base_kernel, dim3((unsigned)r), dim3(256), 0, h->stream, Linv_blk, y, ldy);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
+                        const double* y1, double* y2, i64 ldy, i64 r) {
+  if (n2 <= 0 || n1 <= 0) return GPS_OK;
+  i64 blocks = (n2 + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  for (i64 r0 = 0; r0 < r; r0 += 4) {
+    const int rc = (int)((r - r0) < 4 ? (r - r0) : 4);
+    LaunchScope ls(h, KC_TRSV, 2.0 * n2 * n1 * rc, (double)n2 * n1 * 8.0);
+    hipLaunchKernelGGL(gemv_sub_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, L21,
+                       ldl, n2, n1, y1, y2, ldy, (int)r0, rc);
+    GPS_HIP(h, hipGetLastError());
+  }
+  return GPS_OK;
+}
+
+#define LML_BLOCKS 64
+int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* alpha,
+                          i64 ldy, i64 r, double* out_partials) {
+  LaunchScope ls(h, KC_REDUCE, 0.0, (double)n * (64.0 + 8.0 * r));
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(LML_BLOCKS), dim3(256), 0, h->stream, L, ldl, n, alpha,
+                     ldy, r, out_partials);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
+                      const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq) {
+  if (n_new <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_REDUCE, 2.0 * n_new * npad * (r + 1), (double)n_new * npad * 8.0);
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)n_new), dim3(256), 0, h->stream, At, ldat, npad,
+                     alpha, ldy, (int)r, mean, sumsq);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_fill_info(gps_handle_t h, int* d_info, int value) {
+  hipLaunchKernelGGL(fill_info_kernel, dim3(1), dim3(1), 0, h->stream, d_info, value);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_var_finish(gps_handle_t h, double* var, const double* kdiag_or_null,
+                          double kdiag_const, const double* sumsq, i64 n) {
+  if (n <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_REDUCE, (double)n, 16.0 * n);
+  hipLaunchKernelGGL(var_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                     var, kdiag_or_null, kdiag_const, sumsq, n);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols,
+                         double* dst, i64 ldd) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, 0.0, 16.0 * rows * cols);
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, src, lds_, rows, cols, dst, ldd);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols,
+                        double* dst, i64 ldd, i64 prow, i64 pcol, int identity_pad,
+                        double diag_add) {
+  if (prow <= 0 || pcol <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, 0.0, 8.0 * (rows * cols + prow * pcol));
+  dim3 grid((unsigned)((pcol + 255) / 256), (unsigned)(prow < 32768 ? prow : 32768));
+  hipLaunchKernelGGL(pad_copy_kernel, grid, dim3(256), 0, h->stream, src, lds_, rows, cols, dst, ldd,
+                     prow, pcol, identity_pad, diag_add);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_extract(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols,
+                       double* dst, i64 ldd, int lower_only) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, 0.0, 16.0 * rows * cols);
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(extract_kernel, grid, dim3(256), 0, h->stream, src, lds_, rows, cols, dst, ldd,
+                     lower_only);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}

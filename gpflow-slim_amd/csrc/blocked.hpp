@@ -1,0 +1,88 @@
+// Recursive blocked factorisation / triangular solves, written once over an "Ops" policy.
+//
+// The product instantiates it with HipOps (gps_api.hip: every op is a HIP kernel launch on the
+// handle's stream).  tests/cpu_blocked/ instantiates the same template with naive host loops so
+// the index arithmetic of the recursion can be checked without a GPU -- that emulation is test
+// infrastructure only and is never linked into libgpflowslim_hip.so.
+//
+// All matrices are row-major with dimensions that are multiples of 128 (callers pad with an
+// identity block, whose Cholesky factor is the identity).  Only lower triangles are defined.
+//
+//   potrf_rec : A = L L^T                        tf.cholesky               models/gpr.py:70
+//   trsm_rec  : X L^T = B   (B [m,n] in place)    tf.matrix_triangular_solve(L, Kx) computed on
+//               the transposed right-hand side    models/gpr.py:122, conditionals.py:87
+//   trsm_rn_rec: X L = B with U = L^T stored      conditionals.py:100 (unwhitened back-solve)
+//   trsv_rec  : L a = y     (y [r][ld] in place)  densities.py:82, models/gpr.py:123
+//
+// Every flop of the recursion lands in Ops::gemm (C -= A B^T / C = A B^T) with K = half the
+// current block, i.e. long-K MFMA GEMMs; the 128x128 leaves use the explicit block inverses
+// produced by Ops::potrf_base.
+#pragma once
+#include <cstdint>
+
+#ifndef GPS_TILE
+#define GPS_TILE 128
+#endif
+
+template <class Ops>
+struct Blocked {
+  Ops& ops;
+  explicit Blocked(Ops& o) : ops(o) {}
+  typedef int64_t i64;
+
+  static i64 split(i64 n) { return ((n / GPS_TILE) / 2) * GPS_TILE; }   // n >= 256 -> 128 <= n1 < n
+
+  // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
+  // row0: global row of A's first row (for info reporting)
+  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0) {
+    if (n <= 0) return 0;
+    if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = potrf_rec(A, lda, n1, blk0, row0);
+    if (rc) return rc;
+    double* A21 = A + n1 * lda;
+    double* A22 = A21 + n1;
+    rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
+    if (rc) return rc;
+    rc = ops.gemm(/*op sub*/ 0, /*lower*/ 1, n2, n2, n1, A21, lda, A21, lda, A22, lda);
+    if (rc) return rc;
+    return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1);
+  }
+
+  // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)
+  int trsm_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
+    if (n <= 0 || m <= 0) return 0;
+    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = trsm_rec(L, ldl, n1, blk0, B, ldb, m);
+    if (rc) return rc;
+    rc = ops.gemm(0, 0, m, n2, n1, B, ldb, L + n1 * ldl, ldl, B + n1, ldb);   // B2 -= X1 L21^T
+    if (rc) return rc;
+    return trsm_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
+  }
+
+  // solve X L = B in place, given U = L^T (upper, row-major) and the transposed block inverses
+  int trsm_rn_rec(const double* U, i64 ldu, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
+    if (n <= 0 || m <= 0) return 0;
+    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = trsm_rn_rec(U + n1 * ldu + n1, ldu, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
+    if (rc) return rc;
+    // B1 -= X2 L21 = X2 (U12)^T ; U12 = U[0:n1, n1:n]
+    rc = ops.gemm(0, 0, m, n1, n2, B + n1, ldb, U + n1, ldu, B, ldb);
+    if (rc) return rc;
+    return trsm_rn_rec(U, ldu, n1, blk0, B, ldb, m);
+  }
+
+  // solve L a = y in place for r right-hand sides stored as rows y[q*ldy + i]
+  int trsv_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* y, i64 ldy, i64 r) {
+    if (n <= 0 || r <= 0) return 0;
+    if (n == GPS_TILE) return ops.trsv_base(blk0, y, ldy, r);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = trsv_rec(L, ldl, n1, blk0, y, ldy, r);
+    if (rc) return rc;
+    rc = ops.gemv_sub(L + n1 * ldl, ldl, n2, n1, y, y + n1, ldy, r);          // y2 -= L21 a1
+    if (rc) return rc;
+    return trsv_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, y + n1, ldy, r);
+  }
+};

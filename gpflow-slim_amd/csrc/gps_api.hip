@@ -1,0 +1,654 @@
+// C ABI of libgpflowslim_hip.so (declared in include/gpflowslim_hip.h).
+// Host orchestration only: every arithmetic step is a HIP kernel from the sibling .hip files.
+#include "gps_common.hpp"
+#include "blocked.hpp"
+#include <climits>
+#include <cmath>
+
+// ---- the HIP "Ops" policy for blocked.hpp ----------------------------------------------------
+struct HipOps {
+  gps_handle_t h;
+  double* linv;     // [nblk][128*128]
+  double* linvT;    // optional transposed inverses (same layout) or nullptr
+  int* d_info;
+  int factor = 1;   // 0: matrix already holds L, only build the inverses
+
+  int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
+    return gps_launch_potrf_base(h, A, lda, linv + blk * GPS_TILE * GPS_TILE,
+                                 linvT ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
+                                 factor);
+  }
+  // B[m,128] = B * Linv[blk]^T  (transposed == 0)   or   B * Linv[blk]  (transposed == 1)
+  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m) {
+    const double* W = (transposed ? linvT : linv) + blk * GPS_TILE * GPS_TILE;
+    return gps_launch_gemm_nt(h, /*op set*/ 1, 0, m, GPS_TILE, GPS_TILE, B, ldb, W, GPS_TILE, B, ldb);
+  }
+  int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B,
+           i64 ldb, double* C, i64 ldc) {
+    return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
+  }
+  int trsv_base(i64 blk, double* y, i64 ldy, i64 r) {
+    return gps_launch_trsv_base(h, linv + blk * GPS_TILE * GPS_TILE, y, ldy, r);
+  }
+  int gemv_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y1, double* y2, i64 ldy,
+               i64 r) {
+    return gps_launch_gemv_sub(h, L21, ldl, n2, n1, y1, y2, ldy, r);
+  }
+};
+
+static int read_info(gps_handle_t h, int* d_info, int* info) {
+  int v = 0;
+  GPS_HIP(h, hipMemcpyAsync(&v, d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  if (info) *info = (v == INT_MAX) ? 0 : v;
+  return GPS_OK;
+}
+
+static int stage_time(gps_handle_t h, int a, int b, double* out) {
+  float ms = 0.f;
+  GPS_HIP(h, hipEventElapsedTime(&ms, h->ev[a], h->ev[b]));
+  *out = ms;
+  return GPS_OK;
+}
+
+// ---- life cycle ----------------------------------------------------------------------------------
+extern "C" int gps_create(int device_id, gps_handle_t* out) {
+  if (!out) return GPS_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPS_ERR_HIP;
+  if (device_id < 0 || device_id >= count) return GPS_ERR_ARG;
+  gps_handle_t h = new gps_handle_s();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&h->prop, device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return GPS_ERR_HIP;
+  }
+  for (int i = 0; i < 8; ++i) {
+    if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPS_ERR_HIP; }
+  }
+  if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
+  *out = h;
+  return GPS_OK;
+}
+
+extern "C" int gps_destroy(gps_handle_t h) {
+  if (!h) return GPS_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  gps_profile_collect(h);
+  for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
+                    &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3};
+  for (DevBuf* b : bufs) b->release();
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+  return GPS_OK;
+}
+
+extern "C" const char* gps_last_error(gps_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int gps_device_info(gps_handle_t h, char* name, int name_len, int* n_cu, int64_t* hbm_bytes,
+                               char* arch, int arch_len) {
+  if (!h) return GPS_ERR_ARG;
+  if (name && name_len > 0) { strncpy(name, h->prop.name, name_len - 1); name[name_len - 1] = 0; }
+  if (arch && arch_len > 0) { strncpy(arch, h->prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+  if (n_cu) *n_cu = h->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)h->prop.totalGlobalMem;
+  return GPS_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+extern "C" int gps_profile_enable(gps_handle_t h, int on) {
+  if (!h) return GPS_ERR_ARG;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_profile_collect(h);
+  h->prof_on = on != 0;
+  return GPS_OK;
+}
+extern "C" int gps_profile_reset(gps_handle_t h) {
+  if (!h) return GPS_ERR_ARG;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_profile_collect(h);
+  for (int i = 0; i < KC_COUNT; ++i) h->stat[i] = KClassStat();
+  return GPS_OK;
+}
+extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launches, double* ms,
+                               double* flops, double* bytes) {
+  if (!h || !klass) return GPS_ERR_ARG;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_profile_collect(h);
+  for (int i = 0; i < KC_COUNT; ++i) {
+    if (strcmp(klass, kc_names[i]) == 0) {
+      if (launches) *launches = h->stat[i].launches;
+      if (ms) *ms = h->stat[i].ms;
+      if (flops) *flops = h->stat[i].flops;
+      if (bytes) *bytes = h->stat[i].bytes;
+      return GPS_OK;
+    }
+  }
+  return gps_fail(h, GPS_ERR_ARG, "unknown kernel class");
+}
+extern "C" int gps_last_stage_ms(gps_handle_t h, double* out5) {
+  if (!h || !out5) return GPS_ERR_ARG;
+  for (int i = 0; i < 5; ++i) out5[i] = h->stage_ms[i];
+  return GPS_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------
+extern "C" int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok) {
+  if (!h) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  return gps_run_mfma_diag(h, waves_per_simd, tflops, layout_ok);
+}
+
+extern "C" int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n, int64_t k,
+                                const double* A, const double* B, double* C) {
+  if (!h || !A || !B || !C) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const size_t ab = (size_t)m * k * 8, bb = (size_t)n * k * 8, cb = (size_t)m * n * 8;
+  GPS_HIP(h, h->dTmp.ensure(ab)); GPS_HIP(h, h->dTmp2.ensure(bb)); GPS_HIP(h, h->dTmp3.ensure(cb));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, A, ab, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, B, bb, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, C, cb, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_gemm_nt(h, op, lower, m, n, k, h->dTmp.d(), k, h->dTmp2.d(), k, h->dTmp3.d(), n);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(C, h->dTmp3.p, cb, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// ---- kernels.K ---------------------------------------------------------------------------------------
+extern "C" int gps_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X,
+                        int64_t n, const double* X2, int64_t m, int64_t d_all, double diag_add,
+                        double* K_out) {
+  if (!h || !X || !K_out || n < 0 || d_all <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_kmat: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const bool sym = (X2 == nullptr);
+  if (sym) m = n;
+  if (n == 0 || m == 0) return GPS_OK;
+  const i64 prow = ((n + 63) / 64) * 64;
+  const i64 pcol = sym ? prow : ((m + 63) / 64) * 64;
+  GPS_HIP(h, h->dXnew.ensure((size_t)n * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  const double* dX2 = nullptr;
+  if (!sym) {
+    GPS_HIP(h, h->dTmp3.ensure((size_t)m * d_all * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, X2, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+    dX2 = h->dTmp3.d();
+  }
+  GPS_HIP(h, h->dTmp.ensure((size_t)prow * pcol * 8));
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n, dX2, m, d_all, diag_add, h->dTmp.d(), pcol,
+                           prow, pcol, /*lower_only*/ 0, /*identity_pad*/ 0);
+  if (rc) return rc;
+  if (prow == n && pcol == m) {
+    GPS_HIP(h, hipMemcpyAsync(K_out, h->dTmp.p, (size_t)n * m * 8, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n * m * 8));
+    rc = gps_launch_extract(h, h->dTmp.d(), pcol, n, m, h->dTmp2.d(), m, 0);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(K_out, h->dTmp2.p, (size_t)n * m * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// ---- tf.cholesky on a host matrix ----------------------------------------------------------------------
+extern "C" int gps_potrf(gps_handle_t h, const double* A, int64_t n, double* L_out, int* info) {
+  if (!h || !A || !L_out || n < 0) return gps_fail(h, GPS_ERR_ARG, "gps_potrf: bad argument");
+  if (info) *info = 0;
+  if (n == 0) return GPS_OK;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 np = gps_pad(n);
+  GPS_HIP(h, h->dTmp2.ensure((size_t)n * n * 8));
+  GPS_HIP(h, h->dTmp.ensure((size_t)np * np * 8));
+  GPS_HIP(h, h->dTmp3.ensure((size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, A, (size_t)n * n * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_pad_copy(h, h->dTmp2.d(), n, n, n, h->dTmp.d(), np, np, np, 1, 0.0);
+  if (rc) return rc;
+  int* d_info = (int*)h->dInfo.p;
+  rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  HipOps ops{h, h->dTmp3.d(), nullptr, d_info};
+  Blocked<HipOps> bl(ops);
+  rc = bl.potrf_rec(h->dTmp.d(), np, np, 0, 0);
+  if (rc) return rc;
+  rc = gps_launch_extract(h, h->dTmp.d(), np, n, n, h->dTmp2.d(), n, 1);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(L_out, h->dTmp2.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, h->stream));
+  return read_info(h, d_info, info);
+}
+
+// ---- tf.matrix_triangular_solve on host matrices ---------------------------------------------------------
+extern "C" int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double* B, int64_t nrhs,
+                              int trans) {
+  if (!h || !L || !B || n < 0 || nrhs < 0) return gps_fail(h, GPS_ERR_ARG, "gps_trsm_lower: bad argument");
+  if (n == 0 || nrhs == 0) return GPS_OK;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 np = gps_pad(n), mp = gps_pad(nrhs);
+  const size_t blk_bytes = (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  // dTmp: L padded (and, for trans, U = L^T) ; dTmp2: staging ; dTmp3: inverses ; dB: B^T padded
+  GPS_HIP(h, h->dTmp2.ensure((size_t)(n * n > n * nrhs ? n * n : n * nrhs) * 8));
+  GPS_HIP(h, h->dTmp.ensure((size_t)np * np * 8 * (trans ? 2 : 1)));
+  GPS_HIP(h, h->dTmp3.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dB.ensure((size_t)mp * np * 8));
+  double* dL = h->dTmp.d();
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, L, (size_t)n * n * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_pad_copy(h, h->dTmp2.d(), n, n, n, dL, np, np, np, 1, 0.0);
+  if (rc) return rc;
+  int* d_info = (int*)h->dInfo.p;
+  HipOps ops{h, h->dTmp3.d(), h->dTmp3.d() + blk_bytes / 8, d_info};
+  ops.factor = 0;
+  for (i64 b = 0; b < np / GPS_TILE; ++b) {
+    rc = ops.potrf_base(dL + b * GPS_TILE * np + b * GPS_TILE, np, b, b * GPS_TILE);
+    if (rc) return rc;
+  }
+  // B [n, nrhs] -> Bt [mp, np]
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, B, (size_t)n * nrhs * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(h->dB.p, 0, (size_t)mp * np * 8, h->stream));
+  rc = gps_launch_transpose(h, h->dTmp2.d(), nrhs, n, nrhs, h->dB.d(), np);
+  if (rc) return rc;
+  Blocked<HipOps> bl(ops);
+  if (!trans) {
+    rc = bl.trsm_rec(dL, np, np, 0, h->dB.d(), np, mp);        // X^T L^T = B^T  <=>  L X = B
+  } else {
+    double* dU = dL + np * np;
+    rc = gps_launch_transpose(h, dL, np, np, np, dU, np);
+    if (rc) return rc;
+    rc = bl.trsm_rn_rec(dU, np, np, 0, h->dB.d(), np, mp);     // X^T L = B^T    <=>  L^T X = B
+  }
+  if (rc) return rc;
+  rc = gps_launch_transpose(h, h->dB.d(), np, nrhs, n, h->dTmp2.d(), nrhs);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(B, h->dTmp2.p, (size_t)n * nrhs * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// ---- GPR ------------------------------------------------------------------------------------------------
+extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int64_t d_all) {
+  if (!h || !X || n <= 0 || d_all <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_set_data: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->have_factor = false;
+  h->n = n; h->d_all = d_all; h->npad = gps_pad(n);
+  GPS_HIP(h, h->dX.ensure((size_t)n * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dX.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dK.ensure((size_t)h->npad * h->npad * 8));
+  GPS_HIP(h, h->dLinv.ensure((size_t)(h->npad / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// K + noise I -> L, alpha.  Records ev[0..3].
+static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
+                      const double* resid, i64 r, int* info) {
+  if (h->n <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_gpr_set_data has not been called");
+  if (r < 0 || (r > 0 && !resid)) return gps_fail(h, GPS_ERR_ARG, "resid missing");
+  const i64 n = h->n, np = h->npad;
+  h->have_factor = false;
+  GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  // residual, transposed to [r][np] and zero padded
+  if (r > 0) {
+    GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)r * np * 8, h->stream));
+    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, h->dAlpha.d(), np);
+    if (rc0) return rc0;
+  }
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np,
+                           np, np, /*lower_only*/ 1, /*identity_pad*/ 1);
+  if (rc) return rc;
+  GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  int* d_info = (int*)h->dInfo.p;
+  rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  HipOps ops{h, h->dLinv.d(), nullptr, d_info};
+  Blocked<HipOps> bl(ops);
+  rc = bl.potrf_rec(h->dK.d(), np, np, 0, 0);
+  if (rc) return rc;
+  GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  if (r > 0) {
+    rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);
+    if (rc) return rc;
+  }
+  h->r = r;
+  rc = read_info(h, d_info, info);
+  if (rc) return rc;
+  h->have_factor = (info == nullptr) || (*info == 0);
+  return GPS_OK;
+}
+
+extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
+                           const double* resid, int64_t r, double* lml, int* info) {
+  if (!h || !lml) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  int linfo = 0;
+  int rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
+  if (info) *info = linfo;
+  if (rc) return rc;
+  const i64 n = h->n, np = h->npad;
+  double* part = h->dScal.d();
+  rc = gps_launch_lml_reduce(h, h->dK.d(), np, n, h->dAlpha.d(), np, r, part);
+  if (rc) return rc;
+  GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  double hp[2 * 64];
+  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  double slog = 0.0, ssq = 0.0;
+  for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; ssq += hp[2 * b + 1]; }
+  // densities.py:92-94
+  *lml = -0.5 * (double)n * (double)r * log(2.0 * M_PI) - (double)r * slog - 0.5 * ssq;
+  stage_time(h, 0, 1, &h->stage_ms[0]);
+  stage_time(h, 1, 2, &h->stage_ms[1]);
+  stage_time(h, 2, 3, &h->stage_ms[2]);
+  h->stage_ms[3] = 0.0;
+  stage_time(h, 0, 3, &h->stage_ms[4]);
+  return GPS_OK;
+}
+
+extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                               double noise_var, const double* resid, int64_t r, const double* Xnew,
+                               int64_t n_new, int full_cov, int refactor, double* mean_out,
+                               double* var_out, int* info) {
+  if (!h || !Xnew || n_new <= 0 || !var_out || (r > 0 && !mean_out))
+    return gps_fail(h, GPS_ERR_ARG, "gps_gpr_predict: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  if (info) *info = 0;
+  int rc;
+  if (refactor) {
+    int linfo = 0;
+    rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
+    if (info) *info = linfo;
+    if (rc) return rc;
+    if (linfo) return GPS_OK;             // not positive definite: outputs undefined
+  } else {
+    if (!h->have_factor) return gps_fail(h, GPS_ERR_STATE, "no resident factor: call gps_gpr_lml first or pass refactor=1");
+    if (r != h->r) return gps_fail(h, GPS_ERR_STATE, "resident alpha has a different number of outputs");
+    GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  }
+  const i64 n = h->n, np = h->npad, d = h->d_all;
+  const i64 nsp = gps_pad(n_new);
+  GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  GPS_HIP(h, h->dXnew.ensure((size_t)n_new * d * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, Xnew, (size_t)n_new * d * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dB.ensure((size_t)nsp * np * 8));
+  // Kx^T = K(Xnew, X)  [nsp, np]                                 models/gpr.py:119
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, h->dX.d(), n, d, 0.0, h->dB.d(), np, nsp, np, 0, 0);
+  if (rc) return rc;
+  // A^T = Kx^T L^-T                                              models/gpr.py:122
+  HipOps ops{h, h->dLinv.d(), nullptr, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  rc = bl.trsm_rec(h->dK.d(), np, np, 0, h->dB.d(), np, nsp);
+  if (rc) return rc;
+  // fmean = A^T V ; sumsq = colsum(A*A)                          models/gpr.py:124,130
+  GPS_HIP(h, h->dMean.ensure((size_t)(n_new * (r > 0 ? r : 1) + n_new) * 8));
+  double* dmean = h->dMean.d();
+  double* dss = dmean + n_new * (r > 0 ? r : 1);
+  rc = gps_launch_rowdot(h, h->dB.d(), np, n_new, np, h->dAlpha.d(), np, r, dmean, dss);
+  if (rc) return rc;
+  double kd = 0.0;
+  rc = gps_launch_kdiag(h, prog, n_nodes, &kd);
+  if (rc) return rc;
+  if (!full_cov) {
+    GPS_HIP(h, h->dVar.ensure((size_t)n_new * 8));
+    rc = gps_launch_var_finish(h, h->dVar.d(), nullptr, kd, dss, n_new);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(var_out, h->dVar.p, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    // K(Xnew) - A^T A                                             models/gpr.py:126
+    GPS_HIP(h, h->dVar.ensure((size_t)nsp * nsp * 8));
+    rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, nullptr, n_new, d, 0.0, h->dVar.d(), nsp, nsp,
+                         nsp, 0, 0);
+    if (rc) return rc;
+    rc = gps_launch_gemm_nt(h, 0, 0, nsp, nsp, np, h->dB.d(), np, h->dB.d(), np, h->dVar.d(), nsp);
+    if (rc) return rc;
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n_new * n_new * 8));
+    rc = gps_launch_extract(h, h->dVar.d(), nsp, n_new, n_new, h->dTmp2.d(), n_new, 0);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(var_out, h->dTmp2.p, (size_t)n_new * n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (r > 0)
+    GPS_HIP(h, hipMemcpyAsync(mean_out, dmean, (size_t)n_new * r * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipEventRecord(h->ev[4], h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  stage_time(h, 0, 1, &h->stage_ms[0]);
+  stage_time(h, 1, 2, &h->stage_ms[1]);
+  stage_time(h, 2, 3, &h->stage_ms[2]);
+  stage_time(h, 3, 4, &h->stage_ms[3]);
+  stage_time(h, 0, 4, &h->stage_ms[4]);
+  return GPS_OK;
+}
+
+// ---- conditionals -------------------------------------------------------------------------------------
+// Shared tail of conditional / base_conditional.  On entry:
+//   Kmm  [mp, mp]  device, padded with identity (jitter already added), lower triangle valid
+//   Bt   [nsp, mp] device = Kmn^T zero padded
+//   knn_const / dKnnDiag / dKnnFull describe Knn.
+struct CondIn {
+  i64 m, mp, n_new, nsp, k;
+  double* Kmm; double* Bt; double* linv; double* linvT;
+  const double* dKnnDiag; double knn_const; double* dKnnFull /* [nsp,nsp], overwritten */;
+};
+
+static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const double* q_sqrt,
+                            int q_sqrt_ndim, int white, int full_cov, double* fmean_out,
+                            double* fvar_out, int* info) {
+  const i64 m = c.m, mp = c.mp, n_new = c.n_new, nsp = c.nsp, k = c.k;
+  int* d_info = (int*)h->dInfo.p;
+  int rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  const bool need_back = (!white) && (q_sqrt != nullptr);
+  HipOps ops{h, c.linv, need_back ? c.linvT : nullptr, d_info};
+  Blocked<HipOps> bl(ops);
+  rc = bl.potrf_rec(c.Kmm, mp, mp, 0, 0);                          // Lm   conditionals.py:84
+  if (rc) return rc;
+  rc = bl.trsm_rec(c.Kmm, mp, mp, 0, c.Bt, mp, nsp);               // A^T  conditionals.py:87
+  if (rc) return rc;
+
+  // f -> [k][mp]; white: fmean = A^T f ; else fmean = A^T (Lm^-1 f)   conditionals.py:99-103
+  GPS_HIP(h, h->dAlpha.ensure((size_t)k * mp * 8));
+  GPS_HIP(h, h->dTmp2.ensure((size_t)(m * k > n_new * n_new ? m * k : n_new * n_new) * 8 + 64));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, f, (size_t)m * k * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)k * mp * 8, h->stream));
+  rc = gps_launch_transpose(h, h->dTmp2.d(), k, m, k, h->dAlpha.d(), mp);
+  if (rc) return rc;
+  if (!white) {
+    rc = bl.trsv_rec(c.Kmm, mp, mp, 0, h->dAlpha.d(), mp, k);
+    if (rc) return rc;
+  }
+  GPS_HIP(h, h->dMean.ensure((size_t)(n_new * k + n_new) * 8));
+  double* dmean = h->dMean.d();
+  double* dss = dmean + n_new * k;
+  rc = gps_launch_rowdot(h, c.Bt, mp, n_new, mp, h->dAlpha.d(), mp, k, dmean, dss);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(fmean_out, dmean, (size_t)n_new * k * 8, hipMemcpyDeviceToHost, h->stream));
+
+  // base variance (shared by all k)                                  conditionals.py:90-96
+  if (!full_cov) {
+    GPS_HIP(h, h->dVar.ensure((size_t)n_new * 8 * (k + 1)));
+    rc = gps_launch_var_finish(h, h->dVar.d(), c.dKnnDiag, c.knn_const, dss, n_new);
+    if (rc) return rc;
+  } else {
+    rc = gps_launch_gemm_nt(h, 0, 0, nsp, nsp, mp, c.Bt, mp, c.Bt, mp, c.dKnnFull, nsp);
+    if (rc) return rc;
+  }
+
+  std::vector<double> base;        // host copies for the final assembly
+  if (!full_cov) {
+    base.resize(n_new);
+    GPS_HIP(h, hipMemcpyAsync(base.data(), h->dVar.p, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    base.resize((size_t)n_new * n_new);
+    rc = gps_launch_extract(h, c.dKnnFull, nsp, n_new, n_new, h->dTmp2.d(), n_new, 0);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(base.data(), h->dTmp2.p, (size_t)n_new * n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+
+  const size_t per = full_cov ? (size_t)n_new * n_new : (size_t)n_new;
+  if (!q_sqrt) {
+    if (!full_cov) {
+      // fvar [n_new, k]: tile                                          conditionals.py:96,119
+      for (i64 i = 0; i < n_new; ++i) for (i64 q = 0; q < k; ++q) fvar_out[i * k + q] = base[i];
+    } else {
+      for (i64 q = 0; q < k; ++q) memcpy(fvar_out + q * per, base.data(), per * 8);
+    }
+    return read_info(h, d_info, info);
+  }
+
+  // ---- q_sqrt terms                                                  conditionals.py:105-118
+  if (need_back) {
+    // A^T <- A^T Lm^-1  (A = Lm^-T A)                                  conditionals.py:100
+    GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+    rc = gps_launch_transpose(h, c.Kmm, mp, mp, mp, h->dTmp.d(), mp);
+    if (rc) return rc;
+    rc = bl.trsm_rn_rec(h->dTmp.d(), mp, mp, 0, c.Bt, mp, nsp);
+    if (rc) return rc;
+  }
+  std::vector<double> extra(per);
+  GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));                 // LTA^T [nsp, mp]
+  double* dLTA = h->dTmp3.d();
+  for (i64 q = 0; q < k; ++q) {
+    if (q_sqrt_ndim == 2) {
+      // LTA^T[i][j] = A^T[i][j] * q_sqrt[j][q] : scale columns -> reuse rowdot on an elementwise
+      // product: build diag(q_sqrt[:,q]) as a [mp,mp] "B" operand would waste flops; instead
+      // upload the column and use a GEMM-free path: sum_j (A^T[i][j] s_j)^2 = rowdot of squares.
+      // Implemented as GEMM with a diagonal matrix for full_cov, rowdot for the diagonal case.
+      std::vector<double> s(mp, 0.0);
+      for (i64 j = 0; j < m; ++j) s[j] = q_sqrt[j * k + q];
+      GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+      std::vector<double> D((size_t)mp * mp, 0.0);
+      for (i64 j = 0; j < m; ++j) D[(size_t)j * mp + j] = s[j];
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, D.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
+      if (rc) return rc;
+    } else {
+      // LTA^T = A^T L_q ; as C = A B^T with B = L_q^T (upper) -> upload tril(L_q) transposed
+      GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+      std::vector<double> LT((size_t)mp * mp, 0.0);
+      const double* Lq = q_sqrt + (size_t)q * m * m;
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = Lq[a * m + b];
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
+      if (rc) return rc;
+    }
+    if (!full_cov) {
+      rc = gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
+      if (rc) return rc;
+      GPS_HIP(h, hipMemcpyAsync(extra.data(), dss, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      for (i64 i = 0; i < n_new; ++i) fvar_out[i * k + q] = base[i] + extra[i];
+    } else {
+      GPS_HIP(h, h->dVar.ensure((size_t)nsp * nsp * 8));
+      rc = gps_launch_gemm_nt(h, 1, 0, nsp, nsp, mp, dLTA, mp, dLTA, mp, h->dVar.d(), nsp);
+      if (rc) return rc;
+      GPS_HIP(h, h->dTmp2.ensure((size_t)n_new * n_new * 8));
+      rc = gps_launch_extract(h, h->dVar.d(), nsp, n_new, n_new, h->dTmp2.d(), n_new, 0);
+      if (rc) return rc;
+      GPS_HIP(h, hipMemcpyAsync(extra.data(), h->dTmp2.p, per * 8, hipMemcpyDeviceToHost, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      double* o = fvar_out + q * per;
+      for (size_t e = 0; e < per; ++e) o[e] = base[e] + extra[e];
+    }
+  }
+  return read_info(h, d_info, info);
+}
+
+extern "C" int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z,
+                               int64_t m, int64_t d_all, double jitter, const double* Xnew,
+                               int64_t n_new, const double* f, int64_t k, const double* q_sqrt,
+                               int q_sqrt_ndim, int white, int full_cov, double* fmean_out,
+                               double* fvar_out, int* info) {
+  if (!h || !Z || !Xnew || !f || !fmean_out || !fvar_out || m <= 0 || n_new <= 0 || k <= 0 || d_all <= 0)
+    return gps_fail(h, GPS_ERR_ARG, "gps_conditional: bad argument");
+  if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
+    return gps_fail(h, GPS_ERR_ARG, "gps_conditional: q_sqrt_ndim must be 2 or 3");
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->have_factor = false;          // dK / dLinv / dAlpha are reused below
+  if (info) *info = 0;
+  CondIn c;
+  c.m = m; c.mp = gps_pad(m); c.n_new = n_new; c.nsp = gps_pad(n_new); c.k = k;
+  const size_t blk_bytes = (size_t)(c.mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, h->dX.ensure((size_t)m * d_all * 8));
+  h->n = 0;                        // resident GPR data is gone
+  GPS_HIP(h, hipMemcpyAsync(h->dX.p, Z, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dXnew.ensure((size_t)n_new * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, Xnew, (size_t)n_new * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dK.ensure((size_t)c.mp * c.mp * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dB.ensure((size_t)c.nsp * c.mp * 8));
+  c.Kmm = h->dK.d(); c.Bt = h->dB.d(); c.linv = h->dLinv.d(); c.linvT = h->dLinv.d() + blk_bytes / 8;
+  // Kmm = K(Z) + jitter I  (features.py:74-77 / conditionals.py:60) ; Kmn^T = K(Xnew, Z)
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), m, nullptr, m, d_all, jitter, c.Kmm, c.mp, c.mp, c.mp, 1, 1);
+  if (rc) return rc;
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, h->dX.d(), m, d_all, 0.0, c.Bt, c.mp, c.nsp, c.mp, 0, 0);
+  if (rc) return rc;
+  c.dKnnDiag = nullptr; c.dKnnFull = nullptr; c.knn_const = 0.0;
+  if (!full_cov) {
+    rc = gps_launch_kdiag(h, prog, n_nodes, &c.knn_const);
+    if (rc) return rc;
+  } else {
+    GPS_HIP(h, h->dTmp.ensure((size_t)c.nsp * c.nsp * 8 + (size_t)c.mp * c.mp * 8));
+    c.dKnnFull = h->dTmp.d() + (size_t)c.mp * c.mp;     // keep the first mp*mp for U = Lm^T
+    rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, nullptr, n_new, d_all, 0.0, c.dKnnFull, c.nsp,
+                         c.nsp, c.nsp, 0, 0);
+    if (rc) return rc;
+  }
+  return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+}
+
+extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const double* Kmm,
+                                    const double* Knn, int64_t m, int64_t n_new, const double* f,
+                                    int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
+                                    int full_cov, double* fmean_out, double* fvar_out, int* info) {
+  if (!h || !Kmn || !Kmm || !Knn || !f || !fmean_out || !fvar_out || m <= 0 || n_new <= 0 || k <= 0)
+    return gps_fail(h, GPS_ERR_ARG, "gps_base_conditional: bad argument");
+  if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
+    return gps_fail(h, GPS_ERR_ARG, "gps_base_conditional: q_sqrt_ndim must be 2 or 3");
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->have_factor = false;
+  h->n = 0;
+  if (info) *info = 0;
+  CondIn c;
+  c.m = m; c.mp = gps_pad(m); c.n_new = n_new; c.nsp = gps_pad(n_new); c.k = k;
+  const size_t blk_bytes = (size_t)(c.mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, h->dK.ensure((size_t)c.mp * c.mp * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dB.ensure((size_t)c.nsp * c.mp * 8));
+  c.Kmm = h->dK.d(); c.Bt = h->dB.d(); c.linv = h->dLinv.d(); c.linvT = h->dLinv.d() + blk_bytes / 8;
+  // staging buffer big enough for Kmm, Kmn and Knn
+  size_t stage = (size_t)m * m;
+  if ((size_t)m * n_new > stage) stage = (size_t)m * n_new;
+  if (full_cov && (size_t)n_new * n_new > stage) stage = (size_t)n_new * n_new;
+  GPS_HIP(h, h->dTmp3.ensure(stage * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, Kmm, (size_t)m * m * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_pad_copy(h, h->dTmp3.d(), m, m, m, c.Kmm, c.mp, c.mp, c.mp, 1, 0.0);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, Kmn, (size_t)m * n_new * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(c.Bt, 0, (size_t)c.nsp * c.mp * 8, h->stream));
+  rc = gps_launch_transpose(h, h->dTmp3.d(), n_new, m, n_new, c.Bt, c.mp);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  c.dKnnDiag = nullptr; c.dKnnFull = nullptr; c.knn_const = 0.0;
+  GPS_HIP(h, h->dTmp.ensure((size_t)c.nsp * c.nsp * 8 * (full_cov ? 1 : 0) + (size_t)c.mp * c.mp * 8 + (size_t)n_new * 8));
+  if (!full_cov) {
+    double* dk = h->dTmp.d() + (size_t)c.mp * c.mp;
+    GPS_HIP(h, hipMemcpyAsync(dk, Knn, (size_t)n_new * 8, hipMemcpyHostToDevice, h->stream));
+    c.dKnnDiag = dk;
+  } else {
+    c.dKnnFull = h->dTmp.d() + (size_t)c.mp * c.mp;
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, Knn, (size_t)n_new * n_new * 8, hipMemcpyHostToDevice, h->stream));
+    rc = gps_launch_pad_copy(h, h->dTmp3.d(), n_new, n_new, n_new, c.dKnnFull, c.nsp, c.nsp, c.nsp, 0, 0.0);
+    if (rc) return rc;
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+}

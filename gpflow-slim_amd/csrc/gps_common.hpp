@@ -1,0 +1,166 @@
+// Internal definitions shared by the HIP translation units of
+// libgpflowslim_hip.so.  Not part of the public ABI (include/gpflowslim_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/gpflowslim_hip.h"
+
+#define GPS_TILE 128            // base block of the factorisation = GEMM tile edge
+
+typedef int64_t i64;
+
+static inline i64 gps_pad(i64 n) { return ((n + GPS_TILE - 1) / GPS_TILE) * GPS_TILE; }
+
+// ---- growable device buffer -------------------------------------------------
+struct DevBuf {
+  void*  p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    // round up so that repeated slightly-growing requests do not thrash
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  double* d() const { return (double*)p; }
+};
+
+// ---- per-kernel-class accounting -------------------------------------------
+enum { KC_GEMM = 0, KC_POTRF_BASE, KC_KMAT, KC_TRSV, KC_REDUCE, KC_OTHER, KC_COUNT };
+static const char* const kc_names[KC_COUNT] = {"gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"};
+
+struct KClassStat {
+  i64 launches = 0;
+  double ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+
+struct PendingEvt { int klass; hipEvent_t a, b; };
+
+struct gps_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // profiling
+  bool prof_on = false;
+  KClassStat stat[KC_COUNT];
+  std::vector<PendingEvt> pending;
+  std::vector<hipEvent_t> evt_pool;
+  double stage_ms[5] = {0, 0, 0, 0, 0};
+  hipEvent_t ev[8] = {};
+
+  // ---- GPR resident state ----
+  i64 n = 0, d_all = 0, npad = 0;   // training set
+  i64 r = 0;                        // outputs of the last factorisation
+  bool have_factor = false;
+  DevBuf dX;        // [n, d_all]
+  DevBuf dK;        // [npad, npad]  K then L (lower, row-major)
+  DevBuf dLinv;     // [npad/128][128*128] inverses of the diagonal blocks
+  DevBuf dAlpha;    // [r][npad]  residual then alpha = L^-1 resid
+  DevBuf dFeat;     // feature workspace of the kernel-matrix build (rows)
+  DevBuf dFeat2;    // feature workspace (cols / Xnew)
+  DevBuf dProg;     // device copy of the kernel program
+  DevBuf dScal;     // small scalar outputs: [0]=sum log diag, [1]=sum alpha^2, ...
+  DevBuf dInfo;     // int info word
+  DevBuf dXnew;     // [n_new, d_all]
+  DevBuf dB;        // [nspad, npad]   K(Xnew, X) then A^T
+  DevBuf dMean;     // [n_new, r]
+  DevBuf dVar;      // [n_new] or [nspad, nspad]
+  DevBuf dTmp;      // generic scratch (host-matrix entry points)
+  DevBuf dTmp2;
+  DevBuf dTmp3;
+};
+
+static inline int gps_fail(gps_handle_t h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define GPS_HIP(h, call)                                                         \
+  do {                                                                           \
+    hipError_t e__ = (call);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      return gps_fail(h, GPS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    }                                                                            \
+  } while (0)
+
+// Bracket one kernel launch for the per-class accounting.  The launch itself is
+// the lambda body; events are only recorded when profiling is enabled.
+struct LaunchScope {
+  gps_handle_t h; int klass; hipEvent_t a = nullptr, b = nullptr;
+  LaunchScope(gps_handle_t h_, int klass_, double flops, double bytes) : h(h_), klass(klass_) {
+    KClassStat& s = h->stat[klass];
+    s.launches++; s.flops += flops; s.bytes += bytes;
+    if (h->prof_on) {
+      a = take(); b = take();
+      (void)hipEventRecord(a, h->stream);
+    }
+  }
+  ~LaunchScope() {
+    if (h->prof_on) {
+      (void)hipEventRecord(b, h->stream);
+      h->pending.push_back({klass, a, b});
+    }
+  }
+  hipEvent_t take() {
+    if (!h->evt_pool.empty()) { hipEvent_t e = h->evt_pool.back(); h->evt_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+  }
+};
+
+// fold finished event pairs into the class statistics (stream must be idle)
+static inline void gps_profile_collect(gps_handle_t h) {
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->stat[p.klass].ms += ms;
+    h->evt_pool.push_back(p.a); h->evt_pool.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+// ---- kernel launchers implemented in the .hip files --------------------------
+// gemm_f64.hip : C (op)= A[M,K] * B[N,K]^T, all row-major, M,N multiples of 128,
+// K multiple of 16.  op 0: C -= A B^T ; op 1: C = A B^T ; lower: skip tiles above
+// the diagonal (M == N).
+int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
+                       const double* A, i64 lda, const double* B, i64 ldb,
+                       double* C, i64 ldc);
+// potrf_base.hip : factor one 128x128 diagonal block in place (lower), write its
+// inverse (full 128x128, zero upper) to Linv_blk; info word gets min(index+1) of a
+// non-positive pivot (index counted from row0).
+int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
+                          double* LinvT_blk, int* d_info, i64 row0, int factor);
+// blas1.hip
+int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
+int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
+                        const double* y1, double* y2, i64 ldy, i64 r);
+int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
+                          const double* alpha, i64 ldy, i64 r, double* out2);
+int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
+                      const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq);
+int gps_launch_fill_info(gps_handle_t h, int* d_info, int value);
+int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
+                         double* dst, i64 ldd);
+int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
+                        double* dst, i64 ldd, i64 prow, i64 pcol, int identity_pad,
+                        double diag_add);
+int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
+                       double* dst, i64 ldd, int lower_only);
+int gps_launch_var_finish(gps_handle_t h, double* var, const double* kdiag_or_null,
+                          double kdiag_const, const double* sumsq, i64 n);
+// kmat.hip
+int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                    const double* dX, i64 n, const double* dX2 /*nullptr: symmetric*/, i64 m,
+                    i64 d_all, double diag_add, double* dK, i64 ldk, i64 prow, i64 pcol,
+                    int lower_only, int identity_pad);
+int gps_launch_kdiag(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* kdiag_const);
+// diag.hip
+int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);

@@ -1,0 +1,365 @@
+// Kernel-matrix build: K[i][j] = k(x_i, x'_j) for a whole kernel *program* in one pass.
+//
+// Replaces, fused into one HBM write of K:
+//   Kernel._slice            kernels.py:217-253   (active-dims gather, folded into the prep)
+//   Stationary.square_dist   kernels.py:408-421   (x/l ; -2 a.b + |a|^2 + |b|^2 ; clip >= 0)
+//   Stationary.euclid_dist   kernels.py:424-426   (sqrt(r2 + 1e-12))
+//   RBF / Matern12/32/52 / Exponential .K         kernels.py:436-439, 560-610
+//   Periodic.K               kernels.py:806-819   (via u = (cos, sin) features: the docstring's
+//                                                  own mapping, kernels.py:776 -- avoids the
+//                                                  reference's [N,M,D] temporary and D*N*M sin())
+//   White.K / Constant.K     kernels.py:332-350
+//   Sum.K / Product.K        kernels.py:1071-1084 (RPN program, left folds)
+//   "+ eye(N) * variance"    models/gpr.py:69,120 ; features.py:76 (diag_add)
+//
+// Two kernels: a tiny prep pass turns X[n, d_all] into feature-major rows
+// Ft[feature][point] (scaled inputs x_d / l_d, or cos/sin(2 pi x_d / p)) plus squared norms;
+// the tile pass gives every 256-thread workgroup a 64x64 tile, stages the two 64-point feature
+// slabs of one primitive at a time in LDS, accumulates a 4x4 patch of dot products per thread
+// and pushes k() onto a register-resident evaluation stack.  HBM traffic = one coalesced write
+// of K (512-byte row segments per wave) + O((n+m) F) feature reads.
+#include "gps_common.hpp"
+#include <cmath>
+
+#define KT 64          // tile edge
+#define KLS 64         // LDS slab stride (doubles) per feature row
+#define KMAXF 64       // features per primitive (32 dims x {cos, sin})
+
+struct PrepFeat { int dim; int kind; double param; };   // kind 0: x/param ; 1: cos(2 pi x/param) ; 2: sin(...)
+struct PrepNorm { int f0; int nf; };
+
+struct KNodeDev {
+  int op; int f0; int nf; int norm_row;   // norm_row: row index in Ft holding |a|^2 (or -1)
+  double variance; double c0;             // c0: periodic lengthscale
+};
+struct KProgDev {
+  int n_nodes;
+  KNodeDev nodes[GPS_MAX_NODES];
+};
+
+struct KmatArgs {
+  const double* Fr; const double* Fc;     // feature-major [rows][ldf_r / ldf_c]
+  i64 ldfr, ldfc;
+  double* K; i64 ldk;
+  i64 n, m;                               // real extents
+  int sym; int lower_only; int identity_pad; int maxnf;
+  double diag_add;
+};
+
+// ---- prep: one thread per point ------------------------------------------------------------
+__global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict__ X, i64 n,
+                                                        i64 d_all, i64 npts_pad,
+                                                        const PrepFeat* __restrict__ feats,
+                                                        int nfeat,
+                                                        const PrepNorm* __restrict__ norms,
+                                                        int nnorm, double* __restrict__ Ft,
+                                                        i64 ldf) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts_pad) return;
+  if (i >= n) {
+    for (int f = 0; f < nfeat + nnorm; ++f) Ft[(i64)f * ldf + i] = 0.0;
+    return;
+  }
+  const double* x = X + i * d_all;
+  for (int f = 0; f < nfeat; ++f) {
+    const PrepFeat pf = feats[f];
+    const double xv = x[pf.dim];
+    double v;
+    if (pf.kind == 0) v = xv / pf.param;
+    else {
+      const double ang = 2.0 * M_PI * xv / pf.param;
+      v = (pf.kind == 1) ? cos(ang) : sin(ang);
+    }
+    Ft[(i64)f * ldf + i] = v;
+  }
+  for (int q = 0; q < nnorm; ++q) {
+    const PrepNorm pn = norms[q];
+    double s = 0.0;
+    for (int f = pn.f0; f < pn.f0 + pn.nf; ++f) {
+      const double v = Ft[(i64)f * ldf + i];
+      s += v * v;
+    }
+    Ft[(i64)(nfeat + q) * ldf + i] = s;
+  }
+}
+
+// ---- tile pass --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (a.lower_only && (tj >> 1) > (ti >> 1)) return;     // 128-granular: diagonal blocks stay full
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
+  double* nc_s = nr_s + KT;                                // [KT]
+  double* Fr_s = nc_s + KT;                                // [a.maxnf][KLS]
+  double* Fc_s = Fr_s + a.maxnf * KLS;                     // [a.maxnf][KLS]
+
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const i64 gi0 = (i64)ti * KT, gj0 = (i64)tj * KT;
+
+  double st[GPS_MAX_STACK][16];
+#pragma unroll
+  for (int s = 0; s < GPS_MAX_STACK; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[s][e] = 0.0;
+
+  for (int nd = 0; nd < P.n_nodes; ++nd) {
+    const KNodeDev node = P.nodes[nd];
+    if (node.op == GPS_K_ADD || node.op == GPS_K_MUL) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        st[0][e] = (node.op == GPS_K_ADD) ? (st[1][e] + st[0][e]) : (st[1][e] * st[0][e]);
+#pragma unroll
+        for (int s = 1; s < GPS_MAX_STACK - 1; ++s) st[s][e] = st[s + 1][e];
+      }
+      continue;
+    }
+    // ---- primitive: value v[16] ----
+    double v[16];
+    if (node.op == GPS_K_CONSTANT) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = node.variance;
+    } else if (node.op == GPS_K_WHITE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const i64 gi = gi0 + ty * 4 + (e >> 2), gj = gj0 + tx * 4 + (e & 3);
+        v[e] = (a.sym && gi == gj) ? node.variance : 0.0;
+      }
+    } else {
+      // stage this primitive's feature slabs
+      __syncthreads();
+      for (int idx = tid; idx < node.nf * KT; idx += 256) {
+        const int f = idx >> 6, p = idx & 63;
+        Fr_s[f * KLS + p] = a.Fr[(i64)(node.f0 + f) * a.ldfr + gi0 + p];
+        Fc_s[f * KLS + p] = a.Fc[(i64)(node.f0 + f) * a.ldfc + gj0 + p];
+      }
+      if (node.norm_row >= 0 && tid < KT) {
+        nr_s[tid] = a.Fr[(i64)node.norm_row * a.ldfr + gi0 + tid];
+        nc_s[tid] = a.Fc[(i64)node.norm_row * a.ldfc + gj0 + tid];
+      }
+      __syncthreads();
+      double dot[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dot[e] = 0.0;
+      for (int f = 0; f < node.nf; ++f) {
+        double fr[4], fc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          fr[q] = Fr_s[f * KLS + ty * 4 + q];
+          fc[q] = Fc_s[f * KLS + tx * 4 + q];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dot[e] = fma(fr[e >> 2], fc[e & 3], dot[e]);
+      }
+      if (node.op == GPS_K_PERIODIC) {
+        const double half_d = 0.5 * (double)(node.nf / 2);
+        const double l2 = node.c0 * node.c0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          // sum_d sin^2(pi (x - x')/p) / l^2 = (D - sum_d cos(a_d - b_d)) / (2 l^2)
+          const double rs = (half_d - 0.5 * dot[e]) / l2;
+          v[e] = node.variance * exp(-0.5 * rs);
+        }
+      } else {
+        const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const double ni = nr_s[ty * 4 + (e >> 2)], nj = nc_s[tx * 4 + (e & 3)];
+          double r2 = -2.0 * dot[e] + (ni + nj);
+          r2 = fmax(r2, 0.0);
+          double val;
+          if (node.op == GPS_K_RBF) {
+            val = node.variance * exp(-r2 / 2.0);
+          } else {
+            const double r = sqrt(r2 + 1e-12);
+            if (node.op == GPS_K_MATERN12) val = node.variance * exp(-r);
+            else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * exp(-0.5 * r);
+            else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * exp(-sq3 * r);
+            else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * exp(-sq5 * r);
+          }
+          v[e] = val;
+        }
+      }
+    }
+    // push
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int s = GPS_MAX_STACK - 1; s > 0; --s) st[s][e] = st[s - 1][e];
+      st[0][e] = v[e];
+    }
+  }
+
+  // ---- write the 4x4 patch ----
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const i64 gi = gi0 + ty * 4 + q;
+    double o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const i64 gj = gj0 + tx * 4 + c;
+      double val = st[0][q * 4 + c];
+      if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
+      else if (a.sym && gi == gj) val += a.diag_add;
+      o[c] = val;
+    }
+    double* dst = a.K + gi * a.ldk + gj0 + tx * 4;
+    *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct KCompiled {
+  KProgDev prog;
+  std::vector<PrepFeat> feats;
+  std::vector<PrepNorm> norms;
+};
+
+static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all,
+                        KCompiled& out) {
+  if (!prog || n_nodes <= 0 || n_nodes > GPS_MAX_NODES)
+    return gps_fail(h, GPS_ERR_ARG, "kernel program: 1..GPS_MAX_NODES nodes expected");
+  int depth = 0;
+  out.prog.n_nodes = n_nodes;
+  for (int i = 0; i < n_nodes; ++i) {
+    const gps_kern_node_t& nd = prog[i];
+    KNodeDev& kd = out.prog.nodes[i];
+    kd.op = nd.op; kd.f0 = 0; kd.nf = 0; kd.norm_row = -1; kd.variance = nd.variance; kd.c0 = 0.0;
+    switch (nd.op) {
+      case GPS_K_ADD: case GPS_K_MUL:
+        if (depth < 2) return gps_fail(h, GPS_ERR_ARG, "kernel program: stack underflow");
+        depth -= 1;
+        break;
+      case GPS_K_WHITE: case GPS_K_CONSTANT:
+        depth += 1;
+        break;
+      case GPS_K_RBF: case GPS_K_MATERN12: case GPS_K_MATERN32: case GPS_K_MATERN52:
+      case GPS_K_EXPONENTIAL: case GPS_K_PERIODIC: {
+        if (nd.n_dims <= 0 || nd.n_dims > GPS_MAX_DIMS)
+          return gps_fail(h, GPS_ERR_ARG, "kernel program: n_dims out of range");
+        kd.f0 = (int)out.feats.size();
+        for (int d = 0; d < nd.n_dims; ++d) {
+          if (nd.active_dims[d] < 0 || nd.active_dims[d] >= d_all)
+            return gps_fail(h, GPS_ERR_ARG, "kernel program: active dim outside X");
+        }
+        if (nd.op == GPS_K_PERIODIC) {
+          if (!(nd.period > 0.0) || !(nd.lengthscales[0] > 0.0))
+            return gps_fail(h, GPS_ERR_ARG, "kernel program: period / lengthscale must be positive");
+          for (int d = 0; d < nd.n_dims; ++d) {
+            out.feats.push_back({nd.active_dims[d], 1, nd.period});
+            out.feats.push_back({nd.active_dims[d], 2, nd.period});
+          }
+          kd.nf = 2 * nd.n_dims;
+          kd.c0 = nd.lengthscales[0];
+        } else {
+          for (int d = 0; d < nd.n_dims; ++d) {
+            if (!(nd.lengthscales[d] > 0.0))
+              return gps_fail(h, GPS_ERR_ARG, "kernel program: lengthscale must be positive");
+            out.feats.push_back({nd.active_dims[d], 0, nd.lengthscales[d]});
+          }
+          kd.nf = nd.n_dims;
+          kd.norm_row = (int)out.norms.size();     // fixed up below (offset by total features)
+          out.norms.push_back({kd.f0, kd.nf});
+        }
+        depth += 1;
+        break;
+      }
+      default:
+        return gps_fail(h, GPS_ERR_UNSUPPORTED, "kernel program: unknown op");
+    }
+    if (depth > GPS_MAX_STACK)
+      return gps_fail(h, GPS_ERR_UNSUPPORTED, "kernel program: expression deeper than GPS_MAX_STACK");
+  }
+  if (depth != 1) return gps_fail(h, GPS_ERR_ARG, "kernel program: must leave exactly one value");
+  const int nfeat = (int)out.feats.size();
+  for (int i = 0; i < n_nodes; ++i)
+    if (out.prog.nodes[i].norm_row >= 0) out.prog.nodes[i].norm_row += nfeat;
+  return GPS_OK;
+}
+
+int gps_launch_kdiag(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* kdiag_const) {
+  // Kdiag of every primitive is its variance (kernels.py:428-429, 803-804, 327-328);
+  // Sum.Kdiag / Product.Kdiag fold them (kernels.py:1075-1076, 1083-1084).
+  double st[GPS_MAX_NODES]; int sp = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    if (prog[i].op == GPS_K_ADD || prog[i].op == GPS_K_MUL) {
+      if (sp < 2) return gps_fail(h, GPS_ERR_ARG, "kernel program: stack underflow");
+      const double b = st[--sp], a = st[--sp];
+      st[sp++] = (prog[i].op == GPS_K_ADD) ? a + b : a * b;
+    } else st[sp++] = prog[i].variance;
+  }
+  if (sp != 1) return gps_fail(h, GPS_ERR_ARG, "kernel program: must leave exactly one value");
+  *kdiag_const = st[0];
+  return GPS_OK;
+}
+
+static int run_prep(gps_handle_t h, const KCompiled& kc, const double* dX, i64 n, i64 d_all,
+                    i64 npad, DevBuf& feat, DevBuf& tables, i64* ldf_out) {
+  const int nfeat = (int)kc.feats.size(), nnorm = (int)kc.norms.size();
+  const i64 rows = nfeat + nnorm;
+  *ldf_out = npad;
+  if (rows == 0) return GPS_OK;
+  GPS_HIP(h, feat.ensure((size_t)rows * npad * sizeof(double)));
+  const size_t fb = (size_t)nfeat * sizeof(PrepFeat), nb = (size_t)nnorm * sizeof(PrepNorm);
+  GPS_HIP(h, tables.ensure(fb + nb + 64));
+  if (fb) GPS_HIP(h, hipMemcpyAsync(tables.p, kc.feats.data(), fb, hipMemcpyHostToDevice, h->stream));
+  if (nb) GPS_HIP(h, hipMemcpyAsync((char*)tables.p + fb, kc.norms.data(), nb, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));   // host vectors may die after return
+  LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * (double)(rows + d_all));
+  hipLaunchKernelGGL(kmat_prep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream,
+                     dX, n, d_all, npad, (const PrepFeat*)tables.p,
+                     nfeat, (const PrepNorm*)((char*)tables.p + fb), nnorm, feat.d(), npad);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                    const double* dX, i64 n, const double* dX2, i64 m, i64 d_all,
+                    double diag_add, double* dK, i64 ldk, i64 prow, i64 pcol,
+                    int lower_only, int identity_pad) {
+  KCompiled kc;
+  int rc = compile_prog(h, prog, n_nodes, d_all, kc);
+  if (rc) return rc;
+  const int sym = (dX2 == nullptr);
+  if (sym) m = n;
+  if (prow % KT || pcol % KT || prow < n || pcol < m)
+    return gps_fail(h, GPS_ERR_ARG, "kmat: padded extents must be multiples of 64 covering n, m");
+  if (prow / KT > 65535) return gps_fail(h, GPS_ERR_UNSUPPORTED, "kmat: more than 65535*64 rows");
+  i64 ldfr = 0, ldfc = 0;
+  rc = run_prep(h, kc, dX, n, d_all, prow, h->dFeat, h->dProg, &ldfr);
+  if (rc) return rc;
+  const double* Fc = h->dFeat.d();
+  ldfc = ldfr;
+  if (!sym) {
+    rc = run_prep(h, kc, dX2, m, d_all, pcol, h->dFeat2, h->dProg, &ldfc);
+    if (rc) return rc;
+    Fc = h->dFeat2.d();
+  } else if (pcol != prow) {
+    return gps_fail(h, GPS_ERR_ARG, "kmat: symmetric build needs square padding");
+  }
+  KmatArgs a;
+  a.Fr = h->dFeat.d(); a.Fc = Fc; a.ldfr = ldfr; a.ldfc = ldfc;
+  a.K = dK; a.ldk = ldk; a.n = n; a.m = m; a.sym = sym;
+  a.lower_only = (sym && lower_only) ? 1 : 0; a.identity_pad = identity_pad; a.diag_add = diag_add;
+  double tiles = (double)(prow / KT) * (double)(pcol / KT);
+  if (a.lower_only) tiles = 0.5 * tiles + 0.5 * (double)(prow / KT);
+  const int nfeat_total = (int)kc.feats.size();
+  int maxnf = 1;
+  for (int i = 0; i < n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
+  a.maxnf = maxnf;
+  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
+    attr_set = true;
+  }
+  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);
+  hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds,
+                     h->stream, a, kc.prog);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}

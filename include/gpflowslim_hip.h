@@ -1,0 +1,185 @@
+/*
+ * gpflowslim_hip.h -- C ABI of libgpflowslim_hip.so
+ *
+ * MI355X (gfx950) implementation of GPflow-Slim's exact-GP hot path:
+ *   kernels.K -> Cholesky -> triangular solves -> log-det / posterior.
+ *
+ * The reference has no FFI of its own (it is pure Python over TensorFlow 1.x
+ * builtins), so every entry point below cites the reference *call site* whose
+ * TensorFlow ops it replaces.  Paths are relative to the reference checkout
+ * (gpflowSlim/...).
+ *
+ * Conventions
+ *   - all matrices are C-contiguous row-major fp64 (numpy default);
+ *   - "host" pointers are ordinary process memory owned by the caller;
+ *     device buffers live inside the handle and are never returned;
+ *   - return value 0 = ok, <0 = argument / HIP error (text: gps_last_error),
+ *     LAPACK-style "not positive definite" is reported through *info > 0
+ *     (order of the first non-positive pivot), the analogue of TensorFlow
+ *     raising InvalidArgumentError from tf.cholesky (models/gpr.py:70);
+ *   - a handle is bound to one GPU and is NOT thread-safe; calls return after
+ *     the handle's stream has been synchronised unless stated otherwise.
+ */
+#ifndef GPFLOWSLIM_HIP_H
+#define GPFLOWSLIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPS_MAX_DIMS   32   /* active dims per primitive kernel            */
+#define GPS_MAX_NODES  32   /* instructions per kernel program             */
+#define GPS_MAX_STACK   4   /* evaluation-stack depth of a kernel program  */
+
+#define GPS_OK              0
+#define GPS_ERR_ARG        -1
+#define GPS_ERR_HIP        -2
+#define GPS_ERR_STATE      -3
+#define GPS_ERR_UNSUPPORTED -4
+
+/* Kernel program: the covariance function as a reverse-Polish program.
+ * Mirrors Combination.__init__'s flattening + Sum.K / Product.K left folds
+ * (kernels.py:1009-1037, 1071-1084).  A primitive pushes k(x_i, x_j); ADD /
+ * MUL pop two values and push the result (left operand = deeper element).   */
+enum gps_kern_op {
+  GPS_K_RBF      = 1,  /* RBF.K            kernels.py:436-439 */
+  GPS_K_MATERN12 = 2,  /* Matern12.K       kernels.py:573-577 */
+  GPS_K_MATERN32 = 3,  /* Matern32.K       kernels.py:589-594 */
+  GPS_K_MATERN52 = 4,  /* Matern52.K       kernels.py:605-610 */
+  GPS_K_PERIODIC = 5,  /* Periodic.K       kernels.py:806-819 */
+  GPS_K_WHITE    = 6,  /* White.K          kernels.py:332-338 */
+  GPS_K_CONSTANT = 7,  /* Constant.K       kernels.py:345-350; also the
+                          scalars of Combination.const_list :1026-1027      */
+  GPS_K_EXPONENTIAL = 8, /* Exponential.K  kernels.py:560-565 */
+  GPS_K_ADD      = 16, /* Sum.K     reduce(tf.add, ...)      :1073          */
+  GPS_K_MUL      = 17  /* Product.K reduce(tf.multiply, ...) :1081          */
+};
+
+typedef struct gps_kern_node {
+  int32_t op;                           /* enum gps_kern_op                  */
+  int32_t n_dims;                       /* active dims of a primitive        */
+  int32_t active_dims[GPS_MAX_DIMS];    /* column indices into X (Kernel._slice, kernels.py:217-253) */
+  double  variance;                     /* constrained value                 */
+  double  period;                       /* Periodic only                     */
+  double  lengthscales[GPS_MAX_DIMS];   /* per active dim (ARD) or repeated  */
+} gps_kern_node_t;
+
+typedef struct gps_handle_s* gps_handle_t;
+
+/* ---- life cycle ------------------------------------------------------- */
+int  gps_create(int device_id, gps_handle_t* out);
+int  gps_destroy(gps_handle_t h);
+const char* gps_last_error(gps_handle_t h);
+/* name: >=256 bytes.  Returns CU count, HBM bytes, and the gfx arch string. */
+int  gps_device_info(gps_handle_t h, char* name, int name_len, int* n_cu,
+                     int64_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- kernels.K(X, X2) -------------------------------------------------
+ * Replaces Stationary.square_dist / euclid_dist + RBF/Matern/Periodic.K +
+ * Sum.K / Product.K (kernels.py:408-439, 569-610, 806-819, 1071-1084) and the
+ * "+ eye(N) * variance" of models/gpr.py:69 (diag_add, symmetric case only).
+ * X [n, d_all]; X2 [m, d_all] or NULL (symmetric: m is ignored, out is [n,n]).
+ * K_out host [n, m].                                                        */
+int gps_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+             const double* X, int64_t n, const double* X2, int64_t m,
+             int64_t d_all, double diag_add, double* K_out);
+
+/* ---- tf.cholesky (models/gpr.py:70,121; conditionals.py:84) ------------
+ * A host [n,n] (lower triangle read); L_out host [n,n], upper triangle
+ * zero-filled like tf.cholesky.  A and L_out may alias.                     */
+int gps_potrf(gps_handle_t h, const double* A, int64_t n, double* L_out,
+              int* info);
+
+/* ---- tf.matrix_triangular_solve(L, B, lower=True) ----------------------
+ * (densities.py:82; models/gpr.py:122-123; conditionals.py:87,100)
+ * L host [n,n] lower; B host [n,nrhs] overwritten by the solution of
+ * L X = B (trans=0) or L^T X = B (trans=1).                                 */
+int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double* B,
+                   int64_t nrhs, int trans);
+
+/* ---- GPR: device-resident fused path -----------------------------------
+ * gps_gpr_set_data: GPModel.__init__ storing X (models/model.py:111-119).
+ * X is uploaded once and stays in HBM; K / L never cross PCIe.              */
+int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int64_t d_all);
+
+/* GPR._build_likelihood exact branch (models/gpr.py:69-72) +
+ * densities.multivariate_normal (densities.py:73-95):
+ *   K = kern.K(X) + noise_var*I ; L = chol(K) ; alpha = L^-1 resid ;
+ *   lml = -0.5*n*r*log(2pi) - r*sum(log diag L) - 0.5*sum(alpha^2).
+ * resid host [n, r] = Y - mean_function(X).  Leaves L and alpha resident.   */
+int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                double noise_var, const double* resid, int64_t r,
+                double* lml, int* info);
+
+/* GPR._build_predict exact branch (models/gpr.py:119-131).
+ * refactor != 0: rebuild K, L, V exactly like the reference does on every
+ * predict_f call ("cold"); refactor == 0: reuse L / V left by the previous
+ * gps_gpr_lml / gps_gpr_predict on this handle ("warm"; prog, noise_var and
+ * resid must be unchanged -- the caller vouches for that).
+ * mean_out host [n_new, r]  = A^T V          (caller adds mean_function(Xnew))
+ * var_out  host [n_new]     = Kdiag - colsum(A*A)       (full_cov == 0)
+ *          host [n_new,n_new] = K(Xnew) - A^T A          (full_cov != 0)
+ * (the tiling over r, models/gpr.py:127-131, is a host-side broadcast).     */
+int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                    double noise_var, const double* resid, int64_t r,
+                    const double* Xnew, int64_t n_new, int full_cov,
+                    int refactor, double* mean_out, double* var_out, int* info);
+
+/* ---- conditionals.conditional / base_conditional ------------------------
+ * (conditionals.py:24-66, 80-121; features.py:74-81 for Kuu/Kuf).
+ * Device-resident form: Kmm = kern.K(Z) + jitter*I, Kmn = kern.K(Z, Xnew) are
+ * built on the GPU.  f host [m, k].  q_sqrt: NULL, or host [m, k]
+ * (q_sqrt_ndim == 2), or host [k, m, m] lower-triangular factors
+ * (q_sqrt_ndim == 3; i.e. the reference's [m, m, k] transposed to k-major).
+ * fmean_out host [n_new, k]; fvar_out host [n_new, k] (full_cov == 0) or
+ * [k, n_new, n_new] (full_cov != 0; caller transposes to [n,n,k]).          */
+int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                    const double* Z, int64_t m, int64_t d_all, double jitter,
+                    const double* Xnew, int64_t n_new,
+                    const double* f, int64_t k,
+                    const double* q_sqrt, int q_sqrt_ndim,
+                    int white, int full_cov,
+                    double* fmean_out, double* fvar_out, int* info);
+
+/* base_conditional on caller-supplied matrices (conditionals.py:80-121).
+ * Kmn host [m, n_new]; Kmm host [m, m]; Knn host [n_new] or [n_new, n_new]. */
+int gps_base_conditional(gps_handle_t h, const double* Kmn, const double* Kmm,
+                         const double* Knn, int64_t m, int64_t n_new,
+                         const double* f, int64_t k,
+                         const double* q_sqrt, int q_sqrt_ndim,
+                         int white, int full_cov,
+                         double* fmean_out, double* fvar_out, int* info);
+
+/* ---- measurement --------------------------------------------------------
+ * Per-kernel-class accounting of the calls issued through this handle.
+ * gps_profile_enable(h, 1) brackets every launch with HIP events on the
+ * handle's stream (adds a few us per launch); counters accumulate until
+ * gps_profile_reset.  Classes: "gemm_f64", "potrf_base", "kmat", "trsv",
+ * "reduce", "other".                                                        */
+int gps_profile_enable(gps_handle_t h, int on);
+int gps_profile_reset(gps_handle_t h);
+int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launches,
+                    double* ms, double* flops, double* bytes);
+/* wall-clock (HIP events) of the stages of the last gps_gpr_lml /
+ * gps_gpr_predict: out[0]=kmat out[1]=potrf out[2]=trsv+reductions
+ * out[3]=predict solve out[4]=total (ms).                                   */
+int gps_last_stage_ms(gps_handle_t h, double* out5);
+
+/* ---- diagnostics ---------------------------------------------------------
+ * fp64-MFMA microbenchmark (v_mfma_f64_16x16x4_f64 issue loop on every CU):
+ * measured TFLOP/s, and layout_ok = 1 when the operand / accumulator lane map
+ * used by the GEMM kernel reproduces an exact integer product.              */
+int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops,
+                      int* layout_ok);
+/* raw device GEMM on host matrices, for unit tests:
+ * C[m,n] (op)= A[m,k] * B[n,k]^T ; op: 0 -> C -= A B^T, 1 -> C = A B^T.
+ * lower != 0: only tiles on/below the diagonal are computed (m == n).       */
+int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
+                     int64_t k, const double* A, const double* B, double* C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPFLOWSLIM_HIP_H */

@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libgpflowslim_hip.so.
+// Instantiates gpflow-slim_amd/csrc/blocked.hpp (the recursion used by the product) with naive
+// host loops in place of the HIP kernels, so that the block/index arithmetic of potrf_rec /
+// trsm_rec / trsm_rn_rec / trsv_rec can be checked against scipy on a machine without a GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../gpflow-slim_amd/csrc/blocked.hpp"
+
+typedef int64_t i64;
+static const i64 T = GPS_TILE;
+
+struct CpuOps {
+  std::vector<double> linv, linvT;
+  int info = 0;
+  int n_gemm = 0, n_base = 0;
+  explicit CpuOps(i64 nblk) : linv(nblk * T * T, 0.0), linvT(nblk * T * T, 0.0) {}
+
+  int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
+    ++n_base;
+    for (i64 j = 0; j < T; ++j) {
+      double d = A[j * lda + j];
+      for (i64 k = 0; k < j; ++k) d -= A[j * lda + k] * A[j * lda + k];
+      if (!(d > 0.0) && info == 0) info = (int)(row0 + j + 1);
+      d = std::sqrt(d);
+      A[j * lda + j] = d;
+      for (i64 i = j + 1; i < T; ++i) {
+        double s = A[i * lda + j];
+        for (i64 k = 0; k < j; ++k) s -= A[i * lda + k] * A[j * lda + k];
+        A[i * lda + j] = s / d;
+      }
+    }
+    double* X = &linv[blk * T * T];
+    double* XT = &linvT[blk * T * T];
+    for (i64 c = 0; c < T; ++c) {
+      for (i64 i = 0; i < T; ++i) {
+        double s = (i == c) ? 1.0 : 0.0;
+        for (i64 k = c; k < i; ++k) s -= A[i * lda + k] * X[k * T + c];
+        X[i * T + c] = (i < c) ? 0.0 : s / A[i * lda + i];
+      }
+    }
+    for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) XT[c * T + i] = X[i * T + c];
+    return 0;
+  }
+  int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb,
+           double* C, i64 ldc) {
+    ++n_gemm;
+    if (M % T || N % T || K % 16) return -1;
+    std::vector<double> out((size_t)M * N, 0.0);
+    std::vector<char> done((size_t)M * N, 0);
+    for (i64 i = 0; i < M; ++i)
+      for (i64 j = 0; j < N; ++j) {
+        if (lower && (j / T) > (i / T)) continue;
+        double s = 0.0;
+        for (i64 k = 0; k < K; ++k) s += A[i * lda + k] * B[j * ldb + k];
+        out[i * N + j] = s; done[i * N + j] = 1;
+      }
+    for (i64 i = 0; i < M; ++i)
+      for (i64 j = 0; j < N; ++j)
+        if (done[i * N + j]) C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : out[i * N + j];
+    return 0;
+  }
+  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m) {
+    const double* W = (transposed ? linvT.data() : linv.data()) + blk * T * T;
+    return gemm(1, 0, m, T, T, B, ldb, W, T, B, ldb);
+  }
+  int trsv_base(i64 blk, double* y, i64 ldy, i64 r) {
+    const double* W = linv.data() + blk * T * T;
+    for (i64 q = 0; q < r; ++q) {
+      double tmp[GPS_TILE];
+      for (i64 i = 0; i < T; ++i) { double s = 0; for (i64 c = 0; c < T; ++c) s += W[i * T + c] * y[q * ldy + c]; tmp[i] = s; }
+      for (i64 i = 0; i < T; ++i) y[q * ldy + i] = tmp[i];
+    }
+    return 0;
+  }
+  int gemv_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y1, double* y2, i64 ldy, i64 r) {
+    for (i64 q = 0; q < r; ++q)
+      for (i64 i = 0; i < n2; ++i) {
+        double s = 0; for (i64 k = 0; k < n1; ++k) s += L21[i * ldl + k] * y1[q * ldy + k];
+        y2[q * ldy + i] -= s;
+      }
+    return 0;
+  }
+};
+
+extern "C" {
+// A [n,n] in place -> L (lower valid); B [m,n]: X L^T = B ; B2 [m,n]: X L = B ; y [r][n]: L a = y
+int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, int* info) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rec(A, n, n, 0, 0);
+  if (rc) return rc;
+  *info = ops.info;
+  rc = bl.trsm_rec(A, n, n, 0, B, n, m);
+  if (rc) return rc;
+  std::vector<double> U((size_t)n * n, 0.0);
+  for (i64 i = 0; i < n; ++i) for (i64 j = 0; j <= i; ++j) U[j * n + i] = A[i * n + j];
+  rc = bl.trsm_rn_rec(U.data(), n, n, 0, B2, n, m);
+  if (rc) return rc;
+  return bl.trsv_rec(A, n, n, 0, y, n, r);
+}
+}
