@@ -6,15 +6,17 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double* out, int iters) {
+__global__ __launch_bounds__(256, 2) void mfma_f64_rate_kernel(double* out, int iters) {
   const int lane = threadIdx.x & 63;
   double a = 1.0 + 1e-3 * lane, b = 1.0 - 1e-3 * lane;
   v4d acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int it = 0; it < iters; ++it) {
+  for (int it = 0; it < iters; it += 8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll

@@ -1,0 +1,376 @@
+"""ctypes binding of libgpflowslim_hip.so (C ABI: include/gpflowslim_hip.h).
+
+This is the only place where the Python mirror of the gpflowSlim API touches the device.
+There is deliberately no CPU fallback: if the HIP library cannot be loaded, or no GPU is
+visible, every compute entry point raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+GPS_MAX_DIMS = 32
+GPS_MAX_NODES = 32
+GPS_MAX_STACK = 4
+
+# enum gps_kern_op
+K_RBF, K_MATERN12, K_MATERN32, K_MATERN52, K_PERIODIC, K_WHITE, K_CONSTANT, K_EXPONENTIAL = 1, 2, 3, 4, 5, 6, 7, 8
+K_ADD, K_MUL = 16, 17
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_i64 = ctypes.c_int64
+
+
+class KernNode(ctypes.Structure):
+    """gps_kern_node_t"""
+    _fields_ = [("op", ctypes.c_int32),
+                ("n_dims", ctypes.c_int32),
+                ("active_dims", ctypes.c_int32 * GPS_MAX_DIMS),
+                ("variance", ctypes.c_double),
+                ("period", ctypes.c_double),
+                ("lengthscales", ctypes.c_double * GPS_MAX_DIMS)]
+
+
+def lib_path():
+    env = os.environ.get("GPFLOWSLIM_HIP_LIB")
+    if env:
+        return env
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(here), "lib", "libgpflowslim_hip.so")
+
+
+_SIGNATURES = {
+    "gps_create": [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)],
+    "gps_destroy": [ctypes.c_void_p],
+    "gps_device_info": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, _c_int_p, ctypes.POINTER(_i64),
+                        ctypes.c_char_p, ctypes.c_int],
+    "gps_kmat": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64,
+                 _i64, ctypes.c_double, _c_double_p],
+    "gps_potrf": [ctypes.c_void_p, _c_double_p, _i64, _c_double_p, _c_int_p],
+    "gps_trsm_lower": [ctypes.c_void_p, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int],
+    "gps_gpr_set_data": [ctypes.c_void_p, _c_double_p, _i64, _i64],
+    "gps_gpr_lml": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p, _i64,
+                    _c_double_p, _c_int_p],
+    "gps_gpr_predict": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p,
+                        _i64, _c_double_p, _i64, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_int_p],
+    "gps_conditional": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64,
+                        ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, _c_double_p, ctypes.c_int,
+                        ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_int_p],
+    "gps_base_conditional": [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _i64, _i64, _c_double_p,
+                             _i64, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
+                             _c_double_p, _c_int_p],
+    "gps_profile_enable": [ctypes.c_void_p, ctypes.c_int],
+    "gps_profile_reset": [ctypes.c_void_p],
+    "gps_profile_get": [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_i64), _c_double_p, _c_double_p,
+                        _c_double_p],
+    "gps_last_stage_ms": [ctypes.c_void_p, _c_double_p],
+    "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
+    "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
+                         _c_double_p],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error"])
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Load the C-ABI library (no GPU needed for this step).  Raises if it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "gpflowSlim (MI355X): HIP library not found at %s -- build it with "
+                "`make -C gpflow-slim_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback." % path)
+        lib = ctypes.CDLL(path)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.gps_last_error.argtypes = [ctypes.c_void_p]
+        lib.gps_last_error.restype = ctypes.c_char_p
+        _lib = lib
+        return lib
+
+
+class NotPositiveDefiniteError(ValueError):
+    """Analogue of TensorFlow's InvalidArgumentError from tf.cholesky (models/gpr.py:70)."""
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def make_program(nodes):
+    if len(nodes) == 0 or len(nodes) > GPS_MAX_NODES:
+        raise ValueError("kernel program must have 1..%d nodes, got %d" % (GPS_MAX_NODES, len(nodes)))
+    arr = (KernNode * len(nodes))()
+    for i, nd in enumerate(nodes):
+        arr[i] = nd
+    return arr
+
+
+def primitive_node(op, variance, dims=(), lengthscales=(), period=0.0):
+    nd = KernNode()
+    nd.op = op
+    nd.variance = float(variance)
+    nd.period = float(period)
+    dims = list(dims)
+    if len(dims) > GPS_MAX_DIMS:
+        raise ValueError("a primitive kernel supports at most %d active dims" % GPS_MAX_DIMS)
+    nd.n_dims = len(dims)
+    for i, d in enumerate(dims):
+        nd.active_dims[i] = int(d)
+    ls = np.atleast_1d(np.asarray(lengthscales, dtype=np.float64))
+    if ls.size == 1 and len(dims) > 1:
+        ls = np.repeat(ls, len(dims))
+    for i in range(min(ls.size, GPS_MAX_DIMS)):
+        nd.lengthscales[i] = float(ls[i])
+    return nd
+
+
+def op_node(op):
+    nd = KernNode()
+    nd.op = op
+    return nd
+
+
+class Handle(object):
+    """One GPU, one stream, one set of resident buffers (gps_handle_t)."""
+
+    def __init__(self, device=None):
+        lib = load_library()
+        if device is None:
+            device = int(os.environ.get("GPFLOWSLIM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = ctypes.c_void_p()
+        rc = lib.gps_create(int(device), ctypes.byref(h))
+        if rc != 0 or not h:
+            raise RuntimeError("gpflowSlim (MI355X): gps_create(device=%d) failed with %d -- no usable GPU; "
+                               "there is no CPU fallback" % (device, rc))
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+        self.resident_token = None     # identity of the data set held by gps_gpr_set_data
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.gps_last_error(self._h)
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    # ---- info / measurement
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        arch = ctypes.create_string_buffer(256)
+        ncu = ctypes.c_int(0)
+        hbm = _i64(0)
+        self._check(self._lib.gps_device_info(self._h, name, 256, ctypes.byref(ncu), ctypes.byref(hbm), arch, 256),
+                    "gps_device_info")
+        return {"name": name.value.decode(), "arch": arch.value.decode(), "n_cu": ncu.value, "hbm_bytes": hbm.value}
+
+    def profile_enable(self, on):
+        self._check(self._lib.gps_profile_enable(self._h, 1 if on else 0), "gps_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.gps_profile_reset(self._h), "gps_profile_reset")
+
+    def profile_get(self, klass):
+        n = _i64(0)
+        ms, fl, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.gps_profile_get(self._h, klass.encode(), ctypes.byref(n), ctypes.byref(ms),
+                                              ctypes.byref(fl), ctypes.byref(by)), "gps_profile_get")
+        return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+
+    def last_stage_ms(self):
+        out = np.zeros(5)
+        self._check(self._lib.gps_last_stage_ms(self._h, _ptr(out)), "gps_last_stage_ms")
+        return dict(zip(["kmat", "potrf", "trsv", "predict", "total"], out.tolist()))
+
+    def diag_mfma_f64(self, waves_per_simd=1):
+        tf = ctypes.c_double(0)
+        ok = ctypes.c_int(0)
+        self._check(self._lib.gps_diag_mfma_f64(self._h, waves_per_simd, ctypes.byref(tf), ctypes.byref(ok)),
+                    "gps_diag_mfma_f64")
+        return tf.value, bool(ok.value)
+
+    def diag_gemm_nt(self, op, lower, A, B, C):
+        A, B = _f64(A), _f64(B)
+        C = np.array(C, dtype=np.float64, order="C", copy=True)
+        m, k = A.shape
+        n = B.shape[0]
+        assert B.shape[1] == k and C.shape == (m, n)
+        self._check(self._lib.gps_diag_gemm_nt(self._h, op, int(bool(lower)), m, n, k, _ptr(A), _ptr(B), _ptr(C)),
+                    "gps_diag_gemm_nt")
+        return C
+
+    # ---- kernels.K
+    def kmat(self, prog, X, X2=None, diag_add=0.0):
+        X = _f64(X)
+        n, d = X.shape
+        if X2 is None:
+            out = np.empty((n, n))
+            self._check(self._lib.gps_kmat(self._h, prog, len(prog), _ptr(X), n, None, 0, d, float(diag_add),
+                                           _ptr(out)), "gps_kmat")
+        else:
+            X2 = _f64(X2)
+            if X2.shape[1] != d:
+                raise ValueError("X and X2 must have the same number of columns")
+            m = X2.shape[0]
+            out = np.empty((n, m))
+            self._check(self._lib.gps_kmat(self._h, prog, len(prog), _ptr(X), n, _ptr(X2), m, d, float(diag_add),
+                                           _ptr(out)), "gps_kmat")
+        return out
+
+    # ---- linear algebra on host matrices
+    def potrf(self, A):
+        A = _f64(A)
+        n = A.shape[0]
+        if A.shape != (n, n):
+            raise ValueError("cholesky needs a square matrix")
+        L = np.empty_like(A)
+        info = ctypes.c_int(0)
+        self._check(self._lib.gps_potrf(self._h, _ptr(A), n, _ptr(L), ctypes.byref(info)), "gps_potrf")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
+                % info.value)
+        return L
+
+    def trsm_lower(self, L, B, trans=False):
+        L = _f64(L)
+        B = np.array(B, dtype=np.float64, order="C", copy=True)
+        squeeze = B.ndim == 1
+        if squeeze:
+            B = B[:, None].copy()
+        n = L.shape[0]
+        if L.shape != (n, n) or B.shape[0] != n:
+            raise ValueError("triangular solve: shape mismatch")
+        self._check(self._lib.gps_trsm_lower(self._h, _ptr(L), n, _ptr(B), B.shape[1], 1 if trans else 0),
+                    "gps_trsm_lower")
+        return B[:, 0] if squeeze else B
+
+    # ---- GPR
+    def gpr_set_data(self, X, token):
+        X = _f64(X)
+        self._check(self._lib.gps_gpr_set_data(self._h, _ptr(X), X.shape[0], X.shape[1]), "gps_gpr_set_data")
+        self.resident_token = token
+
+    def gpr_lml(self, prog, noise_var, resid):
+        resid = _f64(resid)
+        lml = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        self._check(self._lib.gps_gpr_lml(self._h, prog, len(prog), float(noise_var), _ptr(resid), resid.shape[1],
+                                          ctypes.byref(lml), ctypes.byref(info)), "gps_gpr_lml")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
+                % info.value)
+        return lml.value
+
+    def gpr_predict(self, prog, noise_var, resid, Xnew, full_cov=False, refactor=True):
+        resid = _f64(resid)
+        Xnew = _f64(Xnew)
+        n_new = Xnew.shape[0]
+        r = resid.shape[1]
+        mean = np.empty((n_new, r))
+        var = np.empty((n_new, n_new) if full_cov else (n_new,))
+        info = ctypes.c_int(0)
+        self._check(self._lib.gps_gpr_predict(self._h, prog, len(prog), float(noise_var), _ptr(resid), r,
+                                              _ptr(Xnew), n_new, 1 if full_cov else 0, 1 if refactor else 0,
+                                              _ptr(mean), _ptr(var), ctypes.byref(info)), "gps_gpr_predict")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
+                % info.value)
+        return mean, var
+
+    # ---- conditionals
+    @staticmethod
+    def _prep_q_sqrt(q_sqrt):
+        if q_sqrt is None:
+            return None, 0
+        q_sqrt = np.asarray(q_sqrt, dtype=np.float64)
+        if q_sqrt.ndim == 2:
+            return _f64(q_sqrt), 2
+        if q_sqrt.ndim == 3:
+            return _f64(np.transpose(q_sqrt, (2, 0, 1))), 3       # [m,m,k] -> [k,m,m]
+        raise ValueError("Bad dimension for q_sqrt: %s" % str(q_sqrt.ndim))
+
+    def _cond_outputs(self, n_new, k, full_cov):
+        fmean = np.empty((n_new, k))
+        fvar = np.empty((k, n_new, n_new) if full_cov else (n_new, k))
+        return fmean, fvar
+
+    def conditional(self, prog, Z, Xnew, f, jitter, q_sqrt=None, white=False, full_cov=False):
+        Z, Xnew, f = _f64(Z), _f64(Xnew), _f64(f)
+        m, d = Z.shape
+        n_new, k = Xnew.shape[0], f.shape[1]
+        q, qnd = self._prep_q_sqrt(q_sqrt)
+        fmean, fvar = self._cond_outputs(n_new, k, full_cov)
+        info = ctypes.c_int(0)
+        self.resident_token = None
+        self._check(self._lib.gps_conditional(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(Xnew),
+                                              n_new, _ptr(f), k, _ptr(q) if q is not None else None, qnd,
+                                              1 if white else 0, 1 if full_cov else 0, _ptr(fmean), _ptr(fvar),
+                                              ctypes.byref(info)), "gps_conditional")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
+        if full_cov:
+            fvar = np.ascontiguousarray(np.transpose(fvar, (1, 2, 0)))     # [n,n,k]  conditionals.py:119
+        return fmean, fvar
+
+    def base_conditional(self, Kmn, Kmm, Knn, f, q_sqrt=None, white=False, full_cov=False):
+        Kmn, Kmm, Knn, f = _f64(Kmn), _f64(Kmm), _f64(Knn), _f64(f)
+        m, n_new = Kmn.shape
+        k = f.shape[1]
+        q, qnd = self._prep_q_sqrt(q_sqrt)
+        fmean, fvar = self._cond_outputs(n_new, k, full_cov)
+        info = ctypes.c_int(0)
+        self.resident_token = None
+        self._check(self._lib.gps_base_conditional(self._h, _ptr(Kmn), _ptr(Kmm), _ptr(Knn), m, n_new, _ptr(f), k,
+                                                   _ptr(q) if q is not None else None, qnd, 1 if white else 0,
+                                                   1 if full_cov else 0, _ptr(fmean), _ptr(fvar),
+                                                   ctypes.byref(info)), "gps_base_conditional")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
+        if full_cov:
+            fvar = np.ascontiguousarray(np.transpose(fvar, (1, 2, 0)))
+        return fmean, fvar
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def get_handle():
+    """Process-wide default handle (device = $GPFLOWSLIM_DEVICE, else $LOCAL_RANK, else 0)."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Handle()
+        return _default
+
+
+def set_handle(handle):
+    global _default
+    with _default_lock:
+        _default = handle

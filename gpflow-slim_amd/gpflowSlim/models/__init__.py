@@ -1,0 +1,2 @@
+from .model import Model, GPModel
+from .gpr import GPR

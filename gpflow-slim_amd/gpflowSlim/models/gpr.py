@@ -1,0 +1,73 @@
+"""Exact Gaussian-process regression on one MI355X.
+
+Mirrors gpflowSlim/models/gpr.py:28-132 (exact branch :69-72, :119-131).  X is uploaded once
+and stays in HBM; every ``likelihood_tensor`` / ``objective`` read rebuilds K, re-factors and
+re-solves on the device, as the reference's ``sess.run(objective)`` does; ``predict_f``
+re-factors too (models/gpr.py:119-121) unless ``reuse_factor`` is switched on.
+"""
+import numpy as np
+
+from .. import likelihoods
+from .. import _backend as be
+from .._settings import settings
+from .model import GPModel
+
+
+class GPR(GPModel):
+    def __init__(self, X, Y, kern, mean_function=None, obs_var=0.1, num_latent=None, min_var=None, **kwargs):
+        """X [N, D], Y [N, R]; kern, mean_function as in the reference (models/gpr.py:41-53)."""
+        X = np.ascontiguousarray(X, dtype=settings.float_type)
+        Y = np.ascontiguousarray(Y, dtype=settings.float_type)
+        if X.ndim != 2 or Y.ndim != 2 or X.shape[0] != Y.shape[0]:
+            raise ValueError("GPR needs X [N, D] and Y [N, R]")
+        likelihood = likelihoods.Gaussian(var=obs_var, min_var=min_var)
+        GPModel.__init__(self, X, Y, kern, likelihood, mean_function, **kwargs)
+        self.num_latent = Y.shape[1] if num_latent is None else num_latent
+        # not in the reference: opt-in reuse of the resident factor by predict_f
+        self.reuse_factor = False
+        self._factor_key = None
+
+    # ---- device plumbing -------------------------------------------------------------------
+    def _handle(self):
+        h = be.get_handle()
+        token = (id(self), self.X.ctypes.data, self.X.shape)
+        if h.resident_token != token:
+            h.gpr_set_data(self.X, token)
+            self._factor_key = None
+        return h
+
+    def _state_key(self):
+        parts = [p.vf_val.tobytes() for p in self.parameters]
+        return (b"|".join(parts), self.Y.ctypes.data, self.Y.shape)
+
+    def _resid(self):
+        return np.ascontiguousarray(self.Y - self.mean_function(self.X))
+
+    # ---- reference API ---------------------------------------------------------------------
+    def _build_likelihood(self):
+        """models/gpr.py:69-72 + densities.py:73-95, fused on the device."""
+        h = self._handle()
+        prog = self.kern._program(self.X.shape[1])
+        self._factor_key = None
+        lml = h.gpr_lml(prog, float(np.squeeze(self.likelihood.variance)), self._resid())
+        self._factor_key = self._state_key()
+        return lml
+
+    def _build_predict(self, Xnew, full_cov=False):
+        """models/gpr.py:119-131"""
+        Xnew = np.ascontiguousarray(Xnew, dtype=settings.float_type)
+        h = self._handle()
+        prog = self.kern._program(self.X.shape[1])
+        key = self._state_key()
+        warm = bool(self.reuse_factor) and self._factor_key is not None and self._factor_key == key
+        self._factor_key = None
+        mean, var = h.gpr_predict(prog, float(np.squeeze(self.likelihood.variance)), self._resid(), Xnew,
+                                  full_cov=full_cov, refactor=not warm)
+        self._factor_key = key
+        fmean = mean + self.mean_function(Xnew)
+        R = self.Y.shape[1]
+        if full_cov:
+            fvar = np.tile(var[:, :, None], [1, 1, R])             # models/gpr.py:127-128
+        else:
+            fvar = np.tile(np.reshape(var, (-1, 1)), [1, R])       # models/gpr.py:131
+        return fmean, fvar

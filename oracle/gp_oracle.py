@@ -1,0 +1,276 @@
+"""CPU oracle for the exact-GP hot path of GPflow-Slim.  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy fp64 *restatement* of the reference algorithm, op for op.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it;
+the product (``gpflow-slim_amd/``) never does and fails loudly when its HIP library is missing.
+
+PARITY UNPINNED BY THE REFERENCE.  The reference is pure Python over TensorFlow 1.x
+(``tf.cholesky`` at gpflowSlim/models/gpr.py:70, ``tensorflow.contrib.eager`` at
+gpflowSlim/models/model.py:26) and TensorFlow is not installable in the build image, so the
+reference cannot be imported or run here, and its only two tests
+(gpflowSlim/models/gpr.py:135-203, gpflowSlim/densities.py:159-174) hold no numeric values.
+The oracle is therefore pinned by (tests/test_oracle.py): analytic known-answer cases,
+50-digit mpmath evaluations of the same formulas, scikit-learn's independent GP implementation,
+and the reference's own structural test (Cholesky predictor == Woodbury predictor) restated.
+
+Reference lines followed (paths relative to the reference checkout, gpflowSlim/...):
+  transforms.py:145-146,177-178   Log1pe forward/backward (softplus + lower)
+  kernels.py:238-245              Kernel._slice (active dims)
+  kernels.py:408-421              Stationary.square_dist (GEMM form, clip at 0)
+  kernels.py:424-426              Stationary.euclid_dist (sqrt(r2 + 1e-12))
+  kernels.py:428-429,803-804      Kdiag
+  kernels.py:436-439              RBF.K
+  kernels.py:560-565,573-577,589-594,605-610   Exponential / Matern12 / Matern32 / Matern52 .K
+  kernels.py:806-819              Periodic.K
+  kernels.py:332-338,345-350      White.K / Constant.K
+  kernels.py:1071-1084            Sum / Product (left folds)
+  models/gpr.py:69-72             GPR._build_likelihood (exact branch)
+  densities.py:73-95              multivariate_normal
+  models/gpr.py:119-131           GPR._build_predict (exact branch)
+  likelihoods.py:180-184, densities.py:24-25   predict_y / predict_density
+  conditionals.py:24-66,80-121    conditional / base_conditional
+  features.py:74-81               InducingPoints.Kuu / Kuf
+"""
+from functools import reduce
+
+import numpy as np
+import scipy.linalg as sl
+
+JITTER = 1e-6            # gpflowrc:11  numerics.jitter_level
+
+
+# ---------------------------------------------------------------------------------------------
+# transforms.py:117-181
+def softplus(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.logaddexp(0.0, x)
+
+
+def log1pe_forward(x, lower=1e-6):
+    """transforms.py:145-146  tf.nn.softplus(x) + lower"""
+    return softplus(x) + lower
+
+
+def log1pe_backward(y, lower=1e-6):
+    """transforms.py:177-178"""
+    ys = np.maximum(np.asarray(y, dtype=np.float64) - lower, np.finfo(np.float64).eps)
+    return ys + np.log(-np.expm1(-ys))
+
+
+def constrained(value, lower=1e-6):
+    """What the reference actually uses after Parameter(value, Log1pe(lower)).value
+    (params.py:142-145,164-166): forward(backward(value))."""
+    return log1pe_forward(log1pe_backward(value, lower), lower)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels: specs are plain dicts so that the oracle shares no code with the product.
+#   {"type": "rbf"|"matern12"|"matern32"|"matern52"|"exponential", "variance": v,
+#    "lengthscales": scalar or [d], "active_dims": [..] or None, "input_dim": d}
+#   {"type": "periodic", "variance": v, "lengthscales": l, "period": p, "active_dims", "input_dim"}
+#   {"type": "white"|"constant", "variance": v}
+#   {"type": "sum"|"product", "children": [spec or float, ...]}
+def _slice(spec, X, X2):
+    """kernels.py:238-245"""
+    ad = spec.get("active_dims")
+    if ad is None:
+        ad = slice(spec["input_dim"])
+    else:
+        ad = np.asarray(ad, dtype=int)
+    X = X[:, ad]
+    if X2 is not None:
+        X2 = X2[:, ad]
+    return X, X2
+
+
+def square_dist(X, X2, lengthscales):
+    """kernels.py:408-421, op for op"""
+    X = X / lengthscales
+    Xs = np.sum(np.square(X), axis=1)
+    if X2 is None:
+        dist = -2 * np.matmul(X, X.T)
+        dist += np.reshape(Xs, (-1, 1)) + np.reshape(Xs, (1, -1))
+        return np.clip(dist, 0., np.inf)
+    X2 = X2 / lengthscales
+    X2s = np.sum(np.square(X2), axis=1)
+    dist = -2 * np.matmul(X, X2.T)
+    dist += np.reshape(Xs, (-1, 1)) + np.reshape(X2s, (1, -1))
+    return np.clip(dist, 0., np.inf)
+
+
+def euclid_dist(X, X2, lengthscales):
+    """kernels.py:424-426"""
+    return np.sqrt(square_dist(X, X2, lengthscales) + 1e-12)
+
+
+def _periodic_K(X, X2, variance, lengthscales, period, chunk=256):
+    """kernels.py:813-819; evaluated in row chunks (the reference's [N,M,D] temporary is 34 GB at
+    N=16384, D=16) -- same arithmetic per entry."""
+    if X2 is None:
+        X2 = X
+    out = np.empty((X.shape[0], X2.shape[0]))
+    f2 = X2[None, :, :]
+    for s in range(0, X.shape[0], chunk):
+        f = X[s:s + chunk, None, :]
+        r = np.pi * (f - f2) / period
+        r = np.sum(np.square(np.sin(r) / lengthscales), 2)
+        out[s:s + chunk] = variance * np.exp(-0.5 * r)
+    return out
+
+
+def K(spec, X, X2=None):
+    """kern.K(X, X2) of the reference for a spec tree."""
+    if isinstance(spec, (int, float)):
+        return spec                                     # kernels.py:1060-1063 _kernel_function
+    t = spec["type"]
+    if t in ("sum", "product"):
+        vals = [K(c, X, X2) for c in spec["children"] if not isinstance(c, (int, float))]
+        consts = [c for c in spec["children"] if isinstance(c, (int, float))]
+        op = np.add if t == "sum" else np.multiply
+        return reduce(op, vals + consts)                # kernels.py:1073 / 1081
+    v = spec["variance"]
+    if t == "white":                                    # kernels.py:332-338
+        if X2 is None:
+            return np.diag(np.full(X.shape[0], v))
+        return np.zeros((X.shape[0], X2.shape[0]))
+    if t == "constant":                                 # kernels.py:345-350
+        return np.full((X.shape[0], X.shape[0] if X2 is None else X2.shape[0]), v)
+    Xs, X2s = _slice(spec, X, X2)
+    if t == "periodic":
+        return _periodic_K(Xs, X2s, v, spec["lengthscales"], spec["period"])
+    ls = np.asarray(spec["lengthscales"], dtype=np.float64)
+    if t == "rbf":                                      # kernels.py:439
+        return v * np.exp(-square_dist(Xs, X2s, ls) / 2)
+    r = euclid_dist(Xs, X2s, ls)
+    if t == "matern12":                                 # kernels.py:576-577
+        return v * np.exp(-r)
+    if t == "exponential":                              # kernels.py:564-565
+        return v * np.exp(-0.5 * r)
+    if t == "matern32":                                 # kernels.py:592-594
+        return v * (1. + np.sqrt(3.) * r) * np.exp(-np.sqrt(3.) * r)
+    if t == "matern52":                                 # kernels.py:608-610
+        return v * (1.0 + np.sqrt(5.) * r + 5. / 3. * np.square(r)) * np.exp(-np.sqrt(5.) * r)
+    raise ValueError("unknown kernel type %r" % t)
+
+
+def Kdiag(spec, X):
+    """kernels.py:428-429, 803-804, 327-328, 1075-1076, 1083-1084"""
+    if isinstance(spec, (int, float)):
+        return spec
+    t = spec["type"]
+    if t in ("sum", "product"):
+        vals = [Kdiag(c, X) for c in spec["children"] if not isinstance(c, (int, float))]
+        consts = [c for c in spec["children"] if isinstance(c, (int, float))]
+        return reduce(np.add if t == "sum" else np.multiply, vals + consts)
+    return np.ones(X.shape[0]) * spec["variance"]
+
+
+# ---------------------------------------------------------------------------------------------
+def multivariate_normal(x, mu, L):
+    """densities.py:73-95"""
+    d = x - mu
+    alpha = sl.solve_triangular(L, d, lower=True)
+    num_col = 1 if x.ndim == 1 else x.shape[1]
+    num_dims = x.shape[0]
+    ret = -0.5 * num_dims * num_col * np.log(2 * np.pi)
+    ret += -num_col * np.sum(np.log(np.diag(L)))
+    ret += -0.5 * np.sum(np.square(alpha))
+    return ret
+
+
+def gaussian_density(x, mu, var):
+    """densities.py:24-25"""
+    return -0.5 * (np.log(2 * np.pi) + np.log(var) + np.square(mu - x) / var)
+
+
+def gpr_lml(spec, X, Y, noise_var, mean_X=None):
+    """models/gpr.py:69-72.  mean_X = mean_function(X) ([N,1] or [N,R]); Zero by default."""
+    Kmat = K(spec, X) + np.eye(X.shape[0]) * noise_var
+    L = np.linalg.cholesky(Kmat)
+    m = np.zeros((X.shape[0], 1)) if mean_X is None else mean_X
+    return multivariate_normal(Y, m, L)
+
+
+def gpr_predict(spec, X, Y, noise_var, Xnew, full_cov=False, mean_X=None, mean_Xnew=None):
+    """models/gpr.py:119-131"""
+    mX = np.zeros((X.shape[0], 1)) if mean_X is None else mean_X
+    mN = np.zeros((Xnew.shape[0], 1)) if mean_Xnew is None else mean_Xnew
+    Kx = K(spec, X, Xnew)
+    Kmat = K(spec, X) + np.eye(X.shape[0]) * noise_var
+    L = np.linalg.cholesky(Kmat)
+    A = sl.solve_triangular(L, Kx, lower=True)
+    V = sl.solve_triangular(L, Y - mX, lower=True)
+    fmean = np.matmul(A.T, V) + mN
+    if full_cov:
+        fvar = K(spec, Xnew) - np.matmul(A.T, A)
+        fvar = np.tile(fvar[:, :, None], [1, 1, Y.shape[1]])
+    else:
+        fvar = Kdiag(spec, Xnew) - np.sum(np.square(A), 0)
+        fvar = np.tile(np.reshape(fvar, (-1, 1)), [1, Y.shape[1]])
+    return fmean, fvar
+
+
+def base_conditional(Kmn, Kmm, Knn, f, full_cov=False, q_sqrt=None, white=False):
+    """conditionals.py:80-121"""
+    num_func = f.shape[1]
+    Lm = np.linalg.cholesky(Kmm)
+    A = sl.solve_triangular(Lm, Kmn, lower=True)
+    if full_cov:
+        fvar = Knn - np.matmul(A.T, A)
+        fvar = np.tile(fvar[None, :, :], [num_func, 1, 1])
+    else:
+        fvar = Knn - np.sum(np.square(A), 0)
+        fvar = np.tile(fvar[None, :], [num_func, 1])
+    if not white:
+        A = sl.solve_triangular(Lm.T, A, lower=False)
+    fmean = np.matmul(A.T, f)
+    if q_sqrt is not None:
+        if q_sqrt.ndim == 2:
+            LTA = A * q_sqrt.T[:, :, None]                          # K x M x N
+        elif q_sqrt.ndim == 3:
+            Lq = np.tril(np.transpose(q_sqrt, (2, 0, 1)))           # K x M x M
+            A_tiled = np.tile(A[None, :, :], [num_func, 1, 1])
+            LTA = np.matmul(np.transpose(Lq, (0, 2, 1)), A_tiled)   # K x M x N
+        else:
+            raise ValueError("Bad dimension for q_sqrt: %s" % str(q_sqrt.ndim))
+        if full_cov:
+            fvar = fvar + np.matmul(np.transpose(LTA, (0, 2, 1)), LTA)
+        else:
+            fvar = fvar + np.sum(np.square(LTA), 1)
+    fvar = np.transpose(fvar)                                       # N x K or N x N x K
+    return fmean, fvar
+
+
+def conditional(Xnew, X, spec, f, full_cov=False, q_sqrt=None, white=False, jitter=JITTER):
+    """conditionals.py:24-66 (also feature_conditional :69-77 with features.py:74-81)"""
+    Kmm = K(spec, X) + np.eye(X.shape[0]) * jitter
+    Kmn = K(spec, X, Xnew)
+    Knn = K(spec, Xnew) if full_cov else Kdiag(spec, Xnew)
+    return base_conditional(Kmn, Kmm, Knn, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py cpu_baseline leg: the same path with LAPACK dpotrf/dtrtrs (algorithm class of TF-CPU's
+# Eigen LLT / triangular solve), K built the unfused way the reference's TF graph does.
+def gpr_lml_timed(spec, X, Y, noise_var):
+    import time
+    t0 = time.perf_counter()
+    Kmat = K(spec, X) + np.eye(X.shape[0]) * noise_var
+    t1 = time.perf_counter()
+    L = sl.cholesky(Kmat, lower=True, overwrite_a=True, check_finite=False)
+    t2 = time.perf_counter()
+    alpha = sl.solve_triangular(L, Y, lower=True, check_finite=False)
+    n, r = Y.shape
+    lml = -0.5 * n * r * np.log(2 * np.pi) - r * np.sum(np.log(np.diag(L))) - 0.5 * np.sum(np.square(alpha))
+    t3 = time.perf_counter()
+    return lml, {"kmat_s": t1 - t0, "potrf_s": t2 - t1, "trsv_s": t3 - t2, "total_s": t3 - t0}
+
+
+def synthetic_gpr_data(n, d, n_new=0, seed=20240607):
+    """SURVEY.md section 8(d) synthetic inputs."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    w = rng.standard_normal((d, 1)) / np.sqrt(d)
+    Y = np.sin(X @ w) + 0.1 * rng.standard_normal((n, 1))
+    Xnew = rng.standard_normal((n_new, d)) if n_new else None
+    return X, Y, Xnew

@@ -1,0 +1,78 @@
+"""GPU unit tests of the individual HIP kernels, through the C ABI (include/gpflowslim_hip.h)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_f64_layout_and_rate(handle):
+    tf1, ok = handle.diag_mfma_f64(1)
+    assert ok, "v_mfma_f64_16x16x4_f64 lane map differs from the one gemm_f64.hip assumes"
+    tf2, _ = handle.diag_mfma_f64(2)
+    print("fp64 MFMA issue rate: %.1f TFLOP/s (1 wave/SIMD), %.1f (2 waves/SIMD)" % (tf1, tf2))
+    assert tf1 > 10.0
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (384, 256, 400), (1024, 1024, 1024)])
+@pytest.mark.parametrize("op", [0, 1])
+def test_gemm_nt_full(handle, m, n, k, op):
+    k = (k // 16) * 16
+    rng = np.random.default_rng(m + n + k + op)
+    A = rng.standard_normal((m, k)); B = rng.standard_normal((n, k)); C = rng.standard_normal((m, n))
+    out = handle.diag_gemm_nt(op, False, A, B, C)
+    ref = (C - A @ B.T) if op == 0 else A @ B.T
+    # fp64: only summation order differs
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,k", [(128, 64), (640, 128), (1152, 256), (2176, 512)])
+def test_gemm_nt_lower(handle, n, k):
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, k)); C = rng.standard_normal((n, n))
+    out = handle.diag_gemm_nt(0, True, A, A, C)
+    ref = C - A @ A.T
+    T = 128
+    for ti in range(n // T):
+        for tj in range(n // T):
+            blk = (slice(ti * T, (ti + 1) * T), slice(tj * T, (tj + 1) * T))
+            if tj <= ti:
+                assert np.abs(out[blk] - ref[blk]).max() <= 1e-11 * np.abs(ref).max(), (ti, tj)
+            else:
+                assert np.array_equal(out[blk], C[blk]), "tile above the diagonal must stay untouched"
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 127, 128, 129, 300, 512, 1000, 2048])
+def test_potrf_matches_lapack(handle, n):
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 3))
+    A = G @ G.T + 0.5 * np.eye(n)
+    L = handle.potrf(A)
+    ref = np.linalg.cholesky(A)
+    assert np.array_equal(np.triu(L, 1), np.zeros_like(L)), "upper triangle is zero-filled like tf.cholesky"
+    assert np.abs(L - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(L @ L.T - A).max() <= 1e-12 * np.abs(A).max() * n
+
+
+def test_potrf_reports_not_positive_definite(handle):
+    import gpflowSlim
+    n = 300
+    rng = np.random.default_rng(0)
+    G = rng.standard_normal((n, n))
+    A = G @ G.T + np.eye(n)
+    A[200, 200] = -1.0
+    with pytest.raises(gpflowSlim.NotPositiveDefiniteError) as e:
+        handle.potrf(A)
+    assert "201" in str(e.value)          # LAPACK-style: first failing leading minor
+
+
+@pytest.mark.parametrize("n,nrhs", [(1, 1), (7, 3), (128, 1), (200, 5), (513, 130), (1024, 1000)])
+@pytest.mark.parametrize("trans", [False, True])
+def test_trsm_lower(handle, n, nrhs, trans):
+    rng = np.random.default_rng(n * 7 + nrhs)
+    G = rng.standard_normal((n, n))
+    L = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    B = rng.standard_normal((n, nrhs))
+    X = handle.trsm_lower(L, B, trans=trans)
+    ref = sl.solve_triangular(L, B, lower=True, trans='T' if trans else 'N')
+    assert np.abs(X - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())

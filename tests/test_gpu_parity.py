@@ -1,0 +1,190 @@
+"""Parity of the HIP path against the CPU oracle (oracle/gp_oracle.py) through the gpflowSlim
+API mirror, i.e. through the C ABI.  Tolerance: 1e-8 relative fp64 (BASELINE.json north_star):
+LML: |d|/|lml| ; mean / var: max|d| / max|ref|."""
+import numpy as np
+import pytest
+
+import oracle.gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_kernel(gpf, kind, d):
+    """(product kernel, oracle spec) pairs with identical constrained hyper-parameters."""
+    k = gpf.kernels
+    c = orc.constrained
+    ls_ard = np.linspace(0.7, 1.9, d)
+    if kind == "rbf_ard":
+        return (k.RBF(d, variance=1.3, lengthscales=ls_ard, ARD=True),
+                {"type": "rbf", "variance": c(1.3), "lengthscales": c(ls_ard), "input_dim": d})
+    if kind == "rbf_iso":
+        return (k.RBF(d, variance=0.8, lengthscales=1.7),
+                {"type": "rbf", "variance": c(0.8), "lengthscales": c(1.7), "input_dim": d})
+    if kind in ("matern12", "matern32", "matern52", "exponential"):
+        cls = {"matern12": k.Matern12, "matern32": k.Matern32, "matern52": k.Matern52, "exponential": k.Exponential}[kind]
+        return (cls(d, variance=1.1, lengthscales=ls_ard * 1.5, ARD=True),
+                {"type": kind, "variance": c(1.1), "lengthscales": c(ls_ard * 1.5), "input_dim": d})
+    if kind == "periodic":
+        return (k.Periodic(d, period=2.0, variance=0.9, lengthscales=1.2),
+                {"type": "periodic", "variance": c(0.9), "lengthscales": c(1.2), "period": c(2.0), "input_dim": d})
+    if kind == "m52_plus_periodic":          # BASELINE config 4
+        a, sa = make_kernel(gpf, "matern52", d)
+        b, sb = make_kernel(gpf, "periodic", d)
+        return a + b, {"type": "sum", "children": [sa, sb]}
+    if kind == "nkn_like":                   # sum of products + constant, with active dims
+        d1 = list(range(0, d, 2))
+        d2 = list(range(1, d, 2)) or [0]
+        k1 = k.RBF(len(d1), variance=0.7, lengthscales=1.3, active_dims=d1)
+        k2 = k.Matern32(len(d2), variance=1.2, lengthscales=0.9, active_dims=d2)
+        k3 = k.Periodic(d, period=3.0, variance=0.5, lengthscales=2.0)
+        k4 = k.White(d, variance=0.05)
+        s1 = {"type": "rbf", "variance": c(0.7), "lengthscales": c(1.3), "active_dims": d1, "input_dim": len(d1)}
+        s2 = {"type": "matern32", "variance": c(1.2), "lengthscales": c(0.9), "active_dims": d2, "input_dim": len(d2)}
+        s3 = {"type": "periodic", "variance": c(0.5), "lengthscales": c(2.0), "period": c(3.0), "input_dim": d}
+        s4 = {"type": "white", "variance": c(0.05)}
+        return (k1 * k2 + k3 * k1 + k4 + 0.25,
+                {"type": "sum", "children": [{"type": "product", "children": [s1, s2]},
+                                             {"type": "product", "children": [s3, s1]}, s4, 0.25]})
+    raise ValueError(kind)
+
+
+KINDS = ["rbf_ard", "rbf_iso", "matern12", "matern32", "matern52", "exponential", "periodic",
+         "m52_plus_periodic", "nkn_like"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (5, 3, 2), (64, 64, 4), (130, 77, 5), (300, 513, 8)])
+def test_kmat_parity(handle, kind, n, m, d):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n * 31 + m)
+    X = rng.standard_normal((n, d)); X2 = rng.standard_normal((m, d))
+    kern, spec = make_kernel(gpf, kind, d)
+    K = kern.K(X)
+    Kr = orc.K(spec, X)
+    assert K.shape == (n, n)
+    # Matern family: r = sqrt(r2 + 1e-12) (kernels.py:426) amplifies the O(1e-15) rounding noise the
+    # GEMM-form r2 leaves on the diagonal ("whatever rounding leaves") to O(1e-9) in K_ii;
+    # two faithful implementations of the reference formula differ at that level on the diagonal.
+    sym_tol = 5e-9 if any(t in kind for t in ("matern", "exponential", "m52", "nkn")) else 1e-12
+    assert rel(K, Kr) <= sym_tol
+    off = ~np.eye(n, dtype=bool)
+    if n > 1:
+        assert np.abs(K[off] - Kr[off]).max() <= 1e-12 * np.abs(Kr).max()
+    assert np.array_equal(K, K.T)
+    Kx = kern.K(X, X2)
+    assert Kx.shape == (n, m)
+    assert rel(Kx, orc.K(spec, X, X2)) <= 1e-12 or np.abs(Kx).max() == 0.0
+    assert np.allclose(kern.Kdiag(X), orc.Kdiag(spec, X), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("n,d,r,ns", [(1, 1, 1, 1), (2, 1, 1, 3), (50, 3, 2, 7), (128, 4, 1, 128),
+                                      (455, 13, 1, 51), (512, 4, 1, 64), (1000, 8, 3, 200)])
+def test_gpr_parity(handle, kind, n, d, r, ns):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + 17 * d + r)
+    X = rng.standard_normal((n, d))
+    Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r))
+    Xs = rng.standard_normal((ns, d))
+    kern, spec = make_kernel(gpf, kind, d)
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    noise = orc.constrained(0.1)
+    assert float(np.squeeze(m.likelihood.variance)) == pytest.approx(float(noise), rel=0, abs=0)
+    lml = m.compute_log_likelihood()
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    assert abs(lml - ref) <= RTOL * abs(ref)
+    assert m.objective == pytest.approx(-ref, rel=RTOL)
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+    assert mu.shape == (ns, r) and var.shape == (ns, r)
+    assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+    # warm path (resident factor) gives the same numbers
+    m.reuse_factor = True
+    mu2, var2 = m.predict_f(Xs)
+    assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
+    if ns <= 200:
+        mu3, cov = m.predict_f_full_cov(Xs)
+        _, rcov = orc.gpr_predict(spec, X, Y, noise, Xs, full_cov=True)
+        assert cov.shape == (ns, ns, r)
+        assert rel(mu3, rmu) <= RTOL and rel(cov, rcov) <= RTOL
+    ymu, yvar = m.predict_y(Xs)
+    assert rel(yvar, rvar + noise) <= RTOL
+    dens = m.predict_density(Xs, np.zeros((ns, r)))
+    assert rel(dens, orc.gaussian_density(np.zeros((ns, r)), rmu, rvar + noise)) <= 1e-7
+
+
+def test_gpr_mean_function_and_min_var(handle):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(3)
+    n, d = 200, 3
+    X = rng.standard_normal((n, d)); Y = X @ rng.standard_normal((d, 2)) + 0.3
+    A = rng.standard_normal((d, 2)); b = np.array([0.1, -0.2])
+    kern, spec = make_kernel(gpf, "rbf_ard", d)
+    m = gpf.models.GPR(X, Y, kern, mean_function=gpf.mean_functions.Linear(A, b), obs_var=0.3, min_var=1e-3)
+    noise = orc.constrained(0.3, lower=1e-3)
+    ref = orc.gpr_lml(spec, X, Y, noise, mean_X=X @ A + b)
+    assert abs(m.compute_log_likelihood() - ref) <= RTOL * abs(ref)
+    Xs = rng.standard_normal((9, d))
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs, mean_X=X @ A + b, mean_Xnew=Xs @ A + b)
+    assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+
+
+def test_gpr_not_positive_definite_raises(handle):
+    import gpflowSlim as gpf
+    # duplicate points + (almost) no noise -> singular K: tf.cholesky would raise InvalidArgumentError
+    X = np.zeros((40, 2)); Y = np.ones((40, 1))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2), obs_var=1e-30, min_var=0.0)
+    m.likelihood._variance.transform._lower = -1.0     # force a negative "variance" on the diagonal
+    with pytest.raises(gpf.NotPositiveDefiniteError):
+        m.compute_log_likelihood()
+
+
+@pytest.mark.parametrize("white", [True, False])
+@pytest.mark.parametrize("full_cov", [False, True])
+@pytest.mark.parametrize("q", [None, 2, 3])
+def test_conditional_parity(handle, white, full_cov, q):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(11)
+    m_, n_, d, k = 150, 97, 3, 2
+    Z = rng.standard_normal((m_, d)); Xn = rng.standard_normal((n_, d)); f = rng.standard_normal((m_, k))
+    kern, spec = make_kernel(gpf, "matern52", d)
+    q_sqrt = None
+    if q == 2:
+        q_sqrt = np.abs(rng.standard_normal((m_, k))) * 0.3
+    elif q == 3:
+        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * 0.05 + np.eye(m_) * 0.2).transpose(1, 2, 0).copy()
+    mu, var = gpf.conditionals.conditional(Xn, Z, kern, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+    rmu, rvar = orc.conditional(Xn, Z, spec, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+    assert mu.shape == rmu.shape and var.shape == rvar.shape
+    assert rel(mu, rmu) <= 1e-7 and rel(var, rvar) <= 1e-7     # Kmm + 1e-6 I: cond ~1e8 eats digits
+    # same through host matrices
+    Kmm = orc.K(spec, Z) + 1e-6 * np.eye(m_); Kmn = orc.K(spec, Z, Xn)
+    Knn = orc.K(spec, Xn) if full_cov else orc.Kdiag(spec, Xn)
+    mu2, var2 = gpf.conditionals.base_conditional(Kmn, Kmm, Knn, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+    assert rel(mu2, rmu) <= 1e-7 and rel(var2, rvar) <= 1e-7
+
+
+def test_large_n_properties(handle):
+    """N = 8192 (BASELINE configs[1]): oracle parity still affordable + size-independent checks."""
+    import gpflowSlim as gpf
+    n, d = 8192, 8
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 256)
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d}
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    lml = m.compute_log_likelihood()
+    ref, _ = orc.gpr_lml_timed(spec, X, Y, orc.constrained(0.1))
+    assert abs(lml - ref) <= RTOL * abs(ref)
+    mu, var = m.predict_f(Xs)
+    # posterior variance in [0, prior variance]; predicting at training inputs reproduces smoothing
+    assert var.min() > 0 and var.max() <= float(kern.variance) * (1 + 1e-12)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
+    assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
