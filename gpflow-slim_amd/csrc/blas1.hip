@@ -17,24 +17,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// y_blk[r][0..127] = Linv[128][128] * y_blk[r]   (grid.x = r)
-__global__ __launch_bounds__(256) void trsv_base_kernel(const double* __restrict__ Linv,
+// y_blk[r][0..127] = Linv * y_blk[r], read through the TRANSPOSED inverse so that consecutive
+// threads read consecutive addresses: out[i] = sum_c LinvT[c][i] * y[c]      (grid.x = r)
+__global__ __launch_bounds__(256) void trsv_base_kernel(const double* __restrict__ LinvT,
                                                         double* __restrict__ y, i64 ldy) {
   __shared__ double ys[128];
-  __shared__ double outs[128];
+  __shared__ double part[128];
   double* yr = y + (i64)blockIdx.x * ldy;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, i = tid & 127, half = tid >> 7;
   if (tid < 128) ys[tid] = yr[tid];
   __syncthreads();
-  const double y0 = ys[lane], y1 = ys[lane + 64];
-  for (int row = wave; row < 128; row += 4) {
-    const double* Lr = Linv + row * 128;
-    double p = Lr[lane] * y0 + Lr[lane + 64] * y1;
-    p = wave_sum(p);
-    if (lane == 0) outs[row] = p;
-  }
+  const double* Lc = LinvT + (half * 64) * 128 + i;
+  double s = 0.0;
+#pragma unroll 16
+  for (int c = 0; c < 64; ++c) s += Lc[c * 128] * ys[half * 64 + c];
+  if (half) part[i] = s;
   __syncthreads();
-  if (tid < 128) yr[tid] = outs[tid];
+  if (!half) yr[i] = s + part[i];
 }
 
 // y2[r][i] -= sum_k L21[i][k] * y1[r][k],  i < n2, k < n1 (n1 multiple of 128).
@@ -192,9 +191,9 @@ __global__ __launch_bounds__(256) void extract_kernel(const double* __restrict__
 }
 
 // ---------------------------------------------------------------------------------
-int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r) {
+int gps_launch_trsv_base(gps_handle_t h, const double* LinvT_blk, double* y, i64 ldy, i64 r) {
   LaunchScope ls(h, KC_TRSV, 2.0 * 128 * 128 * r, 128.0 * 128 * 8);
-  hipLaunchKernelGGL(trsv_base_kernel, dim3((unsigned)r), dim3(256), 0, h->stream, Linv_blk, y, ldy);
+  hipLaunchKernelGGL(trsv_base_kernel, dim3((unsigned)r), dim3(256), 0, h->stream, LinvT_blk, y, ldy);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

@@ -8,22 +8,25 @@
 // Both operands are read "row, k" with k contiguous, so one kernel serves all of
 // them (see DESIGN.md "one GEMM form").
 //
-// Tiling (MI355X first): 128x128 output tile per 256-thread workgroup (4 waves in
-// a 2x2 grid, 64x64 per wave = 4x4 v_mfma_f64_16x16x4_f64 accumulators), BK = 16
+// Tiling (MI355X first): TB x TB output tile per 256-thread workgroup (4 waves in a
+// 2x2 grid, (TB/2)^2 per wave = (TB/32)^2 v_mfma_f64_16x16x4_f64 accumulators), BK = 16
 // staged through LDS with a register prefetch of the next K-slab.  Row stride in
 // LDS is 18 doubles: the 16 rows x 2 k of one ds_read_b64 half-wave then cover all
-// 64 banks exactly once.  2 workgroups per CU (147 KB LDS, <=256 VGPR) so that one
-// workgroup's C read-modify-write epilogue hides under the other's MFMA stream.
+// 64 banks exactly once.
+//
+// fp64 MFMA is slow *per CU* (128 FLOP/clk: a 128x128x128 tile is 15 us of one CU), so
+// what matters for the many small launches on the factorisation's critical path is to
+// spread a launch over all 256 CUs: the launcher picks TB = 128, 64 or 32 so that the
+// grid has enough workgroups.  TB = 128: 2 workgroups per CU (147 KB LDS, <=256 VGPR) so
+// that one workgroup's C read-modify-write epilogue hides under the other's MFMA stream.
 // blockIdx -> tile mapping is XCD-aware: each XCD walks a contiguous range of
-// 8-tile-wide column strips, so the 64 tiles resident on one XCD share 16 operand
-// panels in its private L2.
+// 8-tile-wide column strips, so the tiles resident on one XCD share operand panels in
+// its private L2.
 #include "gps_common.hpp"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-#define BM 128
-#define BN 128
 #define BK 16
 #define LS 18          // LDS row stride in doubles (BK + 2)
 #define STRIP 8        // tile columns per strip
@@ -86,8 +89,15 @@ __device__ __forceinline__ void decode_tile(int id, int Tm, int Tn, int& tm, int
   }
 }
 
-template <bool LOWER, int OP>
+// BM x BN output tile, 4 waves arranged WGM x (4/WGM); every wave owns a
+// (BM/WGM) x (BN/WGN) sub-tile = MI x NI accumulators of 16x16.
+template <int BM, int BN, int WGM, bool LOWER, int OP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile
+  constexpr int MI = WTM / 16, NI = WTN / 16;          // 16x16 MFMA tiles per wave
+  constexpr int LPA = (BM + 31) / 32, LPB = (BN + 31) / 32;   // 16-byte loads per thread per K-slab
+  static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one MFMA tile");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* As = reinterpret_cast<double*>(smem_raw);       // [2][BM][LS]
   double* Bs = As + 2 * BM * LS;                          // [2][BN][LS]
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WGN, wc = wave % WGN;
   const int fr = lane & 15, fk = lane >> 4;
 
   // global -> register staging map: 8 threads cover one 16-double (128 B) row slab
@@ -106,31 +116,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int lk = (tid & 7) * 2;       // 0,2,..,14
   const double* Ag = g.A + (i64)(tm * BM + lrow) * g.lda + lk;
   const double* Bg = g.B + (i64)(tn * BN + lrow) * g.ldb + lk;
+  const bool a_ld = (BM >= 32) || (lrow < BM);          // BM = 16: only half the threads stage A
 
-  v2d ra[4], rb[4];
-  v4d acc[4][4];
+  v2d ra[LPA], rb[LPB];
+  v4d acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   const int nk = g.K / BK;
 
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const v2d*>(Ag + (i64)(i * 32) * g.lda + (i64)kt * BK);
+    for (int i = 0; i < LPA; ++i)
+      if (a_ld) ra[i] = *reinterpret_cast<const v2d*>(Ag + (i64)(i * 32) * g.lda + (i64)kt * BK);
+#pragma unroll
+    for (int i = 0; i < LPB; ++i)
       rb[i] = *reinterpret_cast<const v2d*>(Bg + (i64)(i * 32) * g.ldb + (i64)kt * BK);
-    }
   };
   auto lstore = [&](int buf) {
     double* a = As + buf * BM * LS + lrow * LS + lk;
     double* b = Bs + buf * BN * LS + lrow * LS + lk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<v2d*>(a + i * 32 * LS) = ra[i];
+    for (int i = 0; i < LPA; ++i)
+      if (a_ld) *reinterpret_cast<v2d*>(a + i * 32 * LS) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LPB; ++i)
       *reinterpret_cast<v2d*>(b + i * 32 * LS) = rb[i];
-    }
   };
 
   gload(0);
@@ -141,20 +154,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
 
-    const double* a_base = As + buf * BM * LS + (wr * 64 + fr) * LS + fk;
-    const double* b_base = Bs + buf * BN * LS + (wc * 64 + fr) * LS + fk;
+    const double* a_base = As + buf * BM * LS + (wr * WTM + fr) * LS + fk;
+    const double* b_base = Bs + buf * BN * LS + (wc * WTN + fr) * LS + fk;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[4], b[4];
+      double a[MI], b[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = a_base[i * 16 * LS + kk * 4];
-        b[i] = b_base[i * 16 * LS + kk * 4];
-      }
+      for (int i = 0; i < MI; ++i) a[i] = a_base[i * 16 * LS + kk * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NI; ++j) b[j] = b_base[j * 16 * LS + kk * 4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 
@@ -164,12 +176,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 
   // epilogue.  f64 accumulator map (differs from every other dtype on gfx950):
   //   col = lane & 15, row = (lane >> 4) + 4 * reg.
-  const i64 row0 = (i64)tm * BM + wr * 64 + (lane >> 4);
-  const i64 col0 = (i64)tn * BN + wc * 64 + (lane & 15);
+  const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
+  const i64 col0 = (i64)tn * BN + wc * WTN + (lane & 15);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NI; ++j) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         double* cp = g.C + (row0 + i * 16 + 4 * rg) * g.ldc + col0 + j * 16;
@@ -180,39 +192,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   }
 }
 
-static const size_t kGemmLds = (size_t)(2 * BM * LS + 2 * BN * LS) * sizeof(double);
-
-template <bool LOWER, int OP>
+template <int BM, int BN, int WGM, bool LOWER, int OP>
 static int launch_variant(gps_handle_t h, const GemmArgs& g) {
   static bool attr_set = false;
+  const size_t lds = (size_t)(2 * (BM + BN) * LS) * sizeof(double);
   if (!attr_set) {
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<LOWER, OP>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_f64_kernel<LOWER, OP>), dim3(g.ntiles), dim3(256), kGemmLds, h->stream, g);
+  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), dim3(g.ntiles), dim3(256), lds, h->stream, g);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
 
+template <int BM, int BN, int WGM>
+static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64 N) {
+  g.Tm = (int)(M / BM); g.Tn = (int)(N / BN);
+  const i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
+  if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
+  g.ntiles = (int)nt;
+  if (BM == BN) {
+    if (lower) return op == 0 ? launch_variant<BM, BN, WGM, true, 0>(h, g) : launch_variant<BM, BN, WGM, true, 1>(h, g);
+  }
+  return op == 0 ? launch_variant<BM, BN, WGM, false, 0>(h, g) : launch_variant<BM, BN, WGM, false, 1>(h, g);
+}
+
+// rowpanel != 0: C may alias A (in-place B <- B W^T with N == K == 128): every workgroup then owns
+// complete rows (BN = N = 128), so it has consumed all of its A rows before it stores.
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc) {
   if (M <= 0 || N <= 0 || K <= 0) return GPS_OK;
-  if (M % BM || N % BN || K % BK || (lower && M != N))
+  if (M % 128 || N % 128 || K % BK || (lower && M != N))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: operands must be 16-byte aligned with even leading dimension");
+  const bool rowpanel = (C == A);
+  if (rowpanel && (N != 128 || lower))
+    return gps_fail(h, GPS_ERR_ARG, "gemm_nt: in-place form needs N == 128");
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.Tm = (int)(M / BM); g.Tn = (int)(N / BN); g.K = (int)K;
-  const i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
-  if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
-  g.ntiles = (int)nt;
-  const double flops = 2.0 * (double)nt * BM * BN * (double)K;
-  const double bytes = (double)nt * ((op == 0 ? 2.0 : 1.0) * BM * BN * 8.0) +
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K;
+  // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
+  // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
+  const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
+  const double flops = 2.0 * t128 * 128.0 * 128.0 * (double)K;
+  const double bytes = t128 * ((op == 0 ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);
-  if (lower) return op == 0 ? launch_variant<true, 0>(h, g) : launch_variant<true, 1>(h, g);
-  return op == 0 ? launch_variant<false, 0>(h, g) : launch_variant<false, 1>(h, g);
+  const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used
+  const int force = h->gemm_force_tb;
+  if (rowpanel) {
+    int bm = 16;
+    if (force) bm = force;
+    else if (t128 >= target) bm = 128;
+    else if (2.0 * t128 >= target) bm = 64;
+    else if (4.0 * t128 >= target) bm = 32;
+    if (bm == 128) return launch_cfg<128, 128, 2>(h, op, 0, g, M, N);
+    if (bm == 64) return launch_cfg<64, 128, 2>(h, op, 0, g, M, N);
+    if (bm == 32) return launch_cfg<32, 128, 1>(h, op, 0, g, M, N);
+    return launch_cfg<16, 128, 1>(h, op, 0, g, M, N);
+  }
+  int tb = 32;
+  if (force) tb = force < 32 ? 32 : force;
+  else if (t128 >= target) tb = 128;
+  else if (4.0 * t128 >= target) tb = 64;
+  if (tb == 128) return launch_cfg<128, 128, 2>(h, op, lower, g, M, N);
+  if (tb == 64) return launch_cfg<64, 64, 2>(h, op, lower, g, M, N);
+  return launch_cfg<32, 32, 2>(h, op, lower, g, M, N);
 }

@@ -28,7 +28,8 @@ struct HipOps {
     return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
   }
   int trsv_base(i64 blk, double* y, i64 ldy, i64 r) {
-    return gps_launch_trsv_base(h, linv + blk * GPS_TILE * GPS_TILE, y, ldy, r);
+    if (!linvT) return gps_fail(h, GPS_ERR_STATE, "trsv needs the transposed block inverses");
+    return gps_launch_trsv_base(h, linvT + blk * GPS_TILE * GPS_TILE, y, ldy, r);
   }
   int gemv_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y1, double* y2, i64 ldy,
                i64 r) {
@@ -137,6 +138,13 @@ extern "C" int gps_last_stage_ms(gps_handle_t h, double* out5) {
   return GPS_OK;
 }
 
+extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
+  if (!h || !key) return GPS_ERR_ARG;
+  if (strcmp(key, "gemm_min_tiles") == 0) { h->gemm_min_tiles = (int)value; return GPS_OK; }
+  if (strcmp(key, "gemm_force_tile") == 0) { h->gemm_force_tb = (int)value; return GPS_OK; }
+  return gps_fail(h, GPS_ERR_ARG, "unknown option");
+}
+
 // ---- diagnostics ---------------------------------------------------------------------------------
 extern "C" int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok) {
   if (!h) return GPS_ERR_ARG;
@@ -157,6 +165,31 @@ extern "C" int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, in
   if (rc) return rc;
   GPS_HIP(h, hipMemcpyAsync(C, h->dTmp3.p, cb, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// phase stamps (100 MHz ticks) of one potrf_base launch on a random SPD block: load, eliminate,
+// scale + L store, (gap), inverse level 0, inverse levels, stores
+extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us_out7) {
+  if (!h || !us_out7) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const size_t bb = (size_t)GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, h->dTmp.ensure(4 * bb + 256));
+  std::vector<double> A((size_t)GPS_TILE * GPS_TILE, 0.0);
+  for (int i = 0; i < GPS_TILE; ++i) for (int j = 0; j <= i; ++j) A[(size_t)i * GPS_TILE + j] = (i == j) ? 2.0 + 0.01 * i : 0.3 / (1.0 + i - j);
+  double* dA = h->dTmp.d();
+  long long* dS = (long long*)(dA + 3 * GPS_TILE * GPS_TILE);
+  long long hs[8] = {0};
+  for (int rep = 0; rep < 3; ++rep) {
+    GPS_HIP(h, hipMemcpyAsync(dA, A.data(), bb, hipMemcpyHostToDevice, h->stream));
+    int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
+    if (rc) return rc;
+    rc = gps_launch_potrf_base(h, dA, GPS_TILE, dA + GPS_TILE * GPS_TILE, dA + 2 * GPS_TILE * GPS_TILE, (int*)h->dInfo.p, 0, factor, dS);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(hs, dS, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  for (int q = 0; q < 7; ++q) us_out7[q] = (double)(hs[q] - hs[0]) * 0.01;
   return GPS_OK;
 }
 
@@ -276,7 +309,7 @@ extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int6
   GPS_HIP(h, h->dX.ensure((size_t)n * d_all * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dX.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
   GPS_HIP(h, h->dK.ensure((size_t)h->npad * h->npad * 8));
-  GPS_HIP(h, h->dLinv.ensure((size_t)(h->npad / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(h->npad / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
 }
@@ -305,7 +338,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   int* d_info = (int*)h->dInfo.p;
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
-  HipOps ops{h, h->dLinv.d(), nullptr, d_info};
+  HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
   Blocked<HipOps> bl(ops);
   rc = bl.potrf_rec(h->dK.d(), np, np, 0, 0);
   if (rc) return rc;
@@ -381,7 +414,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
   rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, h->dX.d(), n, d, 0.0, h->dB.d(), np, nsp, np, 0, 0);
   if (rc) return rc;
   // A^T = Kx^T L^-T                                              models/gpr.py:122
-  HipOps ops{h, h->dLinv.d(), nullptr, (int*)h->dInfo.p};
+  HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
   Blocked<HipOps> bl(ops);
   rc = bl.trsm_rec(h->dK.d(), np, np, 0, h->dB.d(), np, nsp);
   if (rc) return rc;
@@ -443,7 +476,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
   int rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   const bool need_back = (!white) && (q_sqrt != nullptr);
-  HipOps ops{h, c.linv, need_back ? c.linvT : nullptr, d_info};
+  HipOps ops{h, c.linv, c.linvT, d_info};
   Blocked<HipOps> bl(ops);
   rc = bl.potrf_rec(c.Kmm, mp, mp, 0, 0);                          // Lm   conditionals.py:84
   if (rc) return rc;

@@ -49,6 +49,11 @@ struct gps_handle_s {
   std::string err;
   hipDeviceProp_t prop;
 
+  // GEMM tile selection (gemm_f64.hip): use the next smaller tile while the grid would have
+  // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
+  int gemm_min_tiles = 768;
+  int gemm_force_tb = 0;
+
   // profiling
   bool prof_on = false;
   KClassStat stat[KC_COUNT];
@@ -137,7 +142,8 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
 // inverse (full 128x128, zero upper) to Linv_blk; info word gets min(index+1) of a
 // non-positive pivot (index counted from row0).
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
-                          double* LinvT_blk, int* d_info, i64 row0, int factor);
+                          double* LinvT_blk, int* d_info, i64 row0, int factor,
+                          long long* d_stamps = nullptr);
 // blas1.hip
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
 int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "gps_profile_get": [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_i64), _c_double_p, _c_double_p,
                         _c_double_p],
     "gps_last_stage_ms": [ctypes.c_void_p, _c_double_p],
+    "gps_set_option": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double],
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
@@ -204,6 +205,9 @@ class Handle(object):
         out = np.zeros(5)
         self._check(self._lib.gps_last_stage_ms(self._h, _ptr(out)), "gps_last_stage_ms")
         return dict(zip(["kmat", "potrf", "trsv", "predict", "total"], out.tolist()))
+
+    def set_option(self, key, value):
+        self._check(self._lib.gps_set_option(self._h, key.encode(), float(value)), "gps_set_option")
 
     def diag_mfma_f64(self, waves_per_simd=1):
         tf = ctypes.c_double(0)

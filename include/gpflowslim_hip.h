@@ -167,6 +167,11 @@ int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launches,
  * out[3]=predict solve out[4]=total (ms).                                   */
 int gps_last_stage_ms(gps_handle_t h, double* out5);
 
+/* tuning knobs (diagnostics; defaults are what bench.py measures):
+ *   "gemm_min_tiles"  workgroups a GEMM launch should have before a larger tile is chosen
+ *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)             */
+int gps_set_option(gps_handle_t h, const char* key, double value);
+
 /* ---- diagnostics ---------------------------------------------------------
  * fp64-MFMA microbenchmark (v_mfma_f64_16x16x4_f64 issue loop on every CU):
  * measured TFLOP/s, and layout_ok = 1 when the operand / accumulator lane map

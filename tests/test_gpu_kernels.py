@@ -14,9 +14,19 @@ def test_mfma_f64_layout_and_rate(handle):
     assert tf1 > 10.0
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (384, 256, 400), (1024, 1024, 1024)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (384, 256, 400), (1024, 1024, 1024),
+                                   (2048, 2304, 256)])
 @pytest.mark.parametrize("op", [0, 1])
-def test_gemm_nt_full(handle, m, n, k, op):
+@pytest.mark.parametrize("tile", [0, 128, 64, 32])
+def test_gemm_nt_full(handle, m, n, k, op, tile):
+    handle.set_option("gemm_force_tile", tile)
+    try:
+        _gemm_nt_full(handle, m, n, k, op)
+    finally:
+        handle.set_option("gemm_force_tile", 0)
+
+
+def _gemm_nt_full(handle, m, n, k, op):
     k = (k // 16) * 16
     rng = np.random.default_rng(m + n + k + op)
     A = rng.standard_normal((m, k)); B = rng.standard_normal((n, k)); C = rng.standard_normal((m, n))
@@ -27,7 +37,16 @@ def test_gemm_nt_full(handle, m, n, k, op):
 
 
 @pytest.mark.parametrize("n,k", [(128, 64), (640, 128), (1152, 256), (2176, 512)])
-def test_gemm_nt_lower(handle, n, k):
+@pytest.mark.parametrize("tile", [0, 128, 64, 32])
+def test_gemm_nt_lower(handle, n, k, tile):
+    handle.set_option("gemm_force_tile", tile)
+    try:
+        _gemm_nt_lower(handle, n, k)
+    finally:
+        handle.set_option("gemm_force_tile", 0)
+
+
+def _gemm_nt_lower(handle, n, k):
     rng = np.random.default_rng(n + k)
     A = rng.standard_normal((n, k)); C = rng.standard_normal((n, n))
     out = handle.diag_gemm_nt(0, True, A, A, C)
@@ -36,8 +55,10 @@ def test_gemm_nt_lower(handle, n, k):
     for ti in range(n // T):
         for tj in range(n // T):
             blk = (slice(ti * T, (ti + 1) * T), slice(tj * T, (tj + 1) * T))
-            if tj <= ti:
+            if tj < ti:
                 assert np.abs(out[blk] - ref[blk]).max() <= 1e-11 * np.abs(ref).max(), (ti, tj)
+            elif tj == ti:       # diagonal block: only its lower triangle is defined
+                assert np.abs(np.tril(out[blk] - ref[blk])).max() <= 1e-11 * np.abs(ref).max(), (ti, tj)
             else:
                 assert np.array_equal(out[blk], C[blk]), "tile above the diagonal must stay untouched"
 
