@@ -1,0 +1,146 @@
+"""CPU tests of the host side: the gpflowSlim API mirror (no device work), the kernel-program
+compiler, and the C-ABI library surface (loads, exports every declared symbol, refuses to run
+without a GPU instead of falling back)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpf():
+    lib = os.path.join(ROOT, "gpflow-slim_amd", "lib", "libgpflowslim_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gpflow-slim_amd", "csrc"), "-j4"])
+    import gpflowSlim
+    return gpflowSlim
+
+
+def test_library_exports_every_declared_symbol(gpf):
+    header = open(os.path.join(ROOT, "include", "gpflowslim_hip.h")).read()
+    declared = set(re.findall(r"\b(gps_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gps_handle_s"}
+    assert len(declared) >= 18
+    lib = gpf.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libgpflowslim_hip.so does not export %s" % name
+    from gpflowSlim import _backend
+    assert declared == set(_backend.EXPORTED_SYMBOLS), "ctypes binding and header disagree"
+
+
+def test_kern_node_struct_layout_matches_header(gpf):
+    from gpflowSlim import _backend as be
+    # int32 op, n_dims, active_dims[32]; double variance, period, lengthscales[32]
+    assert ctypes.sizeof(be.KernNode) == 4 + 4 + 4 * 32 + 8 + 8 + 8 * 32
+    assert be.KernNode.variance.offset == 136 and be.KernNode.lengthscales.offset == 152
+
+
+def test_no_gpu_means_loud_failure_not_fallback(gpf):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gpf.Handle(0)
+    k = gpf.kernels.RBF(2)
+    with pytest.raises(RuntimeError):
+        k.K(np.zeros((3, 2)))
+    m = gpf.models.GPR(np.zeros((3, 2)), np.zeros((3, 1)), k)
+    with pytest.raises(RuntimeError):
+        m.compute_log_likelihood()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gpflow-slim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "gp_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_parameter_and_transforms(gpf):
+    P, T = gpf.params.Parameter, gpf.transforms
+    p = P(2.5, transform=T.positive)
+    assert float(p.value) == pytest.approx(2.5, rel=4e-16)
+    assert float(p.unconstrained_tensor) == pytest.approx(2.5 - 1e-6 + np.log(-np.expm1(-(2.5 - 1e-6))), rel=1e-15)
+    p.assign(0.1)
+    assert float(p.value) == pytest.approx(0.1, rel=1e-15)
+    p.assign_unconstrained(0.0)
+    assert float(p.value) == pytest.approx(np.log(2.0) + 1e-6, rel=1e-15)       # softplus(0) + lower
+    q = P(np.array([1.0, 2.0]), transform=T.Log1pe(1e-3))
+    assert np.allclose(q.value, [1.0, 2.0], rtol=1e-15) and q.shape == (2,) and q.size == 2
+    assert P(3.0).value == 3.0                                                    # Identity
+    assert T.Log1pe().log_jacobian_tensor(np.array([0.0])) == pytest.approx(-np.log(2.0))
+    assert gpf.settings.float_type is np.float64 and gpf.settings.numerics.jitter_level == 1e-6
+    tmp = gpf.settings.get_settings(); tmp.numerics.jitter_level = 1e-3
+    with gpf.settings.temp_settings(tmp):
+        assert gpf.settings.jitter == 1e-3
+    assert gpf.settings.jitter == 1e-6
+
+
+def _ops(nodes):
+    return [n.op for n in nodes]
+
+
+def test_kernel_program_compilation(gpf):
+    from gpflowSlim import _backend as be
+    k = gpf.kernels
+    rbf = k.RBF(3, variance=2.0, lengthscales=[1.0, 2.0, 3.0], ARD=True)
+    (nd,) = rbf._nodes(False, 5)
+    assert nd.op == be.K_RBF and nd.n_dims == 3 and list(nd.active_dims[:3]) == [0, 1, 2]
+    assert nd.variance == pytest.approx(2.0, rel=1e-15) and list(nd.lengthscales[:3]) == pytest.approx([1, 2, 3], rel=1e-15)
+    iso = k.Matern52(2, lengthscales=0.5, active_dims=[4, 1])
+    (nd,) = iso._nodes(False, 5)
+    assert nd.op == be.K_MATERN52 and list(nd.active_dims[:2]) == [4, 1] and list(nd.lengthscales[:2]) == pytest.approx([0.5, 0.5])
+    (nd,) = iso._nodes(True, 2)                      # presliced: columns 0..input_dim-1
+    assert list(nd.active_dims[:2]) == [0, 1]
+    per = k.Periodic(3, period=2.0, lengthscales=1.5)
+    (nd,) = per._nodes(False, 3)
+    assert nd.op == be.K_PERIODIC and nd.period == pytest.approx(2.0) and nd.lengthscales[0] == pytest.approx(1.5)
+    # left folds, flattening of same-class combinations, constants last (kernels.py:1019-1029,1073)
+    s = rbf + iso + per + 2.0
+    assert isinstance(s, k.Sum) and len(s.kern_list) == 3 and s.const_list == [2.0]
+    assert _ops(s._nodes(False, 5)) == [be.K_RBF, be.K_MATERN52, be.K_ADD, be.K_PERIODIC, be.K_ADD, be.K_CONSTANT, be.K_ADD]
+    p = (rbf + iso) * per * k.White(1, variance=0.1)
+    assert isinstance(p, k.Product) and len(p.kern_list) == 3
+    assert _ops(p._nodes(False, 5)) == [be.K_RBF, be.K_MATERN52, be.K_ADD, be.K_PERIODIC, be.K_MUL, be.K_WHITE, be.K_MUL]
+    assert len(s.parameters) == 2 + 2 + 3
+    X = np.zeros((4, 5))
+    assert np.array_equal(s.Kdiag(X), np.full(4, float(rbf.variance) + float(iso.variance) + float(per.variance) + 2.0))
+    assert np.allclose(p.Kdiag(X), (float(rbf.variance) + float(iso.variance)) * float(per.variance) * 0.1, rtol=1e-14)
+    assert not s.on_separate_dimensions
+    assert k.Sum([k.RBF(1, active_dims=[0]), k.RBF(1, active_dims=[1])]).on_separate_dimensions
+    with pytest.raises(ValueError):
+        be.make_program([be.op_node(be.K_ADD)] * 40)
+    with pytest.raises(TypeError):
+        k.Sum([rbf, "x"])
+
+
+def test_gpr_shell_without_device(gpf):
+    X = np.random.default_rng(0).standard_normal((5, 2)); Y = np.ones((5, 2))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2), obs_var=0.1)
+    assert m.num_latent == 2 and len(m.parameters) == 3
+    assert float(m.likelihood.variance) == pytest.approx(0.1, rel=1e-15)
+    assert isinstance(m.mean_function, gpf.mean_functions.Zero) and m.mean_function(X).shape == (5, 1)
+    assert m.prior_tensor == 0.0
+    m2 = gpf.models.GPR(X, Y, gpf.kernels.RBF(2), obs_var=0.5, min_var=1e-2)
+    assert float(m2.likelihood.variance) == pytest.approx(0.5, rel=1e-14)
+    with pytest.raises(ValueError):
+        gpf.models.GPR(X, np.ones(5), gpf.kernels.RBF(2))
+    lin = gpf.mean_functions.Linear(np.ones((2, 2)), np.array([1.0, -1.0]))
+    assert np.allclose(lin(X), X @ np.ones((2, 2)) + [1.0, -1.0])
+    g = gpf.likelihoods.Gaussian(0.2)
+    mu, var = g.predict_mean_and_var(np.zeros((3, 1)), np.ones((3, 1)))
+    assert np.allclose(var, 1.2)
+    assert np.allclose(g.predict_density(np.zeros((1, 1)), np.ones((1, 1)), np.zeros((1, 1))),
+                       -0.5 * (np.log(2 * np.pi) + np.log(1.2)))
+    feat = gpf.features.inducingpoint_wrapper(None, X)
+    assert isinstance(feat, gpf.features.InducingPoints) and len(feat) == 5
+    with pytest.raises(ValueError):
+        gpf.features.inducingpoint_wrapper(feat, X)
