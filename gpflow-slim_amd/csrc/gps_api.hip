@@ -84,7 +84,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
                     &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3};
   for (DevBuf* b : bufs) b->release();
-  (void)hipStreamDestroy(h->stream);
+  (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   delete h;
   return GPS_OK;
 }
@@ -174,12 +174,12 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   if (!h || !us_out7) return GPS_ERR_ARG;
   GPS_HIP(h, hipSetDevice(h->device));
   const size_t bb = (size_t)GPS_TILE * GPS_TILE * 8;
-  GPS_HIP(h, h->dTmp.ensure(4 * bb + 256));
+  GPS_HIP(h, h->dTmp.ensure(4 * bb + 512));
   std::vector<double> A((size_t)GPS_TILE * GPS_TILE, 0.0);
   for (int i = 0; i < GPS_TILE; ++i) for (int j = 0; j <= i; ++j) A[(size_t)i * GPS_TILE + j] = (i == j) ? 2.0 + 0.01 * i : 0.3 / (1.0 + i - j);
   double* dA = h->dTmp.d();
   long long* dS = (long long*)(dA + 3 * GPS_TILE * GPS_TILE);
-  long long hs[8] = {0};
+  long long hs[16] = {0};
   for (int rep = 0; rep < 3; ++rep) {
     GPS_HIP(h, hipMemcpyAsync(dA, A.data(), bb, hipMemcpyHostToDevice, h->stream));
     int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
@@ -190,6 +190,8 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   for (int q = 0; q < 7; ++q) us_out7[q] = (double)(hs[q] - hs[0]) * 0.01;
+  // shader clock (MHz) held during the elimination phase
+  us_out7[0] = (double)(hs[8 + 2] - hs[8 + 1]) / ((double)(hs[2] - hs[1]) * 0.01);
   return GPS_OK;
 }
 
@@ -684,4 +686,180 @@ extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const dou
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+}
+
+
+// ---- block-column distributed factorisation ------------------------------------------------------
+// 1-D block-cyclic columns over P ranks.  Every rank holds the full [np, np] buffer, builds
+// and updates only the block columns it owns (c % P == rank), and receives every factored panel, so that
+// L ends up replicated (the solves / predictions that follow need no further exchange).  The library
+// only provides the per-step pieces; the exchange itself (one broadcast per panel: RCCL through
+// torch.distributed, or gloo in the CPU tests) is driven by gpflowSlim/distributed.py.
+static inline i64 dist_msg_doubles(gps_handle_t h, i64 j) {
+  const i64 rows = h->dist_np - j * h->dist_nb;
+  return rows * h->dist_nb + 2 * (h->dist_nb / GPS_TILE) * GPS_TILE * GPS_TILE;
+}
+
+extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
+  if (!h) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_profile_collect(h);
+  if (external) {                       // hip_stream may be NULL: the legacy default stream
+    if (!h->ext_stream) { h->own_stream = h->stream; h->ext_stream = true; }
+    h->stream = (hipStream_t)hip_stream;
+  } else if (h->ext_stream) {
+    h->stream = h->own_stream; h->ext_stream = false;
+  }
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
+                              const double* resid, int64_t r, int nparts, int part, int64_t nb,
+                              int64_t* n_panels, int64_t* msg_doubles_max) {
+  if (!h || nparts <= 0 || part < 0 || part >= nparts || nb <= 0 || nb % GPS_TILE || r < 0 || (r > 0 && !resid))
+    return gps_fail(h, GPS_ERR_ARG, "gps_dist_begin: bad argument");
+  if (h->n <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_gpr_set_data has not been called");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 n = h->n;
+  const i64 np = ((n + nb - 1) / nb) * nb;
+  const i64 nblk = np / nb;
+  h->have_factor = false;
+  h->npad = np; h->dist_np = np; h->dist_nb = nb; h->dist_P = nparts; h->dist_rank = part; h->dist_r = r;
+  GPS_HIP(h, h->dK.ensure((size_t)np * np * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
+  GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  if (r > 0) {
+    GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)r * np * 8, h->stream));
+    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, h->dAlpha.d(), np);
+    if (rc0) return rc0;
+  }
+  int prep = 1;
+  for (i64 c = part; c < nblk; c += nparts) {
+    double* blk = h->dK.d() + c * nb * np + c * nb;
+    int rc = gps_launch_kmat_block(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, noise_var, blk, np, c * nb,
+                                   np - c * nb, c * nb, nb, prep);
+    if (rc) return rc;
+    prep = 0;
+  }
+  GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
+  if (rc) return rc;
+  if (n_panels) *n_panels = nblk;
+  if (msg_doubles_max) *msg_doubles_max = dist_msg_doubles(h, 0);
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_msg_doubles(gps_handle_t h, int64_t j, int64_t* out) {
+  if (!h || !out || h->dist_nb <= 0 || j < 0 || j * h->dist_nb >= h->dist_np) return gps_fail(h, GPS_ERR_ARG, "gps_dist_msg_doubles: bad argument");
+  *out = dist_msg_doubles(h, j);
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1) {
+  if (!h || !dev_buf0 || !dev_buf1) return gps_fail(h, GPS_ERR_ARG, "gps_dist_set_comm: bad argument");
+  h->dist_comm[0] = (double*)dev_buf0; h->dist_comm[1] = (double*)dev_buf1;
+  return GPS_OK;
+}
+
+#define DIST_CHECK(h, j)                                                                              \
+  if (!h || h->dist_nb <= 0 || j < 0 || j * h->dist_nb >= h->dist_np)                                 \
+    return gps_fail(h, GPS_ERR_ARG, "gps_dist_*: bad panel index or gps_dist_begin not called");      \
+  GPS_HIP(h, hipSetDevice(h->device));                                                                \
+  const i64 np = h->dist_np, nb = h->dist_nb;                                                         \
+  const i64 rows = np - j * nb;                                                                       \
+  const i64 blk0 = j * nb / GPS_TILE, nbb = nb / GPS_TILE;                                            \
+  double* const panel = h->dK.d() + j * nb * np + j * nb;                                             \
+  double* const linv = h->dLinv.d();                                                                  \
+  double* const linvT = linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE;                                 \
+  (void)rows; (void)blk0; (void)nbb; (void)panel; (void)linvT;
+
+// owner of panel j: factor it in place (diagonal nb x nb block + rows below) and pack the message
+extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
+  DIST_CHECK(h, j)
+  if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  HipOps ops{h, linv, linvT, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  int rc = bl.potrf_rec(panel, np, nb, blk0, j * nb);
+  if (rc) return rc;
+  rc = bl.trsm_rec(panel, np, nb, blk0, panel + nb * np, np, rows - nb);
+  if (rc) return rc;
+  double* msg = h->dist_comm[buf];
+  rc = gps_launch_extract(h, panel, np, rows, nb, msg, nb, 0);
+  if (rc) return rc;
+  const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, hipMemcpyAsync(msg + rows * nb, linv + blk0 * GPS_TILE * GPS_TILE, ib, hipMemcpyDeviceToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(msg + rows * nb + nbb * GPS_TILE * GPS_TILE, linvT + blk0 * GPS_TILE * GPS_TILE, ib,
+                            hipMemcpyDeviceToDevice, h->stream));
+  return GPS_OK;
+}
+
+// every other rank: copy the received panel (and its block inverses) into place
+extern "C" int gps_dist_unpack(gps_handle_t h, int64_t j, int buf) {
+  DIST_CHECK(h, j)
+  if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  const double* msg = h->dist_comm[buf];
+  int rc = gps_launch_extract(h, msg, nb, rows, nb, panel, np, 0);
+  if (rc) return rc;
+  const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, hipMemcpyAsync(linv + blk0 * GPS_TILE * GPS_TILE, msg + rows * nb, ib, hipMemcpyDeviceToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(linvT + blk0 * GPS_TILE * GPS_TILE, msg + rows * nb + nbb * GPS_TILE * GPS_TILE, ib,
+                            hipMemcpyDeviceToDevice, h->stream));
+  return GPS_OK;
+}
+
+// apply panel j to the owned block columns c in [c_lo, c_hi), c > j:  A[c*nb:, c] -= L[c*nb:, j] L[c, j]^T
+extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi) {
+  DIST_CHECK(h, j)
+  const i64 nblk = np / nb;
+  if (c_lo <= j) c_lo = j + 1;
+  if (c_hi > nblk) c_hi = nblk;
+  for (i64 c = c_lo; c < c_hi; ++c) {
+    if (c % h->dist_P != h->dist_rank) continue;
+    const double* Lc = h->dK.d() + c * nb * np + j * nb;        // rows c*nb.. of panel j
+    double* C = h->dK.d() + c * nb * np + c * nb;
+    int rc = gps_launch_gemm_nt(h, 0, 0, np - c * nb, nb, nb, Lc, np, Lc, np, C, np);
+    if (rc) return rc;
+  }
+  return GPS_OK;
+}
+
+// after the last panel: alpha = L^-1 resid on the replicated factor, reductions, info
+extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
+  if (!h || !lml || h->dist_nb <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_dist_finish: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 n = h->n, np = h->dist_np, r = h->dist_r;
+  GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  double* linv = h->dLinv.d();
+  HipOps ops{h, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  int rc = 0;
+  if (r > 0) {
+    rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);
+    if (rc) return rc;
+  }
+  double* part = h->dScal.d();
+  rc = gps_launch_lml_reduce(h, h->dK.d(), np, n, h->dAlpha.d(), np, r, part);
+  if (rc) return rc;
+  GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  double hp[2 * 64];
+  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  int linfo = 0;
+  rc = read_info(h, (int*)h->dInfo.p, &linfo);
+  if (rc) return rc;
+  if (info) *info = linfo;
+  double slog = 0.0, ssq = 0.0;
+  for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; ssq += hp[2 * b + 1]; }
+  *lml = -0.5 * (double)n * (double)r * log(2.0 * M_PI) - (double)r * slog - 0.5 * ssq;
+  h->r = r;
+  h->have_factor = (linfo == 0);
+  stage_time(h, 0, 1, &h->stage_ms[0]);
+  stage_time(h, 1, 2, &h->stage_ms[1]);
+  stage_time(h, 2, 3, &h->stage_ms[2]);
+  h->stage_ms[3] = 0.0;
+  stage_time(h, 0, 3, &h->stage_ms[4]);
+  return GPS_OK;
 }

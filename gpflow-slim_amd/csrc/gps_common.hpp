@@ -46,6 +46,8 @@ struct PendingEvt { int klass; hipEvent_t a, b; };
 struct gps_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;   // the handle's own stream while an external one is installed
+  bool ext_stream = false;
   std::string err;
   hipDeviceProp_t prop;
 
@@ -79,6 +81,11 @@ struct gps_handle_s {
   DevBuf dB;        // [nspad, npad]   K(Xnew, X) then A^T
   DevBuf dMean;     // [n_new, r]
   DevBuf dVar;      // [n_new] or [nspad, nspad]
+  // ---- block-column distributed factorisation (gps_dist_*) ----
+  int dist_P = 0, dist_rank = 0;
+  i64 dist_nb = 0, dist_np = 0, dist_r = 0;
+  double* dist_comm[2] = {nullptr, nullptr};
+
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
@@ -167,6 +174,9 @@ int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                     const double* dX, i64 n, const double* dX2 /*nullptr: symmetric*/, i64 m,
                     i64 d_all, double diag_add, double* dK, i64 ldk, i64 prow, i64 pcol,
                     int lower_only, int identity_pad);
+int gps_launch_kmat_block(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX,
+                          i64 n, i64 d_all, i64 npad, double diag_add, double* dKb, i64 ldk, i64 r0,
+                          i64 nrows, i64 c0, i64 ncols, int prep);
 int gps_launch_kdiag(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* kdiag_const);
 // diag.hip
 int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);

@@ -43,6 +43,7 @@ struct KmatArgs {
   double* K; i64 ldk;
   i64 n, m;                               // real extents
   int sym; int lower_only; int identity_pad; int maxnf;
+  i64 row_off, col_off;                   // global index of local row / column 0 (sub-block builds)
   double diag_add;
 };
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict
 // ---- tile pass --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) {
   const int ti = blockIdx.y, tj = blockIdx.x;
-  if (a.lower_only && (tj >> 1) > (ti >> 1)) return;     // 128-granular: diagonal blocks stay full
+  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;   // 128-granular: diagonal blocks stay full
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
     } else if (node.op == GPS_K_WHITE) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const i64 gi = gi0 + ty * 4 + (e >> 2), gj = gj0 + tx * 4 + (e & 3);
+        const i64 gi = a.row_off + gi0 + ty * 4 + (e >> 2), gj = a.col_off + gj0 + tx * 4 + (e & 3);
         v[e] = (a.sym && gi == gj) ? node.variance : 0.0;
       }
     } else {
@@ -194,17 +195,18 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
   // ---- write the 4x4 patch ----
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const i64 gi = gi0 + ty * 4 + q;
+    const i64 li = gi0 + ty * 4 + q;
+    const i64 gi = a.row_off + li;
     double o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const i64 gj = gj0 + tx * 4 + c;
+      const i64 gj = a.col_off + gj0 + tx * 4 + c;
       double val = st[0][q * 4 + c];
       if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
       else if (a.sym && gi == gj) val += a.diag_add;
       o[c] = val;
     }
-    double* dst = a.K + gi * a.ldk + gj0 + tx * 4;
+    double* dst = a.K + li * a.ldk + gj0 + tx * 4;
     *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
     *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
   }
@@ -343,6 +345,7 @@ int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   a.Fr = h->dFeat.d(); a.Fc = Fc; a.ldfr = ldfr; a.ldfc = ldfc;
   a.K = dK; a.ldk = ldk; a.n = n; a.m = m; a.sym = sym;
   a.lower_only = (sym && lower_only) ? 1 : 0; a.identity_pad = identity_pad; a.diag_add = diag_add;
+  a.row_off = 0; a.col_off = 0;
   double tiles = (double)(prow / KT) * (double)(pcol / KT);
   if (a.lower_only) tiles = 0.5 * tiles + 0.5 * (double)(prow / KT);
   const int nfeat_total = (int)kc.feats.size();
@@ -359,6 +362,44 @@ int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   }
   LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);
   hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds,
+                     h->stream, a, kc.prog);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+
+// Sub-block of the symmetric matrix K(X, X) + diag_add I (padded with identity): rows [r0, r0+nrows),
+// columns [c0, c0+ncols) written to dKb (leading dimension ldk).  Used by the block-column
+// distributed factorisation, where every rank builds only the column blocks it owns.  Features of the
+// whole (padded) point set are prepared once per evaluation (prep != 0) and kept in h->dFeat.
+int gps_launch_kmat_block(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX,
+                          i64 n, i64 d_all, i64 npad, double diag_add, double* dKb, i64 ldk, i64 r0,
+                          i64 nrows, i64 c0, i64 ncols, int prep) {
+  KCompiled kc;
+  int rc = compile_prog(h, prog, n_nodes, d_all, kc);
+  if (rc) return rc;
+  if (r0 % KT || c0 % KT || nrows % KT || ncols % KT || r0 + nrows > npad || c0 + ncols > npad || nrows <= 0 || ncols <= 0)
+    return gps_fail(h, GPS_ERR_ARG, "kmat_block: extents must be multiples of 64 inside the padded matrix");
+  if (nrows / KT > 65535) return gps_fail(h, GPS_ERR_UNSUPPORTED, "kmat_block: too many rows");
+  i64 ldf = npad;
+  if (prep) {
+    rc = run_prep(h, kc, dX, n, d_all, npad, h->dFeat, h->dProg, &ldf);
+    if (rc) return rc;
+  }
+  KmatArgs a;
+  a.Fr = h->dFeat.d() + r0; a.Fc = h->dFeat.d() + c0; a.ldfr = ldf; a.ldfc = ldf;
+  a.K = dKb; a.ldk = ldk; a.n = n; a.m = n; a.sym = 1; a.lower_only = 0; a.identity_pad = 1;
+  a.diag_add = diag_add; a.row_off = r0; a.col_off = c0;
+  int maxnf = 1;
+  for (int i = 0; i < n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
+  a.maxnf = maxnf;
+  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
+  GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
+  const double tiles = (double)(nrows / KT) * (double)(ncols / KT);
+  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * (double)kc.feats.size() + 30.0), tiles * KT * KT * 8.0);
+  hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(ncols / KT), (unsigned)(nrows / KT)), dim3(256), lds,
                      h->stream, a, kc.prog);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
                                                         double* __restrict__ LinvT,
                                                         int* __restrict__ info, int row0,
                                                         int factor, long long* __restrict__ stamps) {
-#define STAMP(q) do { if (stamps && threadIdx.x == 0) stamps[q] = (long long)wall_clock64(); } while (0)
+#define STAMP(q) do { if (stamps && threadIdx.x == 0) { stamps[q] = (long long)wall_clock64(); stamps[8 + q] = (long long)clock64(); } } while (0)
   STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);   // [PB][PS]

@@ -67,6 +67,16 @@ _SIGNATURES = {
                         _c_double_p],
     "gps_last_stage_ms": [ctypes.c_void_p, _c_double_p],
     "gps_set_option": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double],
+    "gps_set_stream": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int],
+    "gps_dist_begin": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p, _i64,
+                       ctypes.c_int, ctypes.c_int, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "gps_dist_msg_doubles": [ctypes.c_void_p, _i64, ctypes.POINTER(_i64)],
+    "gps_dist_set_comm": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    "gps_dist_panel_factor": [ctypes.c_void_p, _i64, ctypes.c_int],
+    "gps_dist_unpack": [ctypes.c_void_p, _i64, ctypes.c_int],
+    "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64],
+    "gps_dist_finish": [ctypes.c_void_p, _c_double_p, _c_int_p],
+    "gps_diag_potrf_base_stamps": [ctypes.c_void_p, ctypes.c_int, _c_double_p],
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
@@ -75,6 +85,26 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error"])
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's).  If this library pulled in /opt/rocm's copy first and torch then loaded its
+    bundled one, the process would hold two HSA runtimes and the second would see no GPU.  So when a
+    torch wheel with a bundled runtime is installed, load that copy first (without importing torch);
+    our NEEDED libamdhip64.so.7 then resolves to it by SONAME, whichever of the two is imported first."""
+    if os.environ.get("GPFLOWSLIM_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
 
 
 def load_library():
@@ -88,6 +118,7 @@ def load_library():
             raise RuntimeError(
                 "gpflowSlim (MI355X): HIP library not found at %s -- build it with "
                 "`make -C gpflow-slim_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback." % path)
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(path)
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(lib, name)
@@ -208,6 +239,48 @@ class Handle(object):
 
     def set_option(self, key, value):
         self._check(self._lib.gps_set_option(self._h, key.encode(), float(value)), "gps_set_option")
+
+    def set_stream(self, hip_stream, external=True):
+        """Run the library's kernels on the caller's HIP stream (integer handle, 0 = legacy default
+        stream); external=False restores the handle's own stream."""
+        self._check(self._lib.gps_set_stream(self._h, ctypes.c_void_p(hip_stream or 0), 1 if external else 0),
+                    "gps_set_stream")
+
+    # ---- block-column distributed factorisation (driven by gpflowSlim.distributed)
+    def dist_begin(self, prog, noise_var, resid, nparts, part, nb):
+        resid = _f64(resid)
+        npan, mx = _i64(0), _i64(0)
+        self._check(self._lib.gps_dist_begin(self._h, prog, len(prog), float(noise_var), _ptr(resid), resid.shape[1],
+                                             int(nparts), int(part), int(nb), ctypes.byref(npan), ctypes.byref(mx)),
+                    "gps_dist_begin")
+        return npan.value, mx.value
+
+    def dist_msg_doubles(self, j):
+        out = _i64(0)
+        self._check(self._lib.gps_dist_msg_doubles(self._h, int(j), ctypes.byref(out)), "gps_dist_msg_doubles")
+        return out.value
+
+    def dist_set_comm(self, ptr0, ptr1):
+        self._check(self._lib.gps_dist_set_comm(self._h, ctypes.c_void_p(ptr0), ctypes.c_void_p(ptr1)), "gps_dist_set_comm")
+
+    def dist_panel_factor(self, j, buf):
+        self._check(self._lib.gps_dist_panel_factor(self._h, int(j), int(buf)), "gps_dist_panel_factor")
+
+    def dist_unpack(self, j, buf):
+        self._check(self._lib.gps_dist_unpack(self._h, int(j), int(buf)), "gps_dist_unpack")
+
+    def dist_update(self, j, c_lo, c_hi):
+        self._check(self._lib.gps_dist_update(self._h, int(j), int(c_lo), int(c_hi)), "gps_dist_update")
+
+    def dist_finish(self):
+        lml = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        self._check(self._lib.gps_dist_finish(self._h, ctypes.byref(lml), ctypes.byref(info)), "gps_dist_finish")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
+                % info.value)
+        return lml.value
 
     def diag_mfma_f64(self, waves_per_simd=1):
         tf = ctypes.c_double(0)

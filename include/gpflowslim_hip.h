@@ -167,6 +167,34 @@ int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launches,
  * out[3]=predict solve out[4]=total (ms).                                   */
 int gps_last_stage_ms(gps_handle_t h, double* out5);
 
+/* ---- multi-GPU: 1-D block-cyclic column Cholesky, one process per GPU ------------------------
+ * No reference counterpart (the reference is single-device); the oracle is the single-GPU result.
+ * Rank `part` of `nparts` owns block columns c with c % nparts == part (width nb, multiple of 128),
+ * builds and updates only those, and receives every factored panel so that L ends up replicated.
+ * The library supplies the per-step pieces; the caller moves the panel message (one broadcast per
+ * panel over RCCL / xGMI, root = owner) between gps_dist_panel_factor and gps_dist_unpack:
+ *
+ *   gps_dist_begin(...)                       build owned columns of K + noise I
+ *   for j in panels:  owner: gps_dist_panel_factor(j, buf)   -> message in comm buffer `buf`
+ *                     broadcast(comm[buf][0 : gps_dist_msg_doubles(j)], root = j % nparts)
+ *                     others: gps_dist_unpack(j, buf)
+ *                     all:    gps_dist_update(j, c_lo, c_hi)  (owned columns in [c_lo, c_hi), c > j)
+ *   gps_dist_finish(&lml, &info)              alpha, log-det, sum alpha^2 on the replicated factor
+ *
+ * gps_set_stream(h, s, 1) installs the caller's HIP stream s (e.g. torch's current stream; NULL = the
+ * legacy default stream) so that library kernels and the collective are ordered on one stream;
+ * gps_set_stream(h, NULL, 0) restores the handle's own stream.                                      */
+int gps_set_stream(gps_handle_t h, void* hip_stream, int external);
+int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
+                   const double* resid, int64_t r, int nparts, int part, int64_t nb,
+                   int64_t* n_panels, int64_t* msg_doubles_max);
+int gps_dist_msg_doubles(gps_handle_t h, int64_t j, int64_t* out);
+int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1);
+int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf);
+int gps_dist_unpack(gps_handle_t h, int64_t j, int buf);
+int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi);
+int gps_dist_finish(gps_handle_t h, double* lml, int* info);
+
 /* tuning knobs (diagnostics; defaults are what bench.py measures):
  *   "gemm_min_tiles"  workgroups a GEMM launch should have before a larger tile is chosen
  *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)             */
@@ -183,6 +211,8 @@ int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops,
  * lower != 0: only tiles on/below the diagonal are computed (m == n).       */
 int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
                      int64_t k, const double* A, const double* B, double* C);
+/* phase timestamps (us) of one 128-block potrf_base launch; out7[0] = shader clock in MHz */
+int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
 
 #ifdef __cplusplus
 }
