@@ -487,7 +487,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
 
   // f -> [k][mp]; white: fmean = A^T f ; else fmean = A^T (Lm^-1 f)   conditionals.py:99-103
   GPS_HIP(h, h->dAlpha.ensure((size_t)k * mp * 8));
-  GPS_HIP(h, h->dTmp2.ensure((size_t)(m * k > n_new * n_new ? m * k : n_new * n_new) * 8 + 64));
+  GPS_HIP(h, h->dTmp2.ensure((size_t)((full_cov && n_new * n_new > m * k) ? n_new * n_new : m * k) * 8 + 64));
   GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, f, (size_t)m * k * 8, hipMemcpyHostToDevice, h->stream));
   GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)k * mp * 8, h->stream));
   rc = gps_launch_transpose(h, h->dTmp2.d(), k, m, k, h->dAlpha.d(), mp);
