@@ -13,6 +13,7 @@ from . import densities
 from . import likelihoods
 from . import conditionals
 from . import features
+from . import kullback_leiblers
 from . import models
 from ._backend import NotPositiveDefiniteError, get_handle, set_handle, Handle, load_library
 

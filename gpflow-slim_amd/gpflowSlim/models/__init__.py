@@ -1,2 +1,3 @@
 from .model import Model, GPModel
 from .gpr import GPR
+from .svgp import SVGP

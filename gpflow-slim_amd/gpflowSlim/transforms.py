@@ -84,4 +84,38 @@ class Log1pe(Transform):
         return '+ve'
 
 
+class LowerTriangular(Transform):
+    """transforms.py:294-372: free vector [num_matrices, N(N+1)/2] <-> lower-triangular [N, N, num_matrices]"""
+
+    def __init__(self, N, num_matrices=1, squeeze=False):
+        self.num_matrices = num_matrices
+        self.squeeze = squeeze
+        self.N = N
+
+    def forward(self, x):
+        x = np.asarray(x, dtype=settings.float_type)
+        xr = np.reshape(x, (self.num_matrices, -1))
+        L = xr.shape[1]
+        matsize = int((L * 8 + 1) ** 0.5 * 0.5 - 0.5)
+        if matsize * (matsize + 1) // 2 != L:
+            raise ValueError("The free state must be a triangle number.")
+        var = np.zeros((matsize, matsize, self.num_matrices), settings.float_type)
+        rows, cols = np.tril_indices(matsize, 0)
+        for i in range(self.num_matrices):
+            var[rows, cols, i] = xr[i, :]
+        return var.squeeze() if self.squeeze else var
+
+    def backward(self, y):
+        y = np.asarray(y, dtype=settings.float_type)
+        N = int(np.sqrt(y.size / self.num_matrices))
+        reshaped = np.reshape(y, (N, N, self.num_matrices))
+        return reshaped[np.tril_indices(N, 0)].T
+
+    def log_jacobian_tensor(self, x):
+        return 0.0
+
+    def __str__(self):
+        return "LoTri->vec"
+
+
 positive = Log1pe()      # transforms.py:377

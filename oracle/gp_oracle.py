@@ -30,6 +30,8 @@ Reference lines followed (paths relative to the reference checkout, gpflowSlim/.
   likelihoods.py:180-184, densities.py:24-25   predict_y / predict_density
   conditionals.py:24-66,80-121    conditional / base_conditional
   features.py:74-81               InducingPoints.Kuu / Kuf
+  kullback_leiblers.py:26-105     gauss_kl
+  models/svgp.py:101-130          SVGP bound (Gaussian likelihood)
 """
 from functools import reduce
 
@@ -247,6 +249,48 @@ def conditional(Xnew, X, spec, f, full_cov=False, q_sqrt=None, white=False, jitt
     Kmn = K(spec, X, Xnew)
     Knn = K(spec, Xnew) if full_cov else Kdiag(spec, Xnew)
     return base_conditional(Kmn, Kmm, Knn, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+
+
+def gauss_kl(q_mu, q_sqrt, K=None):
+    """kullback_leiblers.py:26-105"""
+    if K is None:
+        white, alpha = True, q_mu
+    else:
+        white = False
+        Lp = np.linalg.cholesky(K)
+        alpha = sl.solve_triangular(Lp, q_mu, lower=True)
+    if q_sqrt.ndim == 2:
+        diag, num_latent, NM = True, q_sqrt.shape[1], q_sqrt.size
+        Lq = Lq_diag = q_sqrt
+    else:
+        diag, num_latent, NM = False, q_sqrt.shape[2], q_sqrt.shape[1] * q_sqrt.shape[2]
+        Lq = np.tril(np.transpose(q_sqrt, (2, 0, 1)))
+        Lq_diag = np.diagonal(Lq, axis1=1, axis2=2)
+    mahalanobis = np.sum(np.square(alpha))
+    constant = -float(NM)
+    logdet_qcov = np.sum(np.log(np.square(Lq_diag)))
+    if white:
+        trace = np.sum(np.square(Lq))
+    elif diag:
+        Lp_inv = sl.solve_triangular(Lp, np.eye(Lp.shape[0]), lower=True)
+        K_inv = sl.solve_triangular(Lp.T, Lp_inv, lower=False)
+        trace = np.sum(np.diag(K_inv)[:, None] * np.square(q_sqrt))
+    else:
+        trace = sum(np.sum(np.square(sl.solve_triangular(Lp, Lq[i], lower=True))) for i in range(num_latent))
+    twoKL = mahalanobis + constant - logdet_qcov + trace
+    if not white:
+        twoKL += num_latent * np.sum(np.log(np.square(np.diag(Lp))))
+    return 0.5 * twoKL
+
+
+def svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, noise_var, whiten=True, num_data=None, jitter=JITTER):
+    """models/svgp.py:101-130 with likelihoods.Gaussian.variational_expectations (likelihoods.py:186-188)"""
+    Kp = None if whiten else K(spec, Z) + jitter * np.eye(Z.shape[0])
+    KL = gauss_kl(q_mu, q_sqrt, Kp)
+    fmean, fvar = conditional(X, Z, spec, q_mu, full_cov=False, q_sqrt=q_sqrt, white=whiten, jitter=jitter)
+    var_exp = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(noise_var) - 0.5 * (np.square(Y - fmean) + fvar) / noise_var
+    scale = float(num_data or X.shape[0]) / float(X.shape[0])
+    return np.sum(var_exp) * scale - KL
 
 
 # ---------------------------------------------------------------------------------------------

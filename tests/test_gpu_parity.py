@@ -188,3 +188,34 @@ def test_large_n_properties(handle):
     assert var.min() > 0 and var.max() <= float(kern.variance) * (1 + 1e-12)
     rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
     assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+@pytest.mark.parametrize("q_diag", [False, True])
+def test_svgp_bound_parity(handle, whiten, q_diag):
+    """models/svgp.py:101-130 (SVGP ELBO, Gaussian likelihood, mini-batch rescale) vs the oracle."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(21)
+    n, m_, d, k = 400, 60, 3, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, k))) + 0.1 * rng.standard_normal((n, k))
+    Z = X[:m_].copy()
+    kern, spec = make_kernel(gpf, "rbf_ard", d)
+    lik = gpf.likelihoods.Gaussian(0.3)
+    m = gpf.models.SVGP(X, Y, kern, lik, Z=Z, q_diag=q_diag, whiten=whiten, num_data=4 * n)
+    q_mu = rng.standard_normal((m_, k)) * 0.3
+    m._q_mu.assign(q_mu)
+    if q_diag:
+        q_sqrt = np.abs(rng.standard_normal((m_, k))) * 0.4 + 0.2
+    else:
+        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * 0.05 + np.eye(m_) * 0.5).transpose(1, 2, 0).copy()
+    m._q_sqrt.assign(q_sqrt)
+    assert np.allclose(m.q_sqrt, q_sqrt, rtol=1e-14, atol=1e-300)
+    got = m.compute_log_likelihood()
+    ref = orc.svgp_elbo(spec, X, Y, Z, q_mu, np.asarray(m.q_sqrt), orc.constrained(0.3), whiten=whiten, num_data=4 * n)
+    assert abs(got - ref) <= 1e-7 * abs(ref)
+    kl = m.build_prior_KL()
+    Kp = None if whiten else orc.K(spec, Z) + 1e-6 * np.eye(m_)
+    assert abs(kl - orc.gauss_kl(q_mu, np.asarray(m.q_sqrt), Kp)) <= 1e-7 * abs(kl)
+    mu, var = m.predict_f(X[:50])
+    rmu, rvar = orc.conditional(X[:50], Z, spec, q_mu, q_sqrt=np.asarray(m.q_sqrt), white=whiten)
+    assert rel(mu, rmu) <= 1e-7 and rel(var, rvar) <= 1e-7

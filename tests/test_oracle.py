@@ -268,3 +268,42 @@ def test_oracle_reproduces_golden_fixtures(path):
     assert orc.gpr_lml(spec, g["X"], g["Y"], nv) == pytest.approx(float(g["lml"]), rel=1e-12)
     mu, var = orc.gpr_predict(spec, g["X"], g["Y"], nv, g["Xs"])
     assert np.allclose(mu, g["mu"], rtol=1e-10, atol=1e-12) and np.allclose(var, g["var"], rtol=1e-10, atol=1e-12)
+
+
+def test_gauss_kl_closed_forms():
+    """KL[N(m, S) || N(0, K)] = 0.5 (tr(K^-1 S) + m^T K^-1 m - M + log det K - log det S)"""
+    rng = np.random.default_rng(4)
+    M, k = 9, 2
+    q_mu = rng.standard_normal((M, k))
+    Lq = np.tril(rng.standard_normal((k, M, M)) * 0.2 + np.eye(M))
+    q_sqrt3 = np.transpose(Lq, (1, 2, 0)).copy()
+    G = rng.standard_normal((M, M)); K = G @ G.T + M * np.eye(M)
+    ref = 0.0
+    for i in range(k):
+        S = Lq[i] @ Lq[i].T
+        ref += 0.5 * (np.trace(np.linalg.solve(K, S)) + q_mu[:, i] @ np.linalg.solve(K, q_mu[:, i]) - M
+                      + np.linalg.slogdet(K)[1] - np.linalg.slogdet(S)[1])
+    assert orc.gauss_kl(q_mu, q_sqrt3, K) == pytest.approx(ref, rel=1e-12)
+    assert orc.gauss_kl(np.zeros((M, k)), np.transpose(np.array([np.eye(M)] * k), (1, 2, 0)), None) == pytest.approx(0.0, abs=1e-14)
+    qd = np.abs(rng.standard_normal((M, k))) + 0.1
+    refd = sum(0.5 * (np.sum(np.diag(np.linalg.inv(K)) * qd[:, i] ** 2) + q_mu[:, i] @ np.linalg.solve(K, q_mu[:, i]) - M
+                      + np.linalg.slogdet(K)[1] - np.sum(np.log(qd[:, i] ** 2))) for i in range(k))
+    assert orc.gauss_kl(q_mu, qd, K) == pytest.approx(refd, rel=1e-12)
+
+
+def test_svgp_bound_is_tight_at_the_exact_posterior():
+    """With Z = X, Gaussian likelihood and q(u) = exact posterior, the SVGP bound equals the GPR LML."""
+    rng = np.random.default_rng(8)
+    n, d = 25, 2
+    X = rng.standard_normal((n, d)); Y = rng.standard_normal((n, 1))
+    spec = {"type": "rbf", "variance": c(1.3), "lengthscales": c(0.9), "input_dim": d}
+    s2 = c(0.2)
+    Kff = orc.K(spec, X) + orc.JITTER * np.eye(n)
+    A = np.linalg.inv(Kff + s2 * np.eye(n))
+    mu_u = Kff @ A @ Y
+    S_u = Kff - Kff @ A @ Kff
+    Lq = np.linalg.cholesky(S_u + 1e-12 * np.eye(n))
+    elbo = orc.svgp_elbo(spec, X, Y, X, mu_u, Lq[:, :, None], s2, whiten=False)
+    lml_jit = orc.multivariate_normal(Y, np.zeros((n, 1)), np.linalg.cholesky(Kff + s2 * np.eye(n)))
+    # equal up to the O(jitter) mismatch between Kuu (+1e-6 I) and Kuf / Kdiag (no jitter); never above
+    assert elbo == pytest.approx(lml_jit, rel=2e-5) and elbo <= lml_jit + 1e-9
