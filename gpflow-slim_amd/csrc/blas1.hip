@@ -70,6 +70,38 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const double* __restrict_
   }
 }
 
+// y1[q][k] -= sum_i L21[i][k] * y2[q][i]   (transposed panel: backward substitution L^T a = y).
+// One workgroup per 128 columns k, two row-halves per workgroup, fixed summation order (no atomics).
+template <int RC>
+__global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double* __restrict__ L21, i64 ldl,
+                                                         i64 n2, i64 n1,
+                                                         const double* __restrict__ y2,
+                                                         double* __restrict__ y1, i64 ldy, int r0,
+                                                         int rcount) {
+  __shared__ double part[RC][128];
+  const int kk = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const i64 k = (i64)blockIdx.x * 128 + kk;
+  double acc[RC];
+#pragma unroll
+  for (int q = 0; q < RC; ++q) acc[q] = 0.0;
+  for (i64 i = half; i < n2; i += 2) {
+    const double l = L21[i * ldl + k];
+#pragma unroll
+    for (int q = 0; q < RC; ++q)
+      if (q < rcount) acc[q] = fma(l, y2[(i64)(r0 + q) * ldy + i], acc[q]);
+  }
+  if (half) {
+#pragma unroll
+    for (int q = 0; q < RC; ++q) part[q][kk] = acc[q];
+  }
+  __syncthreads();
+  if (!half) {
+#pragma unroll
+    for (int q = 0; q < RC; ++q)
+      if (q < rcount) y1[(i64)(r0 + q) * ldy + k] -= acc[q] + part[q][kk];
+  }
+}
+
 // partial[b][0] = sum_i log L_ii ; partial[b][1] = sum alpha^2   (fixed-order, host adds
 // the gridDim.x partials so the result is bitwise reproducible)
 __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ L, i64 ldl,
@@ -208,6 +240,19 @@ int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 
     LaunchScope ls(h, KC_TRSV, 2.0 * n2 * n1 * rc, (double)n2 * n1 * 8.0);
     hipLaunchKernelGGL(gemv_sub_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, L21,
                        ldl, n2, n1, y1, y2, ldy, (int)r0, rc);
+    GPS_HIP(h, hipGetLastError());
+  }
+  return GPS_OK;
+}
+
+int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
+                          const double* y2, double* y1, i64 ldy, i64 r) {
+  if (n2 <= 0 || n1 <= 0) return GPS_OK;
+  for (i64 r0 = 0; r0 < r; r0 += 4) {
+    const int rc = (int)((r - r0) < 4 ? (r - r0) : 4);
+    LaunchScope ls(h, KC_TRSV, 2.0 * n2 * n1 * rc, (double)n2 * n1 * 8.0);
+    hipLaunchKernelGGL(gemv_t_sub_kernel<4>, dim3((unsigned)(n1 / 128)), dim3(256), 0, h->stream, L21, ldl,
+                       n2, n1, y2, y1, ldy, (int)r0, rc);
     GPS_HIP(h, hipGetLastError());
   }
   return GPS_OK;

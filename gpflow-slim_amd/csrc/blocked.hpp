@@ -13,6 +13,9 @@
 //               the transposed right-hand side    models/gpr.py:122, conditionals.py:87
 //   trsm_rn_rec: X L = B with U = L^T stored      conditionals.py:100 (unwhitened back-solve)
 //   trsv_rec  : L a = y     (y [r][ld] in place)  densities.py:82, models/gpr.py:123
+//   trsv_t_rec / inv_t_rec / lauum_rec : L^T a = y, Y = L^-T, K^-1 = Y Y^T -- the pieces of the analytic
+//               gradient of the log-marginal likelihood (what TF autodiff through tf.cholesky supplies to
+//               examples/gpr.py:53-54)
 //
 // Every flop of the recursion lands in Ops::gemm (C -= A B^T / C = A B^T) with K = half the
 // current block, i.e. long-K MFMA GEMMs; the 128x128 leaves use the explicit block inverses
@@ -72,6 +75,54 @@ struct Blocked {
     rc = ops.gemm(0, 0, m, n1, n2, B + n1, ldb, U + n1, ldu, B, ldb);
     if (rc) return rc;
     return trsm_rn_rec(U, ldu, n1, blk0, B, ldb, m);
+  }
+
+  // solve L^T a = y in place (backward substitution), right-hand sides stored as rows y[q*ldy + i]
+  int trsv_t_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* y, i64 ldy, i64 r) {
+    if (n <= 0 || r <= 0) return 0;
+    if (n == GPS_TILE) return ops.trsv_t_base(blk0, y, ldy, r);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = trsv_t_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, y + n1, ldy, r);
+    if (rc) return rc;
+    rc = ops.gemv_t_sub(L + n1 * ldl, ldl, n2, n1, y + n1, y, ldy, r);        // y1 -= L21^T a2
+    if (rc) return rc;
+    return trsv_t_rec(L, ldl, n1, blk0, y, ldy, r);
+  }
+
+  // Y = L^-T (upper triangular, full storage with explicit zeros below the diagonal)
+  //   L^-T = [[Y11, -Y11 L21^T L22^-T], [0, Y22]]
+  int inv_t_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* Y, i64 ldy) {
+    if (n <= 0) return 0;
+    if (n == GPS_TILE) return ops.copy_linvT(blk0, Y, ldy);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = inv_t_rec(L, ldl, n1, blk0, Y, ldy);
+    if (rc) return rc;
+    rc = inv_t_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, Y + n1 * ldy + n1, ldy);
+    if (rc) return rc;
+    double* Y12 = Y + n1;
+    rc = ops.zero_block(Y12, ldy, n1, n2);
+    if (rc) return rc;
+    rc = ops.zero_block(Y + n1 * ldy, ldy, n2, n1);
+    if (rc) return rc;
+    rc = ops.gemm(0, 0, n1, n2, n1, Y, ldy, L + n1 * ldl, ldl, Y12, ldy);       // Y12 = -Y11 L21^T
+    if (rc) return rc;
+    return trsm_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, Y12, ldy, n1);   // ... L22^-T
+  }
+
+  // Kv (lower triangle) = Y Y^T for upper-triangular Y  (= (L L^T)^-1 when Y = L^-T)
+  int lauum_rec(const double* Y, i64 ldy, i64 n, double* Kv, i64 ldk) {
+    if (n <= 0) return 0;
+    if (n == GPS_TILE) return ops.gemm(1, 1, n, n, n, Y, ldy, Y, ldy, Kv, ldk);
+    const i64 n1 = split(n), n2 = n - n1;
+    int rc = lauum_rec(Y, ldy, n1, Kv, ldk);
+    if (rc) return rc;
+    const double* Y12 = Y + n1;
+    const double* Y22 = Y + n1 * ldy + n1;
+    rc = ops.gemm(2, 1, n1, n1, n2, Y12, ldy, Y12, ldy, Kv, ldk);                // K11 += Y12 Y12^T
+    if (rc) return rc;
+    rc = ops.gemm(1, 0, n2, n1, n2, Y22, ldy, Y12, ldy, Kv + n1 * ldk, ldk);     // K21 = Y22 Y12^T
+    if (rc) return rc;
+    return lauum_rec(Y22, ldy, n2, Kv + n1 * ldk + n1, ldk);
   }
 
   // solve L a = y in place for r right-hand sides stored as rows y[q*ldy + i]

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       for (int rg = 0; rg < 4; ++rg) {
         double* cp = g.C + (row0 + i * 16 + 4 * rg) * g.ldc + col0 + j * 16;
         if (OP == 0) *cp = *cp - acc[i][j][rg];
+        else if (OP == 2) *cp = *cp + acc[i][j][rg];
         else *cp = acc[i][j][rg];
       }
     }
@@ -213,9 +214,15 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
   if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
   g.ntiles = (int)nt;
   if (BM == BN) {
-    if (lower) return op == 0 ? launch_variant<BM, BN, WGM, true, 0>(h, g) : launch_variant<BM, BN, WGM, true, 1>(h, g);
+    if (lower) {
+      if (op == 0) return launch_variant<BM, BN, WGM, true, 0>(h, g);
+      if (op == 2) return launch_variant<BM, BN, WGM, true, 2>(h, g);
+      return launch_variant<BM, BN, WGM, true, 1>(h, g);
+    }
   }
-  return op == 0 ? launch_variant<BM, BN, WGM, false, 0>(h, g) : launch_variant<BM, BN, WGM, false, 1>(h, g);
+  if (op == 0) return launch_variant<BM, BN, WGM, false, 0>(h, g);
+  if (op == 2) return launch_variant<BM, BN, WGM, false, 2>(h, g);
+  return launch_variant<BM, BN, WGM, false, 1>(h, g);
 }
 
 // rowpanel != 0: C may alias A (in-place B <- B W^T with N == K == 128): every workgroup then owns
@@ -237,7 +244,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
   const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
   const double flops = 2.0 * t128 * 128.0 * 128.0 * (double)K;
-  const double bytes = t128 * ((op == 0 ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
+  const double bytes = t128 * ((op != 1 ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);
   const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used

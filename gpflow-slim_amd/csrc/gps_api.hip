@@ -35,6 +35,23 @@ struct HipOps {
                i64 r) {
     return gps_launch_gemv_sub(h, L21, ldl, n2, n1, y1, y2, ldy, r);
   }
+  // ---- pieces of the gradient path
+  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r) {       // y = Linv^T y : the kernel wants M[c][i] = Linv[c][i]
+    return gps_launch_trsv_base(h, linv + blk * GPS_TILE * GPS_TILE, y, ldy, r);
+  }
+  int gemv_t_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y2, double* y1, i64 ldy, i64 r) {
+    return gps_launch_gemv_t_sub(h, L21, ldl, n2, n1, y2, y1, ldy, r);
+  }
+  int copy_linvT(i64 blk, double* Y, i64 ldy) {
+    if (!linvT) return gps_fail(h, GPS_ERR_STATE, "inverse needs the transposed block inverses");
+    GPS_HIP(h, hipMemcpy2DAsync(Y, (size_t)ldy * 8, linvT + blk * GPS_TILE * GPS_TILE, (size_t)GPS_TILE * 8,
+                                (size_t)GPS_TILE * 8, GPS_TILE, hipMemcpyDeviceToDevice, h->stream));
+    return GPS_OK;
+  }
+  int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
+    GPS_HIP(h, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)cols * 8, (size_t)rows, h->stream));
+    return GPS_OK;
+  }
 };
 
 static int read_info(gps_handle_t h, int* d_info, int* info) {
@@ -82,7 +99,8 @@ extern "C" int gps_destroy(gps_handle_t h) {
   for (auto e : h->evt_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
-                    &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3};
+                    &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
+                    &h->dKinv};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   delete h;
@@ -381,6 +399,55 @@ extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   stage_time(h, 2, 3, &h->stage_ms[2]);
   h->stage_ms[3] = 0.0;
   stage_time(h, 0, 3, &h->stage_ms[4]);
+  return GPS_OK;
+}
+
+// LML and its gradient: d/d(kernel parameter slots), d/d(noise variance), d/d(resid) = -K_y^-1 resid ... see header
+extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
+                                const double* resid, int64_t r, double* lml, double* grad_slots,
+                                int n_slots_cap, int* n_slots_out, double* grad_noise, double* kinv_resid,
+                                int* info) {
+  if (!h || !lml || !grad_slots || !grad_noise || r <= 0)
+    return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml_grad: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  int ns = 0;
+  int rc = gps_grad_slots(h, prog, n_nodes, &ns);
+  if (rc) return rc;
+  if (n_slots_out) *n_slots_out = ns;
+  if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml_grad: grad_slots too small");
+  int linfo = 0;
+  rc = gps_gpr_lml(h, prog, n_nodes, noise_var, resid, r, lml, &linfo);
+  if (info) *info = linfo;
+  if (rc || linfo) return rc;
+  const i64 n = h->n, np = h->npad;
+  GPS_HIP(h, hipEventRecord(h->ev[5], h->stream));
+  double* linv = h->dLinv.d();
+  HipOps ops{h, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  // A = K_y^-1 resid = L^-T (L^-1 resid)
+  GPS_HIP(h, h->dA.ensure((size_t)r * np * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dA.p, h->dAlpha.p, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
+  rc = bl.trsv_t_rec(h->dK.d(), np, np, 0, h->dA.d(), np, r);
+  if (rc) return rc;
+  // K_y^-1 = L^-T L^-1
+  GPS_HIP(h, h->dY.ensure((size_t)np * np * 8));
+  GPS_HIP(h, h->dKinv.ensure((size_t)np * np * 8));
+  rc = bl.inv_t_rec(h->dK.d(), np, np, 0, h->dY.d(), np);
+  if (rc) return rc;
+  rc = bl.lauum_rec(h->dY.d(), np, np, h->dKinv.d(), np);
+  if (rc) return rc;
+  rc = gps_launch_grad(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, grad_slots,
+                       grad_noise);
+  if (rc) return rc;
+  if (kinv_resid) {
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
+    rc = gps_launch_transpose(h, h->dA.d(), np, r, n, h->dTmp2.d(), r);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(kinv_resid, h->dTmp2.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  stage_time(h, 5, 6, &h->stage_ms[3]);
   return GPS_OK;
 }
 

@@ -86,6 +86,9 @@ struct gps_handle_s {
   i64 dist_nb = 0, dist_np = 0, dist_r = 0;
   double* dist_comm[2] = {nullptr, nullptr};
 
+  DevBuf dA;        // [r][npad]  K_y^-1 (Y - m)                         (gradient path)
+  DevBuf dY;        // [npad, npad]  L^-T                                 (gradient path)
+  DevBuf dKinv;     // [npad, npad]  K_y^-1, lower triangle               (gradient path)
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
@@ -140,7 +143,7 @@ static inline void gps_profile_collect(gps_handle_t h) {
 
 // ---- kernel launchers implemented in the .hip files --------------------------
 // gemm_f64.hip : C (op)= A[M,K] * B[N,K]^T, all row-major, M,N multiples of 128,
-// K multiple of 16.  op 0: C -= A B^T ; op 1: C = A B^T ; lower: skip tiles above
+// K multiple of 16.  op 0: C -= A B^T ; op 1: C = A B^T ; op 2: C += A B^T ; lower: skip tiles above
 // the diagonal (M == N).
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
@@ -155,6 +158,8 @@ int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
 int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
                         const double* y1, double* y2, i64 ldy, i64 r);
+int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
+                          const double* y2, double* y1, i64 ldy, i64 r);
 int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
                           const double* alpha, i64 ldy, i64 r, double* out2);
 int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
@@ -178,5 +183,10 @@ int gps_launch_kmat_block(gps_handle_t h, const gps_kern_node_t* prog, int n_nod
                           i64 n, i64 d_all, i64 npad, double diag_add, double* dKb, i64 ldk, i64 r0,
                           i64 nrows, i64 c0, i64 ncols, int prep);
 int gps_launch_kdiag(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* kdiag_const);
+// grad.hip
+int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int* n_slots);
+int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                    i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                    double* grad_slots_host, double* grad_noise_host);
 // diag.hip
 int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "gps_gpr_set_data": [ctypes.c_void_p, _c_double_p, _i64, _i64],
     "gps_gpr_lml": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p, _i64,
                     _c_double_p, _c_int_p],
+    "gps_gpr_lml_grad": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p, _i64,
+                         _c_double_p, _c_double_p, ctypes.c_int, _c_int_p, _c_double_p, _c_double_p, _c_int_p],
     "gps_gpr_predict": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p,
                         _i64, _c_double_p, _i64, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_int_p],
     "gps_conditional": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64,
@@ -362,6 +364,27 @@ class Handle(object):
                 "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
                 % info.value)
         return lml.value
+
+    def gpr_lml_grad(self, prog, noise_var, resid):
+        """(lml, grad_slots, grad_noise, K_y^-1 resid)  -- see gps_gpr_lml_grad in the header."""
+        resid = _f64(resid)
+        n, r = resid.shape
+        lml = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        nslots = ctypes.c_int(0)
+        cap = 160
+        slots = np.zeros(cap)
+        gnoise = ctypes.c_double(0)
+        kinv_resid = np.empty((n, r))
+        self._check(self._lib.gps_gpr_lml_grad(self._h, prog, len(prog), float(noise_var), _ptr(resid), r,
+                                               ctypes.byref(lml), _ptr(slots), cap, ctypes.byref(nslots),
+                                               ctypes.byref(gnoise), _ptr(kinv_resid), ctypes.byref(info)),
+                    "gps_gpr_lml_grad")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
+                % info.value)
+        return lml.value, slots[:nslots.value].copy(), gnoise.value, kinv_resid
 
     def gpr_predict(self, prog, noise_var, resid, Xnew, full_cov=False, refactor=True):
         resid = _f64(resid)

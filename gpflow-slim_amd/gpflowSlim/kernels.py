@@ -60,6 +60,11 @@ class Kernel(object):
     def _program(self, d_all, presliced=False):
         return be.make_program(self._nodes(presliced, d_all))
 
+    def _grad_layout(self, d_all):
+        """One entry per gradient slot of gps_gpr_lml_grad, in slot order: (Parameter or None, index
+        into the parameter's flattened value or None = add to every element)."""
+        raise NotImplementedError
+
     # ---- reference API -------------------------------------------------------------------
     def K(self, X, X2=None, presliced=False):
         X = np.asarray(X, dtype=settings.float_type)
@@ -95,12 +100,18 @@ class Static(Kernel):
 class White(Static):
     """kernels.py:328-338"""
 
+    def _grad_layout(self, d_all):
+        return [(self._variance, None)]
+
     def _nodes(self, presliced, d_all):
         return [be.primitive_node(be.K_WHITE, np.squeeze(self.variance))]
 
 
 class Constant(Static):
     """kernels.py:341-350"""
+
+    def _grad_layout(self, d_all):
+        return [(self._variance, None)]
 
     def _nodes(self, presliced, d_all):
         return [be.primitive_node(be.K_CONSTANT, np.squeeze(self.variance))]
@@ -149,6 +160,11 @@ class Stationary(Kernel):
     def Kdiag(self, X, presliced=False):
         """kernels.py:428-429"""
         return np.ones(np.shape(X)[0], dtype=settings.float_type) * self.variance
+
+    def _grad_layout(self, d_all):
+        nd = len(self._dims(False, d_all))
+        ard = np.atleast_1d(self.lengthscales).size > 1
+        return [(self._variance, None)] + [(self._ls, d if ard else None) for d in range(nd)]
 
 
 class RBF(Stationary):
@@ -206,6 +222,9 @@ class Periodic(Kernel):
     def Kdiag(self, X, presliced=False):
         """kernels.py:803-804"""
         return np.full(np.shape(X)[0], np.squeeze(self.variance), dtype=settings.float_type)
+
+    def _grad_layout(self, d_all):
+        return [(self._variance, None), (self._ls, None), (self._period, None)]
 
 
 _SCALARS = (int, float, np.floating, np.integer)
@@ -270,6 +289,13 @@ class Combination(Kernel):
 
     def _fold(self, values):
         raise NotImplementedError
+
+    def _grad_layout(self, d_all):
+        out = []
+        for k in self.kern_list:
+            out.extend(k._grad_layout(d_all))
+        out.extend([(None, None)] * len(self.const_list))     # scalar constants: slot exists, no parameter
+        return out
 
     def Kdiag(self, X, presliced=False):
         return self._fold([k.Kdiag(X) for k in self.kern_list] + self.const_list)

@@ -53,6 +53,49 @@ class GPR(GPModel):
         self._factor_key = self._state_key()
         return lml
 
+    def compute_log_likelihood_and_gradients(self):
+        """LML and d LML / d(unconstrained parameter) for every parameter of the model -- what
+        `tf.gradients(objective, variables)` yields in the reference (examples/gpr.py:53-54) up to the
+        sign of `objective = -LML`.  Returns (lml, [(Parameter, gradient array shaped like
+        Parameter.unconstrained_tensor), ...]) in `self.parameters` order.  Priors are not included."""
+        h = self._handle()
+        d_all = self.X.shape[1]
+        prog = self.kern._program(d_all)
+        layout = self.kern._grad_layout(d_all)
+        resid = self._resid()
+        self._factor_key = None
+        lml, slots, gnoise, kinv_resid = h.gpr_lml_grad(prog, float(np.squeeze(self.likelihood.variance)), resid)
+        self._factor_key = self._state_key()
+        if len(layout) != len(slots):
+            raise RuntimeError("gradient slot layout mismatch: %d vs %d" % (len(layout), len(slots)))
+        grads = {id(p): np.zeros_like(np.atleast_1d(p.vf_val), dtype=settings.float_type) for p in self.parameters}
+        for (param, idx), g in zip(layout, slots):
+            if param is None:
+                continue
+            if idx is None:
+                grads[id(param)] += g
+            else:
+                grads[id(param)][idx] += g
+        grads[id(self.likelihood._variance)] += gnoise
+        # mean function: d LML / d m(X) = K_y^-1 (Y - m) ; Zero has no parameters
+        from ..mean_functions import Constant as _MConst, Linear as _MLin
+        mf = self.mean_function
+
+        def _fit(g, like):           # sum a per-output gradient into a parameter that broadcasts over outputs
+            like = np.atleast_1d(like)
+            return g.reshape(like.shape) if g.size == like.size else np.full(like.shape, np.sum(g))
+
+        if isinstance(mf, _MConst):
+            grads[id(mf.c)] = grads[id(mf.c)] + _fit(np.sum(kinv_resid, axis=0), mf.c.vf_val)
+        elif isinstance(mf, _MLin):
+            grads[id(mf.A)] = grads[id(mf.A)] + _fit(self.X.T @ kinv_resid, mf.A.vf_val)
+            grads[id(mf.b)] = grads[id(mf.b)] + _fit(np.sum(kinv_resid, axis=0), mf.b.vf_val)
+        out = []
+        for p in self.parameters:
+            g = grads[id(p)].reshape(np.atleast_1d(p.vf_val).shape) * np.atleast_1d(p.transform.forward_grad(p.vf_val))
+            out.append((p, g.reshape(p.vf_val.shape)))
+        return lml, out
+
     def _build_predict(self, Xnew, full_cov=False):
         """models/gpr.py:119-131"""
         Xnew = np.ascontiguousarray(Xnew, dtype=settings.float_type)

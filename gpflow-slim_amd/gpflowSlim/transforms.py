@@ -24,6 +24,10 @@ class Transform(object):
     def log_jacobian_tensor(self, x):
         raise NotImplementedError
 
+    def forward_grad(self, x):
+        """d forward(x) / d x, elementwise (chain rule from constrained to unconstrained gradients)."""
+        raise NotImplementedError
+
 
 class Identity(Transform):
     """transforms.py:40-57"""
@@ -36,6 +40,9 @@ class Identity(Transform):
 
     def log_jacobian_tensor(self, x):
         return 0.0
+
+    def forward_grad(self, x):
+        return np.ones_like(np.asarray(x, dtype=settings.float_type))
 
     def __str__(self):
         return '(none)'
@@ -55,6 +62,9 @@ class Exp(Transform):
 
     def log_jacobian_tensor(self, x):
         return float(np.sum(x))
+
+    def forward_grad(self, x):
+        return np.exp(np.asarray(x, dtype=settings.float_type))
 
     def __str__(self):
         return '+ve'
@@ -79,6 +89,11 @@ class Log1pe(Transform):
     def log_jacobian_tensor(self, x):
         # transforms.py:148-149
         return float(-np.sum(np.logaddexp(0.0, -np.asarray(x, dtype=settings.float_type))))
+
+    def forward_grad(self, x):
+        # d softplus / dx = sigmoid(x)
+        x = np.asarray(x, dtype=settings.float_type)
+        return np.exp(-np.logaddexp(0.0, -x))
 
     def __str__(self):
         return '+ve'

@@ -113,6 +113,20 @@ int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                 double noise_var, const double* resid, int64_t r,
                 double* lml, int* info);
 
+/* Log-marginal likelihood AND its gradient -- what TF autodiff through tf.cholesky supplies to the
+ * reference's optimisers (examples/gpr.py:53-54 AdamOptimizer.minimize(objective);
+ * models/model.py:172-187 L-BFGS):   d LML/d theta = 1/2 tr((A A^T - r K_y^-1) dK_y/dtheta),
+ * A = K_y^-1 resid.  grad_slots: for every primitive node of the program in order, [d/d variance] then
+ * stationary kernels one entry per active dim (d/d lengthscale_d; an isotropic kernel sums them),
+ * Periodic [d/d lengthscale, d/d period], White / Constant nothing more -- all w.r.t. the CONSTRAINED
+ * values; the caller applies the transform's chain rule.  grad_noise = d/d noise_var.
+ * kinv_resid (optional) host [n, r] = A = d LML / d resid (chain rule for mean-function parameters).
+ * Programs with more than 4 primitive nodes return GPS_ERR_UNSUPPORTED.                             */
+int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                     double noise_var, const double* resid, int64_t r, double* lml,
+                     double* grad_slots, int n_slots_cap, int* n_slots_out,
+                     double* grad_noise, double* kinv_resid, int* info);
+
 /* GPR._build_predict exact branch (models/gpr.py:119-131).
  * refactor != 0: rebuild K, L, V exactly like the reference does on every
  * predict_f call ("cold"); refactor == 0: reuse L / V left by the previous

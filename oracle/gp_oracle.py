@@ -85,8 +85,21 @@ def _slice(spec, X, X2):
     return X, X2
 
 
+# "gemm": the reference's op order (kernels.py:408-421).  "diff": sum_d ((x_d - x'_d)/l_d)^2 -- the same
+# quantity without the GEMM-form cancellation noise; used only by gpr_lml_grad, whose central differences
+# of K would otherwise amplify the O(1e-16) diagonal noise through sqrt(r2 + 1e-12) (Matern family).
+SQUARE_DIST_MODE = "gemm"
+
+
 def square_dist(X, X2, lengthscales):
     """kernels.py:408-421, op for op"""
+    if SQUARE_DIST_MODE == "diff":
+        A = X / lengthscales
+        B = A if X2 is None else X2 / lengthscales
+        out = np.zeros((A.shape[0], B.shape[0]))
+        for dd in range(A.shape[1]):
+            out += np.square(A[:, dd:dd + 1] - B[None, :, dd])
+        return out
     X = X / lengthscales
     Xs = np.sum(np.square(X), axis=1)
     if X2 is None:
@@ -249,6 +262,37 @@ def conditional(Xnew, X, spec, f, full_cov=False, q_sqrt=None, white=False, jitt
     Kmn = K(spec, X, Xnew)
     Knn = K(spec, Xnew) if full_cov else Kdiag(spec, Xnew)
     return base_conditional(Kmn, Kmm, Knn, f, full_cov=full_cov, q_sqrt=q_sqrt, white=white)
+
+
+def gpr_lml_grad(spec_fn, theta, X, Y, noise_var, rel_step=1e-6):
+    """Gradient of gpr_lml w.r.t. the flat constrained parameter vector `theta` (kernel parameters as
+    consumed by spec_fn(theta) -> spec) and w.r.t. the noise variance.  This is what TF autodiff
+    differentiates in the reference (examples/gpr.py:53-54).  Semi-analytic and independent of the
+    product's derivative formulas:  d LML = 1/2 tr((a a^T - R K_y^-1) dK)  with dK/dtheta_p obtained by
+    central differences of the oracle's own K(spec)."""
+    global SQUARE_DIST_MODE
+    theta = np.asarray(theta, dtype=np.float64)
+    n, R = Y.shape
+    saved, SQUARE_DIST_MODE = SQUARE_DIST_MODE, "diff"
+    try:
+        return _gpr_lml_grad(spec_fn, theta, X, Y, noise_var, rel_step, n, R)
+    finally:
+        SQUARE_DIST_MODE = saved
+
+
+def _gpr_lml_grad(spec_fn, theta, X, Y, noise_var, rel_step, n, R):
+    Ky = K(spec_fn(theta), X) + np.eye(n) * noise_var
+    Kinv = np.linalg.inv(Ky)
+    a = Kinv @ Y
+    W = a @ a.T - R * Kinv
+    g = np.zeros_like(theta)
+    for p in range(theta.size):
+        h = rel_step * max(1.0, abs(theta[p]))
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h; tm[p] -= h
+        dK = (K(spec_fn(tp), X) - K(spec_fn(tm), X)) / (2 * h)
+        g[p] = 0.5 * np.sum(W * dK)
+    return g, 0.5 * np.trace(W), a
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

@@ -58,7 +58,34 @@ struct CpuOps {
       }
     for (i64 i = 0; i < M; ++i)
       for (i64 j = 0; j < N; ++j)
-        if (done[i * N + j]) C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : out[i * N + j];
+        if (done[i * N + j])
+          C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : (op == 2 ? C[i * ldc + j] + out[i * N + j] : out[i * N + j]);
+    return 0;
+  }
+  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r) {
+    const double* W = linv.data() + blk * T * T;
+    for (i64 q = 0; q < r; ++q) {
+      double tmp[GPS_TILE];
+      for (i64 i = 0; i < T; ++i) { double s = 0; for (i64 c = 0; c < T; ++c) s += W[c * T + i] * y[q * ldy + c]; tmp[i] = s; }
+      for (i64 i = 0; i < T; ++i) y[q * ldy + i] = tmp[i];
+    }
+    return 0;
+  }
+  int gemv_t_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y2, double* y1, i64 ldy, i64 r) {
+    for (i64 q = 0; q < r; ++q)
+      for (i64 k = 0; k < n1; ++k) {
+        double s = 0; for (i64 i = 0; i < n2; ++i) s += L21[i * ldl + k] * y2[q * ldy + i];
+        y1[q * ldy + k] -= s;
+      }
+    return 0;
+  }
+  int copy_linvT(i64 blk, double* Y, i64 ldy) {
+    const double* W = linvT.data() + blk * T * T;
+    for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) Y[i * ldy + c] = W[i * T + c];
+    return 0;
+  }
+  int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
+    for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
     return 0;
   }
   int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m) {
@@ -99,5 +126,18 @@ int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, i
   rc = bl.trsm_rn_rec(U.data(), n, n, 0, B2, n, m);
   if (rc) return rc;
   return bl.trsv_rec(A, n, n, 0, y, n, r);
+}
+// A [n,n] SPD in place -> L ; yt [r][n]: L^T a = yt ; Kinv [n,n] (lower valid) = A^-1 ; Yout = L^-T
+int emul_grad_pieces(double* A, i64 n, double* yt, i64 r, double* Yout, double* Kinv) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rec(A, n, n, 0, 0);
+  if (rc) return rc;
+  rc = bl.trsv_t_rec(A, n, n, 0, yt, n, r);
+  if (rc) return rc;
+  for (i64 i = 0; i < n * n; ++i) { Yout[i] = NAN; Kinv[i] = NAN; }
+  rc = bl.inv_t_rec(A, n, n, 0, Yout, n);
+  if (rc) return rc;
+  return bl.lauum_rec(Yout, n, n, Kinv, n);
 }
 }

@@ -47,3 +47,22 @@ def test_blocked_recursion_reports_first_bad_pivot(emul):
     p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
     assert info.value == 301
+
+
+@pytest.mark.parametrize("n,r", [(128, 1), (256, 2), (384, 1), (640, 3)])
+def test_gradient_pieces_match_lapack(emul, n, r):
+    """trsv_t_rec (L^T a = y), inv_t_rec (Y = L^-T) and lauum_rec (K^-1 = Y Y^T)."""
+    rng = np.random.default_rng(n + r)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+    A0 = A.copy()
+    yt = rng.standard_normal((r, n)); y0 = yt.copy()
+    Y = np.zeros((n, n)); Kinv = np.zeros((n, n))
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = emul.emul_grad_pieces(p(A), ctypes.c_int64(n), p(yt), ctypes.c_int64(r), p(Y), p(Kinv))
+    assert rc == 0
+    L = sl.cholesky(A0, lower=True)
+    assert np.abs(yt - sl.solve_triangular(L, y0.T, lower=True, trans='T').T).max() <= 1e-12
+    Linv = np.linalg.inv(L)
+    assert np.abs(Y - Linv.T).max() <= 1e-12 * np.abs(Linv).max()
+    ref = np.linalg.inv(A0)
+    assert np.abs(np.tril(Kinv) - np.tril(ref)).max() <= 1e-12 * np.abs(ref).max()

@@ -1,0 +1,135 @@
+"""Gradient of the log-marginal likelihood ("next" row 1) against the oracle:
+1/2 tr((a a^T - R K^-1) dK/dtheta) with dK/dtheta by central differences of the oracle's K, and
+against finite differences of the product's own LML through the unconstrained parameters."""
+import numpy as np
+import pytest
+
+import oracle.gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+c = orc.constrained
+
+
+def _cases(gpf, d):
+    k = gpf.kernels
+    ls = np.linspace(0.8, 1.7, d)
+
+    def rbf_ard():
+        kern = k.RBF(d, variance=1.3, lengthscales=ls, ARD=True)
+        theta = np.concatenate([[c(1.3)], c(ls)])
+        fn = lambda t: {"type": "rbf", "variance": t[0], "lengthscales": t[1:], "input_dim": d}
+        return kern, theta, fn, [("v", 0)] + [("l", i) for i in range(d)]
+
+    def m52_iso():
+        kern = k.Matern52(d, variance=0.9, lengthscales=1.4)
+        theta = np.array([c(0.9), c(1.4)])
+        fn = lambda t: {"type": "matern52", "variance": t[0], "lengthscales": t[1], "input_dim": d}
+        return kern, theta, fn, None
+
+    def m32_ard():
+        kern = k.Matern32(d, variance=1.1, lengthscales=ls * 1.3, ARD=True)
+        theta = np.concatenate([[c(1.1)], c(ls * 1.3)])
+        fn = lambda t: {"type": "matern32", "variance": t[0], "lengthscales": t[1:], "input_dim": d}
+        return kern, theta, fn, None
+
+    def m12_iso():
+        kern = k.Matern12(d, variance=0.7, lengthscales=2.0)
+        theta = np.array([c(0.7), c(2.0)])
+        fn = lambda t: {"type": "matern12", "variance": t[0], "lengthscales": t[1], "input_dim": d}
+        return kern, theta, fn, None
+
+    def periodic():
+        kern = k.Periodic(d, period=2.5, variance=0.8, lengthscales=1.2)
+        theta = np.array([c(0.8), c(1.2), c(2.5)])
+        fn = lambda t: {"type": "periodic", "variance": t[0], "lengthscales": t[1], "period": t[2], "input_dim": d}
+        return kern, theta, fn, None
+
+    def m52_plus_periodic():       # BASELINE config 4 kernel
+        kern = k.Matern52(d, variance=1.1, lengthscales=ls * 1.5, ARD=True) + k.Periodic(d, period=2.0, variance=0.9, lengthscales=1.2)
+        theta = np.concatenate([[c(1.1)], c(ls * 1.5), [c(0.9), c(1.2), c(2.0)]])
+        fn = lambda t: {"type": "sum", "children": [
+            {"type": "matern52", "variance": t[0], "lengthscales": t[1:1 + d], "input_dim": d},
+            {"type": "periodic", "variance": t[1 + d], "lengthscales": t[2 + d], "period": t[3 + d], "input_dim": d}]}
+        return kern, theta, fn, None
+
+    def rbf_times_periodic_plus_white():
+        kern = k.RBF(d, variance=1.2, lengthscales=1.6) * k.Periodic(d, period=3.0, variance=0.9, lengthscales=1.5) + k.White(d, variance=0.2)
+        theta = np.array([c(1.2), c(1.6), c(0.9), c(1.5), c(3.0), c(0.2)])
+        fn = lambda t: {"type": "sum", "children": [{"type": "product", "children": [
+            {"type": "rbf", "variance": t[0], "lengthscales": t[1], "input_dim": d},
+            {"type": "periodic", "variance": t[2], "lengthscales": t[3], "period": t[4], "input_dim": d}]},
+            {"type": "white", "variance": t[5]}]}
+        return kern, theta, fn, None
+
+    return {"rbf_ard": rbf_ard, "m52_iso": m52_iso, "m32_ard": m32_ard, "m12_iso": m12_iso, "periodic": periodic,
+            "m52_plus_periodic": m52_plus_periodic, "rbf_times_periodic_plus_white": rbf_times_periodic_plus_white}
+
+
+def _flat_constrained_grad(model, grads):
+    """d LML / d(constrained) per kernel parameter element, in kern.parameters order, from the returned
+    unconstrained gradients (divide the chain factor back out)."""
+    out = []
+    for p, g in grads:
+        if p in model.kern.parameters:
+            out.append(np.atleast_1d(g / p.transform.forward_grad(p.vf_val)).ravel())
+    return np.concatenate(out)
+
+
+KINDS = ["rbf_ard", "m52_iso", "m32_ard", "m12_iso", "periodic", "m52_plus_periodic", "rbf_times_periodic_plus_white"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("n,d,r", [(60, 2, 1), (200, 3, 2), (515, 4, 1)])
+def test_lml_gradient_matches_oracle(handle, kind, n, d, r):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d))
+    Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r))
+    kern, theta, fn, _ = _cases(gpf, d)[kind]()
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.15)
+    noise = c(0.15)
+    lml, grads = m.compute_log_likelihood_and_gradients()
+    ref_lml = orc.gpr_lml(fn(theta), X, Y, noise)
+    assert abs(lml - ref_lml) <= 1e-8 * abs(ref_lml)
+    g_ref, gnoise_ref, a_ref = orc.gpr_lml_grad(fn, theta, X, Y, noise)
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == g_ref.shape
+    scale = max(1.0, np.abs(g_ref).max())
+    assert np.abs(got - g_ref).max() <= 2e-6 * scale, (got, g_ref)      # oracle dK is a central difference
+    gn = [g for p, g in grads if p is m.likelihood._variance][0]
+    gn_c = float(gn / m.likelihood._variance.transform.forward_grad(m.likelihood._variance.vf_val))
+    assert abs(gn_c - gnoise_ref) <= 1e-8 * max(1.0, abs(gnoise_ref))      # exact formula on both sides
+
+
+def test_gradient_consistent_with_finite_differences_of_the_product(handle):
+    """d LML / d(unconstrained) including the softplus chain rule and a Linear mean function."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(2)
+    n, d = 150, 3
+    X = rng.standard_normal((n, d)); Y = X @ rng.standard_normal((d, 1)) + 0.2 * rng.standard_normal((n, 1))
+    kern = gpf.kernels.RBF(d, variance=1.5, lengthscales=[0.9, 1.4, 2.0], ARD=True) + gpf.kernels.Constant(d, variance=0.3)
+    mf = gpf.mean_functions.Linear(rng.standard_normal((d, 1)) * 0.1, np.array([0.05]))
+    m = gpf.models.GPR(X, Y, kern, mean_function=mf, obs_var=0.2)
+    lml, grads = m.compute_log_likelihood_and_gradients()
+    for p, g in grads:
+        flat = np.atleast_1d(p.vf_val).ravel().copy()
+        gflat = np.atleast_1d(g).ravel()
+        for i in range(flat.size):
+            h = 1e-5
+            x0 = flat[i]
+            flat[i] = x0 + h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fp = m.compute_log_likelihood()
+            flat[i] = x0 - h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fm = m.compute_log_likelihood()
+            flat[i] = x0; p.assign_unconstrained(flat.reshape(p.vf_val.shape))
+            fd = (fp - fm) / (2 * h)
+            assert abs(gflat[i] - fd) <= 1e-5 * max(1.0, abs(fd)), (p.name, i, gflat[i], fd)
+
+
+def test_gradient_too_many_primitives_is_a_loud_error(handle):
+    import gpflowSlim as gpf
+    d = 2
+    k = gpf.kernels
+    kern = k.RBF(d) + k.Matern32(d) + k.Matern52(d) + k.Periodic(d) + k.Matern12(d)
+    X = np.random.default_rng(0).standard_normal((40, d)); Y = np.ones((40, 1))
+    m = gpf.models.GPR(X, Y, kern)
+    with pytest.raises(RuntimeError, match="more than 4 primitive"):
+        m.compute_log_likelihood_and_gradients()
