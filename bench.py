@@ -159,6 +159,11 @@ def main():
         model.predict_f(Xnew)
         torch.cuda.synchronize(); warm_ms = 1e3 * (time.perf_counter() - t1)
 
+        # LML + analytic gradient (the quantity an optimiser step consumes)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        model.compute_log_likelihood_and_gradients()
+        torch.cuda.synchronize(); grad_ms = 1e3 * (time.perf_counter() - t1)
+
         roofline = None
         if not args.no_roofline:
             # one extra evaluation of the same workload with every launch bracketed by HIP events on the
@@ -223,6 +228,7 @@ def main():
                           "n": n, "d": d, "n_new": args.n_new,
                           "parallelism": "1 GPU" if world == 1 else "%d independent per-GPU evaluations (hyper-parameter sets), no collective" % world},
                "predict_f_latency_ms": {"cold_refactor": round(cold_ms, 2), "warm_resident_factor": round(warm_ms, 2), "n_new": args.n_new},
+               "lml_plus_gradient_ms": round(grad_ms, 2),
                "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
                "lml_last_step": lml,
                "roofline": roofline, "cpu_baseline": cpu}
