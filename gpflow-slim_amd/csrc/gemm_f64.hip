@@ -8,17 +8,17 @@
 // Both operands are read "row, k" with k contiguous, so one kernel serves all of
 // them (see DESIGN.md "one GEMM form").
 //
-// Tiling (MI355X first): TB x TB output tile per 256-thread workgroup (4 waves in a
-// 2x2 grid, (TB/2)^2 per wave = (TB/32)^2 v_mfma_f64_16x16x4_f64 accumulators), BK = 16
-// staged through LDS with a register prefetch of the next K-slab.  Row stride in
-// LDS is 18 doubles: the 16 rows x 2 k of one ds_read_b64 half-wave then cover all
-// 64 banks exactly once.
+// Tiling (MI355X first): BM x BN output tile per 256-thread workgroup (4 waves, each owning
+// MI x NI v_mfma_f64_16x16x4_f64 accumulators: 4x4 at 128x128), BK = 16 staged through LDS
+// with a register prefetch of the next K-slab.  Row stride in LDS is 18 doubles: the
+// 16 rows x 2 k of one ds_read_b64 half-wave then cover all 64 banks exactly once.
 //
 // fp64 MFMA is slow *per CU* (128 FLOP/clk: a 128x128x128 tile is 15 us of one CU), so
 // what matters for the many small launches on the factorisation's critical path is to
-// spread a launch over all 256 CUs: the launcher picks TB = 128, 64 or 32 so that the
-// grid has enough workgroups.  TB = 128: 2 workgroups per CU (147 KB LDS, <=256 VGPR) so
-// that one workgroup's C read-modify-write epilogue hides under the other's MFMA stream.
+// spread a launch over all 256 CUs: the launcher picks 128x128, 64x64 or 32x32 tiles (and
+// 64/32/16 x 128 row panels for the in-place B <- B W^T leaves) so that the grid has
+// enough workgroups.  128x128: 2 workgroups per CU (147 KB LDS, <=256 VGPR) so that one
+// workgroup's C read-modify-write epilogue hides under the other's MFMA stream.
 // blockIdx -> tile mapping is XCD-aware: each XCD walks a contiguous range of
 // 8-tile-wide column strips, so the tiles resident on one XCD share operand panels in
 // its private L2.

@@ -6,13 +6,11 @@
 // X L11^T = B into an MFMA GEMM (gemm_f64.hip) and every vector solve into a
 // 128x128 gemv, which is what makes the recursive trsm / trsv GEMM-only.
 //
-// Factorisation: the block lives in REGISTERS, 2-D cyclic over a 16x16 thread grid
-// (thread (ty,tx) owns A[ty+16a][tx+16b], an 8x8 patch).  Right-looking elimination with
-// deferred column scaling, one barrier per column: the owners of column j publish it (and
-// 1/pivot) into a double-buffered LDS vector, everybody updates its patch with
-// a_ik -= a_ij a_kj / a_jj.  The 16-column groups are unrolled at compile time so that the
-// patch is indexed statically (no scratch) and finished groups / the upper triangle cost
-// nothing.
+// Factorisation: LDS image [128][129], blocked right-looking with panel width 16: the 16x16
+// diagonal block is factored by ONE wave in registers (v_readlane broadcasts, hardware rsqrt + two
+// Newton steps, no barrier), the rows below by one thread each (forward substitution against that
+// block), and the trailing update C_IJ -= P_I P_J^T runs on the fp64 MFMA over 16x16 tiles --
+// 3 barriers per panel (24 in all) instead of one per column.
 //
 // Inverse: LDS image [128][129]; the lower triangle holds L, the strictly upper triangle
 // receives inv(L)^T as it is built (inv(L) is lower triangular, so its transpose fits exactly
@@ -25,62 +23,120 @@
 #define NT 256
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-#define CSTRIDE (PB + 8)
 
-// publish column j (held in patch column B, rows a >= B) and its pivot into the LDS vector cb
-template <int B>
-__device__ __forceinline__ void publish_column(const double (&v)[8][8], double* cb, double* piv,
-                                               int* info, int row0, int j, int ty, bool diag_owner) {
+// wave-uniform broadcast of lane `lane`'s fp64 value (lane is a compile-time constant at every call)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(p): hardware estimate + two Newton steps (full double accuracy; keeps the 16 serial pivots of a
+// diagonal block off the IEEE sqrt/divide sequences)
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  y = y * (1.5 - 0.5 * p * y * y);
+  y = y * (1.5 - 0.5 * p * y * y);
+  return y;
+}
+
+// whole 128x128 block -> LDS image; 16-byte loads, 8 in flight per thread (the upper triangle is
+// loaded too: it is never read before being overwritten)
+__device__ __forceinline__ void load_image(double* a, const double* __restrict__ A, i64 lda, int tid) {
+#pragma unroll 1
+  for (int base = 0; base < PB * PB / 2; base += NT * 8) {
+    double2 v[8];
 #pragma unroll
-  for (int a = B; a < 8; ++a) cb[ty + 16 * a] = v[a][B];
-  if (diag_owner) {
-    const double p = v[B][B];
-    if (!(p > 0.0)) atomicMin(info, row0 + j + 1);
-    cb[PB] = 1.0 / p;
-    piv[j] = p;
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int i = idx >> 6, j = (idx & 63) * 2;
+      v[u] = *reinterpret_cast<const double2*>(A + (i64)i * lda + j);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int i = idx >> 6, j = (idx & 63) * 2;
+      a[i * PS + j] = v[u].x;
+      a[i * PS + j + 1] = v[u].y;
+    }
   }
 }
 
-// one 16-column group of the elimination (BJ compile-time so v[][] is statically indexed).
-// Column j+1 is updated and published FIRST in every step, so that its LDS write and the
-// barrier overlap with the bulk of the rank-1 update.
-template <int BJ>
-__device__ __forceinline__ void eliminate_group(double (&v)[8][8], double* col, double* piv,
-                                                int* info, int row0, int tx, int ty) {
-#pragma unroll 1
-  for (int tj = 0; tj < 16; ++tj) {
-    const int j = BJ * 16 + tj;
-    double* cb = col + (j & 1) * CSTRIDE;
-    double* nb = col + ((j + 1) & 1) * CSTRIDE;
-    __syncthreads();                               // column j is visible
-    const double inv_p = cb[PB];
-    double ci[8], ck[8];
+// Blocked right-looking factorisation of the 128x128 LDS image, panel width 16:
+//   phase 1 (wave 0, registers + v_readlane, no barrier): Cholesky of the 16x16 diagonal block
+//   phase 2 (one thread per row below): forward substitution against that block
+//   phase 3 (all waves, fp64 MFMA): trailing update C_IJ -= P_I P_J^T on 16x16 tiles
+__device__ __forceinline__ void factor_image(double* a, double* dinv, int* info, int row0, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int g = 0; g < 8; ++g) {
+    const int o = 16 * g;
+    // ---- phase 1
+    if (wave == 0) {
+      const int i = lane & 15;
+      double r[16];
 #pragma unroll
-    for (int a = BJ; a < 8; ++a) {
-      ci[a] = cb[ty + 16 * a] * inv_p;
-      ck[a] = cb[tx + 16 * a];
-    }
-    if (tj < 15) {
-      if (tx > tj) {
+      for (int c = 0; c < 16; ++c) r[c] = a[(o + i) * PS + o + c];
 #pragma unroll
-        for (int a = BJ; a < 8; ++a) v[a][BJ] -= ci[a] * ck[BJ];
-        if (tx == tj + 1) publish_column<BJ>(v, nb, piv, info, row0, j + 1, ty, ty == tj + 1);
+      for (int j = 0; j < 16; ++j) {
+        const double p = readlane_f64(r[j], j);
+        if (lane == 0 && !(p > 0.0)) atomicMin(info, row0 + o + j + 1);
+        const double y = rsqrt_nr(p);
+        r[j] = (i == j) ? p * y : r[j] * y;
+        if (lane == j) dinv[o + j] = y;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = readlane_f64(r[j], k);
+          r[k] -= r[j] * lkj;
+        }
       }
+      if (lane < 16) {
 #pragma unroll
-      for (int b = BJ + 1; b < 8; ++b)
-#pragma unroll
-        for (int a = b; a < 8; ++a) v[a][b] -= ci[a] * ck[b];
-    } else {
-      if constexpr (BJ < 7) {
-#pragma unroll
-        for (int a = BJ + 1; a < 8; ++a) v[a][BJ + 1] -= ci[a] * ck[BJ + 1];
-        if (tx == 0) publish_column<BJ + 1>(v, nb, piv, info, row0, j + 1, ty, ty == 0);
-#pragma unroll
-        for (int b = BJ + 2; b < 8; ++b)
-#pragma unroll
-          for (int a = b; a < 8; ++a) v[a][b] -= ci[a] * ck[b];
+        for (int c = 0; c < 16; ++c)
+          if (c <= i) a[(o + i) * PS + o + c] = r[c];
       }
     }
+    __syncthreads();
+    if (g == 7) break;
+    // ---- phase 2
+    const int nrows = PB - o - 16;
+    if (tid < nrows) {
+      const int i = o + 16 + tid;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = a[i * PS + o + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double sacc = x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sacc -= x[k] * a[(o + j) * PS + o + k];
+        x[j] = sacc * dinv[o + j];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[i * PS + o + c] = x[c];
+    }
+    __syncthreads();
+    // ---- phase 3
+    const int nt = 7 - g;
+    const int ntile = nt * (nt + 1) / 2;
+    for (int t = wave; t < ntile; t += 4) {
+      int Ip = 0, rem = t;
+      while (rem >= Ip + 1) { rem -= Ip + 1; ++Ip; }
+      const int I = g + 1 + Ip, J = g + 1 + rem;
+      v4d acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double av = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
+        const double bv = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
+    }
+    __syncthreads();
   }
 }
 
@@ -88,6 +144,69 @@ __device__ __forceinline__ void eliminate_group(double (&v)[8][8], double* col, 
 // X (= inv L, lower) is stored transposed in the strict upper triangle of the image, diag in dinv.
 __device__ __forceinline__ double x_elem(const double* a, const double* dinv, int r, int c) {
   return (r > c) ? a[c * PS + r] : ((r == c) ? dinv[r] : 0.0);
+}
+
+// one doubling level of the block inverse (s = size of the already inverted diagonal blocks)
+template <int S>
+__device__ __forceinline__ void level_step(double* a, const double* dinv, int wave, int fr, int fk) {
+  constexpr int KS = S / 4;                        // k-steps of the longest product
+  constexpr int tps = S / 16;
+  constexpr int tiles_pair = tps * tps;
+  constexpr int ntile = (PB / (2 * S)) * tiles_pair;     // 4, 8, 16
+  constexpr int TPW = (ntile + 3) / 4;                   // tiles per wave: 1, 2, 4
+  // step A: W = L21 * X11 ; W[i][c] -> a[c][i]
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int t = wave + 4 * q;
+    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
+    const int o = pr * 2 * S;
+    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
+    double av[KS], bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = o + 4 * ks + fk;                     // k runs over the TL block
+      av[ks] = a[(i0 + fr) * PS + k];                     // L21[i][k]
+      bv[ks] = x_elem(a, dinv, k, c0 + fr);               // X11[k][c] (0 for k < c)
+    }
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (o + 4 * ks + 3 >= c0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = acc[rg];
+  }
+  __syncthreads();
+  // step B: Z = -X22 * W, kept in registers until every W has been consumed
+  v4d z[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int t = wave + 4 * q;
+    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
+    const int o = pr * 2 * S;
+    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
+    double av[KS], bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = o + S + 4 * ks + fk;                 // k runs over the BR block
+      av[ks] = x_elem(a, dinv, i0 + fr, k);               // X22[i][k] (0 for k > i)
+      bv[ks] = a[(c0 + fr) * PS + k];                     // W[k][c]
+    }
+    z[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (o + S + 4 * ks <= i0 + 15) z[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], z[q], 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int t = wave + 4 * q;
+    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
+    const int o = pr * 2 * S;
+    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = -z[q][rg];
+  }
+  __syncthreads();
 }
 
 // factor != 0: A holds the SPD block, L is written back.  factor == 0: A already holds L
@@ -102,61 +221,25 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);   // [PB][PS]
   double* dinv = a + PB * PS;                        // [PB]
-  double* piv = dinv + PB;                           // [PB]
-  double* col = piv + PB;                            // [2][PB + 8]
 
   const int tid = threadIdx.x;
 
   if (factor) {
-    const int tx = tid & 15, ty = tid >> 4;
-    double v[8][8];
-#pragma unroll
-    for (int a_ = 0; a_ < 8; ++a_)
-#pragma unroll
-      for (int b_ = 0; b_ < 8; ++b_) {
-        const int i = ty + 16 * a_, k = tx + 16 * b_;
-        v[a_][b_] = (k <= i) ? A[(i64)i * lda + k] : 0.0;
-      }
-    for (int q = tid; q < 2 * CSTRIDE; q += NT) col[q] = 0.0;
+    load_image(a, A, lda, tid);
     __syncthreads();
-    if (tx == 0) publish_column<0>(v, col, piv, info, row0, 0, ty, ty == 0);
     STAMP(1);
-    eliminate_group<0>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<1>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<2>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<3>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<4>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<5>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<6>(v, col, piv, info, row0, tx, ty);
-    eliminate_group<7>(v, col, piv, info, row0, tx, ty);
-    __syncthreads();
+    factor_image(a, dinv, info, row0, tid);
     STAMP(2);
-    // scale: L_jj = sqrt(a_jj), L_ij = a_ij / L_jj ; image to LDS
-    if (tid < PB) {
-      const double d = sqrt(piv[tid]);
-      col[tid] = d;                 // reuse: col[0..127] = L_jj
-      dinv[tid] = 1.0 / d;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a_ = 0; a_ < 8; ++a_)
-#pragma unroll
-      for (int b_ = 0; b_ <= a_; ++b_) {
-        const int i = ty + 16 * a_, k = tx + 16 * b_;
-        if (k < i) a[i * PS + k] = v[a_][b_] / col[k];
-        else if (k == i) a[i * PS + k] = col[k];
-      }
-    __syncthreads();
     // L back to HBM (upper triangle of the diagonal block zero-filled, like tf.cholesky)
-    for (int idx = tid; idx < PB * PB; idx += NT) {
-      const int i = idx >> 7, j = idx & 127;
-      A[(i64)i * lda + j] = (j <= i) ? a[i * PS + j] : 0.0;
+    for (int idx = tid; idx < PB * PB / 2; idx += NT) {
+      const int i = idx >> 6, j = (idx & 63) * 2;
+      double2 v;
+      v.x = (j <= i) ? a[i * PS + j] : 0.0;
+      v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
+      *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
     }
   } else {
-    for (int idx = tid; idx < PB * PB; idx += NT) {
-      const int i = idx >> 7, j = idx & 127;
-      if (j <= i) a[i * PS + j] = A[(i64)i * lda + j];
-    }
+    load_image(a, A, lda, tid);
     __syncthreads();
     if (tid < PB) dinv[tid] = 1.0 / a[tid * PS + tid];
     __syncthreads();
@@ -178,78 +261,32 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
 
   STAMP(4);
   // ---- levels s = 16, 32, 64: X21 = -X22 * (L21 * X11) for each pair of s-blocks, on the
-  // fp64 MFMA (16x16x4).  Output tiles are dealt round-robin to the 4 waves.
+  // fp64 MFMA (16x16x4).  Output tiles are dealt round-robin to the 4 waves; all operands of a tile are
+  // fetched from LDS first (KS k-steps, zero outside the triangular range), then the MFMA chain runs.
   {
     const int lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
-    for (int s = 16; s < PB; s <<= 1) {
-      const int tps = s >> 4;                          // 16-tiles per side of an s-block
-      const int tiles_pair = tps * tps;
-      const int ntile = (PB / (2 * s)) * tiles_pair;   // 4, 8, 16
-      // step A: W = L21 * X11 ; W[i][c] -> a[c][i]
-      for (int t = wave; t < ntile; t += 4) {
-        const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-        const int o = pr * 2 * s;
-        const int i0 = o + s + (w / tps) * 16, c0 = o + (w % tps) * 16;
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = c0; k0 < o + s; k0 += 4) {       // X11[k][c] = 0 for k < c
-          const double av = a[(i0 + fr) * PS + k0 + fk];                 // L21[i][k]
-          const double bv = x_elem(a, dinv, k0 + fk, c0 + fr);           // X11[k][c]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = acc[rg];
-      }
-      __syncthreads();
-      // step B: Z = -X22 * W, kept in registers until every W has been consumed
-      v4d z[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        z[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const int t = wave + 4 * q;
-        if (t < ntile) {
-          const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-          const int o = pr * 2 * s;
-          const int i0 = o + s + (w / tps) * 16, c0 = o + (w % tps) * 16;
-          for (int k0 = o + s; k0 < i0 + 16; k0 += 4) {  // X22[i][k] = 0 for k > i
-            const double av = x_elem(a, dinv, i0 + fr, k0 + fk);         // X22[i][k]
-            const double bv = a[(c0 + fr) * PS + k0 + fk];               // W[k][c]
-            z[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z[q], 0, 0, 0);
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = wave + 4 * q;
-        if (t < ntile) {
-          const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-          const int o = pr * 2 * s;
-          const int i0 = o + s + (w / tps) * 16, c0 = o + (w % tps) * 16;
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = -z[q][rg];
-        }
-      }
-      __syncthreads();
-    }
+    level_step<16>(a, dinv, wave, fr, fk);
+    level_step<32>(a, dinv, wave, fr, fk);
+    level_step<64>(a, dinv, wave, fr, fk);
   }
 
   STAMP(5);
-  // inverse to HBM, full block with zero upper triangle
-  for (int idx = tid; idx < PB * PB; idx += NT) {
-    const int i = idx >> 7, c = idx & 127;
-    double v = 0.0;
-    if (c < i) v = a[c * PS + i];
-    else if (c == i) v = dinv[i];
-    Linv[idx] = v;
+  // inverse (and its transpose) to HBM, full blocks with explicit zeros, 16-byte stores
+  for (int idx = tid; idx < PB * PB / 2; idx += NT) {
+    const int i = idx >> 6, c = (idx & 63) * 2;
+    double2 v;
+    v.x = x_elem(a, dinv, i, c);
+    v.y = x_elem(a, dinv, i, c + 1);
+    *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
   }
   if (LinvT) {
-    for (int idx = tid; idx < PB * PB; idx += NT) {
-      const int c = idx >> 7, i = idx & 127;        // LinvT[c][i] = Linv[i][c]
-      double v = 0.0;
-      if (c < i) v = a[c * PS + i];
-      else if (c == i) v = dinv[i];
-      LinvT[idx] = v;
+    for (int idx = tid; idx < PB * PB / 2; idx += NT) {
+      const int c = idx >> 6, i = (idx & 63) * 2;        // LinvT[c][i] = X[i][c]
+      double2 v;
+      v.x = x_elem(a, dinv, i, c);
+      v.y = x_elem(a, dinv, i + 1, c);
+      *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
     }
   }
   __syncthreads();
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor, long long* d_stamps) {
   static bool attr_set = false;
-  const size_t lds = (size_t)(PB * PS + 2 * PB + 2 * CSTRIDE) * sizeof(double);
+  const size_t lds = (size_t)(PB * PS + PB) * sizeof(double);
   if (!attr_set) {
     GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_base_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

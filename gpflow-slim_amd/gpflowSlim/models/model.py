@@ -1,8 +1,8 @@
 """Model / GPModel shells.
 
 Mirrors gpflowSlim/models/model.py:29-166.  ``objective`` / ``likelihood_tensor`` are floats
-(eager), not graph tensors.  ``optimize()`` (eager L-BFGS through TF autodiff, :172-196) is out
-of scope for this path ("next" row 1).
+(eager), not graph tensors.  ``optimize()`` (eager L-BFGS through TF autodiff, :172-196) is not
+mirrored; the gradients it would consume come from ``GPR.compute_log_likelihood_and_gradients``.
 """
 import numpy as np
 
@@ -66,6 +66,19 @@ class GPModel(Model):
     def predict_f_full_cov(self, Xnew):
         """models/model.py:128-133"""
         return self._build_predict(Xnew, full_cov=True)
+
+    def predict_f_samples(self, Xnew, num_samples):
+        """models/model.py:135-148: samples from the posterior over f(Xnew); one Cholesky (on the GPU)
+        of the jittered posterior covariance per latent function.  Returns [num_samples, N*, R]."""
+        from .. import _backend as be
+        mu, var = self._build_predict(Xnew, full_cov=True)
+        jitter = np.eye(mu.shape[0], dtype=settings.float_type) * settings.numerics.jitter_level
+        samples = []
+        for i in range(self.num_latent):
+            L = be.get_handle().potrf(var[:, :, i] + jitter)
+            V = np.random.standard_normal((L.shape[0], num_samples)).astype(settings.float_type)
+            samples.append(mu[:, i:i + 1] + np.matmul(L, V))
+        return np.transpose(np.stack(samples))
 
     def predict_y(self, Xnew):
         """models/model.py:150-155"""

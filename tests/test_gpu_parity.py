@@ -219,3 +219,19 @@ def test_svgp_bound_parity(handle, whiten, q_diag):
     mu, var = m.predict_f(X[:50])
     rmu, rvar = orc.conditional(X[:50], Z, spec, q_mu, q_sqrt=np.asarray(m.q_sqrt), white=whiten)
     assert rel(mu, rmu) <= 1e-7 and rel(var, rvar) <= 1e-7
+
+
+def test_predict_f_samples_moments(handle):
+    """models/model.py:135-148: sample mean / covariance converge to predict_f_full_cov."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(0)
+    n, d, ns = 120, 2, 6
+    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, lengthscales=1.2), obs_var=0.2)
+    Xs = rng.standard_normal((ns, d))
+    np.random.seed(1)
+    S = m.predict_f_samples(Xs, 20000)
+    assert S.shape == (20000, ns, 1)
+    mu, cov = m.predict_f_full_cov(Xs)
+    assert np.abs(S[:, :, 0].mean(0) - mu[:, 0]).max() <= 0.02
+    assert np.abs(np.cov(S[:, :, 0].T) - cov[:, :, 0]).max() <= 0.02
