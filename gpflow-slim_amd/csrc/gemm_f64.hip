@@ -250,11 +250,12 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used
   const int force = h->gemm_force_tb;
   if (rowpanel) {
+    // leaves are latency-bound: aim at ~256 workgroups (one per CU), never fewer rows than 16
     int bm = 16;
     if (force) bm = force;
-    else if (t128 >= target) bm = 128;
-    else if (2.0 * t128 >= target) bm = 64;
-    else if (4.0 * t128 >= target) bm = 32;
+    else if (M / 128 >= 256) bm = 128;
+    else if (M / 64 >= 256) bm = 64;
+    else if (M / 32 >= 256) bm = 32;
     if (bm == 128) return launch_cfg<128, 128, 2>(h, op, 0, g, M, N);
     if (bm == 64) return launch_cfg<64, 128, 2>(h, op, 0, g, M, N);
     if (bm == 32) return launch_cfg<32, 128, 1>(h, op, 0, g, M, N);
