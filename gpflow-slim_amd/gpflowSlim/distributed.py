@@ -73,11 +73,30 @@ class TorchComm(object):
         return w if w is not None else _Done()
 
 
+    def all_gather_rows(self, local, counts):
+        """Concatenate per-rank row blocks `local` [counts[rank], c] (numpy, host) on every rank."""
+        if self.world == 1:
+            return local
+        import torch
+        dev = "cuda" if self._dist.get_backend(self.group) == "nccl" else "cpu"
+        c = local.shape[1]
+        mx = max(counts)
+        pad = np.zeros((mx, c))
+        pad[: local.shape[0]] = local
+        mine = torch.from_numpy(pad).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(parts, mine, group=self.group)
+        return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, counts)], axis=0)
+
+
 class SingleComm(object):
     rank, world = 0, 1
 
     def broadcast(self, tensor, src, async_op):
         return _Done()
+
+    def all_gather_rows(self, local, counts):
+        return local
 
 
 class HipPanelOps(object):
@@ -137,3 +156,35 @@ def gpr_lml_distributed(model, comm=None, nb=512, lookahead=True):
     lml = ops.finish()
     model._factor_key = model._state_key()      # L and alpha are resident (replicated) on every rank
     return lml
+
+
+def predict_f_distributed(model, Xnew, comm=None):
+    """predict_f with the test points sharded over the ranks (the multi-RHS solve is
+    independent over right-hand sides; L is replicated after gpr_lml_distributed, so there is no
+    exchange in the solve -- only the final gather of the [N*, R] outputs).  Every rank passes the same
+    Xnew and gets the full (mean, var) back.  Requires a resident factor (call gpr_lml_distributed or
+    compute_log_likelihood first); models/gpr.py:119-131 per shard."""
+    if comm is None:
+        try:
+            import torch.distributed as dist
+            comm = TorchComm() if dist.is_available() and dist.is_initialized() else SingleComm()
+        except ImportError:
+            comm = SingleComm()
+    Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
+    n_new = Xnew.shape[0]
+    bounds = [(n_new * r) // comm.world for r in range(comm.world + 1)]
+    counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+    lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+    saved = model.reuse_factor
+    model.reuse_factor = True
+    try:
+        if hi > lo:
+            mu, var = model.predict_f(Xnew[lo:hi])
+        else:
+            R = model.Y.shape[1]
+            mu, var = np.zeros((0, R)), np.zeros((0, R))
+    finally:
+        model.reuse_factor = saved
+    both = comm.all_gather_rows(np.concatenate([mu, var], axis=1), counts)
+    R = mu.shape[1]
+    return both[:, :R], both[:, R:]

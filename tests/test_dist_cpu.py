@@ -113,3 +113,36 @@ def test_schedule_single_rank_matches_lapack():
     ops = NumpyPanelOps(A, nb, 1, 0)
     block_column_schedule(ops, SingleComm(), ops.n_panels)
     assert np.abs(np.tril(ops.M) - np.linalg.cholesky(A)).max() <= 1e-10
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
+    import torch.distributed as dist
+    from gpflowSlim.distributed import TorchComm
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        counts = [3, 0, 5][:world]
+        local = np.full((counts[rank], 2), float(rank)) + np.arange(counts[rank])[:, None]
+        out = TorchComm().all_gather_rows(local, counts)
+        q.put((rank, out.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_rows_ragged_gloo():
+    """The gather behind predict_f_distributed: ragged (even empty) row blocks, same result on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [[0.0, 0.0], [1.0, 1.0], [2.0, 2.0]] + [[2.0 + i, 2.0 + i] for i in range(5)]
+    for r in range(world):
+        assert res[r] == expect

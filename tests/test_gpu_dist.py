@@ -60,6 +60,9 @@ def test_single_rank_distributed_equals_fused_path(handle, n, nb, lookahead):
     mu, var = m.predict_f(Xs)
     rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
     assert np.abs(mu - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var - rvar).max() <= 1e-8 * np.abs(rvar).max()
+    from gpflowSlim.distributed import predict_f_distributed
+    mu2, var2 = predict_f_distributed(m, Xs, SingleComm())
+    assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
     # and the ordinary fused path still works on the same handle afterwards
     assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
 
