@@ -75,6 +75,7 @@ struct gps_handle_s {
   DevBuf dFeat;     // feature workspace of the kernel-matrix build (rows)
   DevBuf dFeat2;    // feature workspace (cols / Xnew)
   DevBuf dProg;     // device copy of the kernel program
+  DevBuf dNkn;      // neural-kernel-network layer weights
   DevBuf dScal;     // small scalar outputs: [0]=sum log diag, [1]=sum alpha^2, ...
   DevBuf dInfo;     // int info word
   DevBuf dXnew;     // [n_new, d_all]

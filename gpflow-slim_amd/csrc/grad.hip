@@ -19,6 +19,7 @@
 #define GT_C 32            // tile cols
 #define G_MAXP 4           // primitives per program supported by the gradient kernel
 #define G_MAXSLOT 160
+#define GRAD_MAX_NODES 32
 #define G_MAXF 64          // features per primitive: periodic = 3 per dim (<= 21 dims)
 
 struct GPrepFeat { int dim; int kind; double param; };   // 0: x/param ; 1: cos(2pi x/param) ; 2: sin ; 3: 2pi x/param
@@ -28,7 +29,7 @@ struct GNode {
 };
 struct GProg {
   int n_nodes; int n_prims; int n_slots;
-  GNode nodes[GPS_MAX_NODES];
+  GNode nodes[GRAD_MAX_NODES];
 };
 struct GArgs {
   const double* Ft; i64 ldf;            // feature-major [rows][ldf]
@@ -355,7 +356,9 @@ int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, co
   std::vector<GPrepFeat> feats;
   std::vector<double> ls_of_slot;          // lengthscale that divides a per-dim slot
   P.n_nodes = n_nodes; P.n_prims = 0; P.n_slots = 0;
-  if (n_nodes <= 0 || n_nodes > GPS_MAX_NODES) return gps_fail(h, GPS_ERR_ARG, "gradient: bad program");
+  if (n_nodes <= 0 || n_nodes > GRAD_MAX_NODES) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradient: program too long");
+  for (int i = 0; i < n_nodes; ++i)
+    if (prog[i].op >= GPS_K_NKN_LINROW) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradient: neural-kernel-network programs are not supported yet");
   int depth = 0;
   for (int i = 0; i < n_nodes; ++i) {
     const gps_kern_node_t& nd = prog[i];

@@ -212,11 +212,127 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
   }
 }
 
+
+// ---- Neural Kernel Network epilogue ---------------------------------------------------------------
+// neural_kernel_network/neural_kernel_network.py:41-47 stacks the primitive kernel values of every
+// (i, j) entry into a vector and pushes it through Linear (positive weights) / Product / Activation
+// layers (neural_kernel_network_wrapper.py:90-173): a pure per-entry epilogue.  Here: all primitives'
+// feature slabs of a 64x64 tile sit in LDS at once, every thread walks its 4x4 patch one entry at a
+// time, evaluates up to 8 primitives and runs the network in registers (layer width <= 16, weights
+// zero-padded to 16x16 in LDS so the inner loops are branch-free).
+#define NKN_MAXP 8
+#define NKN_W 16
+#define NKN_MAXL 8
+struct NknLayer { int type; int in_dim; int out_dim; int step; int act; int w_off; };   // type 0 linear, 1 product, 2 act
+struct NknNet { int n_layers; int n_prims; int ftot; int nnorm; NknLayer layers[NKN_MAXL]; };
+
+__device__ __forceinline__ double prim_value(const KNodeDev& node, double dot, double ni, double nj) {
+  if (node.op == GPS_K_PERIODIC) {
+    const double l2 = node.c0 * node.c0;
+    const double rs = (0.5 * (double)(node.nf / 2) - 0.5 * dot) / l2;
+    return node.variance * exp(-0.5 * rs);
+  }
+  const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+  double r2 = -2.0 * dot + (ni + nj);
+  r2 = fmax(r2, 0.0);
+  if (node.op == GPS_K_RBF) return node.variance * exp(-r2 / 2.0);
+  const double r = sqrt(r2 + 1e-12);
+  if (node.op == GPS_K_MATERN12) return node.variance * exp(-r);
+  if (node.op == GPS_K_EXPONENTIAL) return node.variance * exp(-0.5 * r);
+  if (node.op == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * exp(-sq3 * r);
+  return node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * exp(-sq5 * r);
+}
+
+__global__ __launch_bounds__(256) void nkn_tile_kernel(KmatArgs a, KProgDev P, NknNet net,
+                                                       const double* __restrict__ Wg) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int rows_f = net.ftot + net.nnorm;                 // feature rows incl. the norm rows
+  double* Fr_s = reinterpret_cast<double*>(smem_raw);      // [rows_f][64]
+  double* Fc_s = Fr_s + rows_f * KT;                       // [rows_f][64]
+  double* W_s = Fc_s + rows_f * KT;                        // [n_layers][NKN_W][NKN_W + 1] (last col = bias)
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const i64 gi0 = (i64)ti * KT, gj0 = (i64)tj * KT;
+  for (int idx = tid; idx < rows_f * KT; idx += 256) {
+    const int f = idx >> 6, p = idx & 63;
+    Fr_s[idx] = a.Fr[(i64)f * a.ldfr + gi0 + p];
+    Fc_s[idx] = a.Fc[(i64)f * a.ldfc + gj0 + p];
+  }
+  for (int idx = tid; idx < net.n_layers * NKN_W * (NKN_W + 1); idx += 256) W_s[idx] = Wg[idx];
+  __syncthreads();
+
+  for (int e = 0; e < 16; ++e) {
+    const int li = ty * 4 + (e >> 2), lj = tx * 4 + (e & 3);
+    const i64 gi = a.row_off + gi0 + li, gj = a.col_off + gj0 + lj;
+    double vin[NKN_W], vout[NKN_W];
+#pragma unroll
+    for (int q = 0; q < NKN_W; ++q) vin[q] = 0.0;
+    // primitives (program order = input order of the first layer)
+#pragma unroll
+    for (int p = 0; p < NKN_MAXP; ++p) {
+      if (p < net.n_prims) {
+        const KNodeDev node = P.nodes[p];
+        double val;
+        if (node.op == GPS_K_CONSTANT) val = node.variance;
+        else if (node.op == GPS_K_WHITE) val = (a.sym && gi == gj) ? node.variance : 0.0;
+        else {
+          double dot = 0.0;
+          for (int f = 0; f < node.nf; ++f) dot = fma(Fr_s[(node.f0 + f) * KT + li], Fc_s[(node.f0 + f) * KT + lj], dot);
+          double ni = 0.0, nj = 0.0;
+          if (node.norm_row >= 0) { ni = Fr_s[node.norm_row * KT + li]; nj = Fc_s[node.norm_row * KT + lj]; }
+          val = prim_value(node, dot, ni, nj);
+        }
+        vin[p] = val;
+      }
+    }
+    for (int L = 0; L < net.n_layers; ++L) {
+      const NknLayer ly = net.layers[L];
+      if (ly.type == 0) {
+        const double* Wl = W_s + L * NKN_W * (NKN_W + 1);
+#pragma unroll
+        for (int o = 0; o < NKN_W; ++o) {
+          double acc = Wl[o * (NKN_W + 1) + NKN_W];
+#pragma unroll
+          for (int j = 0; j < NKN_W; ++j) acc = fma(Wl[o * (NKN_W + 1) + j], vin[j], acc);
+          vout[o] = acc;
+        }
+      } else if (ly.type == 1) {
+#pragma unroll
+        for (int o = 0; o < NKN_W; ++o) vout[o] = 0.0;
+        if (ly.step == 2) {
+#pragma unroll
+          for (int o = 0; o < NKN_W / 2; ++o) vout[o] = vin[2 * o] * vin[2 * o + 1];
+        } else if (ly.step == 3) {
+#pragma unroll
+          for (int o = 0; o < NKN_W / 3; ++o) vout[o] = vin[3 * o] * vin[3 * o + 1] * vin[3 * o + 2];
+        } else {
+#pragma unroll
+          for (int o = 0; o < NKN_W / 4; ++o) vout[o] = (vin[4 * o] * vin[4 * o + 1]) * (vin[4 * o + 2] * vin[4 * o + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int o = 0; o < NKN_W; ++o) vout[o] = exp(vin[o]);
+      }
+#pragma unroll
+      for (int q = 0; q < NKN_W; ++q) vin[q] = vout[q];
+    }
+    double val = vin[0];
+    if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
+    else if (a.sym && gi == gj) val += a.diag_add;
+    a.K[(gi0 + li) * a.ldk + gj0 + lj] = val;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct KCompiled {
   KProgDev prog;
   std::vector<PrepFeat> feats;
   std::vector<PrepNorm> norms;
+  bool has_nkn = false;
+  NknNet net;
+  std::vector<double> W;       // [n_layers][16][17]
 };
 
 static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all,
@@ -225,7 +341,19 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
     return gps_fail(h, GPS_ERR_ARG, "kernel program: 1..GPS_MAX_NODES nodes expected");
   int depth = 0;
   out.prog.n_nodes = n_nodes;
-  for (int i = 0; i < n_nodes; ++i) {
+  for (int i = 0; i < n_nodes; ++i)
+    if (prog[i].op >= GPS_K_NKN_LINROW) out.has_nkn = true;
+  int n_prim_nodes = n_nodes;
+  if (out.has_nkn) {
+    n_prim_nodes = 0;
+    while (n_prim_nodes < n_nodes && prog[n_prim_nodes].op < GPS_K_ADD) ++n_prim_nodes;
+    if (n_prim_nodes == 0 || n_prim_nodes > NKN_MAXP)
+      return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: 1..8 primitive kernels first");
+    for (int i = n_prim_nodes; i < n_nodes; ++i)
+      if (prog[i].op < GPS_K_NKN_LINROW) return gps_fail(h, GPS_ERR_ARG, "NKN program: layers must follow the primitives");
+    out.prog.n_nodes = n_prim_nodes;
+  }
+  for (int i = 0; i < n_prim_nodes; ++i) {
     const gps_kern_node_t& nd = prog[i];
     KNodeDev& kd = out.prog.nodes[i];
     kd.op = nd.op; kd.f0 = 0; kd.nf = 0; kd.norm_row = -1; kd.variance = nd.variance; kd.c0 = 0.0;
@@ -271,19 +399,112 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
       default:
         return gps_fail(h, GPS_ERR_UNSUPPORTED, "kernel program: unknown op");
     }
-    if (depth > GPS_MAX_STACK)
+    if (!out.has_nkn && depth > GPS_MAX_STACK)
       return gps_fail(h, GPS_ERR_UNSUPPORTED, "kernel program: expression deeper than GPS_MAX_STACK");
   }
-  if (depth != 1) return gps_fail(h, GPS_ERR_ARG, "kernel program: must leave exactly one value");
+  if (!out.has_nkn && depth != 1) return gps_fail(h, GPS_ERR_ARG, "kernel program: must leave exactly one value");
   const int nfeat = (int)out.feats.size();
-  for (int i = 0; i < n_nodes; ++i)
+  for (int i = 0; i < n_prim_nodes; ++i)
     if (out.prog.nodes[i].norm_row >= 0) out.prog.nodes[i].norm_row += nfeat;
+  if (!out.has_nkn) return GPS_OK;
+  // ---- layers
+  NknNet& net = out.net;
+  net.n_layers = 0; net.n_prims = n_prim_nodes; net.ftot = nfeat; net.nnorm = (int)out.norms.size();
+  int width = n_prim_nodes;
+  int i = n_prim_nodes;
+  while (i < n_nodes) {
+    if (net.n_layers >= NKN_MAXL) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: more than 8 layers");
+    NknLayer& ly = net.layers[net.n_layers];
+    const int lid = prog[i].active_dims[0];
+    out.W.resize((size_t)(net.n_layers + 1) * NKN_W * (NKN_W + 1), 0.0);
+    double* Wl = out.W.data() + (size_t)net.n_layers * NKN_W * (NKN_W + 1);
+    ly.w_off = net.n_layers * NKN_W * (NKN_W + 1); ly.step = 0; ly.act = 0;
+    if (prog[i].op == GPS_K_NKN_LINROW) {
+      int o = 0;
+      while (i < n_nodes && prog[i].op == GPS_K_NKN_LINROW && prog[i].active_dims[0] == lid) {
+        if (prog[i].n_dims != width || o >= NKN_W) return gps_fail(h, GPS_ERR_ARG, "NKN program: Linear layer width mismatch (max 16)");
+        for (int j = 0; j < width; ++j) Wl[o * (NKN_W + 1) + j] = prog[i].lengthscales[j];
+        Wl[o * (NKN_W + 1) + NKN_W] = prog[i].variance;
+        ++o; ++i;
+      }
+      ly.type = 0; ly.in_dim = width; ly.out_dim = o; width = o;
+    } else if (prog[i].op == GPS_K_NKN_PRODUCT) {
+      const int step = prog[i].n_dims;
+      if (step < 2 || step > 4 || width % step) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: Product step must be 2, 3 or 4 and divide the width");
+      ly.type = 1; ly.in_dim = width; ly.step = step; ly.out_dim = width / step; width = ly.out_dim; ++i;
+    } else if (prog[i].op == GPS_K_NKN_ACT) {
+      if (prog[i].period != 1.0) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: only the exp activation is available");
+      ly.type = 2; ly.in_dim = width; ly.out_dim = width; ly.act = 1; ++i;
+    } else return gps_fail(h, GPS_ERR_ARG, "NKN program: unknown layer op");
+    ++net.n_layers;
+  }
+  if (width != 1) return gps_fail(h, GPS_ERR_ARG, "NKN program: the network must end with one output");
+  if (nfeat + (int)out.norms.size() > 2 * KMAXF) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: too many features");
+  return GPS_OK;
+}
+
+// launch the tile pass (plain program or NKN) for prepared features
+static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 prow, i64 pcol, int n_nodes,
+                        double tiles) {
+  const int nfeat_total = (int)kc.feats.size();
+  if (kc.has_nkn) {
+    const size_t wbytes = kc.W.size() * 8;
+    GPS_HIP(h, h->dNkn.ensure(wbytes + 64));
+    GPS_HIP(h, hipMemcpyAsync(h->dNkn.p, kc.W.data(), wbytes, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    const int rows_f = kc.net.ftot + kc.net.nnorm;
+    const size_t lds = ((size_t)2 * rows_f * KT + (size_t)kc.net.n_layers * NKN_W * (NKN_W + 1)) * 8;
+    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nkn_tile_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 160 * 1024) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: feature slabs exceed LDS");
+    LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 600.0 * kc.net.n_layers), tiles * KT * KT * 8.0);
+    hipLaunchKernelGGL(nkn_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream,
+                       a, kc.prog, kc.net, (const double*)h->dNkn.p);
+    GPS_HIP(h, hipGetLastError());
+    return GPS_OK;
+  }
+  int maxnf = 1;
+  for (int i = 0; i < kc.prog.n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
+  a.maxnf = maxnf;
+  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
+  GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
+  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);
+  hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds,
+                     h->stream, a, kc.prog);
+  GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
 
 int gps_launch_kdiag(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* kdiag_const) {
   // Kdiag of every primitive is its variance (kernels.py:428-429, 803-804, 327-328);
   // Sum.Kdiag / Product.Kdiag fold them (kernels.py:1075-1076, 1083-1084).
+  bool nkn = false;
+  for (int i = 0; i < n_nodes; ++i) if (prog[i].op >= GPS_K_NKN_LINROW) nkn = true;
+  if (nkn) {
+    // NeuralKernelNetwork.Kdiag (neural_kernel_network.py:35-39): the primitives' Kdiag through the layers
+    KCompiled kc;
+    int rc = compile_prog(h, prog, n_nodes, 1 << 20, kc);
+    if (rc) return rc;
+    double vin[NKN_W] = {0}, vout[NKN_W];
+    for (int p = 0; p < kc.net.n_prims; ++p) vin[p] = prog[p].variance;
+    for (int L = 0; L < kc.net.n_layers; ++L) {
+      const NknLayer& ly = kc.net.layers[L];
+      const double* Wl = kc.W.data() + (size_t)L * NKN_W * (NKN_W + 1);
+      for (int o = 0; o < NKN_W; ++o) vout[o] = 0.0;
+      if (ly.type == 0) {
+        for (int o = 0; o < NKN_W; ++o) { double acc = Wl[o * (NKN_W + 1) + NKN_W]; for (int j = 0; j < NKN_W; ++j) acc = fma(Wl[o * (NKN_W + 1) + j], vin[j], acc); vout[o] = acc; }
+      } else if (ly.type == 1) {
+        for (int o = 0; o < NKN_W / ly.step; ++o) { double pr = 1.0; for (int q = 0; q < ly.step; ++q) pr *= vin[o * ly.step + q]; vout[o] = pr; }
+      } else {
+        for (int o = 0; o < NKN_W; ++o) vout[o] = exp(vin[o]);
+      }
+      for (int o = 0; o < NKN_W; ++o) vin[o] = vout[o];
+    }
+    *kdiag_const = vin[0];
+    return GPS_OK;
+  }
   double st[GPS_MAX_NODES]; int sp = 0;
   for (int i = 0; i < n_nodes; ++i) {
     if (prog[i].op == GPS_K_ADD || prog[i].op == GPS_K_MUL) {
@@ -348,23 +569,8 @@ int gps_launch_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   a.row_off = 0; a.col_off = 0;
   double tiles = (double)(prow / KT) * (double)(pcol / KT);
   if (a.lower_only) tiles = 0.5 * tiles + 0.5 * (double)(prow / KT);
-  const int nfeat_total = (int)kc.feats.size();
-  int maxnf = 1;
-  for (int i = 0; i < n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
-  a.maxnf = maxnf;
-  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
-    attr_set = true;
-  }
-  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);
-  hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds,
-                     h->stream, a, kc.prog);
-  GPS_HIP(h, hipGetLastError());
-  return GPS_OK;
+  a.maxnf = 1;
+  return launch_tiles(h, kc, a, prow, pcol, n_nodes, tiles);
 }
 
 
@@ -390,17 +596,7 @@ int gps_launch_kmat_block(gps_handle_t h, const gps_kern_node_t* prog, int n_nod
   a.Fr = h->dFeat.d() + r0; a.Fc = h->dFeat.d() + c0; a.ldfr = ldf; a.ldfc = ldf;
   a.K = dKb; a.ldk = ldk; a.n = n; a.m = n; a.sym = 1; a.lower_only = 0; a.identity_pad = 1;
   a.diag_add = diag_add; a.row_off = r0; a.col_off = c0;
-  int maxnf = 1;
-  for (int i = 0; i < n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
-  a.maxnf = maxnf;
-  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
-  GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
+  a.maxnf = 1;
   const double tiles = (double)(nrows / KT) * (double)(ncols / KT);
-  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * (double)kc.feats.size() + 30.0), tiles * KT * KT * 8.0);
-  hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(ncols / KT), (unsigned)(nrows / KT)), dim3(256), lds,
-                     h->stream, a, kc.prog);
-  GPS_HIP(h, hipGetLastError());
-  return GPS_OK;
+  return launch_tiles(h, kc, a, nrows, ncols, n_nodes, tiles);
 }

@@ -15,6 +15,7 @@ from . import conditionals
 from . import features
 from . import kullback_leiblers
 from . import models
+from . import neural_kernel_network
 from ._backend import NotPositiveDefiniteError, get_handle, set_handle, Handle, load_library
 
 __version__ = "0.1.0"

@@ -11,12 +11,13 @@ import threading
 import numpy as np
 
 GPS_MAX_DIMS = 32
-GPS_MAX_NODES = 32
+GPS_MAX_NODES = 64
 GPS_MAX_STACK = 4
 
 # enum gps_kern_op
 K_RBF, K_MATERN12, K_MATERN32, K_MATERN52, K_PERIODIC, K_WHITE, K_CONSTANT, K_EXPONENTIAL = 1, 2, 3, 4, 5, 6, 7, 8
 K_ADD, K_MUL = 16, 17
+K_NKN_LINROW, K_NKN_PRODUCT, K_NKN_ACT = 32, 33, 34
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int)

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define GPS_MAX_DIMS   32   /* active dims per primitive kernel            */
-#define GPS_MAX_NODES  32   /* instructions per kernel program             */
+#define GPS_MAX_NODES  64   /* instructions per kernel program             */
 #define GPS_MAX_STACK   4   /* evaluation-stack depth of a kernel program  */
 
 #define GPS_OK              0
@@ -54,7 +54,14 @@ enum gps_kern_op {
                           scalars of Combination.const_list :1026-1027      */
   GPS_K_EXPONENTIAL = 8, /* Exponential.K  kernels.py:560-565 */
   GPS_K_ADD      = 16, /* Sum.K     reduce(tf.add, ...)      :1073          */
-  GPS_K_MUL      = 17  /* Product.K reduce(tf.multiply, ...) :1081          */
+  GPS_K_MUL      = 17, /* Product.K reduce(tf.multiply, ...) :1081          */
+  /* Neural Kernel Network (neural_kernel_network/neural_kernel_network.py:41-47): a program that
+   * contains these ops is "layered": up to 8 primitive nodes first (their values form the input
+   * vector), then the layers in order.  active_dims[0] = layer index.                           */
+  GPS_K_NKN_LINROW  = 32, /* one output of a Linear layer (neural_kernel_network_wrapper.py:90-120):
+                             n_dims = input width, lengthscales[0..n_dims) = weights, variance = bias */
+  GPS_K_NKN_PRODUCT = 33, /* Product layer (:134-152): n_dims = step (2, 3 or 4)                  */
+  GPS_K_NKN_ACT     = 34  /* Activation layer (:155-173): period = 1 -> exp                       */
 };
 
 typedef struct gps_kern_node {

@@ -32,6 +32,8 @@ Reference lines followed (paths relative to the reference checkout, gpflowSlim/.
   features.py:74-81               InducingPoints.Kuu / Kuf
   kullback_leiblers.py:26-105     gauss_kl
   models/svgp.py:101-130          SVGP bound (Gaussian likelihood)
+  neural_kernel_network/neural_kernel_network.py:35-47, neural_kernel_network_wrapper.py:39-44,116-117,145-148
+                                  NeuralKernelNetwork.K / Kdiag and its layers
 """
 from functools import reduce
 
@@ -138,6 +140,8 @@ def K(spec, X, X2=None):
     if isinstance(spec, (int, float)):
         return spec                                     # kernels.py:1060-1063 _kernel_function
     t = spec["type"]
+    if t == "nkn":
+        return nkn_K(spec["primitives"], spec["layers"], X, X2)
     if t in ("sum", "product"):
         vals = [K(c, X, X2) for c in spec["children"] if not isinstance(c, (int, float))]
         consts = [c for c in spec["children"] if isinstance(c, (int, float))]
@@ -168,11 +172,42 @@ def K(spec, X, X2=None):
     raise ValueError("unknown kernel type %r" % t)
 
 
+def nkn_forward(layers, v):
+    """neural_kernel_network_wrapper.py:39-44: v [nm, k] through the layers.
+    layers: [("linear", W [out,in], b [out]) | ("product", step) | ("exp",)]"""
+    for ly in layers:
+        if ly[0] == "linear":
+            v = np.matmul(v, np.transpose(ly[1])) + ly[2]                 # :116-117
+        elif ly[0] == "product":
+            v = np.prod(np.reshape(v, [v.shape[0], -1, ly[1]]), -1)       # :145-148
+        elif ly[0] == "exp":
+            v = np.exp(v)
+        else:
+            raise ValueError(ly[0])
+    return v
+
+
+def nkn_K(prim_specs, layers, X, X2=None):
+    """neural_kernel_network.py:41-47"""
+    vals = [K(s, X, X2) for s in prim_specs]
+    shape = vals[0].shape
+    stacked = np.stack([v.reshape(-1) for v in vals], 1)
+    return nkn_forward(layers, stacked).reshape(shape)
+
+
+def nkn_Kdiag(prim_specs, layers, X):
+    """neural_kernel_network.py:35-39"""
+    stacked = np.stack([Kdiag(s, X) for s in prim_specs], 1)
+    return np.squeeze(nkn_forward(layers, stacked), -1)
+
+
 def Kdiag(spec, X):
     """kernels.py:428-429, 803-804, 327-328, 1075-1076, 1083-1084"""
     if isinstance(spec, (int, float)):
         return spec
     t = spec["type"]
+    if t == "nkn":
+        return nkn_Kdiag(spec["primitives"], spec["layers"], X)
     if t in ("sum", "product"):
         vals = [Kdiag(c, X) for c in spec["children"] if not isinstance(c, (int, float))]
         consts = [c for c in spec["children"] if isinstance(c, (int, float))]

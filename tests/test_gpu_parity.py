@@ -235,3 +235,71 @@ def test_predict_f_samples_moments(handle):
     mu, cov = m.predict_f_full_cov(Xs)
     assert np.abs(S[:, :, 0].mean(0) - mu[:, 0]).max() <= 0.02
     assert np.abs(np.cov(S[:, :, 0].T) - cov[:, :, 0]).max() <= 0.02
+
+
+def _nkn_case(gpf, d, act=False):
+    """NKN of the paper's shape: 6 primitives -> Linear 6->8 -> Product(2) -> Linear 4->2 -> [exp] -> Linear 2->1"""
+    from gpflowSlim.neural_kernel_network import NeuralKernelNetwork, NKNWrapper
+    k = gpf.kernels
+    c = orc.constrained
+    ls = np.linspace(0.8, 1.6, d)
+    prims = [k.RBF(d, variance=1.0, lengthscales=ls, ARD=True), k.RBF(d, variance=0.7, lengthscales=2.5),
+             k.Matern52(d, variance=0.9, lengthscales=1.3), k.Periodic(d, period=2.0, variance=0.8, lengthscales=1.1),
+             k.Matern32(1, variance=0.6, lengthscales=0.9, active_dims=[0]), k.Constant(d, variance=0.3)]
+    pspecs = [{"type": "rbf", "variance": c(1.0), "lengthscales": c(ls), "input_dim": d},
+              {"type": "rbf", "variance": c(0.7), "lengthscales": c(2.5), "input_dim": d},
+              {"type": "matern52", "variance": c(0.9), "lengthscales": c(1.3), "input_dim": d},
+              {"type": "periodic", "variance": c(0.8), "lengthscales": c(1.1), "period": c(2.0), "input_dim": d},
+              {"type": "matern32", "variance": c(0.6), "lengthscales": c(0.9), "input_dim": 1, "active_dims": [0]},
+              {"type": "constant", "variance": c(0.3)}]
+    np.random.seed(3)
+    hp = [{'name': 'Linear', 'params': {'input_dim': 6, 'output_dim': 8, 'name': 'l1'}},
+          {'name': 'Product', 'params': {'input_dim': 8, 'step': 2, 'name': 'p1'}},
+          {'name': 'Linear', 'params': {'input_dim': 4, 'output_dim': 2, 'name': 'l2'}}]
+    if act:
+        hp.append({'name': 'Activation', 'params': {'input_dim': 2, 'activation_fn': 'exp', 'name': 'a1'}})
+    hp.append({'name': 'Linear', 'params': {'input_dim': 2, 'output_dim': 1, 'name': 'l3'}})
+    wrapper = NKNWrapper(hp)
+    kern = NeuralKernelNetwork(d, prims, wrapper)
+    layers = []
+    for l in wrapper._layers:
+        nm = type(l).__name__
+        layers.append(("linear", np.asarray(l.weights), np.asarray(l.bias)) if nm == "Linear" else
+                      (("product", l.step) if nm == "Product" else ("exp",)))
+    return kern, {"type": "nkn", "primitives": pspecs, "layers": layers}
+
+
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("n,m,d", [(5, 3, 2), (130, 77, 3), (300, 200, 4)])
+def test_neural_kernel_network_parity(handle, act, n, m, d):
+    """neural_kernel_network.py:35-47 + wrapper layers, fused into the kernel-matrix build."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m)
+    X = rng.standard_normal((n, d)); X2 = rng.standard_normal((m, d))
+    kern, spec = _nkn_case(gpf, d, act)
+    K = kern.K(X)
+    Kr = orc.K(spec, X)
+    assert rel(K, Kr) <= 5e-9 and np.array_equal(K, K.T)
+    off = ~np.eye(n, dtype=bool)
+    assert np.abs(K[off] - Kr[off]).max() <= 1e-12 * np.abs(Kr).max()
+    assert rel(kern.K(X, X2), orc.K(spec, X, X2)) <= 1e-12
+    assert np.allclose(kern.Kdiag(X), orc.Kdiag(spec, X), rtol=1e-14)
+    assert len(kern.parameters) == 2 * 3 + (2 + 2 + 2 + 3 + 2 + 1)      # 3 Linear layers + the primitives' parameters
+
+
+def test_neural_kernel_network_gpr_parity(handle):
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(5)
+    n, d, ns = 400, 3, 60
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, 1))) + 0.1 * rng.standard_normal((n, 1))
+    Xs = rng.standard_normal((ns, d))
+    kern, spec = _nkn_case(gpf, d, False)
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    noise = orc.constrained(0.1)
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    assert abs(m.compute_log_likelihood() - ref) <= RTOL * abs(ref)
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+    assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        m.compute_log_likelihood_and_gradients()

@@ -117,7 +117,7 @@ def test_kernel_program_compilation(gpf):
     assert not s.on_separate_dimensions
     assert k.Sum([k.RBF(1, active_dims=[0]), k.RBF(1, active_dims=[1])]).on_separate_dimensions
     with pytest.raises(ValueError):
-        be.make_program([be.op_node(be.K_ADD)] * 40)
+        be.make_program([be.op_node(be.K_ADD)] * 70)
     with pytest.raises(TypeError):
         k.Sum([rbf, "x"])
 
