@@ -173,6 +173,19 @@ __global__ void var_finish_kernel(double* __restrict__ var, const double* __rest
   if (i < n) var[i] = (kdiag ? kdiag[i] : kconst) - sumsq[i];
 }
 
+// B <- scale * B + I on an [n, n] matrix (lower triangle is what matters); rows/cols >= n_real: identity
+__global__ __launch_bounds__(256) void scale_add_eye_kernel(double* __restrict__ B, i64 ldb, i64 n, i64 n_real,
+                                                            double scale) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  for (i64 rr = blockIdx.y; rr < n; rr += gridDim.y) {
+    double v;
+    if (rr < n_real && c < n_real) v = scale * B[rr * ldb + c] + (rr == c ? 1.0 : 0.0);
+    else v = (rr == c) ? 1.0 : 0.0;
+    B[rr * ldb + c] = v;
+  }
+}
+
 // dst[c][r] = src[r][c]  (32x32 LDS tiles)
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, i64 lds_,
                                                         i64 rows, i64 cols,
@@ -323,6 +336,15 @@ int gps_launch_extract(gps_handle_t h, const double* src, i64 lds_, i64 rows, i6
   dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
   hipLaunchKernelGGL(extract_kernel, grid, dim3(256), 0, h->stream, src, lds_, rows, cols, dst, ldd,
                      lower_only);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_scale_add_eye(gps_handle_t h, double* B, i64 ldb, i64 n, i64 n_real, double scale) {
+  if (n <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n < 32768 ? n : 32768));
+  hipLaunchKernelGGL(scale_add_eye_kernel, grid, dim3(256), 0, h->stream, B, ldb, n, n_real, scale);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

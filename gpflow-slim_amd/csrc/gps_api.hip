@@ -100,7 +100,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
                     &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn};
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   delete h;
@@ -928,5 +928,158 @@ extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   stage_time(h, 2, 3, &h->stage_ms[2]);
   h->stage_ms[3] = 0.0;
   stage_time(h, 0, 3, &h->stage_ms[4]);
+  return GPS_OK;
+}
+
+
+// ---- SGPR (Titsias 2009): bound and prediction ---------------------------------------------------------
+// models/sgpr.py:121-153 (_build_likelihood) and :155-189 (_build_predict).  Everything O(M^2 N) runs on the
+// device: Kuu potrf, (L^-1 Kuf)^T by trsm_rec, A A^T as one long-K NT GEMM, second potrf, solves.
+extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                        const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                        const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
+                        double* bound_out, double* mean_out, double* var_out, int* info) {
+  if (!h || !Z || !X || !resid || m <= 0 || n <= 0 || d_all <= 0 || r <= 0 || !(noise_var > 0.0))
+    return gps_fail(h, GPS_ERR_ARG, "gps_sgpr: bad argument");
+  if (n_new > 0 && (!Xnew || !mean_out || !var_out)) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr: prediction outputs missing");
+  GPS_HIP(h, hipSetDevice(h->device));
+  if (info) *info = 0;
+  h->have_factor = false; h->n = 0;                       // GPR resident buffers are reused below
+  const i64 mp = gps_pad(m), np = gps_pad(n);
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  const double sigma2 = noise_var;
+  // buffers: dX <- Z ; dXnew <- X (then Xnew) ; dK <- Kuu/L ; dLinv (2 sets for L) ; dS1 <- At [np, mp] ;
+  //          dS2 <- A [mp, np] ; dS3 <- B / LB [mp, mp] ; dS4 <- inverses of LB (2 sets)
+  GPS_HIP(h, h->dX.ensure((size_t)m * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dX.p, Z, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dXnew.ensure((size_t)(n > n_new ? n : n_new) * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dK.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dS1.ensure((size_t)np * mp * 8));
+  GPS_HIP(h, h->dS2.ensure((size_t)mp * np * 8));
+  GPS_HIP(h, h->dS3.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dS4.ensure(2 * blk_bytes));
+  int* d_info = (int*)h->dInfo.p;
+  int rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  // Kuu + jitter I -> L                                                 (features.py:74-77, sgpr.py:133-135)
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), m, nullptr, m, d_all, jitter, h->dK.d(), mp, mp, mp, 1, 1);
+  if (rc) return rc;
+  HipOps opsL{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, d_info};
+  Blocked<HipOps> blL(opsL);
+  rc = blL.potrf_rec(h->dK.d(), mp, mp, 0, 0);
+  if (rc) return rc;
+  // At = K(X, Z) L^-T  = (L^-1 Kuf)^T   [np, mp]                         (sgpr.py:139, without the 1/sigma)
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n, h->dX.d(), m, d_all, 0.0, h->dS1.d(), mp, np, mp, 0, 0);
+  if (rc) return rc;
+  rc = blL.trsm_rec(h->dK.d(), mp, mp, 0, h->dS1.d(), mp, np);
+  if (rc) return rc;
+  // A = At^T [mp, np] ; B = A A^T / sigma^2 + I ; LB = chol(B)           (sgpr.py:140-142)
+  rc = gps_launch_transpose(h, h->dS1.d(), mp, np, mp, h->dS2.d(), np);
+  if (rc) return rc;
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, h->dS2.d(), np, h->dS2.d(), np, h->dS3.d(), mp);
+  if (rc) return rc;
+  rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, 1.0 / sigma2);
+  if (rc) return rc;
+  HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, d_info};
+  Blocked<HipOps> blB(opsB);
+  rc = blB.potrf_rec(h->dS3.d(), mp, mp, 0, 0);
+  if (rc) return rc;
+  // Aerr*sigma = (L^-1 Kuf) err [m, r] and rowsumsq(A*sigma) = sigma^2 diag(AAT)   (sgpr.py:143, 152)
+  GPS_HIP(h, h->dAlpha.ensure((size_t)r * (np > mp ? np : mp) * 8 * 2));
+  double* dErrT = h->dAlpha.d();                                 // [r][np]
+  double* dC = dErrT + (size_t)r * np;                           // [r][mp]
+  GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(dErrT, 0, (size_t)r * np * 8, h->stream));
+  rc = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dErrT, np);
+  if (rc) return rc;
+  GPS_HIP(h, h->dMean.ensure((size_t)(mp * r + mp) * 8 + (size_t)(n_new > 0 ? (n_new * r + 2 * n_new) * 8 : 0)));
+  double* dAerr = h->dMean.d();                                  // [m][r]
+  double* dDiag = dAerr + (size_t)mp * r;                        // [m]
+  rc = gps_launch_rowdot(h, h->dS2.d(), np, m, np, dErrT, np, r, dAerr, dDiag);
+  if (rc) return rc;
+  // c = LB^-1 Aerr / sigma : c*sigma^2 = LB^-1 (Aerr*sigma)              (sgpr.py:144)
+  GPS_HIP(h, hipMemsetAsync(dC, 0, (size_t)r * mp * 8, h->stream));
+  rc = gps_launch_transpose(h, dAerr, r, m, r, dC, mp);
+  if (rc) return rc;
+  rc = blB.trsv_rec(h->dS3.d(), mp, mp, 0, dC, mp, r);
+  if (rc) return rc;
+  // reductions: sum log diag LB, sum (c sigma^2)^2
+  double* part = h->dScal.d();
+  rc = gps_launch_lml_reduce(h, h->dS3.d(), mp, m, dC, mp, r, part);
+  if (rc) return rc;
+  double hp[2 * 64];
+  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> hdiag(m);
+  GPS_HIP(h, hipMemcpyAsync(hdiag.data(), dDiag, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+  int linfo = 0;
+  rc = read_info(h, d_info, &linfo);
+  if (rc) return rc;
+  if (info) *info = linfo;
+  if (linfo) return GPS_OK;
+  double slogLB = 0.0, sc2 = 0.0, trAAT = 0.0, serr2 = 0.0;
+  for (int b = 0; b < 64; ++b) { slogLB += hp[2 * b]; sc2 += hp[2 * b + 1]; }
+  for (i64 i = 0; i < m; ++i) trAAT += hdiag[i];
+  trAAT /= sigma2;
+  sc2 /= (sigma2 * sigma2);                                      // c = (c sigma^2) / sigma^2
+  for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
+  double kdiag = 0.0;
+  rc = gps_launch_kdiag(h, prog, n_nodes, &kdiag);
+  if (rc) return rc;
+  if (bound_out) {
+    const double N = (double)n, R = (double)r;
+    double bound = -0.5 * N * R * log(2.0 * M_PI);               // sgpr.py:147-153
+    bound += -R * slogLB;
+    bound -= 0.5 * N * R * log(sigma2);
+    bound += -0.5 * serr2 / sigma2;
+    bound += 0.5 * sc2;
+    bound += -0.5 * R * (N * kdiag) / sigma2;
+    bound += 0.5 * R * trAAT;
+    *bound_out = bound;
+  }
+  if (n_new <= 0) return GPS_OK;
+  // ---- prediction                                                      (sgpr.py:155-189)
+  const i64 nsp = gps_pad(n_new);
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, Xnew, (size_t)n_new * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dB.ensure((size_t)nsp * mp * 8 * 2));
+  double* T1 = h->dB.d();                                         // tmp1^T [nsp, mp]
+  double* T2 = T1 + (size_t)nsp * mp;                             // tmp2^T
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, h->dX.d(), m, d_all, 0.0, T1, mp, nsp, mp, 0, 0);
+  if (rc) return rc;
+  rc = blL.trsm_rec(h->dK.d(), mp, mp, 0, T1, mp, nsp);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(T2, T1, (size_t)nsp * mp * 8, hipMemcpyDeviceToDevice, h->stream));
+  rc = blB.trsm_rec(h->dS3.d(), mp, mp, 0, T2, mp, nsp);
+  if (rc) return rc;
+  double* dmean = dDiag + mp;                                     // [n_new][r]
+  double* dss2 = dmean + (size_t)n_new * r;
+  double* dss1 = dss2 + n_new;
+  rc = gps_launch_rowdot(h, T2, mp, n_new, mp, dC, mp, r, dmean, dss2);     // tmp2^T (c sigma^2)
+  if (rc) return rc;
+  rc = gps_launch_rowdot(h, T1, mp, n_new, mp, nullptr, mp, 0, nullptr, dss1);
+  if (rc) return rc;
+  std::vector<double> hm((size_t)n_new * r), h2(n_new), h1(n_new);
+  GPS_HIP(h, hipMemcpyAsync(hm.data(), dmean, hm.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h2.data(), dss2, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h1.data(), dss1, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  if (full_cov) {
+    GPS_HIP(h, h->dVar.ensure((size_t)nsp * nsp * 8));
+    rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, nullptr, n_new, d_all, 0.0, h->dVar.d(), nsp, nsp, nsp, 0, 0);
+    if (rc) return rc;
+    rc = gps_launch_gemm_nt(h, 2, 0, nsp, nsp, mp, T2, mp, T2, mp, h->dVar.d(), nsp);
+    if (rc) return rc;
+    rc = gps_launch_gemm_nt(h, 0, 0, nsp, nsp, mp, T1, mp, T1, mp, h->dVar.d(), nsp);
+    if (rc) return rc;
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n_new * n_new * 8));
+    rc = gps_launch_extract(h, h->dVar.d(), nsp, n_new, n_new, h->dTmp2.d(), n_new, 0);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(var_out, h->dTmp2.p, (size_t)n_new * n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < hm.size(); ++i) mean_out[i] = hm[i] / sigma2;       // c = (c sigma^2)/sigma^2
+  if (!full_cov)
+    for (i64 i = 0; i < n_new; ++i) var_out[i] = kdiag + h2[i] - h1[i];
   return GPS_OK;
 }

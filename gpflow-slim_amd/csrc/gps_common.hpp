@@ -90,6 +90,7 @@ struct gps_handle_s {
   DevBuf dA;        // [r][npad]  K_y^-1 (Y - m)                         (gradient path)
   DevBuf dY;        // [npad, npad]  L^-T                                 (gradient path)
   DevBuf dKinv;     // [npad, npad]  K_y^-1, lower triangle               (gradient path)
+  DevBuf dS1, dS2, dS3, dS4;   // SGPR work space (gps_sgpr)
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
@@ -173,6 +174,7 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
                         double diag_add);
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
+int gps_launch_scale_add_eye(gps_handle_t h, double* B, i64 ldb, i64 n, i64 n_real, double scale);
 int gps_launch_var_finish(gps_handle_t h, double* var, const double* kdiag_or_null,
                           double kdiag_const, const double* sumsq, i64 n);
 // kmat.hip

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "gps_base_conditional": [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _i64, _i64, _c_double_p,
                              _i64, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                              _c_double_p, _c_int_p],
+    "gps_sgpr": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
+                 ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int, _c_double_p,
+                 _c_double_p, _c_double_p, _c_int_p],
     "gps_profile_enable": [ctypes.c_void_p, ctypes.c_int],
     "gps_profile_reset": [ctypes.c_void_p],
     "gps_profile_get": [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_i64), _c_double_p, _c_double_p,
@@ -403,6 +406,30 @@ class Handle(object):
                 "Cholesky decomposition was not successful: leading minor of order %d is not positive definite"
                 % info.value)
         return mean, var
+
+    # ---- SGPR
+    def sgpr(self, prog, Z, X, resid, jitter, noise_var, Xnew=None, full_cov=False, want_bound=True):
+        Z, X, resid = _f64(Z), _f64(X), _f64(resid)
+        m, d = Z.shape
+        n, r = resid.shape
+        bound = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        if Xnew is not None:
+            Xnew = _f64(Xnew)
+            n_new = Xnew.shape[0]
+            mean = np.empty((n_new, r))
+            var = np.empty((n_new, n_new) if full_cov else (n_new,))
+            xp, mp_, vp = _ptr(Xnew), _ptr(mean), _ptr(var)
+        else:
+            n_new, mean, var, xp, mp_, vp = 0, None, None, None, None, None
+        self.resident_token = None
+        self._check(self._lib.gps_sgpr(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter),
+                                       float(noise_var), _ptr(resid), r, xp, n_new, 1 if full_cov else 0,
+                                       ctypes.byref(bound) if want_bound else None, mp_, vp, ctypes.byref(info)),
+                    "gps_sgpr")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
+        return bound.value, mean, var
 
     # ---- conditionals
     @staticmethod

@@ -173,6 +173,17 @@ int gps_base_conditional(gps_handle_t h, const double* Kmn, const double* Kmm,
                          int white, int full_cov,
                          double* fmean_out, double* fvar_out, int* info);
 
+/* ---- SGPR (sparse GP regression, Titsias 2009) -------------------------------------------------
+ * models/sgpr.py:121-153 (_build_likelihood: the collapsed bound) and :155-189 (_build_predict).
+ * Z host [m, d] inducing inputs, X host [n, d], resid host [n, r] = Y - mean_function(X).
+ * bound_out (optional): the bound.  If n_new > 0: mean_out host [n_new, r] (caller adds the mean function),
+ * var_out host [n_new] (full_cov == 0) or [n_new, n_new] (caller tiles over r, sgpr.py:181-188).          */
+int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+             const double* Z, int64_t m, const double* X, int64_t n, int64_t d_all,
+             double jitter, double noise_var, const double* resid, int64_t r,
+             const double* Xnew, int64_t n_new, int full_cov,
+             double* bound_out, double* mean_out, double* var_out, int* info);
+
 /* ---- measurement --------------------------------------------------------
  * Per-kernel-class accounting of the calls issued through this handle.
  * gps_profile_enable(h, 1) brackets every launch with HIP events on the

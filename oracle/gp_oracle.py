@@ -32,6 +32,7 @@ Reference lines followed (paths relative to the reference checkout, gpflowSlim/.
   features.py:74-81               InducingPoints.Kuu / Kuf
   kullback_leiblers.py:26-105     gauss_kl
   models/svgp.py:101-130          SVGP bound (Gaussian likelihood)
+  models/sgpr.py:121-189          SGPR collapsed bound and prediction
   neural_kernel_network/neural_kernel_network.py:35-47, neural_kernel_network_wrapper.py:39-44,116-117,145-148
                                   NeuralKernelNetwork.K / Kdiag and its layers
 """
@@ -328,6 +329,57 @@ def _gpr_lml_grad(spec_fn, theta, X, Y, noise_var, rel_step, n, R):
         dK = (K(spec_fn(tp), X) - K(spec_fn(tm), X)) / (2 * h)
         g[p] = 0.5 * np.sum(W * dK)
     return g, 0.5 * np.trace(W), a
+
+
+def sgpr_bound(spec, X, Y, Z, noise_var, mean_X=None, jitter=JITTER):
+    """models/sgpr.py:121-153"""
+    num_inducing, num_data, output_dim = Z.shape[0], Y.shape[0], Y.shape[1]
+    err = Y - (0.0 if mean_X is None else mean_X)
+    Kd = Kdiag(spec, X)
+    Kuf = K(spec, Z, X)
+    Kuu = K(spec, Z) + jitter * np.eye(num_inducing)
+    L = np.linalg.cholesky(Kuu)
+    sigma = np.sqrt(noise_var)
+    A = sl.solve_triangular(L, Kuf, lower=True) / sigma
+    AAT = np.matmul(A, A.T)
+    B = AAT + np.eye(num_inducing)
+    LB = np.linalg.cholesky(B)
+    Aerr = np.matmul(A, err)
+    c = sl.solve_triangular(LB, Aerr, lower=True) / sigma
+    bound = -0.5 * num_data * output_dim * np.log(2 * np.pi)
+    bound += -output_dim * np.sum(np.log(np.diag(LB)))
+    bound -= 0.5 * num_data * output_dim * np.log(noise_var)
+    bound += -0.5 * np.sum(np.square(err)) / noise_var
+    bound += 0.5 * np.sum(np.square(c))
+    bound += -0.5 * output_dim * np.sum(Kd) / noise_var
+    bound += 0.5 * output_dim * np.sum(np.diag(AAT))
+    return bound
+
+
+def sgpr_predict(spec, X, Y, Z, noise_var, Xnew, full_cov=False, mean_X=None, mean_Xnew=None, jitter=JITTER):
+    """models/sgpr.py:155-189"""
+    num_inducing = Z.shape[0]
+    err = Y - (0.0 if mean_X is None else mean_X)
+    Kuf = K(spec, Z, X)
+    Kuu = K(spec, Z) + jitter * np.eye(num_inducing)
+    Kus = K(spec, Z, Xnew)
+    sigma = np.sqrt(noise_var)
+    L = np.linalg.cholesky(Kuu)
+    A = sl.solve_triangular(L, Kuf, lower=True) / sigma
+    B = np.matmul(A, A.T) + np.eye(num_inducing)
+    LB = np.linalg.cholesky(B)
+    Aerr = np.matmul(A, err)
+    c = sl.solve_triangular(LB, Aerr, lower=True) / sigma
+    tmp1 = sl.solve_triangular(L, Kus, lower=True)
+    tmp2 = sl.solve_triangular(LB, tmp1, lower=True)
+    mean = np.matmul(tmp2.T, c)
+    if full_cov:
+        var = K(spec, Xnew) + np.matmul(tmp2.T, tmp2) - np.matmul(tmp1.T, tmp1)
+        var = np.tile(var[:, :, None], [1, 1, Y.shape[1]])
+    else:
+        var = Kdiag(spec, Xnew) + np.sum(np.square(tmp2), 0) - np.sum(np.square(tmp1), 0)
+        var = np.tile(var[:, None], [1, Y.shape[1]])
+    return mean + (0.0 if mean_Xnew is None else mean_Xnew), var
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

@@ -303,3 +303,27 @@ def test_neural_kernel_network_gpr_parity(handle):
     assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
     with pytest.raises((RuntimeError, NotImplementedError)):
         m.compute_log_likelihood_and_gradients()
+
+
+@pytest.mark.parametrize("kind", ["rbf_ard", "m52_plus_periodic"])
+@pytest.mark.parametrize("n,m_,d,r", [(300, 40, 3, 1), (1000, 130, 4, 2)])
+def test_sgpr_parity(handle, kind, n, m_, d, r):
+    """models/sgpr.py:121-189 (collapsed bound + prediction) vs the oracle."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r))
+    Z = X[rng.choice(n, m_, replace=False)].copy()
+    Xs = rng.standard_normal((57, d))
+    kern, spec = make_kernel(gpf, kind, d)
+    m = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.2)
+    noise = orc.constrained(0.2)
+    got = m.compute_log_likelihood()
+    ref = orc.sgpr_bound(spec, X, Y, Z, noise)
+    assert abs(got - ref) <= 1e-7 * abs(ref)                  # Kuu + 1e-6 I: conditioning eats digits
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.sgpr_predict(spec, X, Y, Z, noise, Xs)
+    assert mu.shape == (57, r) and var.shape == (57, r)
+    assert rel(mu, rmu) <= 1e-6 and rel(var, rvar) <= 1e-6
+    _, cov = m.predict_f_full_cov(Xs[:20])
+    _, rcov = orc.sgpr_predict(spec, X, Y, Z, noise, Xs[:20], full_cov=True)
+    assert cov.shape == (20, 20, r) and rel(cov, rcov) <= 1e-6

@@ -307,3 +307,19 @@ def test_svgp_bound_is_tight_at_the_exact_posterior():
     lml_jit = orc.multivariate_normal(Y, np.zeros((n, 1)), np.linalg.cholesky(Kff + s2 * np.eye(n)))
     # equal up to the O(jitter) mismatch between Kuu (+1e-6 I) and Kuf / Kdiag (no jitter); never above
     assert elbo == pytest.approx(lml_jit, rel=2e-5) and elbo <= lml_jit + 1e-9
+
+
+def test_sgpr_bound_limits():
+    """Z = X: the Titsias bound equals the exact LML (up to the jitter); fewer inducing points: below it."""
+    rng = np.random.default_rng(12)
+    n, d = 40, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
+    spec = {"type": "rbf", "variance": c(1.1), "lengthscales": c(1.0), "input_dim": d}
+    s2 = c(0.1)
+    lml = orc.gpr_lml(spec, X, Y, s2)
+    assert orc.sgpr_bound(spec, X, Y, X, s2) == pytest.approx(lml, rel=1e-4)
+    b = orc.sgpr_bound(spec, X, Y, X[:10], s2)
+    assert b < lml
+    mu, var = orc.sgpr_predict(spec, X, Y, X, s2, X[:5])
+    rmu, rvar = orc.gpr_predict(spec, X, Y, s2, X[:5])
+    assert np.allclose(mu, rmu, atol=1e-4) and np.allclose(var, rvar, atol=1e-4)
