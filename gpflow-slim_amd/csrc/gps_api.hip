@@ -617,18 +617,13 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
   double* dLTA = h->dTmp3.d();
   for (i64 q = 0; q < k; ++q) {
     if (q_sqrt_ndim == 2) {
-      // LTA^T[i][j] = A^T[i][j] * q_sqrt[j][q] : scale columns -> reuse rowdot on an elementwise
-      // product: build diag(q_sqrt[:,q]) as a [mp,mp] "B" operand would waste flops; instead
-      // upload the column and use a GEMM-free path: sum_j (A^T[i][j] s_j)^2 = rowdot of squares.
-      // Implemented as GEMM with a diagonal matrix for full_cov, rowdot for the diagonal case.
-      std::vector<double> s(mp, 0.0);
-      for (i64 j = 0; j < m; ++j) s[j] = q_sqrt[j * k + q];
-      GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
-      std::vector<double> D((size_t)mp * mp, 0.0);
-      for (i64 j = 0; j < m; ++j) D[(size_t)j * mp + j] = s[j];
-      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, D.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      // LTA^T[i][j] = A^T[i][j] * q_sqrt[j][q] : one column-scaling pass          conditionals.py:107
+      std::vector<double> sv(mp, 0.0);
+      for (i64 j = 0; j < m; ++j) sv[j] = q_sqrt[j * k + q];
+      GPS_HIP(h, h->dTmp2.ensure((size_t)mp * 8));
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, sv.data(), (size_t)mp * 8, hipMemcpyHostToDevice, h->stream));
       GPS_HIP(h, hipStreamSynchronize(h->stream));
-      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
+      rc = gps_launch_scale_cols(h, c.Bt, mp, nsp, mp, h->dTmp2.d(), dLTA, mp);
       if (rc) return rc;
     } else {
       // LTA^T = A^T L_q ; as C = A B^T with B = L_q^T (upper) -> upload tril(L_q) transposed

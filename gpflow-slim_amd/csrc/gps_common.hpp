@@ -174,6 +174,8 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
                         double diag_add);
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
+int gps_launch_scale_cols(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols, const double* sc,
+                          double* dst, i64 ldd);
 int gps_launch_scale_add_eye(gps_handle_t h, double* B, i64 ldb, i64 n, i64 n_real, double scale);
 int gps_launch_var_finish(gps_handle_t h, double* var, const double* kdiag_or_null,
                           double kdiag_const, const double* sumsq, i64 n);
