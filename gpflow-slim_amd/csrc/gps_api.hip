@@ -192,12 +192,12 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   if (!h || !us_out7) return GPS_ERR_ARG;
   GPS_HIP(h, hipSetDevice(h->device));
   const size_t bb = (size_t)GPS_TILE * GPS_TILE * 8;
-  GPS_HIP(h, h->dTmp.ensure(4 * bb + 512));
+  GPS_HIP(h, h->dTmp.ensure(4 * bb + 1024));
   std::vector<double> A((size_t)GPS_TILE * GPS_TILE, 0.0);
   for (int i = 0; i < GPS_TILE; ++i) for (int j = 0; j <= i; ++j) A[(size_t)i * GPS_TILE + j] = (i == j) ? 2.0 + 0.01 * i : 0.3 / (1.0 + i - j);
   double* dA = h->dTmp.d();
   long long* dS = (long long*)(dA + 3 * GPS_TILE * GPS_TILE);
-  long long hs[16] = {0};
+  long long hs[24] = {0};
   for (int rep = 0; rep < 3; ++rep) {
     GPS_HIP(h, hipMemcpyAsync(dA, A.data(), bb, hipMemcpyHostToDevice, h->stream));
     int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
@@ -210,6 +210,7 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   for (int q = 0; q < 7; ++q) us_out7[q] = (double)(hs[q] - hs[0]) * 0.01;
   // shader clock (MHz) held during the elimination phase
   us_out7[0] = (double)(hs[8 + 2] - hs[8 + 1]) / ((double)(hs[2] - hs[1]) * 0.01);
+  if (factor) fprintf(stderr, "potrf_base phases (us): diag16 %.2f  panel %.2f  mfma update %.2f\n", hs[16] * 0.01, hs[17] * 0.01, hs[18] * 0.01);
   return GPS_OK;
 }
 

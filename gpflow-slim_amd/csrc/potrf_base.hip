@@ -67,39 +67,51 @@ __device__ __forceinline__ void load_image(double* a, const double* __restrict__
 //   phase 1 (wave 0, registers + v_readlane, no barrier): Cholesky of the 16x16 diagonal block
 //   phase 2 (one thread per row below): forward substitution against that block
 //   phase 3 (all waves, fp64 MFMA): trailing update C_IJ -= P_I P_J^T on 16x16 tiles
-__device__ __forceinline__ void factor_image(double* a, double* dinv, int* info, int row0, int tid) {
+__device__ __forceinline__ void factor_image(double* a, double* dinv, int* info, int row0, int tid, long long* stamps) {
+  long long t_p1 = 0, t_p2 = 0, t_p3 = 0, t0 = 0;
+#define PH_BEGIN() do { if (stamps && tid == 0) t0 = (long long)wall_clock64(); } while (0)
+#define PH_END(acc) do { if (stamps && tid == 0) acc += (long long)wall_clock64() - t0; } while (0)
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   for (int g = 0; g < 8; ++g) {
     const int o = 16 * g;
     // ---- phase 1
+    PH_BEGIN();
     if (wave == 0) {
       const int i = lane & 15;
       double r[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) r[c] = a[(o + i) * PS + o + c];
+      // branch-free body (one basic block): the scheduler can overlap column j's trailing updates with
+      // the rsqrt / Newton chain of column j+1
+      int bad = 0x7fffffff;
+      double my_y = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double p = readlane_f64(r[j], j);
-        if (lane == 0 && !(p > 0.0)) atomicMin(info, row0 + o + j + 1);
+        bad = (!(p > 0.0) && bad == 0x7fffffff) ? j : bad;
         const double y = rsqrt_nr(p);
         r[j] = (i == j) ? p * y : r[j] * y;
-        if (lane == j) dinv[o + j] = y;
+        my_y = (i == j) ? y : my_y;
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) {
           const double lkj = readlane_f64(r[j], k);
           r[k] -= r[j] * lkj;
         }
       }
+      if (lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
       if (lane < 16) {
+        dinv[o + i] = my_y;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
           if (c <= i) a[(o + i) * PS + o + c] = r[c];
       }
     }
     __syncthreads();
+    PH_END(t_p1);
     if (g == 7) break;
     // ---- phase 2
+    PH_BEGIN();
     const int nrows = PB - o - 16;
     if (tid < nrows) {
       const int i = o + 16 + tid;
@@ -117,7 +129,9 @@ __device__ __forceinline__ void factor_image(double* a, double* dinv, int* info,
       for (int c = 0; c < 16; ++c) a[i * PS + o + c] = x[c];
     }
     __syncthreads();
+    PH_END(t_p2);
     // ---- phase 3
+    PH_BEGIN();
     const int nt = 7 - g;
     const int ntile = nt * (nt + 1) / 2;
     for (int t = wave; t < ntile; t += 4) {
@@ -137,7 +151,11 @@ __device__ __forceinline__ void factor_image(double* a, double* dinv, int* info,
       for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
     }
     __syncthreads();
+    PH_END(t_p3);
   }
+  if (stamps && tid == 0) { stamps[16] = t_p1; stamps[17] = t_p2; stamps[18] = t_p3; }
+#undef PH_BEGIN
+#undef PH_END
 }
 
 // ---- MFMA helpers for the inverse levels --------------------------------------------------------
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
     load_image(a, A, lda, tid);
     __syncthreads();
     STAMP(1);
-    factor_image(a, dinv, info, row0, tid);
+    factor_image(a, dinv, info, row0, tid, stamps);
     STAMP(2);
     // L back to HBM (upper triangle of the diagonal block zero-filled, like tf.cholesky)
     for (int idx = tid; idx < PB * PB / 2; idx += NT) {
