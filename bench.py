@@ -63,10 +63,14 @@ def main():
         dist.init_process_group(args.backend)
 
     import gpflowSlim as gpf
-    import oracle.gp_oracle as orc       # cpu_baseline leg + parity gate only
 
     n, d = args.n, args.d
-    X, Y, Xnew = orc.synthetic_gpr_data(n, d, args.n_new)
+    # synthetic inputs of SURVEY 8(d)
+    rng = np.random.default_rng(20240607)
+    X = rng.standard_normal((n, d))
+    w = rng.standard_normal((d, 1)) / np.sqrt(d)
+    Y = np.sin(X @ w) + 0.1 * rng.standard_normal((n, 1))
+    Xnew = rng.standard_normal((args.n_new, d))
     ls0 = np.sqrt(d) * np.ones(d)
     kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls0, ARD=True)
     model = gpf.models.GPR(X, Y, kern, obs_var=0.1)
@@ -195,6 +199,7 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline:
+            import oracle.gp_oracle as orc       # the checker: cpu_baseline leg + its parity gate only
             ns = min(args.cpu_sample_n, n)
             Xc, Yc = X[:ns], Y[:ns]
             spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls0), "input_dim": d}
