@@ -24,6 +24,26 @@ __global__ __launch_bounds__(256, 2) void mfma_f64_rate_kernel(double* out, int 
   if (s == 12345.678) out[0] = s;   // keep the chain live
 }
 
+// same issue loop with NCH independent accumulator chains per wave: measures the dependent-issue interval
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void mfma_f64_chain_kernel(double* out, int iters) {
+  const int lane = threadIdx.x & 63;
+  double a = 1.0 + 1e-3 * lane, b = 1.0 - 1e-3 * lane;
+  v4d acc[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+
 // D = A[16x4] * B[4x16] with asymmetric integer data; D written through the assumed map
 __global__ void mfma_f64_layout_kernel(const double* A, const double* B, double* D) {
   const int lane = threadIdx.x & 63;
@@ -70,8 +90,24 @@ int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* l
   GPS_HIP(h, hipEventSynchronize(e1));
   float ms = 0.f;
   GPS_HIP(h, hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   const double flop = (double)blocks * 4.0 * iters * 8.0 * (2.0 * 16 * 16 * 4);
   if (tflops) *tflops = flop / (ms * 1e-3) / 1e12;
+  if (getenv("GPS_DIAG_CHAINS")) {
+    // cycles per MFMA for 1, 2, 4 chains in ONE wave on ONE CU (and with every CU busy)
+    for (int nch = 1; nch <= 4; nch *= 2) {
+      for (int nb = 1; nb <= h->prop.multiProcessorCount; nb *= h->prop.multiProcessorCount) {
+        GPS_HIP(h, hipEventRecord(e0, h->stream));
+        if (nch == 1) hipLaunchKernelGGL(mfma_f64_chain_kernel<1>, dim3(nb), dim3(64), 0, h->stream, d, iters);
+        else if (nch == 2) hipLaunchKernelGGL(mfma_f64_chain_kernel<2>, dim3(nb), dim3(64), 0, h->stream, d, iters);
+        else hipLaunchKernelGGL(mfma_f64_chain_kernel<4>, dim3(nb), dim3(64), 0, h->stream, d, iters);
+        GPS_HIP(h, hipEventRecord(e1, h->stream));
+        GPS_HIP(h, hipEventSynchronize(e1));
+        float t = 0.f;
+        GPS_HIP(h, hipEventElapsedTime(&t, e0, e1));
+        fprintf(stderr, "chains=%d blocks=%d : %.1f ns per MFMA per wave\n", nch, nb, t * 1e6 / ((double)iters * nch));
+      }
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return GPS_OK;
 }

@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   constexpr int MI = WTM / 16, NI = WTN / 16;          // 16x16 MFMA tiles per wave
   constexpr int LPA = (BM + 31) / 32, LPB = (BN + 31) / 32;   // 16-byte loads per thread per K-slab
   static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one MFMA tile");
+  // Small tiles split K over KS accumulator sets (k-step kk of a slab goes to set kk % KS), summed in the
+  // epilogue.  (Measured: a dependent v_mfma_f64_16x16x4_f64 chain already issues every ~67 cycles, so this
+  // is neutral for throughput; it only shortens the dependency chain seen by the scheduler.)
+  constexpr int KS = (MI * NI >= 4) ? 1 : (MI * NI == 2 ? 2 : 4);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* As = reinterpret_cast<double*>(smem_raw);       // [2][BM][LS]
   double* Bs = As + 2 * BM * LS;                          // [2][BN][LS]
@@ -119,11 +123,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const bool a_ld = (BM >= 32) || (lrow < BM);          // BM = 16: only half the threads stage A
 
   v2d ra[LPA], rb[LPB];
-  v4d acc[MI][NI];
+  v4d acc[KS][MI][NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int q = 0; q < KS; ++q)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[q][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   const int nk = g.K / BK;
 
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[kk % KS][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[kk % KS][i][j], 0, 0, 0);
     }
 
     if (kt + 1 < nk) lstore(buf ^ 1);
@@ -176,6 +182,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 
   // epilogue.  f64 accumulator map (differs from every other dtype on gfx950):
   //   col = lane & 15, row = (lane >> 4) + 4 * reg.
+#pragma unroll
+  for (int q = 1; q < KS; ++q)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[0][i][j] += acc[q][i][j];
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
   const i64 col0 = (i64)tn * BN + wc * WTN + (lane & 15);
 #pragma unroll
@@ -185,9 +197,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         double* cp = g.C + (row0 + i * 16 + 4 * rg) * g.ldc + col0 + j * 16;
-        if (OP == 0) *cp = *cp - acc[i][j][rg];
-        else if (OP == 2) *cp = *cp + acc[i][j][rg];
-        else *cp = acc[i][j][rg];
+        if (OP == 0) *cp = *cp - acc[0][i][j][rg];
+        else if (OP == 2) *cp = *cp + acc[0][i][j][rg];
+        else *cp = acc[0][i][j][rg];
       }
     }
   }

@@ -139,14 +139,16 @@ __device__ __forceinline__ void factor_image(double* a, double* dinv, int* info,
       while (rem >= Ip + 1) { rem -= Ip + 1; ++Ip; }
       const int I = g + 1 + Ip, J = g + 1 + rem;
       v4d acc;
+      double av[4], bv[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
+        bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
+      }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const double av = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
-        const double bv = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
     }
@@ -161,68 +163,88 @@ __device__ __forceinline__ void factor_image(double* a, double* dinv, int* info,
 // ---- MFMA helpers for the inverse levels --------------------------------------------------------
 // X (= inv L, lower) is stored transposed in the strict upper triangle of the image, diag in dinv.
 __device__ __forceinline__ double x_elem(const double* a, const double* dinv, int r, int c) {
-  return (r > c) ? a[c * PS + r] : ((r == c) ? dinv[r] : 0.0);
+  // two UNCONDITIONAL LDS reads + selects.  The empty asm pins both loaded values: without it the compiler
+  // sinks the reads back under divergent branches and every MFMA of the inverse levels waits for its own
+  // pair of serialised LDS round trips.
+  double off = a[(r > c) ? (c * PS + r) : 0];
+  double dia = dinv[r & (PB - 1)];
+  asm volatile("" : "+v"(off), "+v"(dia));
+  return (r > c) ? off : ((r == c) ? dia : 0.0);
 }
 
-// one doubling level of the block inverse (s = size of the already inverted diagonal blocks)
+// one doubling level of the block inverse (S = size of the already inverted diagonal blocks).
+// Every wave walks its TPW tiles together (KSPL partial sums per tile) so that the LDS operand reads of
+// several products are in flight at once; zero operands outside the triangular ranges (x_elem) make
+// every product unconditional.
 template <int S>
 __device__ __forceinline__ void level_step(double* a, const double* dinv, int wave, int fr, int fk) {
-  constexpr int KS = S / 4;                        // k-steps of the longest product
+  constexpr int KSTEPS = S / 4;
   constexpr int tps = S / 16;
   constexpr int tiles_pair = tps * tps;
   constexpr int ntile = (PB / (2 * S)) * tiles_pair;     // 4, 8, 16
-  constexpr int TPW = (ntile + 3) / 4;                   // tiles per wave: 1, 2, 4
-  // step A: W = L21 * X11 ; W[i][c] -> a[c][i]
+  constexpr int TPW = ntile / 4;                         // tiles per wave: 1, 2, 4
+  constexpr int KSPL = 4 / TPW;                          // partial sums per tile: 4, 2, 1
+  int i0[TPW], c0[TPW], ob[TPW];
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int t = wave + 4 * q;
     const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-    const int o = pr * 2 * S;
-    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
-    double av[KS], bv[KS];
+    ob[q] = pr * 2 * S;
+    i0[q] = ob[q] + S + (w / tps) * 16;
+    c0[q] = ob[q] + (w % tps) * 16;
+  }
+  // step A: W = L21 * X11 ; W[i][c] -> a[c][i]
+  {
+    v4d acc[TPW][KSPL];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = o + 4 * ks + fk;                     // k runs over the TL block
-      av[ks] = a[(i0 + fr) * PS + k];                     // L21[i][k]
-      bv[ks] = x_elem(a, dinv, k, c0 + fr);               // X11[k][c] (0 for k < c)
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+      for (int u = 0; u < KSPL; ++u) acc[q][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int k = ob[q] + 4 * ks + fk;                       // k runs over the TL block
+        const double av = a[(i0[q] + fr) * PS + k];              // L21[i][k]
+        const double bv = x_elem(a, dinv, k, c0[q] + fr);        // X11[k][c] (0 for k < c)
+        acc[q][ks % KSPL] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q][ks % KSPL], 0, 0, 0);
+      }
     }
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    __syncthreads();          // every L21 / X11 operand has been read before W overwrites the slot
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      if (o + 4 * ks + 3 >= c0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+    for (int q = 0; q < TPW; ++q) {
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = acc[rg];
+      for (int u = 1; u < KSPL; ++u) acc[q][0] += acc[q][u];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) a[(c0[q] + fr) * PS + i0[q] + fk + 4 * rg] = acc[q][0][rg];
+    }
   }
   __syncthreads();
   // step B: Z = -X22 * W, kept in registers until every W has been consumed
-  v4d z[TPW];
+  {
+    v4d z[TPW][KSPL];
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int t = wave + 4 * q;
-    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-    const int o = pr * 2 * S;
-    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
-    double av[KS], bv[KS];
+    for (int q = 0; q < TPW; ++q)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = o + S + 4 * ks + fk;                 // k runs over the BR block
-      av[ks] = x_elem(a, dinv, i0 + fr, k);               // X22[i][k] (0 for k > i)
-      bv[ks] = a[(c0 + fr) * PS + k];                     // W[k][c]
+      for (int u = 0; u < KSPL; ++u) z[q][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int k = ob[q] + S + 4 * ks + fk;                   // k runs over the BR block
+        const double av = x_elem(a, dinv, i0[q] + fr, k);        // X22[i][k] (0 for k > i)
+        const double bv = a[(c0[q] + fr) * PS + k];              // W[k][c]
+        z[q][ks % KSPL] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z[q][ks % KSPL], 0, 0, 0);
+      }
     }
-    z[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      if (o + S + 4 * ks <= i0 + 15) z[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], z[q], 0, 0, 0);
-  }
-  __syncthreads();
+    for (int q = 0; q < TPW; ++q) {
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int t = wave + 4 * q;
-    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-    const int o = pr * 2 * S;
-    const int i0 = o + S + (w / tps) * 16, c0 = o + (w % tps) * 16;
+      for (int u = 1; u < KSPL; ++u) z[q][0] += z[q][u];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) a[(c0 + fr) * PS + i0 + fk + 4 * rg] = -z[q][rg];
+      for (int rg = 0; rg < 4; ++rg) a[(c0[q] + fr) * PS + i0[q] + fk + 4 * rg] = -z[q][0][rg];
+    }
   }
   __syncthreads();
 }
