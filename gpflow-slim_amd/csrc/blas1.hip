@@ -71,35 +71,80 @@ __global__ __launch_bounds__(256) void gemv_sub_kernel(const double* __restrict_
 }
 
 // y1[q][k] -= sum_i L21[i][k] * y2[q][i]   (transposed panel: backward substitution L^T a = y).
-// One workgroup per 128 columns k, two row-halves per workgroup, fixed summation order (no atomics).
+// Workgroup (bx, s) owns 128 columns k and the s-th slice of the n2 rows: a single column block has too little
+// memory parallelism to stream a tall panel (one CU draws ~20-50 GB/s), so the rows are split over gridDim.y
+// workgroups.  Their partial sums go to `ws`; the workgroup that arrives last at the column block's counter
+// adds them in slice order, so the result does not depend on arrival order (no floating-point atomics).
 template <int RC>
 __global__ __launch_bounds__(256) void gemv_t_sub_kernel(const double* __restrict__ L21, i64 ldl,
                                                          i64 n2, i64 n1,
                                                          const double* __restrict__ y2,
                                                          double* __restrict__ y1, i64 ldy, int r0,
-                                                         int rcount) {
-  __shared__ double part[RC][128];
-  const int kk = threadIdx.x & 127, half = threadIdx.x >> 7;
-  const i64 k = (i64)blockIdx.x * 128 + kk;
-  double acc[RC];
+                                                         int rcount, double* __restrict__ ws,
+                                                         unsigned* __restrict__ counters) {
+  __shared__ double part[4][RC][128];
+  __shared__ unsigned ticket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = (int)gridDim.y, sl = (int)blockIdx.y;
+  const i64 k = (i64)blockIdx.x * 128 + 2 * lane;
+  const i64 rows_per = ((n2 + S - 1) / S + 3) & ~(i64)3;
+  const i64 i0 = (i64)sl * rows_per, i1 = min(n2, i0 + rows_per);
+  double acc[RC][2];
 #pragma unroll
-  for (int q = 0; q < RC; ++q) acc[q] = 0.0;
-  for (i64 i = half; i < n2; i += 2) {
-    const double l = L21[i * ldl + k];
+  for (int q = 0; q < RC; ++q) acc[q][0] = acc[q][1] = 0.0;
+  // wave w takes rows i0 + w, i0 + w + 4, ...; 8 row loads in flight per wave
+  i64 i = i0 + wave;
+  for (; i + 28 < i1; i += 32) {
+    v2d l[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l[u] = *reinterpret_cast<const v2d*>(L21 + (i + 4 * u) * ldl + k);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < RC; ++q)
+        if (q < rcount) {
+          const double v = y2[(i64)(r0 + q) * ldy + i + 4 * u];
+          acc[q][0] = fma(l[u].x, v, acc[q][0]);
+          acc[q][1] = fma(l[u].y, v, acc[q][1]);
+        }
+  }
+  for (; i < i1; i += 4) {
+    const v2d l = *reinterpret_cast<const v2d*>(L21 + i * ldl + k);
 #pragma unroll
     for (int q = 0; q < RC; ++q)
-      if (q < rcount) acc[q] = fma(l, y2[(i64)(r0 + q) * ldy + i], acc[q]);
+      if (q < rcount) {
+        const double v = y2[(i64)(r0 + q) * ldy + i];
+        acc[q][0] = fma(l.x, v, acc[q][0]);
+        acc[q][1] = fma(l.y, v, acc[q][1]);
+      }
   }
-  if (half) {
 #pragma unroll
-    for (int q = 0; q < RC; ++q) part[q][kk] = acc[q];
-  }
+  for (int q = 0; q < RC; ++q) { part[wave][q][2 * lane] = acc[q][0]; part[wave][q][2 * lane + 1] = acc[q][1]; }
   __syncthreads();
-  if (!half) {
-#pragma unroll
-    for (int q = 0; q < RC; ++q)
-      if (q < rcount) y1[(i64)(r0 + q) * ldy + k] -= acc[q] + part[q][kk];
+  const int kk = threadIdx.x & 127, qh = threadIdx.x >> 7;     // 2 right-hand sides per pass
+  double* wsb = ws + ((i64)blockIdx.x * S) * (RC * 128);
+  for (int q = qh; q < RC; q += 2) {
+    const double t = (part[0][q][kk] + part[1][q][kk]) + (part[2][q][kk] + part[3][q][kk]);
+    if (S == 1) {
+      if (q < rcount) y1[(i64)(r0 + q) * ldy + (i64)blockIdx.x * 128 + kk] -= t;
+    } else {
+      wsb[(i64)sl * (RC * 128) + q * 128 + kk] = t;
+    }
   }
+  if (S == 1) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(&counters[blockIdx.x], 1u);
+  __syncthreads();
+  if (ticket != (unsigned)(S - 1)) return;
+  __threadfence();
+  for (int q = qh; q < RC; q += 2) {
+    if (q >= rcount) continue;
+    double t = 0.0;
+    for (int s2 = 0; s2 < S; ++s2) t += __builtin_nontemporal_load(&wsb[(i64)s2 * (RC * 128) + q * 128 + kk]);
+    y1[(i64)(r0 + q) * ldy + (i64)blockIdx.x * 128 + kk] -= t;
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0;     // ready for the next launch on this stream
 }
 
 // partial[b][0] = sum_i log L_ii ; partial[b][1] = sum alpha^2   (fixed-order, host adds
@@ -270,11 +315,21 @@ int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 
 int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
                           const double* y2, double* y1, i64 ldy, i64 r) {
   if (n2 <= 0 || n1 <= 0) return GPS_OK;
+  const i64 cb = n1 / 128;
+  i64 S = (1024 + cb - 1) / cb;                 // aim at ~1024 workgroups ...
+  if (S > n2 / 128) S = n2 / 128;               // ... of at least 128 rows each
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  const size_t ws_bytes = (size_t)cb * S * 4 * 128 * sizeof(double), cnt_bytes = (size_t)cb * sizeof(unsigned);
+  const bool fresh = h->dGemvCnt.cap < cnt_bytes;
+  GPS_HIP(h, h->dGemvWs.ensure(ws_bytes));
+  GPS_HIP(h, h->dGemvCnt.ensure(cnt_bytes));
+  if (fresh) GPS_HIP(h, hipMemsetAsync(h->dGemvCnt.p, 0, h->dGemvCnt.cap, h->stream));
   for (i64 r0 = 0; r0 < r; r0 += 4) {
     const int rc = (int)((r - r0) < 4 ? (r - r0) : 4);
     LaunchScope ls(h, KC_TRSV, 2.0 * n2 * n1 * rc, (double)n2 * n1 * 8.0);
-    hipLaunchKernelGGL(gemv_t_sub_kernel<4>, dim3((unsigned)(n1 / 128)), dim3(256), 0, h->stream, L21, ldl,
-                       n2, n1, y2, y1, ldy, (int)r0, rc);
+    hipLaunchKernelGGL(gemv_t_sub_kernel<4>, dim3((unsigned)cb, (unsigned)S), dim3(256), 0, h->stream, L21, ldl,
+                       n2, n1, y2, y1, ldy, (int)r0, rc, h->dGemvWs.d(), (unsigned*)h->dGemvCnt.p);
     GPS_HIP(h, hipGetLastError());
   }
   return GPS_OK;

@@ -104,7 +104,7 @@ struct Blocked {
     if (rc) return rc;
     rc = ops.zero_block(Y + n1 * ldy, ldy, n2, n1);
     if (rc) return rc;
-    rc = ops.gemm(0, 0, n1, n2, n1, Y, ldy, L + n1 * ldl, ldl, Y12, ldy);       // Y12 = -Y11 L21^T
+    rc = ops.gemm(0, /*A upper triangular*/ 2, n1, n2, n1, Y, ldy, L + n1 * ldl, ldl, Y12, ldy);   // Y12 = -Y11 L21^T
     if (rc) return rc;
     return trsm_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, Y12, ldy, n1);   // ... L22^-T
   }
@@ -120,7 +120,7 @@ struct Blocked {
     const double* Y22 = Y + n1 * ldy + n1;
     rc = ops.gemm(2, 1, n1, n1, n2, Y12, ldy, Y12, ldy, Kv, ldk);                // K11 += Y12 Y12^T
     if (rc) return rc;
-    rc = ops.gemm(1, 0, n2, n1, n2, Y22, ldy, Y12, ldy, Kv + n1 * ldk, ldk);     // K21 = Y22 Y12^T
+    rc = ops.gemm(1, /*A upper triangular*/ 2, n2, n1, n2, Y22, ldy, Y12, ldy, Kv + n1 * ldk, ldk);   // K21 = Y22 Y12^T
     if (rc) return rc;
     return lauum_rec(Y22, ldy, n2, Kv + n1 * ldk + n1, ldk);
   }

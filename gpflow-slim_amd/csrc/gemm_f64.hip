@@ -37,6 +37,7 @@ struct GemmArgs {
   int Tm, Tn;       // tiles
   int K;
   int ntiles;
+  int triA;         // A is upper triangular (A[i][k] == 0 for k < i): tile row tm starts its K loop at tm*BM
 };
 
 // bijective XCD remap: blocks b, b+8, b+16 ... (same XCD) get consecutive ids
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       for (int j = 0; j < NI; ++j) acc[q][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   const int nk = g.K / BK;
+  const int kt0 = g.triA ? (tm * BM) / BK : 0;
 
   auto gload = [&](int kt) {
 #pragma unroll
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       *reinterpret_cast<v2d*>(b + i * 32 * LS) = rb[i];
   };
 
-  gload(0);
-  lstore(0);
+  gload(kt0);
+  lstore(kt0 & 1);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
 
@@ -239,10 +241,17 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
 
 // rowpanel != 0: C may alias A (in-place B <- B W^T with N == K == 128): every workgroup then owns
 // complete rows (BN = N = 128), so it has consumed all of its A rows before it stores.
+// lower: 0 = all of C, 1 = lower triangle of a square C only, 2 = all of C with A (M == K) upper triangular:
+// the zero part of A is skipped (half the flops; used by the L^-T / K^-1 recursions of the gradient).
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc) {
   if (M <= 0 || N <= 0 || K <= 0) return GPS_OK;
+  const int triA = (lower == 2);
+  if (triA) {
+    if (M != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: triangular A must be square");
+    lower = 0;
+  }
   if (M % 128 || N % 128 || K % BK || (lower && M != N))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
@@ -251,11 +260,12 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   if (rowpanel && (N != 128 || lower))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: in-place form needs N == 128");
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
   const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
-  const double flops = 2.0 * t128 * 128.0 * 128.0 * (double)K;
+  const double flops = triA ? 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)   // sum_i 2 (K - 128 i)
+                            : 2.0 * t128 * 128.0 * 128.0 * (double)K;
   const double bytes = t128 * ((op != 1 ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);

@@ -94,6 +94,7 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
+  DevBuf dGemvWs, dGemvCnt;   // slice partials + arrival counters of the split transposed gemv (blas1.hip)
 };
 
 static inline int gps_fail(gps_handle_t h, int code, const std::string& msg) {

@@ -51,9 +51,10 @@ struct CpuOps {
     std::vector<char> done((size_t)M * N, 0);
     for (i64 i = 0; i < M; ++i)
       for (i64 j = 0; j < N; ++j) {
-        if (lower && (j / T) > (i / T)) continue;
+        if (lower == 1 && (j / T) > (i / T)) continue;
         double s = 0.0;
-        for (i64 k = 0; k < K; ++k) s += A[i * lda + k] * B[j * ldb + k];
+        // lower == 2: A is upper triangular; the device kernel never reads A's blocks left of the diagonal block
+        for (i64 k = (lower == 2) ? (i / T) * T : 0; k < K; ++k) s += A[i * lda + k] * B[j * ldb + k];
         out[i * N + j] = s; done[i * N + j] = 1;
       }
     for (i64 i = 0; i < M; ++i)

@@ -16,3 +16,10 @@ for n in [int(a) for a in sys.argv[1:]] or [2048, 8192, 32768]:
         st = h.last_stage_ms()
         print("N=%d lml+grad %.1f ms (lml part %.1f, grad part %.1f)" % (n, 1e3 * (t1 - t0), st["total"], st["predict"]))
     print("   grads:", [np.round(np.atleast_1d(x), 4).tolist() for _, x in g])
+    h.profile_reset(); h.profile_enable(True)
+    m.compute_log_likelihood_and_gradients()
+    h.profile_enable(False)
+    for kc in ["gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"]:
+        p = h.profile_get(kc)
+        if p["launches"]:
+            print("   %-10s launches=%6d ms=%9.3f  TFLOP/s=%7.2f  GB/s=%8.1f" % (kc, p["launches"], p["ms"], p["flops"] / max(p["ms"], 1e-9) / 1e9, p["bytes"] / max(p["ms"], 1e-9) / 1e6))
