@@ -111,3 +111,47 @@ int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* l
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return GPS_OK;
 }
+
+// ---- GEMM timeline: device-resident pseudo-random operands, one launch, per-workgroup stamps ----
+__global__ void diag_fill_kernel(double* p, long long n, unsigned seed) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = ((double)(x & 0xffffff) - 8388608.0) * (1.0 / 8388608.0);
+  }
+}
+
+int gps_run_gemm_timeline(gps_handle_t h, int op, int lower, i64 m, i64 n, i64 k, int reps, long long* stamps_out,
+                          i64 cap_blocks, i64* nblocks, double* ms_out) {
+  const size_t ab = (size_t)m * k * 8, bb = (size_t)n * k * 8, cb = (size_t)m * n * 8;
+  GPS_HIP(h, h->dTmp.ensure(ab)); GPS_HIP(h, h->dTmp2.ensure(bb)); GPS_HIP(h, h->dTmp3.ensure(cb));
+  GPS_HIP(h, h->dGemvWs.ensure((size_t)cap_blocks * 6 * sizeof(long long)));
+  hipLaunchKernelGGL(diag_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->dTmp.d(), (long long)(m * k), 1u);
+  hipLaunchKernelGGL(diag_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->dTmp2.d(), (long long)(n * k), 2u);
+  hipLaunchKernelGGL(diag_fill_kernel, dim3(2048), dim3(256), 0, h->stream, h->dTmp3.d(), (long long)(m * n), 3u);
+  GPS_HIP(h, hipMemsetAsync(h->dGemvWs.p, 0, (size_t)cap_blocks * 6 * sizeof(long long), h->stream));
+  const double* B = (lower == 1) ? h->dTmp.d() : h->dTmp2.d();       // syrk form: B = A
+  int rc = GPS_OK;
+  for (int i = 0; i < 2 && !rc; ++i) rc = gps_launch_gemm_nt(h, op, lower, m, n, k, h->dTmp.d(), k, B, k, h->dTmp3.d(), n);   // warm
+  if (rc) return rc;
+  hipEvent_t e0, e1;
+  GPS_HIP(h, hipEventCreate(&e0)); GPS_HIP(h, hipEventCreate(&e1));
+  GPS_HIP(h, hipEventRecord(e0, h->stream));
+  for (int i = 0; i < reps && !rc; ++i) rc = gps_launch_gemm_nt(h, op, lower, m, n, k, h->dTmp.d(), k, B, k, h->dTmp3.d(), n);
+  GPS_HIP(h, hipEventRecord(e1, h->stream));
+  if (rc) return rc;
+  h->gemm_stamps = (long long*)h->dGemvWs.p;
+  rc = gps_launch_gemm_nt(h, op, lower, m, n, k, h->dTmp.d(), k, B, k, h->dTmp3.d(), n);
+  h->gemm_stamps = nullptr;
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(stamps_out, h->dGemvWs.p, (size_t)cap_blocks * 6 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  GPS_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_out) *ms_out = ms / reps;
+  i64 nb = 0;
+  for (i64 b = 0; b < cap_blocks; ++b) if (stamps_out[6 * b + 1] != 0) nb = b + 1;
+  if (nblocks) *nblocks = nb;
+  return GPS_OK;
+}

@@ -38,6 +38,7 @@ struct GemmArgs {
   int K;
   int ntiles;
   int triA;         // A is upper triangular (A[i][k] == 0 for k < i): tile row tm starts its K loop at tm*BM
+  long long* stamps;  // diagnostics (gps_diag_gemm_timeline): [blockIdx][6] = start, end, HW_ID, XCC_ID, K loop start, K loop end (100 MHz ticks); else null
 };
 
 // bijective XCD remap: blocks b, b+8, b+16 ... (same XCD) get consecutive ids
@@ -109,6 +110,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 
   int tm, tn;
   decode_tile<LOWER>(xcd_remap((int)blockIdx.x, g.ntiles), g.Tm, g.Tn, tm, tn);
+  if (g.stamps && threadIdx.x == 0) {
+    long long* st = g.stamps + 6 * (long long)blockIdx.x;
+    st[0] = (long long)wall_clock64();
+    st[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    st[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   lstore(kt0 & 1);
   __syncthreads();
 
+  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 4] = (long long)wall_clock64();
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     __syncthreads();
   }
 
+  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 5] = (long long)wall_clock64();
   // epilogue.  f64 accumulator map (differs from every other dtype on gfx950):
   //   col = lane & 15, row = (lane >> 4) + 4 * reg.
 #pragma unroll
@@ -205,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       }
     }
   }
+  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
 }
 
 template <int BM, int BN, int WGM, bool LOWER, int OP>
@@ -261,6 +271,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: in-place form needs N == 128");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
+  g.stamps = h->gemm_stamps;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
   const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);

@@ -186,6 +186,13 @@ extern "C" int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, in
   return GPS_OK;
 }
 
+extern "C" int gps_diag_gemm_timeline(gps_handle_t h, int op, int lower, int64_t m, int64_t n, int64_t k, int reps,
+                                      long long* stamps_out, int64_t cap_blocks, int64_t* nblocks, double* ms_per_launch) {
+  if (!h || !stamps_out || cap_blocks <= 0 || reps <= 0) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  return gps_run_gemm_timeline(h, op, lower, m, n, k, reps, stamps_out, cap_blocks, nblocks, ms_per_launch);
+}
+
 // phase stamps (100 MHz ticks) of one potrf_base launch on a random SPD block: load, eliminate,
 // scale + L store, (gap), inverse level 0, inverse levels, stores
 extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us_out7) {

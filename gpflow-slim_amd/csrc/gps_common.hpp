@@ -55,6 +55,7 @@ struct gps_handle_s {
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
   int gemm_min_tiles = 768;
   int gemm_force_tb = 0;
+  long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
   // profiling
   bool prof_on = false;
@@ -196,3 +197,5 @@ int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, co
                     double* grad_slots_host, double* grad_noise_host);
 // diag.hip
 int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);
+int gps_run_gemm_timeline(gps_handle_t h, int op, int lower, i64 m, i64 n, i64 k, int reps, long long* stamps_out,
+                          i64 cap_blocks, i64* nblocks, double* ms_out);

@@ -86,6 +86,8 @@ _SIGNATURES = {
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
+    "gps_diag_gemm_timeline": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_longlong), _i64, ctypes.POINTER(ctypes.c_int64), _c_double_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error"])
 
@@ -301,9 +303,18 @@ class Handle(object):
         m, k = A.shape
         n = B.shape[0]
         assert B.shape[1] == k and C.shape == (m, n)
-        self._check(self._lib.gps_diag_gemm_nt(self._h, op, int(bool(lower)), m, n, k, _ptr(A), _ptr(B), _ptr(C)),
+        self._check(self._lib.gps_diag_gemm_nt(self._h, op, int(lower), m, n, k, _ptr(A), _ptr(B), _ptr(C)),
                     "gps_diag_gemm_nt")
         return C
+
+    def diag_gemm_timeline(self, op, lower, m, n, k, reps=5, cap_blocks=1 << 17):
+        """(ms per launch, stamps [nblocks, 6] = start, end (100 MHz ticks), HW_ID, XCC_ID, K-loop start, K-loop end) on random device data."""
+        st = np.zeros((cap_blocks, 6), dtype=np.int64)
+        nb, ms = ctypes.c_int64(), ctypes.c_double()
+        self._check(self._lib.gps_diag_gemm_timeline(self._h, op, int(lower), m, n, k, reps,
+                                                     st.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), cap_blocks,
+                                                     ctypes.byref(nb), ctypes.byref(ms)), "gps_diag_gemm_timeline")
+        return ms.value, st[:nb.value]
 
     # ---- kernels.K
     def kmat(self, prog, X, X2=None, diag_add=0.0):

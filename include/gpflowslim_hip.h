@@ -243,6 +243,12 @@ int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops,
  * lower != 0: only tiles on/below the diagonal are computed (m == n).       */
 int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
                      int64_t k, const double* A, const double* B, double* C);
+/* device-resident GEMM of the given shape on pseudo-random operands (lower == 1: syrk form, B = A): average
+ * launch time over `reps`, plus one instrumented launch whose workgroups record
+ * stamps_out[6*b + {0..5}] = start, end (100 MHz ticks), HW_ID, XCC_ID, K-loop start, K-loop end.               */
+int gps_diag_gemm_timeline(gps_handle_t h, int op, int lower, int64_t m, int64_t n, int64_t k, int reps,
+                           long long* stamps_out, int64_t cap_blocks, int64_t* nblocks,
+                           double* ms_per_launch);
 /* phase timestamps (us) of one 128-block potrf_base launch; out7[0] = shader clock in MHz */
 int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
 

@@ -36,6 +36,28 @@ def _gemm_nt_full(handle, m, n, k, op):
     assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("m,n", [(128, 128), (384, 256), (1024, 640), (2048, 128)])
+@pytest.mark.parametrize("op", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 128, 64, 32])
+def test_gemm_nt_triangular_a(handle, m, n, op, tile):
+    """lower == 2: A [m, m] upper triangular, the kernel skips k < (first row of the tile); whatever sits below
+    A's diagonal blocks must not be read (NaN there)."""
+    rng = np.random.default_rng(m + n + op)
+    A = np.triu(rng.standard_normal((m, m)))
+    Apoison = A.copy()
+    for ti in range(m // 128):
+        Apoison[ti * 128:(ti + 1) * 128, :ti * 128] = np.nan
+    B = rng.standard_normal((n, m)); C = rng.standard_normal((m, n))
+    handle.set_option("gemm_force_tile", tile)
+    try:
+        out = handle.diag_gemm_nt(op, 2, Apoison, B, C)
+    finally:
+        handle.set_option("gemm_force_tile", 0)
+    ref = {0: C - A @ B.T, 1: A @ B.T, 2: C + A @ B.T}[op]
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n,k", [(128, 64), (640, 128), (1152, 256), (2176, 512)])
 @pytest.mark.parametrize("tile", [0, 128, 64, 32])
 def test_gemm_nt_lower(handle, n, k, tile):
