@@ -240,6 +240,14 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(const double* __restric
   for (i64 rr = blockIdx.y; rr < rows; rr += gridDim.y) dst[rr * ldd + c] = src[rr * lds_ + c] * f;
 }
 
+// A[r][c] *= s[r]   (row scaling in place: the FITC weights 1/sqrt(nu_i), sgpr.py:244)
+__global__ __launch_bounds__(256) void scale_rows_kernel(double* __restrict__ A, i64 lda, i64 rows, i64 cols,
+                                                         const double* __restrict__ sc) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (i64 rr = blockIdx.y; rr < rows; rr += gridDim.y) A[rr * lda + c] *= sc[rr];
+}
+
 // dst[c][r] = src[r][c]  (32x32 LDS tiles)
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, i64 lds_,
                                                         i64 rows, i64 cols,
@@ -409,6 +417,15 @@ int gps_launch_scale_add_eye(gps_handle_t h, double* B, i64 ldb, i64 n, i64 n_re
   LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n < 32768 ? n : 32768));
   hipLaunchKernelGGL(scale_add_eye_kernel, grid, dim3(256), 0, h->stream, B, ldb, n, n_real, scale);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_scale_rows(gps_handle_t h, double* A, i64 lda, i64 rows, i64 cols, const double* sc) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, (double)rows * cols, 16.0 * rows * cols);
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(scale_rows_kernel, grid, dim3(256), 0, h->stream, A, lda, rows, cols, sc);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

@@ -938,10 +938,13 @@ extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
 // ---- SGPR (Titsias 2009): bound and prediction ---------------------------------------------------------
 // models/sgpr.py:121-153 (_build_likelihood) and :155-189 (_build_predict).  Everything O(M^2 N) runs on the
 // device: Kuu potrf, (L^-1 Kuf)^T by trsm_rec, A A^T as one long-K NT GEMM, second potrf, solves.
-extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
-                        const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
-                        const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
-                        double* bound_out, double* mean_out, double* var_out, int* info) {
+// Shared by gps_sgpr (fitc == 0: every data point weighs 1/sigma^2) and gps_fitc (fitc == 1: point i weighs
+// 1/nu_i, nu_i = Kdiag_i - Qff_ii + sigma^2, sgpr.py:232-250).  With W = rows of (L^-1 Kuf)^T scaled by sqrt(weight)
+// both are  B = I + W^T W,  c = LB^-1 W^T (err * sqrt(weight)).
+static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                           const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                           const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
+                           double* bound_out, double* mean_out, double* var_out, int* info) {
   if (!h || !Z || !X || !resid || m <= 0 || n <= 0 || d_all <= 0 || r <= 0 || !(noise_var > 0.0))
     return gps_fail(h, GPS_ERR_ARG, "gps_sgpr: bad argument");
   if (n_new > 0 && (!Xnew || !mean_out || !var_out)) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr: prediction outputs missing");
@@ -978,12 +981,36 @@ extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   if (rc) return rc;
   rc = blL.trsm_rec(h->dK.d(), mp, mp, 0, h->dS1.d(), mp, np);
   if (rc) return rc;
-  // A = At^T [mp, np] ; B = A A^T / sigma^2 + I ; LB = chol(B)           (sgpr.py:140-142)
+  double kdiag = 0.0;
+  rc = gps_launch_kdiag(h, prog, n_nodes, &kdiag);
+  if (rc) return rc;
+  std::vector<double> wsq;                                       // FITC: 1/sqrt(nu_i)
+  double sum_log_nu = 0.0;
+  if (fitc) {
+    // diag Qff = rowsumsq((L^-1 Kuf)^T) ; nu = Kdiag - diag Qff + sigma^2          (sgpr.py:241-242)
+    GPS_HIP(h, h->dTmp3.ensure((size_t)np * 8));
+    rc = gps_launch_rowdot(h, h->dS1.d(), mp, n, mp, nullptr, mp, 0, nullptr, h->dTmp3.d());
+    if (rc) return rc;
+    wsq.assign((size_t)np, 0.0);
+    GPS_HIP(h, hipMemcpyAsync(wsq.data(), h->dTmp3.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    for (i64 i = 0; i < n; ++i) {
+      const double nu = kdiag - wsq[i] + sigma2;
+      if (!(nu > 0.0)) return gps_fail(h, GPS_ERR_ARG, "gps_fitc: non-positive FITC variance nu");
+      sum_log_nu += log(nu);
+      wsq[i] = 1.0 / sqrt(nu);
+    }
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, wsq.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
+    rc = gps_launch_scale_rows(h, h->dS1.d(), mp, n, mp, h->dTmp3.d());
+    if (rc) return rc;
+  }
+  const double wgt = fitc ? 1.0 : 1.0 / sigma2;                  // what multiplies A A^T and the c terms
+  // A = At^T [mp, np] ; B = A A^T * weight + I ; LB = chol(B)              (sgpr.py:140-142, 244-245)
   rc = gps_launch_transpose(h, h->dS1.d(), mp, np, mp, h->dS2.d(), np);
   if (rc) return rc;
   rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, h->dS2.d(), np, h->dS2.d(), np, h->dS3.d(), mp);
   if (rc) return rc;
-  rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, 1.0 / sigma2);
+  rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, wgt);
   if (rc) return rc;
   HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, d_info};
   Blocked<HipOps> blB(opsB);
@@ -998,6 +1025,10 @@ extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   GPS_HIP(h, hipMemsetAsync(dErrT, 0, (size_t)r * np * 8, h->stream));
   rc = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dErrT, np);
   if (rc) return rc;
+  if (fitc) {                                                    // beta * sqrt(nu) = err / sqrt(nu)
+    rc = gps_launch_scale_cols(h, dErrT, np, r, n, h->dTmp3.d(), dErrT, np);
+    if (rc) return rc;
+  }
   GPS_HIP(h, h->dMean.ensure((size_t)(mp * r + mp) * 8 + (size_t)(n_new > 0 ? (n_new * r + 2 * n_new) * 8 : 0)));
   double* dAerr = h->dMean.d();                                  // [m][r]
   double* dDiag = dAerr + (size_t)mp * r;                        // [m]
@@ -1025,13 +1056,19 @@ extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   double slogLB = 0.0, sc2 = 0.0, trAAT = 0.0, serr2 = 0.0;
   for (int b = 0; b < 64; ++b) { slogLB += hp[2 * b]; sc2 += hp[2 * b + 1]; }
   for (i64 i = 0; i < m; ++i) trAAT += hdiag[i];
-  trAAT /= sigma2;
-  sc2 /= (sigma2 * sigma2);                                      // c = (c sigma^2) / sigma^2
-  for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
-  double kdiag = 0.0;
-  rc = gps_launch_kdiag(h, prog, n_nodes, &kdiag);
-  if (rc) return rc;
-  if (bound_out) {
+  h->sparse_terms[0] = slogLB; h->sparse_terms[1] = trAAT; h->sparse_terms[2] = sc2 * wgt * wgt;
+  h->sparse_terms[3] = kdiag; h->sparse_terms[4] = sum_log_nu;
+  trAAT *= wgt;
+  sc2 *= wgt * wgt;                                              // SGPR: c = (c sigma^2) / sigma^2
+  if (fitc) {
+    for (i64 i = 0; i < n; ++i) for (i64 q = 0; q < r; ++q) { const double e = resid[i * r + q] * wsq[i]; serr2 += e * e; }
+  } else {
+    for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
+  }
+  if (bound_out && fitc) {
+    const double N = (double)n, R = (double)r;                   // sgpr.py:256-290
+    *bound_out = -0.5 * serr2 + 0.5 * sc2 + R * (-0.5 * N * log(2.0 * M_PI) - 0.5 * sum_log_nu - slogLB);
+  } else if (bound_out) {
     const double N = (double)n, R = (double)r;
     double bound = -0.5 * N * R * log(2.0 * M_PI);               // sgpr.py:147-153
     bound += -R * slogLB;
@@ -1081,8 +1118,30 @@ extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
     GPS_HIP(h, hipMemcpyAsync(var_out, h->dTmp2.p, (size_t)n_new * n_new * 8, hipMemcpyDeviceToHost, h->stream));
   }
   GPS_HIP(h, hipStreamSynchronize(h->stream));
-  for (size_t i = 0; i < hm.size(); ++i) mean_out[i] = hm[i] / sigma2;       // c = (c sigma^2)/sigma^2
+  for (size_t i = 0; i < hm.size(); ++i) mean_out[i] = hm[i] * wgt;          // SGPR: c = (c sigma^2)/sigma^2
   if (!full_cov)
     for (i64 i = 0; i < n_new; ++i) var_out[i] = kdiag + h2[i] - h1[i];
+  return GPS_OK;
+}
+
+extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                        const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                        const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
+                        double* bound_out, double* mean_out, double* var_out, int* info) {
+  return sparse_gpr_impl(h, 0, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, Xnew, n_new, full_cov,
+                         bound_out, mean_out, var_out, info);
+}
+
+extern "C" int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                        const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                        const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
+                        double* bound_out, double* mean_out, double* var_out, int* info) {
+  return sparse_gpr_impl(h, 1, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, Xnew, n_new, full_cov,
+                         bound_out, mean_out, var_out, info);
+}
+
+extern "C" int gps_sparse_last_terms(gps_handle_t h, double* out5) {
+  if (!h || !out5) return GPS_ERR_ARG;
+  for (int i = 0; i < 5; ++i) out5[i] = h->sparse_terms[i];
   return GPS_OK;
 }

@@ -69,6 +69,7 @@ struct gps_handle_s {
   i64 n = 0, d_all = 0, npad = 0;   // training set
   i64 r = 0;                        // outputs of the last factorisation
   bool have_factor = false;
+  double sparse_terms[5] = {0, 0, 0, 0, 0};   // gps_sparse_last_terms
   DevBuf dX;        // [n, d_all]
   DevBuf dK;        // [npad, npad]  K then L (lower, row-major)
   DevBuf dLinv;     // [npad/128][128*128] inverses of the diagonal blocks
@@ -176,6 +177,7 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
                         double diag_add);
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
+int gps_launch_scale_rows(gps_handle_t h, double* A, i64 lda, i64 rows, i64 cols, const double* sc);
 int gps_launch_scale_cols(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols, const double* sc,
                           double* dst, i64 ldd);
 int gps_launch_scale_add_eye(gps_handle_t h, double* B, i64 ldb, i64 n, i64 n_real, double scale);

@@ -67,6 +67,10 @@ _SIGNATURES = {
     "gps_sgpr": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
                  ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int, _c_double_p,
                  _c_double_p, _c_double_p, _c_int_p],
+    "gps_fitc": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
+                 ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int, _c_double_p,
+                 _c_double_p, _c_double_p, _c_int_p],
+    "gps_sparse_last_terms": [ctypes.c_void_p, _c_double_p],
     "gps_profile_enable": [ctypes.c_void_p, ctypes.c_int],
     "gps_profile_reset": [ctypes.c_void_p],
     "gps_profile_get": [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(_i64), _c_double_p, _c_double_p,
@@ -419,7 +423,8 @@ class Handle(object):
         return mean, var
 
     # ---- SGPR
-    def sgpr(self, prog, Z, X, resid, jitter, noise_var, Xnew=None, full_cov=False, want_bound=True):
+    def sgpr(self, prog, Z, X, resid, jitter, noise_var, Xnew=None, full_cov=False, want_bound=True, fitc=False):
+        """gps_sgpr (Titsias bound) or, with fitc=True, gps_fitc (Snelson & Ghahramani)."""
         Z, X, resid = _f64(Z), _f64(X), _f64(resid)
         m, d = Z.shape
         n, r = resid.shape
@@ -434,13 +439,20 @@ class Handle(object):
         else:
             n_new, mean, var, xp, mp_, vp = 0, None, None, None, None, None
         self.resident_token = None
-        self._check(self._lib.gps_sgpr(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter),
-                                       float(noise_var), _ptr(resid), r, xp, n_new, 1 if full_cov else 0,
-                                       ctypes.byref(bound) if want_bound else None, mp_, vp, ctypes.byref(info)),
-                    "gps_sgpr")
+        fn = self._lib.gps_fitc if fitc else self._lib.gps_sgpr
+        self._check(fn(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter),
+                       float(noise_var), _ptr(resid), r, xp, n_new, 1 if full_cov else 0,
+                       ctypes.byref(bound) if want_bound else None, mp_, vp, ctypes.byref(info)),
+                    "gps_fitc" if fitc else "gps_sgpr")
         if info.value > 0:
             raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
         return bound.value, mean, var
+
+    def sparse_last_terms(self):
+        """sum log diag LB, tr(A A^T), sum c^2, Kdiag constant, sum log nu of the last sgpr() call."""
+        out = np.zeros(5)
+        self._check(self._lib.gps_sparse_last_terms(self._h, _ptr(out)), "gps_sparse_last_terms")
+        return dict(sum_log_diag_LB=out[0], tr_AAT=out[1], sum_c2=out[2], kdiag=out[3], sum_log_nu=out[4])
 
     # ---- conditionals
     @staticmethod

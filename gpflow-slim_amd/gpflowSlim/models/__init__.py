@@ -1,4 +1,4 @@
 from .model import Model, GPModel
 from .gpr import GPR
 from .svgp import SVGP
-from .sgpr import SGPR
+from .sgpr import SGPR, GPRFITC

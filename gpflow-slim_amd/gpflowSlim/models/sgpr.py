@@ -2,8 +2,9 @@
 
 Mirrors gpflowSlim/models/sgpr.py:85-189 (SGPR.__init__, _build_likelihood, _build_predict).  All
 O(M^2 N) work -- Kuu potrf, (L^-1 Kuf), A A^T, the second potrf and the solves -- runs in gps_sgpr on
-the GPU; Kuf ([M, N], 32 GB at M = 4096, N = 10^6) never leaves HBM.  GPRFITC and the upper bound
-(sgpr.py:30-82, 192-326) are not mirrored.
+the GPU; Kuf ([M, N], 32 GB at M = 4096, N = 10^6) never leaves HBM.  GPRFITC (sgpr.py:190-326) runs through
+gps_fitc (the same pipeline with per-point weights 1/nu_i), and SGPRUpperMixin.compute_upper_bound
+(sgpr.py:30-82) is assembled from the terms of two such device evaluations.
 """
 import numpy as np
 
@@ -14,7 +15,32 @@ from .._settings import settings
 from .model import GPModel
 
 
-class SGPR(GPModel):
+class SGPRUpperMixin(object):
+    """Upper bound for the GP regression marginal likelihood (models/sgpr.py:30-82, Titsias 2014)."""
+
+    def compute_upper_bound(self):
+        """models/sgpr.py:55-82.  With A = L^-1 Kuf:  chol(Kuu + s^-2 Kuf Kuf^T) = L chol(I + s^-2 A A^T), so
+        logdet = -sum log diag(LB) and |v|^2 = |LB_c^-1 A Y|^2 / s_c^4 -- both are terms of gps_sgpr, evaluated once
+        at the likelihood variance and once at the corrected noise (with Y, not Y - m(X), as the reference does)."""
+        h = be.get_handle()
+        prog = self.kern._program(self.X.shape[1])
+        Y = np.ascontiguousarray(self.Y)
+        num_data = float(self.Y.shape[0])
+        s2 = float(np.squeeze(self.likelihood.variance))
+        jit = settings.numerics.jitter_level
+        h.sgpr(prog, self.feature.Z, self.X, Y, jit, s2)
+        t = h.sparse_last_terms()
+        c = num_data * t["kdiag"] - t["tr_AAT"]                       # trace bound, sgpr.py:67
+        corrected_noise = s2 + c
+        const = -0.5 * num_data * np.log(2 * np.pi * s2)
+        logdet = -t["sum_log_diag_LB"]
+        h.sgpr(prog, self.feature.Z, self.X, Y, jit, corrected_noise)
+        tc = h.sparse_last_terms()
+        quad = -0.5 / corrected_noise * np.sum(Y ** 2.0) + 0.5 * tc["sum_c2"]
+        return const + logdet + quad
+
+
+class SGPR(GPModel, SGPRUpperMixin):
     def __init__(self, X, Y, kern, feat=None, mean_function=None, Z=None, obs_var=0.1, num_data=None,
                  num_latent=None, **kwargs):
         X = np.ascontiguousarray(X, dtype=settings.float_type)
@@ -48,3 +74,45 @@ class SGPR(GPModel):
         else:
             var = np.tile(var[:, None], [1, R])
         return mean + self.mean_function(Xnew), var
+
+
+class GPRFITC(GPModel, SGPRUpperMixin):
+    """GP regression with the FITC approximation (models/sgpr.py:190-326, Snelson & Ghahramani 2006)."""
+
+    def __init__(self, X, Y, kern, feat=None, mean_function=None, Z=None, obs_var=0.1, num_data=None,
+                 num_latent=None, **kwargs):
+        X = np.ascontiguousarray(X, dtype=settings.float_type)
+        Y = np.ascontiguousarray(Y, dtype=settings.float_type)
+        likelihood = likelihoods.Gaussian(var=obs_var)
+        GPModel.__init__(self, X, Y, kern, likelihood, mean_function, **kwargs)
+        self.feature = features.inducingpoint_wrapper(feat, Z)
+        self.num_data = X.shape[0] if num_data is None else num_data
+        self.num_latent = Y.shape[1] if num_latent is None else num_latent
+        self._parameters = self._parameters + [self.feature._Z]
+
+    def _call(self, Xnew=None, full_cov=False, want_bound=True):
+        err = np.ascontiguousarray(self.Y - self.mean_function(self.X))
+        prog = self.kern._program(self.X.shape[1])
+        return be.get_handle().sgpr(prog, self.feature.Z, self.X, err, settings.numerics.jitter_level,
+                                    float(np.squeeze(self.likelihood.variance)), Xnew=Xnew, full_cov=full_cov,
+                                    want_bound=want_bound, fitc=True)
+
+    def _build_likelihood(self):
+        """models/sgpr.py:252-291"""
+        bound, _, _ = self._call()
+        return bound
+
+    def _build_predict(self, Xnew, full_cov=False):
+        """models/sgpr.py:293-318"""
+        Xnew = np.ascontiguousarray(Xnew, dtype=settings.float_type)
+        _, mean, var = self._call(Xnew=Xnew, full_cov=full_cov, want_bound=False)
+        R = self.num_latent
+        if full_cov:
+            var = np.tile(var[:, :, None], [1, 1, R])
+        else:
+            var = np.tile(var[:, None], [1, R])
+        return mean + self.mean_function(Xnew), var
+
+    @property
+    def Z(self):
+        raise NotImplementedError("Inducing points are now in `model.feature.Z`.")

@@ -184,6 +184,20 @@ int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
              const double* Xnew, int64_t n_new, int full_cov,
              double* bound_out, double* mean_out, double* var_out, int* info);
 
+/* GP regression with the FITC approximation: models.GPRFITC._build_likelihood / _build_predict
+ * (models/sgpr.py:229-318: Luu = chol(Kuu), V = Luu^-1 Kuf, nu = Kdiag - colsumsq(V) + sigma^2,
+ * L = chol(I + (V/nu) V^T), gamma = L^-1 V (err/nu)).  Same arguments, layouts and outputs as gps_sgpr;
+ * bound_out receives the FITC log-likelihood.  Kdiag must be constant (stationary kernels).          */
+int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+             const double* Z, int64_t m, const double* X, int64_t n, int64_t d_all,
+             double jitter, double noise_var, const double* resid, int64_t r,
+             const double* Xnew, int64_t n_new, int full_cov,
+             double* bound_out, double* mean_out, double* var_out, int* info);
+/* terms of the last gps_sgpr / gps_fitc call, for SGPRUpperMixin.compute_upper_bound (models/sgpr.py:55-85):
+ * out[0] = sum log diag(LB), out[1] = tr(A A^T) with A = L^-1 Kuf (gps_fitc: rows weighted by 1/nu),
+ * out[2] = sum c^2, out[3] = Kdiag constant, out[4] = sum log nu (gps_fitc only).                      */
+int gps_sparse_last_terms(gps_handle_t h, double* out5);
+
 /* ---- measurement --------------------------------------------------------
  * Per-kernel-class accounting of the calls issued through this handle.
  * gps_profile_enable(h, 1) brackets every launch with HIP events on the

@@ -382,6 +382,71 @@ def sgpr_predict(spec, X, Y, Z, noise_var, Xnew, full_cov=False, mean_X=None, me
     return mean + (0.0 if mean_Xnew is None else mean_Xnew), var
 
 
+def _fitc_common(spec, X, Y, Z, noise_var, mean_X, jitter):
+    """GPRFITC._build_common_terms, models/sgpr.py:232-250"""
+    num_inducing = Z.shape[0]
+    err = Y - (0.0 if mean_X is None else mean_X)
+    Kd = Kdiag(spec, X)
+    Kuf = K(spec, Z, X)
+    Kuu = K(spec, Z) + jitter * np.eye(num_inducing)
+    Luu = np.linalg.cholesky(Kuu)
+    V = sl.solve_triangular(Luu, Kuf, lower=True)
+    diagQff = np.sum(np.square(V), 0)
+    nu = Kd - diagQff + noise_var
+    B = np.eye(num_inducing) + np.matmul(V / nu, V.T)
+    L = np.linalg.cholesky(B)
+    beta = err / nu[:, None]
+    alpha = np.matmul(V, beta)
+    gamma = sl.solve_triangular(L, alpha, lower=True)
+    return err, nu, Luu, L, alpha, beta, gamma
+
+
+def fitc_lml(spec, X, Y, Z, noise_var, mean_X=None, jitter=JITTER):
+    """GPRFITC._build_likelihood, models/sgpr.py:252-291"""
+    err, nu, Luu, L, alpha, beta, gamma = _fitc_common(spec, X, Y, Z, noise_var, mean_X, jitter)
+    num_data, num_latent = Y.shape[0], Y.shape[1]
+    mahalanobisTerm = -0.5 * np.sum(np.square(err) / nu[:, None]) + 0.5 * np.sum(np.square(gamma))
+    constantTerm = -0.5 * num_data * np.log(2.0 * np.pi)
+    logDeterminantTerm = -0.5 * np.sum(np.log(nu)) - np.sum(np.log(np.diag(L)))
+    return mahalanobisTerm + (constantTerm + logDeterminantTerm) * num_latent
+
+
+def fitc_predict(spec, X, Y, Z, noise_var, Xnew, full_cov=False, mean_X=None, mean_Xnew=None, jitter=JITTER):
+    """GPRFITC._build_predict, models/sgpr.py:293-318"""
+    _, _, Luu, L, _, _, gamma = _fitc_common(spec, X, Y, Z, noise_var, mean_X, jitter)
+    Kus = K(spec, Z, Xnew)
+    w = sl.solve_triangular(Luu, Kus, lower=True)
+    tmp = sl.solve_triangular(L.T, gamma, lower=False)
+    mean = np.matmul(w.T, tmp) + (0.0 if mean_Xnew is None else mean_Xnew)
+    intermediateA = sl.solve_triangular(L, w, lower=True)
+    if full_cov:
+        var = K(spec, Xnew) - np.matmul(w.T, w) + np.matmul(intermediateA.T, intermediateA)
+        var = np.tile(var[:, :, None], [1, 1, Y.shape[1]])
+    else:
+        var = Kdiag(spec, Xnew) - np.sum(np.square(w), 0) + np.sum(np.square(intermediateA), 0)
+        var = np.tile(var[:, None], [1, Y.shape[1]])
+    return mean, var
+
+
+def sgpr_upper_bound(spec, X, Y, Z, noise_var, jitter=JITTER):
+    """SGPRUpperMixin.compute_upper_bound, models/sgpr.py:55-82"""
+    num_data = float(Y.shape[0])
+    Kd = Kdiag(spec, X)
+    Kuu = K(spec, Z) + jitter * np.eye(Z.shape[0])
+    Kuf = K(spec, Z, X)
+    L = np.linalg.cholesky(Kuu)
+    LB = np.linalg.cholesky(Kuu + noise_var ** -1.0 * np.matmul(Kuf, Kuf.T))
+    LinvKuf = sl.solve_triangular(L, Kuf, lower=True)
+    c = np.sum(Kd) - np.sum(LinvKuf ** 2.0)
+    corrected_noise = noise_var + c
+    const = -0.5 * num_data * np.log(2 * np.pi * noise_var)
+    logdet = np.sum(np.log(np.diag(L))) - np.sum(np.log(np.diag(LB)))
+    LC = np.linalg.cholesky(Kuu + corrected_noise ** -1.0 * np.matmul(Kuf, Kuf.T))
+    v = sl.solve_triangular(LC, corrected_noise ** -1.0 * np.matmul(Kuf, Y), lower=True)
+    quad = -0.5 * corrected_noise ** -1.0 * np.sum(Y ** 2.0) + 0.5 * np.sum(v ** 2.0)
+    return const + logdet + quad
+
+
 def gauss_kl(q_mu, q_sqrt, K=None):
     """kullback_leiblers.py:26-105"""
     if K is None:

@@ -327,3 +327,33 @@ def test_sgpr_parity(handle, kind, n, m_, d, r):
     _, cov = m.predict_f_full_cov(Xs[:20])
     _, rcov = orc.sgpr_predict(spec, X, Y, Z, noise, Xs[:20], full_cov=True)
     assert cov.shape == (20, 20, r) and rel(cov, rcov) <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["rbf_ard", "m52_plus_periodic"])
+@pytest.mark.parametrize("n,m_,d,r", [(300, 40, 3, 1), (1000, 130, 4, 2)])
+def test_fitc_parity(handle, kind, n, m_, d, r):
+    """models/sgpr.py:229-318 (GPRFITC likelihood + prediction) and :55-82 (upper bound) vs the oracle."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_ + 1)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r))
+    Z = X[rng.choice(n, m_, replace=False)].copy()
+    Xs = rng.standard_normal((57, d))
+    kern, spec = make_kernel(gpf, kind, d)
+    m = gpf.models.GPRFITC(X, Y, kern, Z=Z, obs_var=0.2)
+    noise = orc.constrained(0.2)
+    got = m.compute_log_likelihood()
+    ref = orc.fitc_lml(spec, X, Y, Z, noise)
+    assert abs(got - ref) <= 1e-7 * abs(ref)
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.fitc_predict(spec, X, Y, Z, noise, Xs)
+    assert mu.shape == (57, r) and var.shape == (57, r)
+    assert rel(mu, rmu) <= 1e-6 and rel(var, rvar) <= 1e-6
+    _, cov = m.predict_f_full_cov(Xs[:20])
+    _, rcov = orc.fitc_predict(spec, X, Y, Z, noise, Xs[:20], full_cov=True)
+    assert cov.shape == (20, 20, r) and rel(cov, rcov) <= 1e-6
+    # upper bound, on both sparse models (same inducing points)
+    ub_ref = orc.sgpr_upper_bound(spec, X, Y, Z, noise)
+    assert abs(m.compute_upper_bound() - ub_ref) <= 1e-7 * abs(ub_ref)
+    ms = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.2)
+    assert abs(ms.compute_upper_bound() - ub_ref) <= 1e-7 * abs(ub_ref)
+    assert ms.compute_log_likelihood() <= ub_ref

@@ -323,3 +323,33 @@ def test_sgpr_bound_limits():
     mu, var = orc.sgpr_predict(spec, X, Y, X, s2, X[:5])
     rmu, rvar = orc.gpr_predict(spec, X, Y, s2, X[:5])
     assert np.allclose(mu, rmu, atol=1e-4) and np.allclose(var, rvar, atol=1e-4)
+
+
+def test_fitc_and_upper_bound_limits():
+    """GPRFITC (models/sgpr.py:229-318) and the upper bound (:55-82): with Z = X both collapse onto the exact GP
+    (up to the Kuu jitter); with few inducing points lower bound <= exact LML <= upper bound."""
+    rng = np.random.default_rng(13)
+    n, d = 40, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
+    spec = {"type": "rbf", "variance": c(1.1), "lengthscales": c(1.0), "input_dim": d}
+    s2 = c(0.1)
+    lml = orc.gpr_lml(spec, X, Y, s2)
+    assert orc.fitc_lml(spec, X, Y, X, s2) == pytest.approx(lml, rel=1e-4)
+    mu, var = orc.fitc_predict(spec, X, Y, X, s2, X[:5])
+    rmu, rvar = orc.gpr_predict(spec, X, Y, s2, X[:5])
+    assert np.allclose(mu, rmu, atol=1e-4) and np.allclose(var, rvar, atol=1e-4)
+    # FITC's likelihood is the density of N(0, Qff + diag(nu)): check against the dense form
+    Z = X[:10]
+    Kuf = orc.K(spec, Z, X); Kuu = orc.K(spec, Z) + orc.JITTER * np.eye(10)
+    Qff = Kuf.T @ np.linalg.solve(Kuu, Kuf)
+    Kfitc = Qff + np.diag(orc.Kdiag(spec, X) - np.diag(Qff) + s2)
+    dense = orc.multivariate_normal(Y, np.zeros((n, 1)), np.linalg.cholesky(Kfitc))
+    assert orc.fitc_lml(spec, X, Y, Z, s2) == pytest.approx(dense, rel=1e-9)
+    # full-covariance prediction: its diagonal is the marginal variance
+    _, cov = orc.fitc_predict(spec, X, Y, Z, s2, X[:6], full_cov=True)
+    _, var6 = orc.fitc_predict(spec, X, Y, Z, s2, X[:6])
+    assert np.allclose(np.diagonal(cov[:, :, 0]), var6[:, 0], atol=1e-12)
+    lower = orc.sgpr_bound(spec, X, Y, Z, s2)
+    upper = orc.sgpr_upper_bound(spec, X, Y, Z, s2)
+    assert lower < lml < upper
+    assert orc.sgpr_upper_bound(spec, X, Y, X, s2) == pytest.approx(lml, rel=1e-4)
