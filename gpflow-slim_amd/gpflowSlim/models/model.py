@@ -1,8 +1,9 @@
 """Model / GPModel shells.
 
 Mirrors gpflowSlim/models/model.py:29-166.  ``objective`` / ``likelihood_tensor`` are floats
-(eager), not graph tensors.  ``optimize()`` (eager L-BFGS through TF autodiff, :172-196) is not
-mirrored; the gradients it would consume come from ``GPR.compute_log_likelihood_and_gradients``.
+(eager), not graph tensors.  ``optimize()`` (:172-196: eager L-BFGS over TF autodiff gradients, with an
+Adam fall-back) drives the same loop with the analytic gradients of
+``compute_log_likelihood_and_gradients`` (models that have them: GPR) -- L-BFGS-B from scipy, or Adam.
 """
 import numpy as np
 
@@ -48,6 +49,78 @@ class Model(object):
 
     def _build_likelihood(self):
         raise NotImplementedError
+
+    # ---- fitting (models/model.py:172-196, LBFGS.py) ----------------------------------------------------------
+    def _pack(self):
+        return np.concatenate([np.atleast_1d(p.vf_val).ravel() for p in self.parameters]) if self.parameters else np.zeros(0)
+
+    def _unpack(self, x):
+        k = 0
+        for p in self.parameters:
+            shape = np.shape(p.vf_val)
+            size = int(np.prod(shape)) if shape else 1
+            p.assign_unconstrained(np.asarray(x[k:k + size], dtype=settings.float_type).reshape(shape))
+            k += size
+
+    def _objective_and_grad(self, x):
+        """objective = -(LML + priors) and its gradient w.r.t. the packed unconstrained parameters."""
+        if not hasattr(self, "compute_log_likelihood_and_gradients"):
+            raise NotImplementedError("%s has no analytic gradients" % type(self).__name__)
+        self._unpack(x)
+        lml, grads = self.compute_log_likelihood_and_gradients()
+        g = np.concatenate([np.atleast_1d(gi).ravel() if getattr(p, "trainable", True) else np.zeros(np.size(gi))
+                            for p, gi in grads])
+        if any(p.prior is not None for p in self.parameters):
+            raise NotImplementedError("optimize(): priors are not differentiated")
+        return -float(lml), -g
+
+    def optimize(self, max_iter=1000, method="L-BFGS-B", learning_rate=1e-2, callback=None, tol=None):
+        """Minimise ``objective`` over the unconstrained parameters.  method: 'L-BFGS-B' (scipy, 20 corrections
+        like the reference's LBFGS(nCorrection=20)) or 'adam'.  A non-positive-definite step (Cholesky failure)
+        is treated as +inf by the line search.  Returns the final objective."""
+        from .._backend import NotPositiveDefiniteError
+        x0 = self._pack()
+
+        def fg(x):
+            try:
+                f, g = self._objective_and_grad(x)
+            except NotPositiveDefiniteError:
+                return 1e300, np.zeros_like(x)
+            if not np.isfinite(f) or not np.all(np.isfinite(g)):
+                return 1e300, np.zeros_like(x)
+            return f, g
+
+        if method.lower() == "adam":
+            x = x0.copy()
+            m1 = np.zeros_like(x); m2 = np.zeros_like(x)
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            best_f, best_x = np.inf, x.copy()
+            for it in range(1, max_iter + 1):
+                f, g = fg(x)
+                if f < best_f:
+                    best_f, best_x = f, x.copy()
+                m1 = b1 * m1 + (1 - b1) * g
+                m2 = b2 * m2 + (1 - b2) * g * g
+                x = x - learning_rate * (m1 / (1 - b1 ** it)) / (np.sqrt(m2 / (1 - b2 ** it)) + eps)
+                if callback is not None:
+                    callback(it, f)
+            f, _ = fg(x)
+            if f > best_f:
+                x, f = best_x, best_f
+            self._unpack(x)
+            return f
+        from scipy.optimize import minimize
+        it = [0]
+
+        def cb(xk):
+            it[0] += 1
+            if callback is not None:
+                callback(it[0], None)
+
+        res = minimize(fg, x0, jac=True, method="L-BFGS-B", callback=cb,
+                       options={"maxiter": max_iter, "maxcor": 20, **({"ftol": tol} if tol is not None else {})})
+        self._unpack(res.x)
+        return float(res.fun)
 
 
 class GPModel(Model):

@@ -133,3 +133,34 @@ def test_gradient_too_many_primitives_is_a_loud_error(handle):
     m = gpf.models.GPR(X, Y, kern)
     with pytest.raises(RuntimeError, match="more than 4 primitive"):
         m.compute_log_likelihood_and_gradients()
+
+
+@pytest.mark.gpu
+def test_gpr_optimize_lbfgs_and_adam():
+    """GPR.optimize (models/model.py:172-196 with examples/gpr.py's model): L-BFGS-B on the analytic gradients
+    reaches a stationary point of the LML (small projected gradient, objective far below the start), and the
+    fitted model explains held-out data; Adam lowers the objective too."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(5)
+    n, d = 300, 3
+    X = rng.standard_normal((n, d)); w = np.array([[1.5], [0.0], [-0.7]])
+    f = lambda A: np.sin(A @ w)
+    Y = f(X) + 0.1 * rng.standard_normal((n, 1))
+    Xs = rng.standard_normal((100, d))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, ARD=True))
+    start = m.objective
+    final = m.optimize(max_iter=200)
+    assert final < start - 50.0
+    assert m.objective == pytest.approx(final, rel=1e-10)
+    _, grads = m.compute_log_likelihood_and_gradients()
+    gnorm = max(float(np.max(np.abs(g))) for _, g in grads)
+    assert gnorm < 1e-2 * max(1.0, abs(final)), gnorm
+    ls = np.asarray(m.kern.lengthscales)
+    assert ls[1] > 3.0 * max(ls[0], ls[2])                   # the irrelevant input is switched off
+    assert 0.005 < float(np.squeeze(m.likelihood.variance)) < 0.03      # noise variance 0.01 recovered
+    mu, var = m.predict_f(Xs)
+    assert np.sqrt(np.mean((mu - f(Xs)) ** 2)) < 0.1
+    m2 = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, ARD=True))
+    s2 = m2.objective
+    f2 = m2.optimize(max_iter=150, method="adam", learning_rate=0.05)
+    assert f2 < s2 - 50.0

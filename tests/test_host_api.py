@@ -144,3 +144,35 @@ def test_gpr_shell_without_device(gpf):
     assert isinstance(feat, gpf.features.InducingPoints) and len(feat) == 5
     with pytest.raises(ValueError):
         gpf.features.inducingpoint_wrapper(feat, X)
+
+
+def test_optimize_drivers_on_a_quadratic():
+    """Model.optimize (models/model.py:172-196): the L-BFGS-B and Adam drivers, packing / unpacking of the
+    unconstrained parameters and the trainable mask, on a model whose 'likelihood' is a concave quadratic
+    (no GPU involved)."""
+    import gpflowSlim as gpf
+    from gpflowSlim.params import Parameter
+    from gpflowSlim.models.model import Model
+
+    class Quad(Model):
+        def __init__(self):
+            Model.__init__(self)
+            self.a = Parameter(np.array([3.0, -2.0]), name="a")
+            self.b = Parameter(0.5, name="b")
+            self.c = Parameter(7.0, trainable=False, name="c")
+            self._parameters = [self.a, self.b, self.c]
+            self.target = [np.array([1.0, 2.0]), -1.5, 0.0]
+
+        def _build_likelihood(self):
+            return -sum(float(np.sum((np.atleast_1d(p.vf_val) - t) ** 2)) for p, t in zip(self._parameters, self.target))
+
+        def compute_log_likelihood_and_gradients(self):
+            return self._build_likelihood(), [(p, -2.0 * (p.vf_val - t)) for p, t in zip(self._parameters, self.target)]
+
+    for method, kw in (("L-BFGS-B", {}), ("adam", {"learning_rate": 0.1, "max_iter": 600})):
+        m = Quad()
+        f = m.optimize(method=method, **kw)
+        assert np.allclose(m.a.vf_val, [1.0, 2.0], atol=1e-3) and abs(float(m.b.vf_val) + 1.5) < 1e-3
+        assert float(m.c.vf_val) == 7.0                       # not trainable: untouched
+        assert f == pytest.approx(49.0, abs=1e-4)             # what the frozen parameter leaves
+        assert m.objective == pytest.approx(f, abs=1e-9)
