@@ -190,6 +190,136 @@ def test_large_n_properties(handle):
     assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
 
 
+def test_full_size_block_separable(handle):
+    """N = 32768, D = 8 (BASELINE configs[2] size), where the oracle cannot go: 64 clusters of 512 points on a
+    4 x 4 x 4 grid, 60 length-scales apart (far enough for exp(-r^2/2) to underflow, near enough for the
+    reference's |a|^2 + |b|^2 - 2ab distance form to keep its digits), so every cross-cluster covariance is exactly
+    0 and
+        LML(X, Y) = sum over clusters of LML(X_c, Y_c),   predict_f(x*) depends on x*'s cluster only.
+    Each 512-point cluster spans four 128-blocks of the factorisation and is checked against the oracle."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(32768)
+    nc, per, d = 64, 512, 8
+    ls = np.sqrt(d) * np.ones(d)
+    Xc = [rng.standard_normal((per, d)) for _ in range(nc)]
+    w = rng.standard_normal((d, 1)) / np.sqrt(d)
+    Yc = [np.sin(x @ w) + 0.1 * rng.standard_normal((per, 1)) for x in Xc]
+    def shift(c):
+        o = np.zeros((1, d))
+        o[0, 0], o[0, 1], o[0, 2] = 60.0 * ls[0] * (c % 4), 60.0 * ls[1] * ((c // 4) % 4), 60.0 * ls[2] * (c // 16)
+        return o
+    order = rng.permutation(nc * per)                       # clusters interleaved in memory
+    X = np.concatenate([x + shift(c) for c, x in enumerate(Xc)])[order]
+    Y = np.concatenate(Yc)[order]
+    kern = gpf.kernels.RBF(d, variance=1.3, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.3), "lengthscales": orc.constrained(ls), "input_dim": d}
+    noise = orc.constrained(0.1)
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    lml = m.compute_log_likelihood()
+    ref = sum(orc.gpr_lml(spec, x, y, noise) for x, y in zip(Xc, Yc))
+    assert abs(lml - ref) <= 1e-9 * abs(ref)
+    picks = [0, 17, 63]
+    Xs = np.concatenate([rng.standard_normal((40, d)) + shift(c) for c in picks])
+    m.reuse_factor = True
+    mu, var = m.predict_f(Xs)
+    for k, c in enumerate(picks):
+        rmu, rvar = orc.gpr_predict(spec, Xc[c], Yc[c], noise, Xs[40 * k:40 * (k + 1)] - shift(c))
+        assert rel(mu[40 * k:40 * (k + 1)], rmu) <= RTOL and rel(var[40 * k:40 * (k + 1)], rvar) <= RTOL
+
+
+def test_full_size_dense_invariances(handle):
+    """N = 32768, D = 8, dense covariance (the bench workload): the LML does not depend on the order of the data
+    (a different factorisation of a permuted matrix), the posterior mean is linear in Y and the posterior variance
+    does not depend on Y or on the number of outputs."""
+    import gpflowSlim as gpf
+    n, d = 32768, 8
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 300)
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
+    rng = np.random.default_rng(7)
+    Y2 = np.cos(X[:, :1] * 1.3) + 0.1 * rng.standard_normal((n, 1))
+    m1 = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    lml1 = m1.compute_log_likelihood()
+    perm = rng.permutation(n)
+    mp = gpf.models.GPR(X[perm], Y[perm], kern, obs_var=0.1)
+    lmlp = mp.compute_log_likelihood()
+    assert abs(lml1 - lmlp) <= 1e-9 * abs(lml1)
+    m3 = gpf.models.GPR(X, np.hstack([Y, Y2, 2.0 * Y - 3.0 * Y2]), kern, obs_var=0.1)
+    lml3 = m3.compute_log_likelihood()
+    m3.reuse_factor = True
+    mu3, var3 = m3.predict_f(Xs)
+    assert rel(mu3[:, 2:3], 2.0 * mu3[:, 0:1] - 3.0 * mu3[:, 1:2]) <= 1e-9
+    assert np.array_equal(var3[:, 0], var3[:, 1]) and np.array_equal(var3[:, 0], var3[:, 2])
+    assert var3.min() > 0 and var3.max() <= 1.0 + 1e-12
+    m1.reuse_factor = True
+    mu1, var1 = m1.predict_f(Xs)
+    assert rel(mu3[:, 0:1], mu1) <= 1e-10 and rel(var3[:, 0:1], var1) <= 1e-10
+    # R outputs: R log-determinants and the sum of the quadratic forms (densities.py:93-94)
+    m2 = gpf.models.GPR(X, Y2, kern, obs_var=0.1)
+    lml2 = m2.compute_log_likelihood()
+    mc = gpf.models.GPR(X, 2.0 * Y - 3.0 * Y2, kern, obs_var=0.1)
+    lmlc = mc.compute_log_likelihood()
+    assert abs(lml3 - (lml1 + lml2 + lmlc)) <= 1e-9 * abs(lml3)
+
+
+def test_full_size_config4_invariances(handle):
+    """BASELINE configs[3]: Matern-5/2(ARD) + Periodic, N = 16384, D = 16 (the reference would need a 34 GB
+    [N, N, D] temporary here).  Permutation invariance of the LML, linearity of the posterior mean, variance bounds;
+    plus oracle parity of the posterior on a 1024-point subsample model (same kernel program)."""
+    import gpflowSlim as gpf
+    n, d = 16384, 16
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 200)
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.Matern52(d, variance=1.0, lengthscales=ls, ARD=True) + \
+        gpf.kernels.Periodic(d, period=2.0, variance=0.7, lengthscales=1.0)
+    rng = np.random.default_rng(4)
+    m = gpf.models.GPR(X, np.hstack([Y, -0.5 * Y]), kern, obs_var=0.1)
+    lml = m.compute_log_likelihood()
+    m.reuse_factor = True
+    mu, var = m.predict_f(Xs)
+    assert rel(mu[:, 1:2], -0.5 * mu[:, 0:1]) <= 1e-10
+    assert var.min() > 0 and var.max() <= 1.7 + 1e-12
+    perm = rng.permutation(n)
+    lmlp = gpf.models.GPR(X[perm], np.hstack([Y, -0.5 * Y])[perm], kern, obs_var=0.1).compute_log_likelihood()
+    assert abs(lml - lmlp) <= 1e-9 * abs(lml)
+    spec = {"type": "sum", "children": [
+        {"type": "matern52", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d},
+        {"type": "periodic", "variance": orc.constrained(0.7), "lengthscales": orc.constrained(1.0),
+         "period": orc.constrained(2.0), "input_dim": d}]}
+    sub = rng.choice(n, 1024, replace=False)
+    ms = gpf.models.GPR(X[sub], Y[sub], kern, obs_var=0.1)
+    noise = orc.constrained(0.1)
+    assert abs(ms.compute_log_likelihood() - orc.gpr_lml(spec, X[sub], Y[sub], noise)) <= RTOL * abs(lml)
+    smu, svar = ms.predict_f(Xs)
+    rmu, rvar = orc.gpr_predict(spec, X[sub], Y[sub], noise, Xs)
+    assert rel(smu, rmu) <= RTOL and rel(svar, rvar) <= RTOL
+
+
+def test_full_size_config5_conditional_consistency(handle):
+    """BASELINE configs[4] shape: conditional() with M = 4096 inducing points at N = 250 000 test points (a quarter
+    of the 10^6 of the config, to keep the host arrays small): test points are independent, so any slice of the big
+    call equals a small call on that slice, which in turn is checked against the oracle."""
+    import gpflowSlim as gpf
+    M, N, d = 4096, 250000, 8
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, d)); Z = X[:M].copy()
+    f = rng.standard_normal((M, 2))
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d}
+    idx = np.sort(rng.choice(N, 300, replace=False))
+    for white in (True, False):
+        mu, var = gpf.conditionals.conditional(X, Z, kern, f, white=white)
+        assert mu.shape == (N, 2) and var.shape == (N, 2)
+        smu, svar = gpf.conditionals.conditional(X[idx], Z, kern, f, white=white)
+        # different tile shapes -> different summation order, amplified by cond(Kuu + 1e-6 I) ~ 1e6
+        assert rel(mu[idx], smu) <= 1e-7 and np.abs(var[idx] - svar).max() <= 1e-7
+        rmu, rvar = orc.conditional(X[idx], Z, spec, f, white=white)
+        # Kuu + 1e-6 I with 4096 close inducing points is ill-conditioned: both sides lose digits
+        assert rel(smu, rmu) <= 1e-5 and np.abs(svar - rvar).max() <= 1e-6
+        assert var.min() > -1e-6 and var.max() <= 1.0 + 1e-9
+
+
 @pytest.mark.parametrize("whiten", [True, False])
 @pytest.mark.parametrize("q_diag", [False, True])
 def test_svgp_bound_parity(handle, whiten, q_diag):
