@@ -369,11 +369,15 @@ class Handle(object):
     # ---- GPR
     def gpr_set_data(self, X, token):
         X = _f64(X)
+        _need(X.ndim == 2 and X.shape[0] > 0 and X.shape[1] > 0, "GPR needs a non-empty X [N, D]")
+        self.resident_shape = X.shape
         self._check(self._lib.gps_gpr_set_data(self._h, _ptr(X), X.shape[0], X.shape[1]), "gps_gpr_set_data")
         self.resident_token = token
 
     def gpr_lml(self, prog, noise_var, resid):
         resid = _f64(resid)
+        shape = getattr(self, "resident_shape", None)
+        _need(shape is not None and resid.ndim == 2 and resid.shape[0] == shape[0], "Y must have one row per row of X")
         lml = ctypes.c_double(0)
         info = ctypes.c_int(0)
         self._check(self._lib.gps_gpr_lml(self._h, prog, len(prog), float(noise_var), _ptr(resid), resid.shape[1],
@@ -408,10 +412,16 @@ class Handle(object):
     def gpr_predict(self, prog, noise_var, resid, Xnew, full_cov=False, refactor=True):
         resid = _f64(resid)
         Xnew = _f64(Xnew)
+        shape = getattr(self, "resident_shape", None)
+        _need(Xnew.ndim == 2 and shape is not None and Xnew.shape[1] == shape[1],
+              "Xnew must be [N*, %s]" % (shape[1] if shape else "D"))
+        _need(resid.ndim == 2 and resid.shape[0] == shape[0], "Y must have one row per row of X")
         n_new = Xnew.shape[0]
         r = resid.shape[1]
         mean = np.empty((n_new, r))
         var = np.empty((n_new, n_new) if full_cov else (n_new,))
+        if n_new == 0:                       # nothing to predict: the reference returns empty tensors
+            return mean, var
         info = ctypes.c_int(0)
         self._check(self._lib.gps_gpr_predict(self._h, prog, len(prog), float(noise_var), _ptr(resid), r,
                                               _ptr(Xnew), n_new, 1 if full_cov else 0, 1 if refactor else 0,
@@ -428,10 +438,15 @@ class Handle(object):
         Z, X, resid = _f64(Z), _f64(X), _f64(resid)
         m, d = Z.shape
         n, r = resid.shape
+        _need(X.ndim == 2 and X.shape == (n, d) and m > 0 and n > 0, "sparse GP regression needs Z [M, D], X [N, D], Y [N, R]")
         bound = ctypes.c_double(0)
         info = ctypes.c_int(0)
+        if Xnew is not None and np.shape(Xnew)[0] == 0:
+            _need(np.ndim(Xnew) == 2 and np.shape(Xnew)[1] == d, "Xnew must be [N*, %d]" % d)
+            return 0.0, np.empty((0, r)), np.empty((0, 0) if full_cov else (0,))
         if Xnew is not None:
             Xnew = _f64(Xnew)
+            _need(Xnew.ndim == 2 and Xnew.shape[1] == d, "Xnew must be [N*, %d]" % d)
             n_new = Xnew.shape[0]
             mean = np.empty((n_new, r))
             var = np.empty((n_new, n_new) if full_cov else (n_new,))
@@ -466,6 +481,12 @@ class Handle(object):
             return _f64(np.transpose(q_sqrt, (2, 0, 1))), 3       # [m,m,k] -> [k,m,m]
         raise ValueError("Bad dimension for q_sqrt: %s" % str(q_sqrt.ndim))
 
+    @staticmethod
+    def _check_q_sqrt(q, qnd, m, k):
+        if q is None:
+            return
+        _need(q.shape == ((m, k) if qnd == 2 else (k, m, m)), "q_sqrt must be [M, K] or [M, M, K]")
+
     def _cond_outputs(self, n_new, k, full_cov):
         fmean = np.empty((n_new, k))
         fvar = np.empty((k, n_new, n_new) if full_cov else (n_new, k))
@@ -474,9 +495,14 @@ class Handle(object):
     def conditional(self, prog, Z, Xnew, f, jitter, q_sqrt=None, white=False, full_cov=False):
         Z, Xnew, f = _f64(Z), _f64(Xnew), _f64(f)
         m, d = Z.shape
+        _need(Xnew.ndim == 2 and Xnew.shape[1] == d, "Xnew must be [N*, %d]" % d)
+        _need(f.ndim == 2 and f.shape[0] == m and m > 0, "f must be [M, K] with one row per row of X")
         n_new, k = Xnew.shape[0], f.shape[1]
         q, qnd = self._prep_q_sqrt(q_sqrt)
+        self._check_q_sqrt(q, qnd, m, k)
         fmean, fvar = self._cond_outputs(n_new, k, full_cov)
+        if n_new == 0:
+            return fmean, (np.empty((0, 0, k)) if full_cov else fvar)
         info = ctypes.c_int(0)
         self.resident_token = None
         self._check(self._lib.gps_conditional(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(Xnew),
@@ -491,10 +517,17 @@ class Handle(object):
 
     def base_conditional(self, Kmn, Kmm, Knn, f, q_sqrt=None, white=False, full_cov=False):
         Kmn, Kmm, Knn, f = _f64(Kmn), _f64(Kmm), _f64(Knn), _f64(f)
+        _need(Kmn.ndim == 2 and f.ndim == 2, "Kmn must be [M, N] and f [M, K]")
         m, n_new = Kmn.shape
         k = f.shape[1]
+        _need(Kmm.shape == (m, m) and f.shape[0] == m and m > 0, "Kmm must be [M, M] and f [M, K]")
+        _need(Knn.shape == ((n_new, n_new) if full_cov else (n_new,)),
+              "Knn must be [N, N] with full_cov and [N] without")
         q, qnd = self._prep_q_sqrt(q_sqrt)
+        self._check_q_sqrt(q, qnd, m, k)
         fmean, fvar = self._cond_outputs(n_new, k, full_cov)
+        if n_new == 0:
+            return fmean, (np.empty((0, 0, k)) if full_cov else fvar)
         info = ctypes.c_int(0)
         self.resident_token = None
         self._check(self._lib.gps_base_conditional(self._h, _ptr(Kmn), _ptr(Kmm), _ptr(Knn), m, n_new, _ptr(f), k,
@@ -506,6 +539,13 @@ class Handle(object):
         if full_cov:
             fvar = np.ascontiguousarray(np.transpose(fvar, (1, 2, 0)))
         return fmean, fvar
+
+
+def _need(cond, msg):
+    """Shape errors surface as ValueError before any pointer reaches the library (the reference gets the
+    equivalent InvalidArgumentError from the TF op that sees the mismatching shapes)."""
+    if not cond:
+        raise ValueError(msg)
 
 
 _default = None

@@ -487,3 +487,44 @@ def test_fitc_parity(handle, kind, n, m_, d, r):
     ms = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.2)
     assert abs(ms.compute_upper_bound() - ub_ref) <= 1e-7 * abs(ub_ref)
     assert ms.compute_log_likelihood() <= ub_ref
+
+
+def test_shape_errors_and_empty_inputs(handle):
+    """Mismatching shapes raise ValueError before anything reaches the device (the reference's TF ops raise
+    InvalidArgumentError for the same inputs); zero test points give empty results like the reference's graph."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((50, 3)); Y = rng.standard_normal((50, 2))
+    k = gpf.kernels.RBF(3)
+    assert k.K(X, np.zeros((0, 3))).shape == (50, 0) and k.K(np.zeros((0, 3))).shape == (0, 0)
+    with pytest.raises(ValueError):
+        k.K(X, np.zeros((4, 2)))
+    m = gpf.models.GPR(X, Y, k)
+    mu, var = m.predict_f(np.zeros((0, 3)))
+    assert mu.shape == (0, 2) and var.shape == (0, 2)
+    mu, cov = m.predict_f_full_cov(np.zeros((0, 3)))
+    assert mu.shape == (0, 2) and cov.shape == (0, 0, 2)
+    with pytest.raises(ValueError):
+        m.predict_f(np.zeros((4, 2)))
+    with pytest.raises(ValueError):
+        gpf.models.GPR(X, Y[:10], k)
+    with pytest.raises(ValueError):
+        gpf.models.GPR(np.zeros((0, 3)), np.zeros((0, 1)), k).compute_log_likelihood()
+    mu, var = gpf.conditionals.conditional(np.zeros((0, 3)), X, k, Y)
+    assert mu.shape == (0, 2) and var.shape == (0, 2)
+    with pytest.raises(ValueError):
+        gpf.conditionals.conditional(np.zeros((5, 2)), X, k, Y)
+    with pytest.raises(ValueError):
+        gpf.conditionals.conditional(X[:5], X, k, Y[:7])
+    with pytest.raises(ValueError):
+        gpf.conditionals.conditional(X[:5], X, k, Y, q_sqrt=np.ones((49, 2)))
+    Kmm = k.K(X) + 1e-6 * np.eye(50); Kmn = k.K(X, X[:5])
+    with pytest.raises(ValueError):
+        gpf.conditionals.base_conditional(Kmn, Kmm[:, :40], np.ones(5), Y)
+    with pytest.raises(ValueError):
+        gpf.conditionals.base_conditional(Kmn, Kmm, np.ones(4), Y)
+    s = gpf.models.SGPR(X, Y, k, Z=X[:7].copy())
+    with pytest.raises(ValueError):
+        s.predict_f(np.zeros((3, 5)))
+    mu, var = s.predict_f(np.zeros((0, 3)))
+    assert mu.shape == (0, 2) and var.shape == (0, 2)
