@@ -219,13 +219,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 
 template <int BM, int BN, int WGM, bool LOWER, int OP>
 static int launch_variant(gps_handle_t h, const GemmArgs& g) {
-  static bool attr_set = false;
   const size_t lds = (size_t)(2 * (BM + BN) * LS) * sizeof(double);
-  if (!attr_set) {
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), (int)lds);
+  if (rc) return rc;
   hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), dim3(g.ntiles), dim3(256), lds, h->stream, g);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;

@@ -68,6 +68,7 @@ struct gps_handle_s {
   // ---- GPR resident state ----
   i64 n = 0, d_all = 0, npad = 0;   // training set
   i64 r = 0;                        // outputs of the last factorisation
+  std::vector<const void*> dyn_lds_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
   bool have_factor = false;
   double sparse_terms[5] = {0, 0, 0, 0, 0};   // gps_sparse_last_terms
   DevBuf dX;        // [n, d_all]
@@ -103,6 +104,10 @@ static inline int gps_fail(gps_handle_t h, int code, const std::string& msg) {
   if (h) h->err = msg;
   return code;
 }
+
+// forward: raise a kernel's dynamic-LDS limit once per handle (= per device; the attribute is per device, so a
+// process-wide flag would leave a second GPU of the same process at the 64 KB default)
+static inline int gps_dyn_lds(gps_handle_t h, const void* fn, int bytes);
 
 #define GPS_HIP(h, call)                                                         \
   do {                                                                           \
@@ -147,6 +152,13 @@ static inline void gps_profile_collect(gps_handle_t h) {
 }
 
 // ---- kernel launchers implemented in the .hip files --------------------------
+static inline int gps_dyn_lds(gps_handle_t h, const void* fn, int bytes) {
+  for (const void* f : h->dyn_lds_done) if (f == fn) return GPS_OK;
+  GPS_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  h->dyn_lds_done.push_back(fn);
+  return GPS_OK;
+}
+
 // gemm_f64.hip : C (op)= A[M,K] * B[N,K]^T, all row-major, M,N multiples of 128,
 // K multiple of 16.  op 0: C -= A B^T ; op 1: C = A B^T ; op 2: C += A B^T ; lower: skip tiles above
 // the diagonal (M == N).

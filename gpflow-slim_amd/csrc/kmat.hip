@@ -454,8 +454,8 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
     GPS_HIP(h, hipStreamSynchronize(h->stream));
     const int rows_f = kc.net.ftot + kc.net.nnorm;
     const size_t lds = ((size_t)2 * rows_f * KT + (size_t)kc.net.n_layers * NKN_W * (NKN_W + 1)) * 8;
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nkn_tile_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&nkn_tile_kernel), 160 * 1024);
+    if (rcl) return rcl;
     if (lds > 160 * 1024) return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: feature slabs exceed LDS");
     LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 600.0 * kc.net.n_layers), tiles * KT * KT * 8.0);
     hipLaunchKernelGGL(nkn_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream,
@@ -467,9 +467,8 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
   for (int i = 0; i < kc.prog.n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
   a.maxnf = maxnf;
   const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
-  GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmat_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double))));
+  int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_tile_kernel), (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double)));
+  if (rcl) return rcl;
   LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);
   hipLaunchKernelGGL(kmat_tile_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds,
                      h->stream, a, kc.prog);

@@ -336,13 +336,9 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
 
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor, long long* d_stamps) {
-  static bool attr_set = false;
   const size_t lds = (size_t)(PB * PS + PB) * sizeof(double);
-  if (!attr_set) {
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_base_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&potrf_base_kernel), (int)lds);
+  if (rc0) return rc0;
   // potrf n^3/3 + trtri n^3/3
   LaunchScope ls(h, KC_POTRF_BASE, 2.0 * PB * PB * PB / 3.0, 3.0 * PB * PB * 8.0);
   hipLaunchKernelGGL(potrf_base_kernel, dim3(1), dim3(NT), lds, h->stream, A, lda, Linv_blk,
