@@ -17,7 +17,7 @@
 //               gradient of the log-marginal likelihood (what TF autodiff through tf.cholesky supplies to
 //               examples/gpr.py:53-54)
 //
-// Every flop of the recursion lands in Ops::gemm (C -= A B^T / C = A B^T) with K = half the
+// Every flop of the recursion lands in Ops::gemm (C -= A B^T / C = A B^T / C += A B^T / C = -A B^T) with K = half the
 // current block, i.e. long-K MFMA GEMMs; the 128x128 leaves use the explicit block inverses
 // produced by Ops::potrf_base.
 #pragma once
@@ -100,11 +100,11 @@ struct Blocked {
     rc = inv_t_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, Y + n1 * ldy + n1, ldy);
     if (rc) return rc;
     double* Y12 = Y + n1;
-    rc = ops.zero_block(Y12, ldy, n1, n2);
-    if (rc) return rc;
-    rc = ops.zero_block(Y + n1 * ldy, ldy, n2, n1);
-    if (rc) return rc;
-    rc = ops.gemm(0, /*A upper triangular*/ 2, n1, n2, n1, Y, ldy, L + n1 * ldl, ldl, Y12, ldy);   // Y12 = -Y11 L21^T
+    if (ops.fill_zeros()) {                   // only for a caller that reads Y as a full matrix: lauum_rec never
+      rc = ops.zero_block(Y + n1 * ldy, ldy, n2, n1);      // touches the blocks below the diagonal
+      if (rc) return rc;
+    }
+    rc = ops.gemm(/*C = -A B^T*/ 3, /*A upper triangular*/ 2, n1, n2, n1, Y, ldy, L + n1 * ldl, ldl, Y12, ldy);   // Y12 = -Y11 L21^T
     if (rc) return rc;
     return trsm_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, Y12, ldy, n1);   // ... L22^-T
   }

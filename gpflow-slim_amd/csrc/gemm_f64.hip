@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
         double* cp = g.C + (row0 + i * 16 + 4 * rg) * g.ldc + col0 + j * 16;
         if (OP == 0) *cp = *cp - acc[0][i][j][rg];
         else if (OP == 2) *cp = *cp + acc[0][i][j][rg];
+        else if (OP == 3) *cp = -acc[0][i][j][rg];
         else *cp = acc[0][i][j][rg];
       }
     }
@@ -237,11 +238,13 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     if (lower) {
       if (op == 0) return launch_variant<BM, BN, WGM, true, 0>(h, g);
       if (op == 2) return launch_variant<BM, BN, WGM, true, 2>(h, g);
+      if (op == 3) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: op 3 has no lower-triangle form");
       return launch_variant<BM, BN, WGM, true, 1>(h, g);
     }
   }
   if (op == 0) return launch_variant<BM, BN, WGM, false, 0>(h, g);
   if (op == 2) return launch_variant<BM, BN, WGM, false, 2>(h, g);
+  if (op == 3) return launch_variant<BM, BN, WGM, false, 3>(h, g);
   return launch_variant<BM, BN, WGM, false, 1>(h, g);
 }
 
@@ -273,7 +276,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
   const double flops = triA ? 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)   // sum_i 2 (K - 128 i)
                             : 2.0 * t128 * 128.0 * 128.0 * (double)K;
-  const double bytes = t128 * ((op != 1 ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
+  const double bytes = t128 * (((op == 0 || op == 2) ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);
   const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used

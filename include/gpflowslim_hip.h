@@ -253,8 +253,9 @@ int gps_set_option(gps_handle_t h, const char* key, double value);
 int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops,
                       int* layout_ok);
 /* raw device GEMM on host matrices, for unit tests:
- * C[m,n] (op)= A[m,k] * B[n,k]^T ; op: 0 -> C -= A B^T, 1 -> C = A B^T.
- * lower != 0: only tiles on/below the diagonal are computed (m == n).       */
+ * C[m,n] (op)= A[m,k] * B[n,k]^T ; op: 0 -> C -= A B^T, 1 -> C = A B^T, 2 -> C += A B^T, 3 -> C = -A B^T.
+ * lower == 1: only tiles on/below the diagonal are computed (m == n); lower == 2: A (m == k) is upper
+ * triangular and its zero part is skipped.                                   */
 int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
                      int64_t k, const double* A, const double* B, double* C);
 /* device-resident GEMM of the given shape on pseudo-random operands (lower == 1: syrk form, B = A): average

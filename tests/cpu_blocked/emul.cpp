@@ -60,7 +60,7 @@ struct CpuOps {
     for (i64 i = 0; i < M; ++i)
       for (i64 j = 0; j < N; ++j)
         if (done[i * N + j])
-          C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : (op == 2 ? C[i * ldc + j] + out[i * N + j] : out[i * N + j]);
+          C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : (op == 2 ? C[i * ldc + j] + out[i * N + j] : (op == 3 ? -out[i * N + j] : out[i * N + j]));
     return 0;
   }
   int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r) {
@@ -85,6 +85,7 @@ struct CpuOps {
     for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) Y[i * ldy + c] = W[i * T + c];
     return 0;
   }
+  bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
     return 0;

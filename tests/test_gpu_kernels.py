@@ -37,7 +37,7 @@ def _gemm_nt_full(handle, m, n, k, op):
 
 
 @pytest.mark.parametrize("m,n", [(128, 128), (384, 256), (1024, 640), (2048, 128)])
-@pytest.mark.parametrize("op", [0, 1, 2])
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
 @pytest.mark.parametrize("tile", [0, 128, 64, 32])
 def test_gemm_nt_triangular_a(handle, m, n, op, tile):
     """lower == 2: A [m, m] upper triangular, the kernel skips k < (first row of the tile); whatever sits below
@@ -53,7 +53,7 @@ def test_gemm_nt_triangular_a(handle, m, n, op, tile):
         out = handle.diag_gemm_nt(op, 2, Apoison, B, C)
     finally:
         handle.set_option("gemm_force_tile", 0)
-    ref = {0: C - A @ B.T, 1: A @ B.T, 2: C + A @ B.T}[op]
+    ref = {0: C - A @ B.T, 1: A @ B.T, 2: C + A @ B.T, 3: -(A @ B.T)}[op]
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
