@@ -198,7 +198,7 @@ def main():
                         "per_class_ms": {k: round(v["ms"], 3) for k, v in classes.items()}}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU stand-in is timed at N = 1 only
             import oracle.gp_oracle as orc       # the checker: cpu_baseline leg + its parity gate only
             ns = min(args.cpu_sample_n, n)
             Xc, Yc = X[:ns], Y[:ns]
