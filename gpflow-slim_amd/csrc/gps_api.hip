@@ -785,6 +785,19 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
   return GPS_OK;
 }
 
+// diagnostics: replace the handle's own stream by one restricted to the CUs of `mask` (hipExtStreamCreateWithCUMask)
+extern "C" int gps_diag_set_cu_mask(gps_handle_t h, const uint32_t* mask, int n_words) {
+  if (!h || !mask || n_words <= 0 || h->ext_stream) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_profile_collect(h);
+  hipStream_t s = nullptr;
+  GPS_HIP(h, hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+  (void)hipStreamDestroy(h->stream);
+  h->stream = s;
+  return GPS_OK;
+}
+
 extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
                               const double* resid, int64_t r, int nparts, int part, int64_t nb,
                               int64_t* n_panels, int64_t* msg_doubles_max) {

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
+    "gps_diag_set_cu_mask": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int],
     "gps_diag_gemm_timeline": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_longlong), _i64, ctypes.POINTER(ctypes.c_int64), _c_double_p],
 }
@@ -310,6 +311,10 @@ class Handle(object):
         self._check(self._lib.gps_diag_gemm_nt(self._h, op, int(lower), m, n, k, _ptr(A), _ptr(B), _ptr(C)),
                     "gps_diag_gemm_nt")
         return C
+
+    def diag_set_cu_mask(self, words):
+        arr = (ctypes.c_uint32 * len(words))(*[int(w) & 0xffffffff for w in words])
+        self._check(self._lib.gps_diag_set_cu_mask(self._h, arr, len(words)), "gps_diag_set_cu_mask")
 
     def diag_gemm_timeline(self, op, lower, m, n, k, reps=5, cap_blocks=1 << 17):
         """(ms per launch, stamps [nblocks, 6] = start, end (100 MHz ticks), HW_ID, XCC_ID, K-loop start, K-loop end) on random device data."""

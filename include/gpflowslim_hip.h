@@ -264,6 +264,9 @@ int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
 int gps_diag_gemm_timeline(gps_handle_t h, int op, int lower, int64_t m, int64_t n, int64_t k, int reps,
                            long long* stamps_out, int64_t cap_blocks, int64_t* nblocks,
                            double* ms_per_launch);
+/* replace the handle's stream by one restricted to the CUs set in mask[0 .. n_words) (experiments with
+ * concurrent streams; hipExtStreamCreateWithCUMask)                           */
+int gps_diag_set_cu_mask(gps_handle_t h, const uint32_t* mask, int n_words);
 /* phase timestamps (us) of one 128-block potrf_base launch; out7[0] = shader clock in MHz */
 int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
 
