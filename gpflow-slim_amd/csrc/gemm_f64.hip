@@ -38,6 +38,10 @@ struct GemmArgs {
   int K;
   int ntiles;
   int triA;         // A is upper triangular (A[i][k] == 0 for k < i): tile row tm starts its K loop at tm*BM
+  // Tail split (nsplit > 1, grid = nfull + (ntiles - nfull) * nsplit): see the comment at the kernel.
+  int nfull, nsplit;
+  double* ws;         // [(ntiles - nfull) * nsplit][BM * BN] slice partials
+  unsigned* cnt;      // [ntiles - nfull] arrival counters (left at 0)
   long long* stamps;  // diagnostics (gps_diag_gemm_timeline): [blockIdx][6] = start, end, HW_ID, XCC_ID, K loop start, K loop end (100 MHz ticks); else null
 };
 
@@ -108,8 +112,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   double* As = reinterpret_cast<double*>(smem_raw);       // [2][BM][LS]
   double* Bs = As + 2 * BM * LS;                          // [2][BN][LS]
 
+  // Tail split.  Tiles of one launch are equal, so a launch whose tile count is slightly above a multiple of the
+  // resident workgroup slots (512 at 128x128: e.g. the 2080 tiles of a lower-triangular 8192 update) ends with a
+  // round in which a few tiles run for a whole tile time while the rest of the GPU idles.  The first
+  // nfull = multiple-of-512 tiles run as usual; each of the remaining tiles is cut into nsplit K-slices handled by
+  // different workgroups, whose partial sums go to `ws`; the slice that arrives last at the tile's counter adds
+  // them in slice order and applies the result to C (deterministic: no floating-point atomics, and the split is
+  // a function of the launch shape only).
+  int tile_id, slice = -1, tail = 0;
+  if ((int)blockIdx.x < g.nfull || g.nsplit <= 1) {
+    tile_id = xcd_remap((int)blockIdx.x, g.nsplit > 1 ? g.nfull : g.ntiles);
+  } else {
+    const int q = (int)blockIdx.x - g.nfull;
+    tail = q / g.nsplit;
+    slice = q - tail * g.nsplit;
+    tile_id = g.nfull + tail;
+  }
   int tm, tn;
-  decode_tile<LOWER>(xcd_remap((int)blockIdx.x, g.ntiles), g.Tm, g.Tn, tm, tn);
+  decode_tile<LOWER>(tile_id, g.Tm, g.Tn, tm, tn);
   if (g.stamps && threadIdx.x == 0) {
     long long* st = g.stamps + 6 * (long long)blockIdx.x;
     st[0] = (long long)wall_clock64();
@@ -139,8 +159,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[q][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  const int nk = g.K / BK;
-  const int kt0 = g.triA ? (tm * BM) / BK : 0;
+  int nk = g.K / BK;
+  int kt0 = g.triA ? (tm * BM) / BK : 0;
+  if (slice >= 0) {                      // slabs [kt0, nk) of this slice: an even split of K / BK, remainder to the first slices
+    const int per = nk / g.nsplit, rem = nk - per * g.nsplit;
+    kt0 = slice * per + min(slice, rem);
+    nk = kt0 + per + (slice < rem ? 1 : 0);
+  }
 
   auto gload = [&](int kt) {
 #pragma unroll
@@ -199,6 +224,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[0][i][j] += acc[q][i][j];
+  if (slice >= 0) {
+    __shared__ unsigned s_ticket;
+    double* mine = g.ws + ((i64)tail * g.nsplit + slice) * (BM * BN) + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) mine[((i * NI + j) * 4 + rg) * 256] = acc[0][i][j][rg];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(&g.cnt[tail], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(g.nsplit - 1)) return;
+    __threadfence();
+    const double* all = g.ws + (i64)tail * g.nsplit * (BM * BN) + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          double t = 0.0;
+          for (int sl = 0; sl < g.nsplit; ++sl)
+            t += __builtin_nontemporal_load(all + (i64)sl * (BM * BN) + ((i * NI + j) * 4 + rg) * 256);
+          acc[0][i][j][rg] = t;
+        }
+    if (tid == 0) g.cnt[tail] = 0;       // ready for the next launch on this stream
+  }
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
   const i64 col0 = (i64)tn * BN + wc * WTN + (lane & 15);
 #pragma unroll
@@ -223,7 +277,8 @@ static int launch_variant(gps_handle_t h, const GemmArgs& g) {
   const size_t lds = (size_t)(2 * (BM + BN) * LS) * sizeof(double);
   int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), dim3(g.ntiles), dim3(256), lds, h->stream, g);
+  const int grid = g.nsplit > 1 ? g.nfull + (g.ntiles - g.nfull) * g.nsplit : g.ntiles;
+  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), dim3(grid), dim3(256), lds, h->stream, g);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
@@ -234,6 +289,23 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
   const i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
   if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
   g.ntiles = (int)nt;
+  // tail split: 128x128 tiles only (512 resident slots on 256 CUs), never for the in-place or triangular-A forms
+  g.nfull = g.ntiles; g.nsplit = 1; g.ws = nullptr; g.cnt = nullptr;
+  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.C != g.A && h->prop.multiProcessorCount == 256) {
+    const int slots = 512;
+    const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
+    int ns = r > 0 ? slots / r : 1;
+    if (ns > 16) ns = 16;
+    while (ns > 1 && (g.K / BK) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
+    if (nfull >= slots && ns > 1) {
+      GPS_HIP(h, h->dGemmWs.ensure((size_t)r * ns * BM * BN * sizeof(double)));
+      if (h->dGemmCnt.cap == 0) {
+        GPS_HIP(h, h->dGemmCnt.ensure(512 * sizeof(unsigned)));
+        GPS_HIP(h, hipMemsetAsync(h->dGemmCnt.p, 0, 512 * sizeof(unsigned), h->stream));
+      }
+      g.nfull = nfull; g.nsplit = ns; g.ws = h->dGemmWs.d(); g.cnt = (unsigned*)h->dGemmCnt.p;
+    }
+  }
   if (BM == BN) {
     if (lower) {
       if (op == 0) return launch_variant<BM, BN, WGM, true, 0>(h, g);

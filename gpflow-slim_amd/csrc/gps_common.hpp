@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/gpflowslim_hip.h"
@@ -26,6 +27,10 @@ struct DevBuf {
     size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    // test aid: GPS_POISON_ALLOC=1 fills every new buffer with NaN bit patterns, so that a kernel that reads memory
+    // nobody wrote shows up deterministically instead of depending on what the allocator hands back
+    static const bool poison = getenv("GPS_POISON_ALLOC") != nullptr;
+    if (e == hipSuccess && poison) { e = hipMemset(p, 0xff, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
     return e;
   }
   void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
@@ -55,6 +60,7 @@ struct gps_handle_s {
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
   int gemm_min_tiles = 768;
   int gemm_force_tb = 0;
+  int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
   // profiling
@@ -97,6 +103,7 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
+  DevBuf dGemmWs, dGemmCnt;   // slice partials + arrival counters of the GEMM tail split
   DevBuf dGemvWs, dGemvCnt;   // slice partials + arrival counters of the split transposed gemv (blas1.hip)
 };
 

@@ -243,7 +243,9 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
 
 /* tuning knobs (diagnostics; defaults are what bench.py measures):
  *   "gemm_min_tiles"  workgroups a GEMM launch should have before a larger tile is chosen
- *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)             */
+ *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)
+ *   "gemm_tail_split" 1 (default): the tiles of a partial last round of a 128x128 launch are cut into
+ *                     K-slices over the idle workgroup slots; 0: one workgroup per tile          */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------

@@ -58,6 +58,35 @@ def test_gemm_nt_triangular_a(handle, m, n, op, tile):
     assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("op,lower,m,n,k", [(0, 0, 8192, 1152, 1024), (1, 0, 8192, 1152, 512), (2, 0, 9216, 1024, 256),
+                                             (3, 0, 8192, 1152, 384), (0, 1, 4224, 4224, 256), (2, 1, 4480, 4480, 1024)])
+def test_gemm_nt_tail_split(handle, op, lower, m, n, k):
+    """Launches whose 128x128 tile count is a little above a multiple of the 512 resident workgroup slots: the
+    tiles of the partial last round are cut into K-slices whose partial sums are added in a fixed order.  Same
+    answer as one workgroup per tile (up to summation order), bit-identical from run to run."""
+    rng = np.random.default_rng(m + n + k + op)
+    A = rng.standard_normal((m, k)); B = A if lower else rng.standard_normal((n, k)); C = rng.standard_normal((m, n))
+    ref = {0: C - A @ B.T, 1: A @ B.T, 2: C + A @ B.T, 3: -(A @ B.T)}[op]
+    outs = {}
+    handle.set_option("gemm_force_tile", 128)          # (the tile heuristic would pick 64x64 below 768 tiles)
+    try:
+        for split in (1, 0, 1):
+            handle.set_option("gemm_tail_split", split)
+            outs.setdefault(split, []).append(handle.diag_gemm_nt(op, lower, A, B, C))
+    finally:
+        handle.set_option("gemm_tail_split", 1)
+        handle.set_option("gemm_force_tile", 0)
+    mask = np.tril(np.ones((m, n), dtype=bool)) if lower else np.ones((m, n), dtype=bool)
+    if lower:          # whole diagonal 128-blocks are computed; only their lower triangles are defined
+        for out in outs[0] + outs[1]:
+            out[~mask] = ref[~mask]
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(outs[0][0] - ref).max() <= 1e-11 * scale
+    assert np.abs(outs[1][0] - ref).max() <= 1e-11 * scale
+    assert np.array_equal(outs[1][0], outs[1][1])
+    assert not np.array_equal(outs[1][0], outs[0][0]) or k <= 128       # the split really ran
+
+
 @pytest.mark.parametrize("n,k", [(128, 64), (640, 128), (1152, 256), (2176, 512)])
 @pytest.mark.parametrize("tile", [0, 128, 64, 32])
 def test_gemm_nt_lower(handle, n, k, tile):
