@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     __syncthreads();
     if (tid == 0) s_ticket = __hip_atomic_fetch_add(&g.cnt[tail], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_ticket != (unsigned)(g.nsplit - 1)) return;
+    if (s_ticket != (unsigned)(g.nsplit - 1)) {
+      if (g.stamps && tid == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
+      return;
+    }
     __threadfence();
     const double* all = g.ws + (i64)tail * g.nsplit * (BM * BN) + tid;
 #pragma unroll
