@@ -369,9 +369,18 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
+  {
+    // the factorisation itself only needs the block inverses; their transposes (for the vector solves) are produced
+    // by one batched launch afterwards rather than by 128 KB of extra stores on the critical path of every block
+    HipOps fops = ops;
+    fops.linvT = nullptr;
+    Blocked<HipOps> fbl(fops);
+    rc = fbl.potrf_rec(h->dK.d(), np, np, 0, 0);
+    if (rc) return rc;
+    rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
+    if (rc) return rc;
+  }
   Blocked<HipOps> bl(ops);
-  rc = bl.potrf_rec(h->dK.d(), np, np, 0, 0);
-  if (rc) return rc;
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   if (r > 0) {
     rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);

@@ -196,6 +196,7 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
                         double diag_add);
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
+int gps_launch_transpose_blocks(gps_handle_t h, const double* src, double* dst, i64 nblk);
 int gps_launch_scale_rows(gps_handle_t h, double* A, i64 lda, i64 rows, i64 cols, const double* sc);
 int gps_launch_scale_cols(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols, const double* sc,
                           double* dst, i64 ldd);
