@@ -41,25 +41,23 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   return y;
 }
 
-// whole 128x128 block -> LDS image; 16-byte loads, 8 in flight per thread (the upper triangle is
-// loaded too: it is never read before being overwritten)
+// whole 128x128 block -> LDS image; 16-byte loads, all 32 of a thread in flight at once (one memory round trip:
+// a lone workgroup draws ~40 GB/s, so the tile load is latency, not bandwidth); the upper triangle is loaded too:
+// it is never read before being overwritten
 __device__ __forceinline__ void load_image(double* a, const double* __restrict__ A, i64 lda, int tid) {
-#pragma unroll 1
-  for (int base = 0; base < PB * PB / 2; base += NT * 8) {
-    double2 v[8];
+  double2 v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * NT + tid;
-      const int i = idx >> 6, j = (idx & 63) * 2;
-      v[u] = *reinterpret_cast<const double2*>(A + (i64)i * lda + j);
-    }
+  for (int u = 0; u < 32; ++u) {
+    const int idx = u * NT + tid;
+    const int i = idx >> 6, j = (idx & 63) * 2;
+    v[u] = *reinterpret_cast<const double2*>(A + (i64)i * lda + j);
+  }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * NT + tid;
-      const int i = idx >> 6, j = (idx & 63) * 2;
-      a[i * PS + j] = v[u].x;
-      a[i * PS + j + 1] = v[u].y;
-    }
+  for (int u = 0; u < 32; ++u) {
+    const int idx = u * NT + tid;
+    const int i = idx >> 6, j = (idx & 63) * 2;
+    a[i * PS + j] = v[u].x;
+    a[i * PS + j + 1] = v[u].y;
   }
 }
 
