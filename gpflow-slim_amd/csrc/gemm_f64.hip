@@ -38,6 +38,11 @@ struct GemmArgs {
   int K;
   int ntiles;
   int triA;         // A is upper triangular (A[i][k] == 0 for k < i): tile row tm starts its K loop at tm*BM
+  // Block-cyclic columns (cb_tiles > 0; the multi-GPU trailing update): tile column tn lies in owned block
+  // tn / cb_tiles, whose rows of B and columns of C start cb_stride elements after those of the previous owned
+  // block; tiles entirely above a block's first row are skipped (the update is lower-trapezoidal).
+  int cb_tiles;
+  i64 cb_stride;
   // Tail split (nsplit > 1, grid = nfull + (ntiles - nfull) * nsplit): see the comment at the kernel.
   int nfull, nsplit;
   double* ws;         // [(ntiles - nfull) * nsplit][BM * BN] slice partials
@@ -129,7 +134,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     tile_id = g.nfull + tail;
   }
   int tm, tn;
-  decode_tile<LOWER>(tile_id, g.Tm, g.Tn, tm, tn);
+  i64 bcol;                              // first row of B / first column of C of this tile
+  if (g.cb_tiles > 0) {
+    // only the needed tiles are enumerated (so that the XCD chunks carry equal work): owned block ob holds
+    // (Tm - ob * q) tile rows x cb_tiles tile columns, q = cb_stride / BM
+    const int q = (int)(g.cb_stride / BM);
+    int ob = 0, rem = tile_id;
+    for (;;) {
+      const int cnt = (g.Tm - ob * q) * g.cb_tiles;
+      if (rem < cnt) break;
+      rem -= cnt; ++ob;
+    }
+    tm = ob * q + rem / g.cb_tiles;
+    const int wi = rem % g.cb_tiles;
+    tn = ob * g.cb_tiles + wi;
+    bcol = (i64)ob * g.cb_stride + (i64)wi * BN;
+  } else {
+    decode_tile<LOWER>(tile_id, g.Tm, g.Tn, tm, tn);
+    bcol = (i64)tn * BN;
+  }
   if (g.stamps && threadIdx.x == 0) {
     long long* st = g.stamps + 6 * (long long)blockIdx.x;
     st[0] = (long long)wall_clock64();
@@ -147,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int lrow = tid >> 3;          // 0..31
   const int lk = (tid & 7) * 2;       // 0,2,..,14
   const double* Ag = g.A + (i64)(tm * BM + lrow) * g.lda + lk;
-  const double* Bg = g.B + (i64)(tn * BN + lrow) * g.ldb + lk;
+  const double* Bg = g.B + (bcol + lrow) * g.ldb + lk;
   const bool a_ld = (BM >= 32) || (lrow < BM);          // BM = 16: only half the threads stage A
 
   v2d ra[LPA], rb[LPB];
@@ -257,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     if (tid == 0) g.cnt[tail] = 0;       // ready for the next launch on this stream
   }
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
-  const i64 col0 = (i64)tn * BN + wc * WTN + (lane & 15);
+  const i64 col0 = bcol + wc * WTN + (lane & 15);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -289,12 +312,17 @@ static int launch_variant(gps_handle_t h, const GemmArgs& g) {
 template <int BM, int BN, int WGM>
 static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64 N) {
   g.Tm = (int)(M / BM); g.Tn = (int)(N / BN);
-  const i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
+  i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
+  if (g.cb_tiles > 0) {                  // needed tiles of the lower-trapezoidal block-cyclic update
+    const i64 q = g.cb_stride / BM, nblocks = g.Tn / g.cb_tiles;
+    nt = 0;
+    for (i64 ob = 0; ob < nblocks; ++ob) nt += ((i64)g.Tm - ob * q) * g.cb_tiles;
+  }
   if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
   g.ntiles = (int)nt;
   // tail split: 128x128 tiles only (512 resident slots on 256 CUs), never for the in-place or triangular-A forms
   g.nfull = g.ntiles; g.nsplit = 1; g.ws = nullptr; g.cnt = nullptr;
-  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.C != g.A && h->prop.multiProcessorCount == 256) {
+  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256) {
     const int slots = 512;
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
     int ns = r > 0 ? slots / r : 1;
@@ -346,6 +374,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
   g.stamps = h->gemm_stamps;
+  g.cb_tiles = 0; g.cb_stride = 0;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
   const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
@@ -375,4 +404,29 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   if (tb == 128) return launch_cfg<128, 128, 2>(h, op, lower, g, M, N);
   if (tb == 64) return launch_cfg<64, 64, 2>(h, op, lower, g, M, N);
   return launch_cfg<32, 32, 2>(h, op, lower, g, M, N);
+}
+
+// Trailing update of the block-column (multi-GPU) factorisation in one launch:  for every owned column block
+// b = 0 .. nblocks-1 (nb columns each, block b starts `stride` rows / columns after block b-1):
+//     C[r][b*stride + c] -= sum_k A[r][k] * A[b*stride + c][k]     for rows r >= b*stride, c < nb
+// A: [M, K] panel rows from the first owned block on; C points at the same first row / first owned column.
+int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
+                              double* C, i64 ldc) {
+  if (M <= 0 || nblocks <= 0) return GPS_OK;
+  if (M % 128 || nb % 128 || stride % 128 || K % BK || stride < nb || (nblocks - 1) * stride + nb > M)
+    return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
+  GemmArgs g;
+  g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;
+  g.stamps = h->gemm_stamps;
+  // needed 128x128 tiles: block b uses rows >= b*stride
+  double t128 = 0.0;
+  for (i64 b = 0; b < nblocks; ++b) { const i64 rows = M - b * stride; if (rows > 0) t128 += (double)(rows / 128) * (double)(nb / 128); }
+  const double flops = 2.0 * t128 * 128.0 * 128.0 * (double)K;
+  LaunchScope ls(h, KC_GEMM, flops, t128 * 2.0 * 128.0 * 128.0 * 8.0 + 8.0 * (double)K * (double)(M + nblocks * nb));
+  const double target = (double)h->gemm_min_tiles;
+  g.cb_stride = stride;
+  if (t128 >= target) { g.cb_tiles = (int)(nb / 128); return launch_cfg<128, 128, 2>(h, 0, 0, g, M, nblocks * nb); }
+  if (4.0 * t128 >= target) { g.cb_tiles = (int)(nb / 64); return launch_cfg<64, 64, 2>(h, 0, 0, g, M, nblocks * nb); }
+  g.cb_tiles = (int)(nb / 32);
+  return launch_cfg<32, 32, 2>(h, 0, 0, g, M, nblocks * nb);
 }

@@ -911,14 +911,13 @@ extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t 
   const i64 nblk = np / nb;
   if (c_lo <= j) c_lo = j + 1;
   if (c_hi > nblk) c_hi = nblk;
-  for (i64 c = c_lo; c < c_hi; ++c) {
-    if (c % h->dist_P != h->dist_rank) continue;
-    const double* Lc = h->dK.d() + c * nb * np + j * nb;        // rows c*nb.. of panel j
-    double* C = h->dK.d() + c * nb * np + c * nb;
-    int rc = gps_launch_gemm_nt(h, 0, 0, np - c * nb, nb, nb, Lc, np, Lc, np, C, np);
-    if (rc) return rc;
-  }
-  return GPS_OK;
+  // owned column blocks in [c_lo, c_hi): first, first + P, ...  -> one lower-trapezoidal launch
+  i64 first = c_lo + ((h->dist_rank - c_lo % h->dist_P) + h->dist_P) % h->dist_P;
+  if (first >= c_hi) return GPS_OK;
+  const i64 count = (c_hi - 1 - first) / h->dist_P + 1;
+  const double* Lc = h->dK.d() + first * nb * np + j * nb;          // rows first*nb.. of panel j
+  double* C = h->dK.d() + first * nb * np + first * nb;
+  return gps_launch_gemm_nt_cyclic(h, np - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, np, C, np);
 }
 
 // after the last panel: alpha = L^-1 resid on the replicated factor, reductions, info

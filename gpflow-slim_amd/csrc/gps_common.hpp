@@ -172,6 +172,8 @@ static inline int gps_dyn_lds(gps_handle_t h, const void* fn, int bytes) {
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc);
+int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
+                              double* C, i64 ldc);
 // potrf_base.hip : factor one 128x128 diagonal block in place (lower), write its
 // inverse (full 128x128, zero upper) to Linv_blk; info word gets min(index+1) of a
 // non-positive pivot (index counted from row0).
