@@ -13,6 +13,20 @@ from .._settings import settings
 from .model import GPModel
 
 
+class _FactorKey(object):
+    """What the resident factor was computed from: the hyper-parameter bytes and the X / Y array OBJECTS (held, so
+    that their addresses cannot be recycled while the key is alive)."""
+
+    def __init__(self, params, X, Y):
+        self.params, self.X, self.Y = params, X, Y
+
+    def __eq__(self, other):
+        return isinstance(other, _FactorKey) and self.params == other.params and self.X is other.X and self.Y is other.Y
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
 class GPR(GPModel):
     def __init__(self, X, Y, kern, mean_function=None, obs_var=0.1, num_latent=None, min_var=None, **kwargs):
         """X [N, D], Y [N, R]; kern, mean_function as in the reference (models/gpr.py:41-53)."""
@@ -30,15 +44,17 @@ class GPR(GPModel):
     # ---- device plumbing -------------------------------------------------------------------
     def _handle(self):
         h = be.get_handle()
-        token = (id(self), self.X.ctypes.data, self.X.shape)
-        if h.resident_token != token:
-            h.gpr_set_data(self.X, token)
+        # The handle keeps a reference to the array it uploaded, so "is" cannot be fooled by a new array that the
+        # allocator placed at a freed model's address (ids and data pointers are reused; object identity of a live
+        # object is not).  X is treated as immutable, like the reference's tensor; assign a new array to change it.
+        if h.resident_token is not self.X:
+            h.gpr_set_data(self.X, self.X)
             self._factor_key = None
         return h
 
     def _state_key(self):
         parts = [p.vf_val.tobytes() for p in self.parameters]
-        return (b"|".join(parts), self.Y.ctypes.data, self.Y.shape)
+        return _FactorKey(b"|".join(parts), self.X, self.Y)
 
     def _resid(self):
         return np.ascontiguousarray(self.Y - self.mean_function(self.X))

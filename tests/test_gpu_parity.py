@@ -528,3 +528,26 @@ def test_shape_errors_and_empty_inputs(handle):
         s.predict_f(np.zeros((3, 5)))
     mu, var = s.predict_f(np.zeros((0, 3)))
     assert mu.shape == (0, 2) and var.shape == (0, 2)
+
+
+def test_resident_data_is_not_confused_by_recycled_addresses(handle):
+    """X is uploaded once per model and kept resident.  Models created and dropped in a loop get recycled Python
+    ids and numpy buffers (same shape -> same address); the residency check must still see a new data set every
+    time (it compares the identity of a live array object, not ids or data pointers)."""
+    import gc
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(99)
+    kern, spec = make_kernel(gpf, "periodic", 3)
+    noise = orc.constrained(0.1)
+    for it in range(25):
+        X = rng.standard_normal((64, 3)); Y = rng.standard_normal((64, 1))
+        m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+        got = m.compute_log_likelihood()
+        ref = orc.gpr_lml(spec, X, Y, noise)
+        assert abs(got - ref) <= RTOL * abs(ref), it
+        m.reuse_factor = True
+        mu, _ = m.predict_f(X[:5])
+        rmu, _ = orc.gpr_predict(spec, X, Y, noise, X[:5])
+        assert rel(mu, rmu) <= RTOL, it
+        del m, X, Y
+        gc.collect()
