@@ -205,6 +205,7 @@ class Handle(object):
         self._h = h
         self.device = int(device)
         self.resident_token = None     # identity of the data set held by gps_gpr_set_data
+        self.factor_key = None         # what the resident Cholesky factor / alpha were computed from (models/gpr.py)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -378,6 +379,7 @@ class Handle(object):
         self.resident_shape = X.shape
         self._check(self._lib.gps_gpr_set_data(self._h, _ptr(X), X.shape[0], X.shape[1]), "gps_gpr_set_data")
         self.resident_token = token
+        self.factor_key = None
 
     def gpr_lml(self, prog, noise_var, resid):
         resid = _f64(resid)
@@ -459,6 +461,7 @@ class Handle(object):
         else:
             n_new, mean, var, xp, mp_, vp = 0, None, None, None, None, None
         self.resident_token = None
+        self.factor_key = None
         fn = self._lib.gps_fitc if fitc else self._lib.gps_sgpr
         self._check(fn(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter),
                        float(noise_var), _ptr(resid), r, xp, n_new, 1 if full_cov else 0,
@@ -510,6 +513,7 @@ class Handle(object):
             return fmean, (np.empty((0, 0, k)) if full_cov else fvar)
         info = ctypes.c_int(0)
         self.resident_token = None
+        self.factor_key = None
         self._check(self._lib.gps_conditional(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(Xnew),
                                               n_new, _ptr(f), k, _ptr(q) if q is not None else None, qnd,
                                               1 if white else 0, 1 if full_cov else 0, _ptr(fmean), _ptr(fvar),
@@ -535,6 +539,7 @@ class Handle(object):
             return fmean, (np.empty((0, 0, k)) if full_cov else fvar)
         info = ctypes.c_int(0)
         self.resident_token = None
+        self.factor_key = None
         self._check(self._lib.gps_base_conditional(self._h, _ptr(Kmn), _ptr(Kmm), _ptr(Knn), m, n_new, _ptr(f), k,
                                                    _ptr(q) if q is not None else None, qnd, 1 if white else 0,
                                                    1 if full_cov else 0, _ptr(fmean), _ptr(fvar),

@@ -39,9 +39,18 @@ class GPR(GPModel):
         self.num_latent = Y.shape[1] if num_latent is None else num_latent
         # not in the reference: opt-in reuse of the resident factor by predict_f
         self.reuse_factor = False
-        self._factor_key = None
 
     # ---- device plumbing -------------------------------------------------------------------
+    @property
+    def _factor_key(self):
+        """What the factor resident on the device was computed from (kept on the HANDLE: several models may share
+        one handle, and even one X array; the factor belongs to whoever evaluated last)."""
+        return be.get_handle().factor_key
+
+    @_factor_key.setter
+    def _factor_key(self, key):
+        be.get_handle().factor_key = key
+
     def _handle(self):
         h = be.get_handle()
         # The handle keeps a reference to the array it uploaded, so "is" cannot be fooled by a new array that the

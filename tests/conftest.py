@@ -9,6 +9,22 @@ for p in (os.path.join(ROOT, "gpflow-slim_amd"), ROOT):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--shuffle", type=int, default=None, metavar="SEED",
+                     help="run the collected tests in a seeded random order (state-leak hunting; -1 = reversed)")
+
+
+def pytest_collection_modifyitems(config, items):
+    seed = config.getoption("--shuffle")
+    if seed is None:
+        return
+    if seed < 0:
+        items.reverse()
+    else:
+        import random
+        random.Random(seed).shuffle(items)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

@@ -551,3 +551,26 @@ def test_resident_data_is_not_confused_by_recycled_addresses(handle):
         assert rel(mu, rmu) <= RTOL, it
         del m, X, Y
         gc.collect()
+
+
+def test_resident_factor_belongs_to_the_last_evaluation(handle):
+    """Two models that share one X array (and one device handle): the factor resident on the device is the one of
+    whoever evaluated last, so `reuse_factor` on the other model must re-factorise instead of picking it up."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((200, 3)); Xs = rng.standard_normal((20, 3))
+    Y1 = rng.standard_normal((200, 1)); Y2 = rng.standard_normal((200, 3))
+    kern, spec = make_kernel(gpf, "rbf_ard", 3)
+    noise = orc.constrained(0.1)
+    m1 = gpf.models.GPR(X, Y1, kern, obs_var=0.1); m1.reuse_factor = True
+    m2 = gpf.models.GPR(X, Y2, kern, obs_var=0.1); m2.reuse_factor = True
+    m1.compute_log_likelihood()
+    m2.compute_log_likelihood()
+    mu1, var1 = m1.predict_f(Xs)                     # device holds m2's factor / alpha (3 outputs)
+    r1 = orc.gpr_predict(spec, X, Y1, noise, Xs)
+    assert rel(mu1, r1[0]) <= RTOL and rel(var1, r1[1]) <= RTOL
+    mu2, var2 = m2.predict_f(Xs)                     # ... and now m1's
+    r2 = orc.gpr_predict(spec, X, Y2, noise, Xs)
+    assert rel(mu2, r2[0]) <= RTOL and rel(var2, r2[1]) <= RTOL
+    mu2b, _ = m2.predict_f(Xs)                       # warm this time
+    assert np.array_equal(mu2, mu2b)
