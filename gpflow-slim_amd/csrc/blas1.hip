@@ -341,10 +341,11 @@ int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i6
   if (S > 64) S = 64;
   if (S < 1) S = 1;
   const size_t ws_bytes = (size_t)cb * S * 4 * 128 * sizeof(double), cnt_bytes = (size_t)cb * sizeof(unsigned);
-  const bool fresh = h->dGemvCnt.cap < cnt_bytes;
   GPS_HIP(h, h->dGemvWs.ensure(ws_bytes));
-  GPS_HIP(h, h->dGemvCnt.ensure(cnt_bytes));
-  if (fresh) GPS_HIP(h, hipMemsetAsync(h->dGemvCnt.p, 0, h->dGemvCnt.cap, h->stream));
+  if (h->dGemvCnt.cap < cnt_bytes) {          // the counters persist (every launch leaves them at zero)
+    GPS_HIP(h, h->dGemvCnt.ensure(cnt_bytes));
+    GPS_HIP(h, hipMemsetAsync(h->dGemvCnt.p, 0, h->dGemvCnt.cap, h->stream));
+  }
   for (i64 r0 = 0; r0 < r; r0 += 4) {
     const int rc = (int)((r - r0) < 4 ? (r - r0) : 4);
     LaunchScope ls(h, KC_TRSV, 2.0 * n2 * n1 * rc, (double)n2 * n1 * 8.0);

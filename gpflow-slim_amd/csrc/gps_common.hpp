@@ -21,15 +21,19 @@ struct DevBuf {
   void*  p = nullptr;
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
+    // test aid: GPS_POISON_ALLOC=1 fills every NEW buffer with NaN bit patterns, =2 also every buffer that is
+    // requested again (only valid for call sequences that do not rely on a resident factor): a kernel that reads
+    // memory nobody wrote then shows up deterministically instead of depending on what the allocator hands back
+    static const int poison = getenv("GPS_POISON_ALLOC") ? atoi(getenv("GPS_POISON_ALLOC")) : 0;
+    if (bytes <= cap) {
+      if (poison >= 2 && p) { hipError_t e = hipDeviceSynchronize(); if (e == hipSuccess) e = hipMemset(p, 0xff, cap); if (e == hipSuccess) e = hipDeviceSynchronize(); return e; }
+      return hipSuccess;
+    }
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
     // round up so that repeated slightly-growing requests do not thrash
     size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
-    // test aid: GPS_POISON_ALLOC=1 fills every new buffer with NaN bit patterns, so that a kernel that reads memory
-    // nobody wrote shows up deterministically instead of depending on what the allocator hands back
-    static const bool poison = getenv("GPS_POISON_ALLOC") != nullptr;
     if (e == hipSuccess && poison) { e = hipMemset(p, 0xff, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
     return e;
   }
