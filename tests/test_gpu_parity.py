@@ -574,3 +574,38 @@ def test_resident_factor_belongs_to_the_last_evaluation(handle):
     assert rel(mu2, r2[0]) <= RTOL and rel(var2, r2[1]) <= RTOL
     mu2b, _ = m2.predict_f(Xs)                       # warm this time
     assert np.array_equal(mu2, mu2b)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_shapes_against_oracle(handle, seed):
+    """Seeded sweep over (N, D, R, N*, kernel, noise): block counts that are not powers of two, ragged last
+    blocks, single test points, several outputs -- five cases per seed, every one checked against the oracle
+    (LML, mean, variance, and a full covariance on a slice)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ["rbf_ard", "rbf_iso", "matern12", "matern32", "matern52", "periodic", "m52_plus_periodic", "nkn_like"]
+    for case in range(5):
+        n = int(rng.choice([1, 2, 3, 17, 127, 128, 129, 255, 256, 257, 300, 383, 385, 511, 513, 640, 700, 897]))
+        d = int(rng.integers(1, 7))
+        r = int(rng.integers(1, 4))
+        ns = int(rng.choice([1, 2, 31, 128, 129, 200]))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        obs = float(rng.choice([0.05, 0.1, 0.7]))
+        X = rng.standard_normal((n, d)); Y = rng.standard_normal((n, r)); Xs = rng.standard_normal((ns, d))
+        kern, spec = make_kernel(gpf, kind, d)
+        noise = orc.constrained(obs)
+        m = gpf.models.GPR(X, Y, kern, obs_var=obs)
+        tag = (seed, case, n, d, r, ns, kind, obs)
+        lml = m.compute_log_likelihood()
+        ref = orc.gpr_lml(spec, X, Y, noise)
+        assert abs(lml - ref) <= RTOL * max(1.0, abs(ref)), tag
+        m.reuse_factor = bool(rng.integers(2))
+        mu, var = m.predict_f(Xs)
+        rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+        assert mu.shape == (ns, r) and var.shape == (ns, r), tag
+        assert np.abs(mu - rmu).max() <= RTOL * max(1.0, np.abs(rmu).max()), tag
+        assert np.abs(var - rvar).max() <= 10 * RTOL * max(1.0, np.abs(rvar).max()), tag
+        k = min(ns, 9)
+        _, cov = m.predict_f_full_cov(Xs[:k])
+        _, rcov = orc.gpr_predict(spec, X, Y, noise, Xs[:k], full_cov=True)
+        assert cov.shape == (k, k, r) and np.abs(cov - rcov).max() <= 10 * RTOL * max(1.0, np.abs(rcov).max()), tag
