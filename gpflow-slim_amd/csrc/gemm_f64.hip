@@ -8,6 +8,12 @@
 // Both operands are read "row, k" with k contiguous, so one kernel serves all of
 // them (see DESIGN.md "one GEMM form").
 //
+// The 128x128 C -= A B^T kernel has a second instantiation whose steady-state K-loop body is branch-free and
+// ordered with __builtin_amdgcn_sched_group_barrier (ablation: with one workgroup pair per CU the MFMA + LDS-read
+// stream alone runs at the MFMA peak; 9 % of the loop went to the global->LDS staging at the slab boundary and 3.5 %
+// to the barrier): the next slab's ds_write_b128 are interleaved with the slab's last 16 MFMAs, the second half's
+// ds_read2_b64 with its first 8.
+//
 // Tiling (MI355X first): BM x BN output tile per 256-thread workgroup (4 waves, each owning
 // MI x NI v_mfma_f64_16x16x4_f64 accumulators: 4x4 at 128x128), BK = 16 staged through LDS
 // with a register prefetch of the next K-slab.  Row stride in LDS is 18 doubles: the
@@ -102,7 +108,7 @@ __device__ __forceinline__ void decode_tile(int id, int Tm, int Tn, int& tm, int
 
 // BM x BN output tile, 4 waves arranged WGM x (4/WGM); every wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile = MI x NI accumulators of 16x16.
-template <int BM, int BN, int WGM, bool LOWER, int OP>
+template <int BM, int BN, int WGM, bool LOWER, int OP, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   constexpr int WGN = 4 / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile
@@ -214,6 +220,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   __syncthreads();
 
   if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 4] = (long long)wall_clock64();
+  if (PIPE) {
+    // Scheduled K loop (128x128): branch-free steady-state body; the next slab's LDS writes are interleaved with the
+    // last MFMAs of the current slab and the second half's fragment reads with the first MFMAs, so that only the
+    // barrier itself is left between two slabs' MFMA streams.
+    auto slab = [&](int buf) {
+      const double* a_base = As + buf * BM * LS + (wr * WTM + fr) * LS + fk;
+      const double* b_base = Bs + buf * BN * LS + (wc * WTN + fr) * LS + fk;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = a_base[i * 16 * LS + kk * 4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = b_base[j * 16 * LS + kk * 4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[0][i][j], 0, 0, 0);
+      }
+    };
+    for (int kt = kt0; kt + 1 < nk; ++kt) {
+      const int buf = kt & 1;
+      gload(kt + 1);
+      slab(buf);
+      lstore(buf ^ 1);
+      // order of the block: 8 global loads, 8 ds_read2 (k-steps 0,1), then MFMAs with the other 8 ds_read2 among the
+      // first ones and the 8 ds_write_b128 among the last ones
+      __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __syncthreads();
+    }
+    slab((nk - 1) & 1);
+    __syncthreads();
+  } else
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
@@ -298,13 +350,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
 }
 
-template <int BM, int BN, int WGM, bool LOWER, int OP>
+template <int BM, int BN, int WGM, bool LOWER, int OP, bool PIPE = false>
 static int launch_variant(gps_handle_t h, const GemmArgs& g) {
   const size_t lds = (size_t)(2 * (BM + BN) * LS) * sizeof(double);
-  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), (int)lds);
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE>), (int)lds);
   if (rc) return rc;
   const int grid = g.nsplit > 1 ? g.nfull + (g.ntiles - g.nfull) * g.nsplit : g.ntiles;
-  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP>), dim3(grid), dim3(256), lds, h->stream, g);
+  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE>), dim3(grid), dim3(256), lds, h->stream, g);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
@@ -336,6 +388,10 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
       }
       g.nfull = nfull; g.nsplit = ns; g.ws = h->dGemmWs.d(); g.cnt = (unsigned*)h->dGemmCnt.p;
     }
+  }
+  if (BM == 128 && BN == 128 && h->gemm_pipe && op == 0) {
+    if (lower && (h->gemm_pipe == 1 || h->gemm_pipe == 3)) return launch_variant<128, 128, 2, true, 0, true>(h, g);
+    if (!lower && (h->gemm_pipe == 1 || h->gemm_pipe == 2)) return launch_variant<128, 128, 2, false, 0, true>(h, g);
   }
   if (BM == BN) {
     if (lower) {
