@@ -389,9 +389,14 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
       g.nfull = nfull; g.nsplit = ns; g.ws = h->dGemmWs.d(); g.cnt = (unsigned*)h->dGemmCnt.p;
     }
   }
-  if (BM == 128 && BN == 128 && h->gemm_pipe && op == 0) {
-    if (lower && (h->gemm_pipe == 1 || h->gemm_pipe == 3)) return launch_variant<128, 128, 2, true, 0, true>(h, g);
-    if (!lower && (h->gemm_pipe == 1 || h->gemm_pipe == 2)) return launch_variant<128, 128, 2, false, 0, true>(h, g);
+  if (BM == 128 && BN == 128 && h->gemm_pipe) {        // scheduled K loop (see the kernel)
+    if (lower && op == 0 && (h->gemm_pipe == 1 || h->gemm_pipe == 3)) return launch_variant<128, 128, 2, true, 0, true>(h, g);
+    if (!lower && (h->gemm_pipe == 1 || h->gemm_pipe == 2)) {
+      if (op == 0) return launch_variant<128, 128, 2, false, 0, true>(h, g);
+      if (op == 2) return launch_variant<128, 128, 2, false, 2, true>(h, g);
+      if (op == 3) return launch_variant<128, 128, 2, false, 3, true>(h, g);
+      return launch_variant<128, 128, 2, false, 1, true>(h, g);
+    }
   }
   if (BM == BN) {
     if (lower) {
