@@ -64,8 +64,7 @@ struct gps_handle_s {
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
   int gemm_min_tiles = 768;
   int gemm_force_tb = 0;
-  int gemm_pipe = 2;           // scheduled K loop of the 128x128 C -= A B^T kernel: 0 off, 1 all, 2 full-C launches only
-                               // (measured: -2.4 ms per N = 32768 evaluation; the lower-triangular launches lose 1.8 ms with it), 3 lower only
+  int gemm_pipe = 1;           // scheduled K loop of the 128x128 kernel: 0 off, 1 every launch, 2 full-C launches only, 3 lower only
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
