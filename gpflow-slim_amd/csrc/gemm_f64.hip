@@ -363,19 +363,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   }
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
   const i64 col0 = bcol + wc * WTN + (lane & 15);
+  // C read-modify-write in batches: all loads of a batch are issued before the first store.  (Written as
+  // `*cp = *cp - acc` per element the compiler has to assume that a store may alias the next load -- ldc is a
+  // run-time value -- and emits load / wait / store one element at a time: 64 memory round trips per thread,
+  // 96 us per tile when every workgroup of a round does it at the same moment.)
+  constexpr int IB = (MI >= 2) ? 2 : 1;                 // tile rows of 16 per batch
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int i0 = 0; i0 < MI; i0 += IB) {
+    double cv[IB][NI][4];
+    if (OP == 0 || OP == 2) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+      for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        double* cp = g.C + (row0 + i * 16 + 4 * rg) * g.ldc + col0 + j * 16;
-        if (OP == 0) *cp = *cp - acc[0][i][j][rg];
-        else if (OP == 2) *cp = *cp + acc[0][i][j][rg];
-        else if (OP == 3) *cp = -acc[0][i][j][rg];
-        else *cp = acc[0][i][j][rg];
-      }
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            cv[ii][j][rg] = g.C[(row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16];
     }
+#pragma unroll
+    for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          double* cp = g.C + (row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16;
+          const double av = acc[0][i0 + ii][j][rg];
+          if (OP == 0) *cp = cv[ii][j][rg] - av;
+          else if (OP == 2) *cp = cv[ii][j][rg] + av;
+          else if (OP == 3) *cp = -av;
+          else *cp = av;
+        }
   }
   if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
 }
