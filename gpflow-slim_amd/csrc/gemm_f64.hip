@@ -265,17 +265,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
         rd(1, buf, 3); mm(0, 0, MI);
         mm(1, 0, MI / 2);
         lstore(buf ^ 1);
-        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);     // global loads
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // F0 <- k-step 0
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // deferred MFMAs
+        // order of the block (counts for a BM x BN tile: NLD 16-byte global loads / LDS writes per thread, MI + NI
+        // fragment reads per k-step pair -- the compiler pairs k-steps into ds_read2_b64 --, MI * NI MFMAs per k-step)
+        constexpr int NLD = LPA + LPB, NFR = MI + NI, NMM = MI * NI;
+        __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);   // global loads of the next slab
+        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);   // fragments of k-steps 0, 1
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2, 0);   // deferred MFMAs of the previous slab
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {                         // k-steps 0..2: 48 MFMAs, 24 fragment reads
+        for (int q = 0; q < 3 * NMM / 2; ++q) {                // k-steps 0..2 with the remaining fragment reads
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                          // first half of k-step 3 + next slab's LDS writes
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        for (int q = 0; q < NLD; ++q) {                        // first half of k-step 3 + the next slab's LDS writes
+          __builtin_amdgcn_sched_group_barrier(0x008, (NMM / 2 + NLD - 1) / NLD, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __syncthreads();
@@ -408,6 +411,20 @@ static int launch_variant(gps_handle_t h, const GemmArgs& g) {
   return GPS_OK;
 }
 
+template <int BM, int BN, int WGM, int PIPE>
+static int dispatch_ops(gps_handle_t h, int op, int lower, const GemmArgs& g) {
+  if (BM == BN && lower) {
+    if (op == 0) return launch_variant<BM, BN, WGM, true, 0, PIPE>(h, g);
+    if (op == 2) return launch_variant<BM, BN, WGM, true, 2, PIPE>(h, g);
+    if (op == 3) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: op 3 has no lower-triangle form");
+    return launch_variant<BM, BN, WGM, true, 1, PIPE>(h, g);
+  }
+  if (op == 0) return launch_variant<BM, BN, WGM, false, 0, PIPE>(h, g);
+  if (op == 2) return launch_variant<BM, BN, WGM, false, 2, PIPE>(h, g);
+  if (op == 3) return launch_variant<BM, BN, WGM, false, 3, PIPE>(h, g);
+  return launch_variant<BM, BN, WGM, false, 1, PIPE>(h, g);
+}
+
 template <int BM, int BN, int WGM>
 static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64 N) {
   g.Tm = (int)(M / BM); g.Tn = (int)(N / BN);
@@ -436,27 +453,10 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
       g.nfull = nfull; g.nsplit = ns; g.ws = h->dGemmWs.d(); g.cnt = (unsigned*)h->dGemmCnt.p;
     }
   }
-  if (BM == 128 && BN == 128 && h->gemm_pipe) {        // scheduled K loop (see the kernel): 2 = full-C launches, 1 = all, 3 = lower only
-    if (lower && op == 0 && (h->gemm_pipe == 1 || h->gemm_pipe == 3)) return launch_variant<128, 128, 2, true, 0, 2>(h, g);
-    if (!lower && (h->gemm_pipe == 1 || h->gemm_pipe == 2)) {
-      if (op == 0) return launch_variant<128, 128, 2, false, 0, 2>(h, g);
-      if (op == 2) return launch_variant<128, 128, 2, false, 2, 2>(h, g);
-      if (op == 3) return launch_variant<128, 128, 2, false, 3, 2>(h, g);
-      return launch_variant<128, 128, 2, false, 1, 2>(h, g);
-    }
-  }
-  if (BM == BN) {
-    if (lower) {
-      if (op == 0) return launch_variant<BM, BN, WGM, true, 0>(h, g);
-      if (op == 2) return launch_variant<BM, BN, WGM, true, 2>(h, g);
-      if (op == 3) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: op 3 has no lower-triangle form");
-      return launch_variant<BM, BN, WGM, true, 1>(h, g);
-    }
-  }
-  if (op == 0) return launch_variant<BM, BN, WGM, false, 0>(h, g);
-  if (op == 2) return launch_variant<BM, BN, WGM, false, 2>(h, g);
-  if (op == 3) return launch_variant<BM, BN, WGM, false, 3>(h, g);
-  return launch_variant<BM, BN, WGM, false, 1>(h, g);
+  // scheduled K loop (see the kernel) for the square 128x128 and 64x64 tiles; "gemm_pipe" = 0 keeps the compiler's order
+  constexpr int P = ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) ? 2 : 0;
+  if (P && h->gemm_pipe) return dispatch_ops<BM, BN, WGM, P>(h, op, lower, g);
+  return dispatch_ops<BM, BN, WGM, 0>(h, op, lower, g);
 }
 
 // rowpanel != 0: C may alias A (in-place B <- B W^T with N == K == 128): every workgroup then owns

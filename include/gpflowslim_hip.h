@@ -244,8 +244,8 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
 /* tuning knobs (diagnostics; defaults are what bench.py measures):
  *   "gemm_min_tiles"  workgroups a GEMM launch should have before a larger tile is chosen
  *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)
- *   "gemm_pipe"       hand-scheduled K loop (sched_group_barrier) of the 128x128 C -= A B^T kernel:
- *                     0 off, 1 (default) every launch, 2 full-C launches only, 3 lower-triangular only
+ *   "gemm_pipe"       1 (default): hand-scheduled K loop (sched_group_barrier) of the 128x128 and 64x64 tiles;
+ *                     0: the compiler's instruction order
  *   "gemm_tail_split" 1 (default): the tiles of a partial last round of a 128x128 launch are cut into
  *                     K-slices over the idle workgroup slots; 0: one workgroup per tile          */
 int gps_set_option(gps_handle_t h, const char* key, double value);
