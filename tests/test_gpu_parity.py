@@ -609,3 +609,51 @@ def test_randomised_shapes_against_oracle(handle, seed):
         _, cov = m.predict_f_full_cov(Xs[:k])
         _, rcov = orc.gpr_predict(spec, X, Y, noise, Xs[:k], full_cov=True)
         assert cov.shape == (k, k, r) and np.abs(cov - rcov).max() <= 10 * RTOL * max(1.0, np.abs(rcov).max()), tag
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_sparse_and_conditional_against_oracle(handle, seed):
+    """Seeded sweep over the conditional / sparse-GP entry points: ragged M, N, K, 2-D and 3-D q_sqrt, white or not,
+    SGPR and GPRFITC bounds and predictions, all against the oracle."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(2000 + seed)
+    kinds = ["rbf_ard", "matern32", "matern52", "m52_plus_periodic"]
+    for case in range(3):
+        m_ = int(rng.choice([1, 7, 128, 129, 200, 257]))
+        n = int(rng.choice([1, 5, 127, 130, 300, 513]))
+        d = int(rng.integers(1, 5)); k = int(rng.integers(1, 4))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        white = bool(rng.integers(2)); full_cov = bool(rng.integers(2)) and n <= 130
+        qmode = int(rng.integers(3))
+        Z = rng.standard_normal((m_, d)); Xn = rng.standard_normal((n, d)); f = rng.standard_normal((m_, k))
+        q = None
+        if qmode == 1:
+            q = np.abs(rng.standard_normal((m_, k))) + 0.1
+        elif qmode == 2:
+            q = np.stack([np.tril(rng.standard_normal((m_, m_))) * 0.3 + np.eye(m_) for _ in range(k)], axis=2)
+        kern, spec = make_kernel(gpf, kind, d)
+        tag = (seed, case, m_, n, d, k, kind, white, full_cov, qmode)
+        mu, var = gpf.conditionals.conditional(Xn, Z, kern, f, full_cov=full_cov, q_sqrt=q, white=white)
+        rmu, rvar = orc.conditional(Xn, Z, spec, f, full_cov=full_cov, q_sqrt=q, white=white)
+        assert mu.shape == rmu.shape and var.shape == rvar.shape, tag
+        # Kuu + 1e-6 I: the conditioning of M random points sets how many digits survive on both sides
+        tol = 1e-6
+        assert np.abs(mu - rmu).max() <= tol * max(1.0, np.abs(rmu).max()), tag
+        assert np.abs(var - rvar).max() <= tol * max(1.0, np.abs(rvar).max()), tag
+    for case in range(2):
+        n = int(rng.choice([50, 129, 400])); m_ = int(rng.choice([5, 40, 130])); m_ = min(m_, n)
+        d = int(rng.integers(1, 4)); r = int(rng.integers(1, 3)); ns = int(rng.choice([1, 33, 140]))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.2 * rng.standard_normal((n, r))
+        Z = X[rng.choice(n, m_, replace=False)].copy(); Xs = rng.standard_normal((ns, d))
+        kern, spec = make_kernel(gpf, kind, d)
+        noise = orc.constrained(0.3)
+        for cls, lb, pred in ((gpf.models.SGPR, orc.sgpr_bound, orc.sgpr_predict), (gpf.models.GPRFITC, orc.fitc_lml, orc.fitc_predict)):
+            mdl = cls(X, Y, kern, Z=Z, obs_var=0.3)
+            tag = (seed, case, cls.__name__, n, m_, d, r, ns, kind)
+            ref = lb(spec, X, Y, Z, noise)
+            assert abs(mdl.compute_log_likelihood() - ref) <= 1e-6 * max(1.0, abs(ref)), tag
+            mu, var = mdl.predict_f(Xs)
+            rmu, rvar = pred(spec, X, Y, Z, noise, Xs)
+            assert np.abs(mu - rmu).max() <= 1e-6 * max(1.0, np.abs(rmu).max()), tag
+            assert np.abs(var - rvar).max() <= 1e-6 * max(1.0, np.abs(rvar).max()), tag
