@@ -35,8 +35,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-#define BK 16
-#define LS 18          // LDS row stride in doubles (BK + 2)
+#define BK_MIN 16      // K must be a multiple of this (the slab depth of the square tiles)
 #define STRIP 8        // tile columns per strip
 
 struct GemmArgs {
@@ -110,12 +109,16 @@ __device__ __forceinline__ void decode_tile(int id, int Tm, int Tn, int& tm, int
 
 // BM x BN output tile, 4 waves arranged WGM x (4/WGM); every wave owns a
 // (BM/WGM) x (BN/WGN) sub-tile = MI x NI accumulators of 16x16.
-template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0>
+// BKT: K-slab depth.  The per-slab cost of the staging and the barrier (~0.3 us) is fixed, so the small tiles, whose
+// slab holds only 4-16 MFMAs per wave, use deeper slabs (fewer of them); the square MFMA-bound tiles keep 16.
+template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0, int BKT = 16>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
+  constexpr int BK = BKT, LS = BKT + 2;           // (shadow the file-level defaults)
+  constexpr int TPR = BKT / 2, RPP = 256 / TPR;   // threads per staged row (16 bytes each), rows per pass
   constexpr int WGN = 4 / WGM;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile
   constexpr int MI = WTM / 16, NI = WTN / 16;          // 16x16 MFMA tiles per wave
-  constexpr int LPA = (BM + 31) / 32, LPB = (BN + 31) / 32;   // 16-byte loads per thread per K-slab
+  constexpr int LPA = (BM + RPP - 1) / RPP, LPB = (BN + RPP - 1) / RPP;   // 16-byte loads per thread per K-slab
   static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one MFMA tile");
   // Small tiles split K over KS accumulator sets (k-step kk of a slab goes to set kk % KS), summed in the
   // epilogue.  (Measured: a dependent v_mfma_f64_16x16x4_f64 chain already issues every ~67 cycles, so this
@@ -175,11 +178,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   const int fr = lane & 15, fk = lane >> 4;
 
   // global -> register staging map: 8 threads cover one 16-double (128 B) row slab
-  const int lrow = tid >> 3;          // 0..31
-  const int lk = (tid & 7) * 2;       // 0,2,..,14
+  const int lrow = tid / TPR;         // 0..RPP-1
+  const int lk = (tid % TPR) * 2;     // 0,2,..,BKT-2
   const double* Ag = g.A + (i64)(tm * BM + lrow) * g.lda + lk;
   const double* Bg = g.B + (bcol + lrow) * g.ldb + lk;
-  const bool a_ld = (BM >= 32) || (lrow < BM);          // BM = 16: only half the threads stage A
+  const bool a_ld = (BM >= RPP) || (lrow < BM);         // BM < RPP: only some of the threads stage A
 
   v2d ra[LPA], rb[LPB];
   v4d acc[KS][MI][NI];
@@ -201,20 +204,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   auto gload = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
-      if (a_ld) ra[i] = *reinterpret_cast<const v2d*>(Ag + (i64)(i * 32) * g.lda + (i64)kt * BK);
+      if (a_ld) ra[i] = *reinterpret_cast<const v2d*>(Ag + (i64)(i * RPP) * g.lda + (i64)kt * BK);
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
-      rb[i] = *reinterpret_cast<const v2d*>(Bg + (i64)(i * 32) * g.ldb + (i64)kt * BK);
+      rb[i] = *reinterpret_cast<const v2d*>(Bg + (i64)(i * RPP) * g.ldb + (i64)kt * BK);
   };
   auto lstore = [&](int buf) {
     double* a = As + buf * BM * LS + lrow * LS + lk;
     double* b = Bs + buf * BN * LS + lrow * LS + lk;
 #pragma unroll
     for (int i = 0; i < LPA; ++i)
-      if (a_ld) *reinterpret_cast<v2d*>(a + i * 32 * LS) = ra[i];
+      if (a_ld) *reinterpret_cast<v2d*>(a + i * RPP * LS) = ra[i];
 #pragma unroll
     for (int i = 0; i < LPB; ++i)
-      *reinterpret_cast<v2d*>(b + i * 32 * LS) = rb[i];
+      *reinterpret_cast<v2d*>(b + i * RPP * LS) = rb[i];
   };
 
   gload(kt0);
@@ -400,29 +403,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
 }
 
-template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0>
+template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0, int BKT = 16>
 static int launch_variant(gps_handle_t h, const GemmArgs& g) {
-  const size_t lds = (size_t)(2 * (BM + BN) * LS) * sizeof(double);
-  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE>), (int)lds);
+  const size_t lds = (size_t)(2 * (BM + BN) * (BKT + 2)) * sizeof(double);
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE, BKT>), (int)lds);
   if (rc) return rc;
   const int grid = g.nsplit > 1 ? g.nfull + (g.ntiles - g.nfull) * g.nsplit : g.ntiles;
-  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE>), dim3(grid), dim3(256), lds, h->stream, g);
+  hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE, BKT>), dim3(grid), dim3(256), lds, h->stream, g);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
 
-template <int BM, int BN, int WGM, int PIPE>
+template <int BM, int BN, int WGM, int PIPE, int BKT = 16>
 static int dispatch_ops(gps_handle_t h, int op, int lower, const GemmArgs& g) {
   if (BM == BN && lower) {
-    if (op == 0) return launch_variant<BM, BN, WGM, true, 0, PIPE>(h, g);
-    if (op == 2) return launch_variant<BM, BN, WGM, true, 2, PIPE>(h, g);
+    if (op == 0) return launch_variant<BM, BN, WGM, true, 0, PIPE, BKT>(h, g);
+    if (op == 2) return launch_variant<BM, BN, WGM, true, 2, PIPE, BKT>(h, g);
     if (op == 3) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: op 3 has no lower-triangle form");
-    return launch_variant<BM, BN, WGM, true, 1, PIPE>(h, g);
+    return launch_variant<BM, BN, WGM, true, 1, PIPE, BKT>(h, g);
   }
-  if (op == 0) return launch_variant<BM, BN, WGM, false, 0, PIPE>(h, g);
-  if (op == 2) return launch_variant<BM, BN, WGM, false, 2, PIPE>(h, g);
-  if (op == 3) return launch_variant<BM, BN, WGM, false, 3, PIPE>(h, g);
-  return launch_variant<BM, BN, WGM, false, 1, PIPE>(h, g);
+  if (op == 0) return launch_variant<BM, BN, WGM, false, 0, PIPE, BKT>(h, g);
+  if (op == 2) return launch_variant<BM, BN, WGM, false, 2, PIPE, BKT>(h, g);
+  if (op == 3) return launch_variant<BM, BN, WGM, false, 3, PIPE, BKT>(h, g);
+  return launch_variant<BM, BN, WGM, false, 1, PIPE, BKT>(h, g);
 }
 
 template <int BM, int BN, int WGM>
@@ -443,7 +446,7 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
     int ns = r > 0 ? slots / r : 1;
     if (ns > 16) ns = 16;
-    while (ns > 1 && (g.K / BK) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
+    while (ns > 1 && (g.K / BK_MIN) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
     if (nfull >= slots && ns > 1) {
       GPS_HIP(h, h->dGemmWs.ensure((size_t)r * ns * BM * BN * sizeof(double)));
       if (h->dGemmCnt.cap == 0) {
@@ -456,6 +459,9 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
   // scheduled K loop (see the kernel) for the square 128x128 and 64x64 tiles; "gemm_pipe" = 0 keeps the compiler's order
   constexpr int P = ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) ? 2 : 0;
   if (P && h->gemm_pipe) return dispatch_ops<BM, BN, WGM, P>(h, op, lower, g);
+  // deeper K slabs for the latency-bound small tiles (when K allows it)
+  constexpr int DEEP = (BM == 32 && BN == 32) ? 64 : ((BN == 128 && BM <= 32) ? 32 : 16);
+  if (DEEP > 16 && h->gemm_deep_slabs && g.K % DEEP == 0) return dispatch_ops<BM, BN, WGM, 0, DEEP>(h, op, lower, g);
   return dispatch_ops<BM, BN, WGM, 0>(h, op, lower, g);
 }
 
@@ -472,7 +478,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
     if (M != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: triangular A must be square");
     lower = 0;
   }
-  if (M % 128 || N % 128 || K % BK || (lower && M != N))
+  if (M % 128 || N % 128 || K % BK_MIN || (lower && M != N))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: operands must be 16-byte aligned with even leading dimension");
@@ -521,7 +527,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
 int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
                               double* C, i64 ldc) {
   if (M <= 0 || nblocks <= 0) return GPS_OK;
-  if (M % 128 || nb % 128 || stride % 128 || K % BK || stride < nb || (nblocks - 1) * stride + nb > M)
+  if (M % 128 || nb % 128 || stride % 128 || K % BK_MIN || stride < nb || (nblocks - 1) * stride + nb > M)
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
   GemmArgs g;
   g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;

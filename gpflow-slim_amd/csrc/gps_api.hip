@@ -161,6 +161,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (!h || !key) return GPS_ERR_ARG;
   if (strcmp(key, "gemm_min_tiles") == 0) { h->gemm_min_tiles = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_force_tile") == 0) { h->gemm_force_tb = (int)value; return GPS_OK; }
+  if (strcmp(key, "gemm_deep_slabs") == 0) { h->gemm_deep_slabs = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
