@@ -62,7 +62,7 @@ struct gps_handle_s {
 
   // GEMM tile selection (gemm_f64.hip): use the next smaller tile while the grid would have
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
-  int gemm_min_tiles = 768;
+  int gemm_min_tiles = 512;
   int gemm_force_tb = 0;
   int gemm_deep_slabs = 1;     // 32x32 tiles use 64-deep K slabs, the 16/32 x 128 row panels 32-deep ones
   int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
