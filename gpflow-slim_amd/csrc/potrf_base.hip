@@ -287,13 +287,24 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
   // ---- inverse, level 0: the eight 16x16 diagonal blocks, one column per thread.
   // X[i][c] is stored at a[c][i] (i > c); X[c][c] = dinv[c].
   if (tid < PB) {
-    const int c = tid;
-    const int e = (c | 15);                    // last row of this 16-block
-    for (int i = c + 1; i <= e; ++i) {
-      double s = a[i * PS + c] * dinv[c];      // k = c term
-      for (int k = c + 1; k < i; ++k) s += a[i * PS + k] * a[c * PS + k];
-      a[c * PS + i] = -s * dinv[i];
+    // the column stays in registers: reading back the X entries this thread has just written would make every
+    // step wait for an LDS store -> load round trip (15 dependent ones for the first column of a block: 4.4 us)
+    const int c = tid, rem = 15 - (c & 15);    // rows below c inside its 16-block
+    double x[16];
+    x[0] = dinv[c];
+#pragma unroll
+    for (int d = 1; d < 16; ++d) {
+      if (d <= rem) {
+        const int i = c + d;
+        double s = a[i * PS + c] * x[0];
+#pragma unroll
+        for (int t = 1; t < d; ++t) s += a[i * PS + c + t] * x[t];
+        x[d] = -s * dinv[i];
+      }
     }
+#pragma unroll
+    for (int d = 1; d < 16; ++d)
+      if (d <= rem) a[c * PS + c + d] = x[d];
   }
   __syncthreads();
 
