@@ -40,6 +40,8 @@ struct Blocked {
   int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0) {
     if (n <= 0) return 0;
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
+    if (n <= ops.rl_max()) return potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
+    if (n <= ops.rl2_max() && n > ops.rl2_nb() && ops.rl2_nb() >= GPS_TILE) return potrf_rl(A, lda, n, ops.rl2_nb(), blk0, row0);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = potrf_rec(A, lda, n1, blk0, row0);
     if (rc) return rc;
@@ -50,6 +52,31 @@ struct Blocked {
     rc = ops.gemm(/*op sub*/ 0, /*lower*/ 1, n2, n2, n1, A21, lda, A21, lda, A22, lda);
     if (rc) return rc;
     return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1);
+  }
+
+  // Right-looking sweep over nbp-column panels.
+  //  nbp = 128 for a small diagonal block (n <= Ops::rl_max()): at this size every launch of the recursion sits at
+  //  the launch-latency floor, so what counts is the number of launches between two consecutive potrf_base calls:
+  //  here always two (one solve of all rows below, one lower-triangular K = 128 update of the whole remainder)
+  //  instead of up to 2 log2(n/128) + 1.  The K = 128 update re-reads and re-writes the remainder once per panel,
+  //  so the sweep loses against the recursion once that traffic costs more than the launches saved.
+  //  nbp > 128 (Ops::rl2_nb() for n <= Ops::rl2_max()): the same sweep one level up, panels factored by potrf_rec.
+  int potrf_rl(double* A, i64 lda, i64 n, i64 nbp, i64 blk0, i64 row0) {
+    for (i64 c = 0; c < n; c += nbp) {
+      const i64 w = (n - c < nbp) ? n - c : nbp;
+      double* Ajj = A + c * lda + c;
+      const i64 blk = blk0 + c / GPS_TILE;
+      int rc = (w == GPS_TILE) ? ops.potrf_base(Ajj, lda, blk, row0 + c) : potrf_rec(Ajj, lda, w, blk, row0 + c);
+      if (rc) return rc;
+      const i64 m = n - c - w;
+      if (m == 0) break;
+      double* B = Ajj + w * lda;                      // rows below the diagonal block
+      rc = trsm_rec(Ajj, lda, w, blk, B, lda, m);
+      if (rc) return rc;
+      rc = ops.gemm(0, 1, m, m, w, B, lda, B, lda, B + w, lda);
+      if (rc) return rc;
+    }
+    return 0;
   }
 
   // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)

@@ -497,6 +497,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   const double bytes = t128 * (((op == 0 || op == 2) ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);
+  ls.tag[0] = M; ls.tag[1] = N; ls.tag[2] = K; ls.tag[3] = op + 10 * lower + 20 * triA + 100 * (rowpanel ? 1 : 0);
   const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used
   const int force = h->gemm_force_tb;
   if (rowpanel) {

@@ -50,7 +50,7 @@ struct KClassStat {
   double ms = 0.0, flops = 0.0, bytes = 0.0;
 };
 
-struct PendingEvt { int klass; hipEvent_t a, b; };
+struct PendingEvt { int klass; hipEvent_t a, b; i64 t[4]; };
 
 struct gps_handle_s {
   int device = 0;
@@ -66,6 +66,8 @@ struct gps_handle_s {
   int gemm_force_tb = 0;
   int gemm_deep_slabs = 1;     // 32x32 tiles use 64-deep K slabs, the 16/32 x 128 row panels 32-deep ones
   int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
+  int potrf_rl2_max = 0, potrf_rl2_nb = 0;   // the same sweep one level up: blocks up to rl2_max in panels of rl2_nb columns
+  int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
@@ -134,6 +136,7 @@ static inline int gps_dyn_lds(gps_handle_t h, const void* fn, int bytes);
 // the lambda body; events are only recorded when profiling is enabled.
 struct LaunchScope {
   gps_handle_t h; int klass; hipEvent_t a = nullptr, b = nullptr;
+  i64 tag[4] = {0, 0, 0, 0};     // diagnostics: shape of the launch for the GPS_PROF_DUMP per-launch list
   LaunchScope(gps_handle_t h_, int klass_, double flops, double bytes) : h(h_), klass(klass_) {
     KClassStat& s = h->stat[klass];
     s.launches++; s.flops += flops; s.bytes += bytes;
@@ -145,7 +148,7 @@ struct LaunchScope {
   ~LaunchScope() {
     if (h->prof_on) {
       (void)hipEventRecord(b, h->stream);
-      h->pending.push_back({klass, a, b});
+      h->pending.push_back({klass, a, b, {tag[0], tag[1], tag[2], tag[3]}});
     }
   }
   hipEvent_t take() {
@@ -156,11 +159,16 @@ struct LaunchScope {
 
 // fold finished event pairs into the class statistics (stream must be idle)
 static inline void gps_profile_collect(gps_handle_t h) {
+  // diagnostics: GPS_PROF_DUMP=<file> appends one line per profiled launch (class, shape tag, microseconds)
+  static const char* dump_path = getenv("GPS_PROF_DUMP");
+  FILE* df = (dump_path && !h->pending.empty()) ? fopen(dump_path, "a") : nullptr;
   for (auto& p : h->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->stat[p.klass].ms += ms;
+    if (df) fprintf(df, "%s %lld %lld %lld %lld %.3f\n", kc_names[p.klass], (long long)p.t[0], (long long)p.t[1], (long long)p.t[2], (long long)p.t[3], 1e3 * ms);
     h->evt_pool.push_back(p.a); h->evt_pool.push_back(p.b);
   }
+  if (df) fclose(df);
   h->pending.clear();
 }
 

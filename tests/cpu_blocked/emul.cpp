@@ -11,6 +11,9 @@
 typedef int64_t i64;
 static const i64 T = GPS_TILE;
 
+static i64 g_rl2_max = 0, g_rl2_nb = 0;
+static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
+
 struct CpuOps {
   std::vector<double> linv, linvT;
   int info = 0;
@@ -85,6 +88,9 @@ struct CpuOps {
     for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) Y[i * ldy + c] = W[i * T + c];
     return 0;
   }
+  i64 rl_max() const { return g_rl_max; }
+  i64 rl2_max() const { return g_rl2_max; }
+  i64 rl2_nb() const { return g_rl2_nb; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -114,6 +120,8 @@ struct CpuOps {
 };
 
 extern "C" {
+void emul_set_rl_max(i64 v) { g_rl_max = v; }
+void emul_set_rl2(i64 mx, i64 nb) { g_rl2_max = mx; g_rl2_nb = nb; }
 // A [n,n] in place -> L (lower valid); B [m,n]: X L^T = B ; B2 [m,n]: X L = B ; y [r][n]: L a = y
 int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, int* info) {
   CpuOps ops(n / T);

@@ -20,8 +20,11 @@ def emul():
     return lib
 
 
+@pytest.mark.parametrize("rl_max,rl2", [(0, (0, 0)), (256, (0, 0)), (1024, (0, 0)), (128, (1024, 256)), (256, (1024, 384))])
 @pytest.mark.parametrize("n,m,r", [(128, 128, 1), (256, 128, 2), (384, 256, 3), (640, 128, 1), (896, 128, 2)])
-def test_blocked_recursion_matches_lapack(emul, n, m, r):
+def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, rl2):
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))      # diagonal blocks up to rl_max: right-looking sweep (potrf_rl)
+    emul.emul_set_rl2(ctypes.c_int64(rl2[0]), ctypes.c_int64(rl2[1]))     # ... and the panel sweep one level up
     rng = np.random.default_rng(n + m)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     B = rng.standard_normal((m, n)); B2 = B.copy(); y = rng.standard_normal((r, n))
@@ -37,7 +40,10 @@ def test_blocked_recursion_matches_lapack(emul, n, m, r):
     assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
 
 
-def test_blocked_recursion_reports_first_bad_pivot(emul):
+@pytest.mark.parametrize("rl_max", [0, 512])
+def test_blocked_recursion_reports_first_bad_pivot(emul, rl_max):
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_rl2(ctypes.c_int64(0), ctypes.c_int64(0))
     n = 384
     rng = np.random.default_rng(1)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
@@ -52,6 +58,8 @@ def test_blocked_recursion_reports_first_bad_pivot(emul):
 @pytest.mark.parametrize("n,r", [(128, 1), (256, 2), (384, 1), (640, 3)])
 def test_gradient_pieces_match_lapack(emul, n, r):
     """trsv_t_rec (L^T a = y), inv_t_rec (Y = L^-T) and lauum_rec (K^-1 = Y Y^T)."""
+    emul.emul_set_rl_max(ctypes.c_int64(0))
+    emul.emul_set_rl2(ctypes.c_int64(0), ctypes.c_int64(0))
     rng = np.random.default_rng(n + r)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     A0 = A.copy()
