@@ -209,13 +209,16 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   if (!h || !us_out7) return GPS_ERR_ARG;
   GPS_HIP(h, hipSetDevice(h->device));
   const size_t bb = (size_t)GPS_TILE * GPS_TILE * 8;
-  GPS_HIP(h, h->dTmp.ensure(4 * bb + 1024));
+  GPS_HIP(h, h->dTmp.ensure(4 * bb + 2048));
   std::vector<double> A((size_t)GPS_TILE * GPS_TILE, 0.0);
   for (int i = 0; i < GPS_TILE; ++i) for (int j = 0; j <= i; ++j) A[(size_t)i * GPS_TILE + j] = (i == j) ? 2.0 + 0.01 * i : 0.3 / (1.0 + i - j);
   double* dA = h->dTmp.d();
   long long* dS = (long long*)(dA + 3 * GPS_TILE * GPS_TILE);
-  long long hs[24] = {0};
+  long long hs[96] = {0};
+  const bool per_wave = getenv("GPS_PB_WAVE_STAMPS") != nullptr;      // per-wave phase-A stamps perturb the timing they measure
   for (int rep = 0; rep < 3; ++rep) {
+    GPS_HIP(h, hipMemsetAsync(dS, 0, 96 * sizeof(long long), h->stream));
+    if (per_wave) { const long long one = 1; GPS_HIP(h, hipMemcpyAsync(dS + 31, &one, sizeof(one), hipMemcpyHostToDevice, h->stream)); }
     GPS_HIP(h, hipMemcpyAsync(dA, A.data(), bb, hipMemcpyHostToDevice, h->stream));
     int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
     if (rc) return rc;
@@ -227,7 +230,14 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   for (int q = 0; q < 7; ++q) us_out7[q] = (double)(hs[q] - hs[0]) * 0.01;
   // shader clock (MHz) held during the elimination phase
   us_out7[0] = (double)(hs[8 + 2] - hs[8 + 1]) / ((double)(hs[2] - hs[1]) * 0.01);
-  if (factor) fprintf(stderr, "potrf_base phases (us): diag16 %.2f  panel %.2f  mfma update %.2f\n", hs[16] * 0.01, hs[17] * 0.01, hs[18] * 0.01);
+  if (factor) {
+    fprintf(stderr, "potrf_base phases (us): A (panel | update + inverse in its shadow) %.2f  B (next block column) %.2f\n", hs[16] * 0.01, hs[17] * 0.01);
+    for (int g = 0; g < 8 && per_wave; ++g) {
+      fprintf(stderr, "  step %d: per-wave end of phase A (us):", g);
+      for (int w = 0; w < 8; ++w) fprintf(stderr, " %.2f", hs[32 + 8 * g + w] * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
   return GPS_OK;
 }
 

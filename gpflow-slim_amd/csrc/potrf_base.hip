@@ -6,21 +6,32 @@
 // X L11^T = B into an MFMA GEMM (gemm_f64.hip) and every vector solve into a
 // 128x128 gemv, which is what makes the recursive trsm / trsv GEMM-only.
 //
-// Factorisation: LDS image [128][129], blocked right-looking with panel width 16: the 16x16
-// diagonal block is factored by ONE wave in registers (v_readlane broadcasts, hardware rsqrt + two
-// Newton steps, no barrier), the rows below by one thread each (forward substitution against that
-// block), and the trailing update C_IJ -= P_I P_J^T runs on the fp64 MFMA over 16x16 tiles --
-// 3 barriers per panel (24 in all) instead of one per column.
+// One workgroup of 8 waves, LDS image [128][129], 8 steps of 16 columns.  The kernel is one long dependent chain
+// (128 pivots), so the waves are specialised and everything that is not on the chain runs in its shadow:
 //
-// Inverse: LDS image [128][129]; the lower triangle holds L, the strictly upper triangle
-// receives inv(L)^T as it is built (inv(L) is lower triangular, so its transpose fits exactly
-// there), 1/L_ii sits in dinv[].  16x16 diagonal blocks by substitution, then three
-// doubling levels X21 = -X22 L21 X11.  Stride 129 makes row and column walks conflict free.
+//   phase A(g)  PANEL waves: each holds the 16 rows of the diagonal block g in lanes 0..15 (every panel wave factors
+//               it, redundantly, in registers: v_readlane broadcasts, hardware rsqrt + two Newton steps, no barrier)
+//               and rows below it in its other lanes -- those lanes execute the very same instruction stream, which
+//               for them IS the forward substitution x L_gg^T = b against the block, so the whole 16-column panel is
+//               finished when the diagonal block is.  Lanes 16..31 of wave 0 start from the rows of the identity
+//               instead: what they end with is e_c^T L_gg^-T, i.e. column c of inv(L_gg) -- the 16x16 triangular
+//               inverse costs no instruction of its own.  (Wave 0: 32 rows below the block, the others 48 each.)
+//               UPDATE waves (all others), meanwhile: the rest of the trailing update of step g-1 (16x16 tiles
+//               C_IJ -= P_I P_J^T on the fp64 MFMA, J >= g+1) and block row g-1 of the inverse (below).
+//   phase B(g)  waves 1..7: the tiles of block column g+1 of the trailing update of step g (the only ones the next
+//               panel needs), one per wave; wave 0 puts the factored block and its inverse back into the image.
+//
+// Inverse X = inv(L), built by block rows in the shadow of the factorisation: the lower triangle of the image holds
+// L, the strictly upper triangle receives X^T (X is lower triangular, so its transpose fits exactly there), 1/L_ii
+// sits in dinv[].  X_gc = -X_gg * sum_{c <= k < g} L_gk X_kc for c < g: two MFMA chains per 16x16 tile, the first
+// product handed to the second in registers (its accumulator layout is the B-operand layout).  Block row g trails the
+// factorisation by one step; after the last panel only block row 7 is left.  Stride 129 makes row and column walks
+// conflict free.
 #include "gps_common.hpp"
 
 #define PB 128
 #define PS 129
-#define NT 256
+#define NT 512
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -41,19 +52,19 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   return y;
 }
 
-// whole 128x128 block -> LDS image; 16-byte loads, all 32 of a thread in flight at once (one memory round trip:
+// whole 128x128 block -> LDS image; 16-byte loads, all 16 of a thread in flight at once (one memory round trip:
 // a lone workgroup draws ~40 GB/s, so the tile load is latency, not bandwidth); the upper triangle is loaded too:
 // it is never read before being overwritten
 __device__ __forceinline__ void load_image(double* a, const double* __restrict__ A, i64 lda, int tid) {
-  double2 v[32];
+  double2 v[16];
 #pragma unroll
-  for (int u = 0; u < 32; ++u) {
+  for (int u = 0; u < 16; ++u) {
     const int idx = u * NT + tid;
     const int i = idx >> 6, j = (idx & 63) * 2;
     v[u] = *reinterpret_cast<const double2*>(A + (i64)i * lda + j);
   }
 #pragma unroll
-  for (int u = 0; u < 32; ++u) {
+  for (int u = 0; u < 16; ++u) {
     const int idx = u * NT + tid;
     const int i = idx >> 6, j = (idx & 63) * 2;
     a[i * PS + j] = v[u].x;
@@ -61,108 +72,10 @@ __device__ __forceinline__ void load_image(double* a, const double* __restrict__
   }
 }
 
-// Blocked right-looking factorisation of the 128x128 LDS image, panel width 16:
-//   phase 1 (wave 0, registers + v_readlane, no barrier): Cholesky of the 16x16 diagonal block
-//   phase 2 (one thread per row below): forward substitution against that block
-//   phase 3 (all waves, fp64 MFMA): trailing update C_IJ -= P_I P_J^T on 16x16 tiles
-__device__ __forceinline__ void factor_image(double* a, double* dinv, int* info, int row0, int tid, long long* stamps) {
-  long long t_p1 = 0, t_p2 = 0, t_p3 = 0, t0 = 0;
-#define PH_BEGIN() do { if (stamps && tid == 0) t0 = (long long)wall_clock64(); } while (0)
-#define PH_END(acc) do { if (stamps && tid == 0) acc += (long long)wall_clock64() - t0; } while (0)
-  const int lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, fk = lane >> 4;
-  for (int g = 0; g < 8; ++g) {
-    const int o = 16 * g;
-    // ---- phase 1
-    PH_BEGIN();
-    if (wave == 0) {
-      const int i = lane & 15;
-      double r[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = a[(o + i) * PS + o + c];
-      // branch-free body (one basic block): the scheduler can overlap column j's trailing updates with
-      // the rsqrt / Newton chain of column j+1
-      int bad = 0x7fffffff;
-      double my_y = 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double p = readlane_f64(r[j], j);
-        bad = (!(p > 0.0) && bad == 0x7fffffff) ? j : bad;
-        const double y = rsqrt_nr(p);
-        r[j] = (i == j) ? p * y : r[j] * y;
-        my_y = (i == j) ? y : my_y;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = readlane_f64(r[j], k);
-          r[k] -= r[j] * lkj;
-        }
-      }
-      if (lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
-      if (lane < 16) {
-        dinv[o + i] = my_y;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          if (c <= i) a[(o + i) * PS + o + c] = r[c];
-      }
-    }
-    __syncthreads();
-    PH_END(t_p1);
-    if (g == 7) break;
-    // ---- phase 2
-    PH_BEGIN();
-    const int nrows = PB - o - 16;
-    if (tid < nrows) {
-      const int i = o + 16 + tid;
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = a[i * PS + o + c];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double sacc = x[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) sacc -= x[k] * a[(o + j) * PS + o + k];
-        x[j] = sacc * dinv[o + j];
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[i * PS + o + c] = x[c];
-    }
-    __syncthreads();
-    PH_END(t_p2);
-    // ---- phase 3
-    PH_BEGIN();
-    const int nt = 7 - g;
-    const int ntile = nt * (nt + 1) / 2;
-    for (int t = wave; t < ntile; t += 4) {
-      int Ip = 0, rem = t;
-      while (rem >= Ip + 1) { rem -= Ip + 1; ++Ip; }
-      const int I = g + 1 + Ip, J = g + 1 + rem;
-      v4d acc;
-      double av[4], bv[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
-        bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
-    }
-    __syncthreads();
-    PH_END(t_p3);
-  }
-  if (stamps && tid == 0) { stamps[16] = t_p1; stamps[17] = t_p2; stamps[18] = t_p3; }
-#undef PH_BEGIN
-#undef PH_END
-}
-
-// ---- MFMA helpers for the inverse levels --------------------------------------------------------
 // X (= inv L, lower) is stored transposed in the strict upper triangle of the image, diag in dinv.
 __device__ __forceinline__ double x_elem(const double* a, const double* dinv, int r, int c) {
   // two UNCONDITIONAL LDS reads + selects.  The empty asm pins both loaded values: without it the compiler
-  // sinks the reads back under divergent branches and every MFMA of the inverse levels waits for its own
+  // sinks the reads back under divergent branches and every MFMA of the inverse waits for its own
   // pair of serialised LDS round trips.
   double off = a[(r > c) ? (c * PS + r) : 0];
   double dia = dinv[r & (PB - 1)];
@@ -170,86 +83,157 @@ __device__ __forceinline__ double x_elem(const double* a, const double* dinv, in
   return (r > c) ? off : ((r == c) ? dia : 0.0);
 }
 
-// one doubling level of the block inverse (S = size of the already inverted diagonal blocks).
-// Every wave walks its TPW tiles together (KSPL partial sums per tile) so that the LDS operand reads of
-// several products are in flight at once; zero operands outside the triangular ranges (x_elem) make
-// every product unconditional.
-template <int S>
-__device__ __forceinline__ void level_step(double* a, const double* dinv, int wave, int fr, int fk) {
-  constexpr int KSTEPS = S / 4;
-  constexpr int tps = S / 16;
-  constexpr int tiles_pair = tps * tps;
-  constexpr int ntile = (PB / (2 * S)) * tiles_pair;     // 4, 8, 16
-  constexpr int TPW = ntile / 4;                         // tiles per wave: 1, 2, 4
-  constexpr int KSPL = 4 / TPW;                          // partial sums per tile: 4, 2, 1
-  int i0[TPW], c0[TPW], ob[TPW];
+// ---- phase A, panel wave: 16 columns o..o+15.  Lanes 0..15: rows of the diagonal block.  Owner (wave 0): lanes
+// 16..31 rows of the identity (-> columns of the block's inverse), lanes 32..63 rows o+16 .. o+47; other panel waves:
+// lanes 16..63 rows xrow0 .. xrow0+47 (rows >= 128 are idle lanes).  Branch-free body (one basic block): the scheduler
+// can overlap column j's trailing updates with the rsqrt / Newton chain of column j+1.
+// The rows below go back to the image here; the diagonal block's rows and the inverse's columns stay in r[] (lanes
+// 0..31 of the owner) and are written by the caller AFTER the barrier that ends the phase: the other panel waves read
+// the same block.
+__device__ __forceinline__ void panel_step(double* a, int* info, int row0, int o, int lane, int xrow0, bool owner,
+                                           double (&r)[16]) {
+  const bool is_diag = lane < 16;
+  const bool is_inv = owner && lane >= 16 && lane < 32;
+  const int row = is_diag ? o + lane : (owner ? o + lane - 16 : xrow0 + lane - 16);
+  const bool valid = row < PB;
+  const int rr = valid ? row : PB - 1;
 #pragma unroll
-  for (int q = 0; q < TPW; ++q) {
-    const int t = wave + 4 * q;
-    const int pr = t / tiles_pair, w = t - pr * tiles_pair;
-    ob[q] = pr * 2 * S;
-    i0[q] = ob[q] + S + (w / tps) * 16;
-    c0[q] = ob[q] + (w % tps) * 16;
+  for (int c = 0; c < 16; ++c) {
+    const double v = a[rr * PS + o + c];
+    r[c] = is_inv ? ((c == lane - 16) ? 1.0 : 0.0) : v;
   }
-  // step A: W = L21 * X11 ; W[i][c] -> a[c][i]
+  // Column j: pivot p = L_jj^2 broadcast, y = 1/sqrt(p) (hardware estimate + two Newton steps), scale the column,
+  // then r[k] -= r[j] * L_kj for k > j (L_kj broadcast from diagonal lane k).  Only the update of column j+1 is on
+  // the dependent chain; the others are issued in the latency gaps of column j+1's rsqrt / Newton chain.  The order
+  // is pinned with sched_barrier: left alone, the compiler finishes all of column j's updates before it starts the
+  // next pivot, and the 16 chains (one rsqrt + 7 dependent fp64 operations each) run exposed.
+#define PB_UPD(kk) do { if ((kk) < 16) { const double l_ = readlane_f64(r[j], (kk)); r[(kk)] -= r[j] * l_; } } while (0)
+#define PB_FENCE() __builtin_amdgcn_sched_barrier(0)
+  int bad = 0x7fffffff;
   {
-    v4d acc[TPW][KSPL];
+    const double p = readlane_f64(r[0], 0);
+    bad = !(p > 0.0) ? 0 : bad;
+    const double y = rsqrt_nr(p);
+    r[0] = (lane == 0) ? p * y : r[0] * y;       // rows below: x_j = (a_ij - sum_k<j x_k l_jk) / l_jj
+  }
 #pragma unroll
-    for (int q = 0; q < TPW; ++q)
+  for (int j = 0; j < 15; ++j) {
+    PB_UPD(j + 1);
+    PB_FENCE();
+    const double p = readlane_f64(r[j + 1], j + 1);
+    bad = (!(p > 0.0) && bad == 0x7fffffff) ? j + 1 : bad;
+    const double hp = 0.5 * p;
+    double y = __builtin_amdgcn_rsq(p);
+    PB_UPD(j + 2); PB_UPD(j + 3);
+    PB_FENCE();
+    double t = hp * y;
+    PB_UPD(j + 4);
+    PB_FENCE();
+    t = __builtin_fma(-y, t, 1.5);
+    PB_UPD(j + 5);
+    PB_FENCE();
+    y = y * t;
+    PB_UPD(j + 6);
+    PB_FENCE();
+    t = hp * y;
+    PB_UPD(j + 7);
+    PB_FENCE();
+    t = __builtin_fma(-y, t, 1.5);
+    PB_UPD(j + 8);
+    PB_FENCE();
+    y = y * t;
+    PB_UPD(j + 9); PB_UPD(j + 10);
+    PB_FENCE();
+    const double py = p * y;
+    PB_UPD(j + 11); PB_UPD(j + 12); PB_UPD(j + 13); PB_UPD(j + 14); PB_UPD(j + 15);
+    PB_FENCE();
+    r[j + 1] = (lane == j + 1) ? py : r[j + 1] * y;
+  }
+#undef PB_UPD
+#undef PB_FENCE
+  if (owner && lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
+  if (!is_diag && !is_inv && valid) {
 #pragma unroll
-      for (int u = 0; u < KSPL; ++u) acc[q][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 16; ++c) a[row * PS + o + c] = r[c];
+  }
+}
+
+// trailing-update tile: C_IJ -= P_I P_J^T, P = columns o..o+15 (one wave, fp64 MFMA 16x16x4)
+__device__ __forceinline__ void update_tile(double* a, int I, int J, int o, int fr, int fk) {
+  v4d acc;
+  double av[4], bv[4];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+  for (int s4 = 0; s4 < 4; ++s4) {
+    av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
+    bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
+  }
 #pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int k = ob[q] + 4 * ks + fk;                       // k runs over the TL block
-        const double av = a[(i0[q] + fr) * PS + k];              // L21[i][k]
-        const double bv = x_elem(a, dinv, k, c0[q] + fr);        // X11[k][c] (0 for k < c)
-        acc[q][ks % KSPL] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q][ks % KSPL], 0, 0, 0);
-      }
-    }
-    __syncthreads();          // every L21 / X11 operand has been read before W overwrites the slot
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
+  for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
-      for (int u = 1; u < KSPL; ++u) acc[q][0] += acc[q][u];
+  for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
+}
+
+// tile t (row-major over the lower triangle I >= J) of the blocks j0..7
+__device__ __forceinline__ void tri_index(int t, int j0, int& I, int& J) {
+  int Ip = 0, rem = t;
+  while (rem >= Ip + 1) { rem -= Ip + 1; ++Ip; }
+  I = j0 + Ip; J = j0 + rem;
+}
+
+// 16x16 triangular inverse of diagonal block gb, one column per lane (lanes 0..15 of one wave).
+// X[i][c] is stored at a[c][i] (i > c); X[c][c] = dinv[c].  The column stays in registers: reading back the X
+// entries this lane has just written would make every step wait for an LDS store -> load round trip.
+__device__ __forceinline__ void inv_diag16(double* a, const double* dinv, int c) {
+  const int rem = 15 - (c & 15);    // rows below c inside its 16-block
+  double x[16];
+  x[0] = dinv[c];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) a[(c0[q] + fr) * PS + i0[q] + fk + 4 * rg] = acc[q][0][rg];
+  for (int d = 1; d < 16; ++d) {
+    if (d <= rem) {
+      const int i = c + d;
+      double s = a[i * PS + c] * x[0];
+#pragma unroll
+      for (int t = 1; t < d; ++t) s += a[i * PS + c + t] * x[t];
+      x[d] = -s * dinv[i];
     }
   }
-  __syncthreads();
-  // step B: Z = -X22 * W, kept in registers until every W has been consumed
-  {
-    v4d z[TPW][KSPL];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q)
+  for (int d = 1; d < 16; ++d)
+    if (d <= rem) a[c * PS + c + d] = x[d];
+}
+
+// block (gp, c), c < gp, of the inverse:  X_gp,c = -X_gp,gp * sum_{c <= kb < gp} L_gp,kb X_kb,c   (one wave)
+__device__ __forceinline__ void inv_row_tile(double* a, const double* dinv, int gp, int c, int fr, int fk) {
+  v4d t0 = (v4d){0.0, 0.0, 0.0, 0.0}, t1 = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int kb = c; kb < gp; ++kb) {
+    double av[4], bv[4];
 #pragma unroll
-      for (int u = 0; u < KSPL; ++u) z[q][u] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-      for (int q = 0; q < TPW; ++q) {
-        const int k = ob[q] + S + 4 * ks + fk;                   // k runs over the BR block
-        const double av = x_elem(a, dinv, i0[q] + fr, k);        // X22[i][k] (0 for k > i)
-        const double bv = a[(c0[q] + fr) * PS + k];              // W[k][c]
-        z[q][ks % KSPL] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z[q][ks % KSPL], 0, 0, 0);
-      }
+    for (int s = 0; s < 4; ++s) {
+      const int k = 16 * kb + 4 * s + fk;
+      av[s] = a[(16 * gp + fr) * PS + k];                 // L[16 gp + fr][k]
+      bv[s] = x_elem(a, dinv, k, 16 * c + fr);            // X[k][16 c + fr]  (0 above the diagonal of X_cc)
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-#pragma unroll
-      for (int u = 1; u < KSPL; ++u) z[q][0] += z[q][u];
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) a[(c0[q] + fr) * PS + i0[q] + fk + 4 * rg] = -z[q][0][rg];
-    }
+    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], t1, 0, 0, 0);
+    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], t1, 0, 0, 0);
   }
-  __syncthreads();
+  t0 += t1;      // T[4 s + fk][fr] = t0[s]: exactly the B operand of k-step s of the second product
+  double xv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) xv[s] = x_elem(a, dinv, 16 * gp + fr, 16 * gp + 4 * s + fk);   // X_gp,gp[fr][4 s + fk]
+  v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[s], t0[s], z, 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) a[(16 * c + fr) * PS + 16 * gp + fk + 4 * rg] = -z[rg];   // X[16 gp + fk + 4 rg][16 c + fr]
 }
 
 // factor != 0: A holds the SPD block, L is written back.  factor == 0: A already holds L
 // (caller-supplied factor); only the inverse is produced.  LinvT (optional) receives inv(L)^T.
-__global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, i64 lda,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void potrf_base_kernel(double* __restrict__ A, i64 lda,
                                                         double* __restrict__ Linv,
                                                         double* __restrict__ LinvT,
                                                         int* __restrict__ info, int row0,
@@ -258,17 +242,72 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
   STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);   // [PB][PS]
-  double* dinv = a + PB * PS;                        // [PB]
+  double* dinv = a + PB * PS;                        // [PB], then 64 dummy slots (masked stores)
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  load_image(a, A, lda, tid);
+  __syncthreads();
+  STAMP(1);
 
   if (factor) {
-    load_image(a, A, lda, tid);
-    __syncthreads();
-    STAMP(1);
-    factor_image(a, dinv, info, row0, tid, stamps);
+    long long t_a = 0, t_b = 0, t0 = 0;
+    for (int g = 0; g < 8; ++g) {
+      const int o = 16 * g;
+      const int nrows = PB - o - 16;                       // rows below the diagonal block
+      const int npanel = nrows > 32 ? 1 + (nrows - 32 + 47) / 48 : 1;   // wave 0 takes 32 of them, every further panel wave 48
+      if (stamps && (tid == 0 || (lane == 0 && stamps[31]))) t0 = (long long)wall_clock64();
+      // ---- phase A
+      double r[16];
+      if (wave < npanel) {
+        panel_step(a, info, row0, o, lane, o + 48 * wave, wave == 0, r);
+      } else if (g >= 1) {
+        const int nuw = 8 - npanel;
+        int item = wave - npanel;
+        // rest of the trailing update of step g-1: tiles (I, J), g+1 <= J <= I <= 7
+        const int nt = 7 - g, ntile = nt * (nt + 1) / 2;
+        for (; item < ntile; item += nuw) {
+          int I, J;
+          tri_index(item, g + 1, I, J);
+          update_tile(a, I, J, o - 16, fr, fk);
+        }
+        item -= ntile;
+        // block row g-1 of the inverse
+        for (; item < g - 1; item += nuw) inv_row_tile(a, dinv, g - 1, item, fr, fk);
+      }
+      if (stamps && lane == 0 && stamps[31]) stamps[32 + 8 * g + wave] = (long long)wall_clock64() - t0;   // diagnostics (stamps[31] != 0): per-wave end of phase A
+      __syncthreads();
+      if (stamps && tid == 0) { const long long t1 = (long long)wall_clock64(); t_a += t1 - t0; t0 = t1; }
+      // ---- phase B: the factored diagonal block and its inverse go back to the image (wave 0), block column g+1
+      // of the trailing update of step g (neither reads the other's data)
+      if (wave == 0) {
+        // row o+c of the image = [ L[c][0..c] (lane c) | X[c+1..15][c] (lane 16+c: column c of inv(L_gg), transposed) ];
+        // masked-out elements go to a per-lane dummy slot instead of a divergent branch per element
+        const int c = lane & 15;
+        const bool lo = lane < 16, act = lane < 32;
+        double dc = r[0];                      // X[c][c] = 1 / L_cc (the pivot's Newton reciprocal square root)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) dc = (k == c) ? r[k] : dc;
+        if (act && !lo) dinv[o + c] = dc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const bool w = act && (lo ? (k <= c) : (k > c));
+          a[w ? (o + c) * PS + o + k : PB * PS + PB + lane] = r[k];
+        }
+      }
+      else {
+        const int I = g + wave;                                  // waves 1..7: tiles (g+1 .. 7, g+1)
+        if (I < 8) update_tile(a, I, g + 1, o, fr, fk);
+      }
+      __syncthreads();
+      if (stamps && tid == 0) t_b += (long long)wall_clock64() - t0;
+    }
+    if (stamps && tid == 0) { stamps[16] = t_a; stamps[17] = t_b; stamps[18] = 0; }
     STAMP(2);
-    // L back to HBM (upper triangle of the diagonal block zero-filled, like tf.cholesky)
+    // L back to HBM (upper triangle of the diagonal block zero-filled, like tf.cholesky); the stores drain while
+    // the last block rows of the inverse are computed
     for (int idx = tid; idx < PB * PB / 2; idx += NT) {
       const int i = idx >> 6, j = (idx & 63) * 2;
       double2 v;
@@ -276,48 +315,22 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
       v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
       *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
     }
-  } else {
-    load_image(a, A, lda, tid);
+    STAMP(3);
+    // ---- what is left of the inverse: block row 7
+    STAMP(4);
+    if (wave < 7) inv_row_tile(a, dinv, 7, wave, fr, fk);
     __syncthreads();
+  } else {
     if (tid < PB) dinv[tid] = 1.0 / a[tid * PS + tid];
     __syncthreads();
-  }
-
-  STAMP(3);
-  // ---- inverse, level 0: the eight 16x16 diagonal blocks, one column per thread.
-  // X[i][c] is stored at a[c][i] (i > c); X[c][c] = dinv[c].
-  if (tid < PB) {
-    // the column stays in registers: reading back the X entries this thread has just written would make every
-    // step wait for an LDS store -> load round trip (15 dependent ones for the first column of a block: 4.4 us)
-    const int c = tid, rem = 15 - (c & 15);    // rows below c inside its 16-block
-    double x[16];
-    x[0] = dinv[c];
-#pragma unroll
-    for (int d = 1; d < 16; ++d) {
-      if (d <= rem) {
-        const int i = c + d;
-        double s = a[i * PS + c] * x[0];
-#pragma unroll
-        for (int t = 1; t < d; ++t) s += a[i * PS + c + t] * x[t];
-        x[d] = -s * dinv[i];
-      }
+    STAMP(2); STAMP(3);
+    if (tid < PB) inv_diag16(a, dinv, tid);
+    __syncthreads();
+    STAMP(4);
+    for (int gp = 1; gp < 8; ++gp) {
+      if (wave < gp) inv_row_tile(a, dinv, gp, wave, fr, fk);
+      __syncthreads();
     }
-#pragma unroll
-    for (int d = 1; d < 16; ++d)
-      if (d <= rem) a[c * PS + c + d] = x[d];
-  }
-  __syncthreads();
-
-  STAMP(4);
-  // ---- levels s = 16, 32, 64: X21 = -X22 * (L21 * X11) for each pair of s-blocks, on the
-  // fp64 MFMA (16x16x4).  Output tiles are dealt round-robin to the 4 waves; all operands of a tile are
-  // fetched from LDS first (KS k-steps, zero outside the triangular range), then the MFMA chain runs.
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fk = lane >> 4;
-    level_step<16>(a, dinv, wave, fr, fk);
-    level_step<32>(a, dinv, wave, fr, fk);
-    level_step<64>(a, dinv, wave, fr, fk);
   }
 
   STAMP(5);
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(NT) void potrf_base_kernel(double* __restrict__ A, 
 
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor, long long* d_stamps) {
-  const size_t lds = (size_t)(PB * PS + PB) * sizeof(double);
+  const size_t lds = (size_t)(PB * PS + PB + 64) * sizeof(double);   // image, dinv, 64 dummy slots
   int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&potrf_base_kernel), (int)lds);
   if (rc0) return rc0;
   // potrf n^3/3 + trtri n^3/3
