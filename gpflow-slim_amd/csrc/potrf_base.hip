@@ -90,8 +90,8 @@ __device__ __forceinline__ double x_elem(const double* a, const double* dinv, in
 // The rows below go back to the image here; the diagonal block's rows and the inverse's columns stay in r[] (lanes
 // 0..31 of the owner) and are written by the caller AFTER the barrier that ends the phase: the other panel waves read
 // the same block.
-__device__ __forceinline__ void panel_step(double* a, int* info, int row0, int o, int lane, int xrow0, bool owner,
-                                           double (&r)[16]) {
+__device__ __forceinline__ void panel_step(double* a, double* scr, int* info, int row0, int o, int lane, int xrow0,
+                                           bool owner, double (&r)[16]) {
   const bool is_diag = lane < 16;
   const bool is_inv = owner && lane >= 16 && lane < 32;
   const int row = is_diag ? o + lane : (owner ? o + lane - 16 : xrow0 + lane - 16);
@@ -103,11 +103,16 @@ __device__ __forceinline__ void panel_step(double* a, int* info, int row0, int o
     r[c] = is_inv ? ((c == lane - 16) ? 1.0 : 0.0) : v;
   }
   // Column j: pivot p = L_jj^2 broadcast, y = 1/sqrt(p) (hardware estimate + two Newton steps), scale the column,
-  // then r[k] -= r[j] * L_kj for k > j (L_kj broadcast from diagonal lane k).  Only the update of column j+1 is on
-  // the dependent chain; the others are issued in the latency gaps of column j+1's rsqrt / Newton chain.  The order
-  // is pinned with sched_barrier: left alone, the compiler finishes all of column j's updates before it starts the
-  // next pivot, and the 16 chains (one rsqrt + 7 dependent fp64 operations each) run exposed.
+  // then r[k] -= r[j] * L_kj for k > j, L_kj broadcast from diagonal lane k.  Only the updates of columns j+1 and j+2
+  // are urgent: they take the v_readlane path (two readlanes + a dependent-SGPR wait per value).  For k >= j+3 the
+  // diagonal lanes publish the scaled column in an LDS scratch of this wave and every lane reads it back as
+  // broadcast ds_read_b128 (two values per read, no SGPR traffic); those updates are applied one column later, in
+  // the latency gaps of the next pivot's rsqrt / Newton chain.  (Updates of one register commute; r[k] is complete
+  // before pivot k because its LDS-path updates come from columns <= k-3, applied by the end of column k-2.)
+  // The order is pinned with sched_barrier: left alone, the compiler finishes every update of column j before it
+  // starts the next pivot, and the 16 chains (one rsqrt + 7 dependent fp64 operations each) run exposed.
 #define PB_UPD(kk) do { if ((kk) < 16) { const double l_ = readlane_f64(r[j], (kk)); r[(kk)] -= r[j] * l_; } } while (0)
+#define PB_LUPD(kk) do { if (j >= 1 && (kk) < 16) r[(kk)] -= r[j - 1] * lq[(kk)]; } while (0)
 #define PB_FENCE() __builtin_amdgcn_sched_barrier(0)
   int bad = 0x7fffffff;
   {
@@ -116,40 +121,56 @@ __device__ __forceinline__ void panel_step(double* a, int* info, int row0, int o
     const double y = rsqrt_nr(p);
     r[0] = (lane == 0) ? p * y : r[0] * y;       // rows below: x_j = (a_ij - sum_k<j x_k l_jk) / l_jj
   }
+  double lq[16];                                  // L_k,j-1 (k >= j+2) of the column whose LDS-path updates are pending
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lq[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < 15; ++j) {
+    double ln[16];
+    if (j + 3 < 16) {
+      scr[lane] = r[j];          // slots 16..63 are never read: an unconditional store keeps the column loop one basic block
+#pragma unroll
+      for (int m = (j + 3) / 2; m < 8; ++m) {
+        const double2 v = *reinterpret_cast<const double2*>(scr + 2 * m);
+        ln[2 * m] = v.x; ln[2 * m + 1] = v.y;
+      }
+    }
+    PB_FENCE();
     PB_UPD(j + 1);
     PB_FENCE();
     const double p = readlane_f64(r[j + 1], j + 1);
     bad = (!(p > 0.0) && bad == 0x7fffffff) ? j + 1 : bad;
     const double hp = 0.5 * p;
     double y = __builtin_amdgcn_rsq(p);
-    PB_UPD(j + 2); PB_UPD(j + 3);
+    PB_UPD(j + 2);
     PB_FENCE();
     double t = hp * y;
-    PB_UPD(j + 4);
+    PB_LUPD(j + 2); PB_LUPD(j + 3);
     PB_FENCE();
     t = __builtin_fma(-y, t, 1.5);
-    PB_UPD(j + 5);
+    PB_LUPD(j + 4); PB_LUPD(j + 5);
     PB_FENCE();
     y = y * t;
-    PB_UPD(j + 6);
+    PB_LUPD(j + 6); PB_LUPD(j + 7);
     PB_FENCE();
     t = hp * y;
-    PB_UPD(j + 7);
+    PB_LUPD(j + 8); PB_LUPD(j + 9);
     PB_FENCE();
     t = __builtin_fma(-y, t, 1.5);
-    PB_UPD(j + 8);
+    PB_LUPD(j + 10); PB_LUPD(j + 11);
     PB_FENCE();
     y = y * t;
-    PB_UPD(j + 9); PB_UPD(j + 10);
+    PB_LUPD(j + 12); PB_LUPD(j + 13);
     PB_FENCE();
     const double py = p * y;
-    PB_UPD(j + 11); PB_UPD(j + 12); PB_UPD(j + 13); PB_UPD(j + 14); PB_UPD(j + 15);
+    PB_LUPD(j + 14); PB_LUPD(j + 15);
     PB_FENCE();
     r[j + 1] = (lane == j + 1) ? py : r[j + 1] * y;
+#pragma unroll
+    for (int k = j + 3; k < 16; ++k) lq[k] = ln[k];
   }
 #undef PB_UPD
+#undef PB_LUPD
 #undef PB_FENCE
   if (owner && lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
   if (!is_diag && !is_inv && valid) {
@@ -204,26 +225,38 @@ __device__ __forceinline__ void inv_diag16(double* a, const double* dinv, int c)
     if (d <= rem) a[c * PS + c + d] = x[d];
 }
 
-// block (gp, c), c < gp, of the inverse:  X_gp,c = -X_gp,gp * sum_{c <= kb < gp} L_gp,kb X_kb,c   (one wave)
+// block (gp, c), c < gp, of the inverse:  X_gp,c = -X_gp,gp * sum_{c <= kb < gp} L_gp,kb X_kb,c   (one wave).
+// The kb = c term reads the triangular X_cc through x_elem (zeros above its diagonal); for kb > c both operands are
+// plain tiles of the image, fetched one iteration ahead of the MFMAs that consume them.
 __device__ __forceinline__ void inv_row_tile(double* a, const double* dinv, int gp, int c, int fr, int fk) {
   v4d t0 = (v4d){0.0, 0.0, 0.0, 0.0}, t1 = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int kb = c; kb < gp; ++kb) {
-    double av[4], bv[4];
+  const double* la = a + (16 * gp + fr) * PS + fk;          // L[16 gp + fr][k]     at la[k - fk]
+  const double* xb = a + (16 * c + fr) * PS + fk;           // X[k][16 c + fr]      at xb[k - fk]   (k >= 16 (c + 1))
+  double av[4], bv[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = 16 * kb + 4 * s + fk;
-      av[s] = a[(16 * gp + fr) * PS + k];                 // L[16 gp + fr][k]
-      bv[s] = x_elem(a, dinv, k, 16 * c + fr);            // X[k][16 c + fr]  (0 above the diagonal of X_cc)
-    }
+  for (int s = 0; s < 4; ++s) {
+    av[s] = la[16 * c + 4 * s];
+    bv[s] = x_elem(a, dinv, 16 * c + 4 * s + fk, 16 * c + fr);
+  }
+  for (int kb = c + 1; kb < gp; ++kb) {
+    double an[4], bn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { an[s] = la[16 * kb + 4 * s]; bn[s] = xb[16 * kb + 4 * s]; }
     t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], t0, 0, 0, 0);
     t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], t1, 0, 0, 0);
     t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], t0, 0, 0, 0);
     t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], t1, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { av[s] = an[s]; bv[s] = bn[s]; }
   }
-  t0 += t1;      // T[4 s + fk][fr] = t0[s]: exactly the B operand of k-step s of the second product
   double xv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) xv[s] = x_elem(a, dinv, 16 * gp + fr, 16 * gp + 4 * s + fk);   // X_gp,gp[fr][4 s + fk]
+  t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], t0, 0, 0, 0);
+  t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], t1, 0, 0, 0);
+  t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], t0, 0, 0, 0);
+  t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], t1, 0, 0, 0);
+  t0 += t1;      // T[4 s + fk][fr] = t0[s]: exactly the B operand of k-step s of the second product
   v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int s = 0; s < 4; ++s) z = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[s], t0[s], z, 0, 0, 0);
@@ -242,7 +275,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   STAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);   // [PB][PS]
-  double* dinv = a + PB * PS;                        // [PB], then 64 dummy slots (masked stores)
+  double* dinv = a + PB * PS;                        // [PB], then 3 x 64 slots: panel-wave scratch (phase A) / dummy store targets (phase B)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // ---- phase A
       double r[16];
       if (wave < npanel) {
-        panel_step(a, info, row0, o, lane, o + 48 * wave, wave == 0, r);
+        panel_step(a, dinv + PB + 64 * wave, info, row0, o, lane, o + 48 * wave, wave == 0, r);
       } else if (g >= 1) {
         const int nuw = 8 - npanel;
         int item = wave - npanel;
@@ -276,6 +309,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         item -= ntile;
         // block row g-1 of the inverse
         for (; item < g - 1; item += nuw) inv_row_tile(a, dinv, g - 1, item, fr, fk);
+        // last step: rows 0..111 of L are final and go back to HBM in the last panel's shadow (upper triangle
+        // zero-filled, like tf.cholesky), 16 rows per update wave
+        if (g == 7) {
+          const int r0 = 16 * (wave - 1), r1 = r0 + 16;
+#pragma unroll 4
+          for (int i = r0; i < r1; ++i) {
+            const int j = 2 * lane;
+            double2 v;
+            v.x = (j <= i) ? a[i * PS + j] : 0.0;
+            v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
+            *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
+          }
+        }
       }
       if (stamps && lane == 0 && stamps[31]) stamps[32 + 8 * g + wave] = (long long)wall_clock64() - t0;   // diagnostics (stamps[31] != 0): per-wave end of phase A
       __syncthreads();
@@ -306,9 +352,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     if (stamps && tid == 0) { stamps[16] = t_a; stamps[17] = t_b; stamps[18] = 0; }
     STAMP(2);
-    // L back to HBM (upper triangle of the diagonal block zero-filled, like tf.cholesky); the stores drain while
-    // the last block rows of the inverse are computed
-    for (int idx = tid; idx < PB * PB / 2; idx += NT) {
+    // rows 112..127 of L
+    for (int idx = 112 * 64 + tid; idx < PB * PB / 2; idx += NT) {
       const int i = idx >> 6, j = (idx & 63) * 2;
       double2 v;
       v.x = (j <= i) ? a[i * PS + j] : 0.0;
@@ -358,7 +403,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor, long long* d_stamps) {
-  const size_t lds = (size_t)(PB * PS + PB + 64) * sizeof(double);   // image, dinv, 64 dummy slots
+  const size_t lds = (size_t)(PB * PS + PB + 192) * sizeof(double);   // image, dinv, 3 x 64 scratch / dummy slots
   int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&potrf_base_kernel), (int)lds);
   if (rc0) return rc0;
   // potrf n^3/3 + trtri n^3/3
