@@ -41,7 +41,6 @@ struct Blocked {
     if (n <= 0) return 0;
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
     if (n <= ops.rl_max()) return potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
-    if (n <= ops.rl2_max() && n > ops.rl2_nb() && ops.rl2_nb() >= GPS_TILE) return potrf_rl(A, lda, n, ops.rl2_nb(), blk0, row0);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = potrf_rec(A, lda, n1, blk0, row0);
     if (rc) return rc;
@@ -60,7 +59,8 @@ struct Blocked {
   //  here always two (one solve of all rows below, one lower-triangular K = 128 update of the whole remainder)
   //  instead of up to 2 log2(n/128) + 1.  The K = 128 update re-reads and re-writes the remainder once per panel,
   //  so the sweep loses against the recursion once that traffic costs more than the launches saved.
-  //  nbp > 128 (Ops::rl2_nb() for n <= Ops::rl2_max()): the same sweep one level up, panels factored by potrf_rec.
+  //  nbp > 128: the same sweep with panels factored by potrf_rec and solved by trsm_rec (measured on MI355X for
+  //  blocks of 4096 .. 32768 columns in panels of 256 .. 4096: always behind the recursion; not used by potrf_rec).
   int potrf_rl(double* A, i64 lda, i64 n, i64 nbp, i64 blk0, i64 row0) {
     for (i64 c = 0; c < n; c += nbp) {
       const i64 w = (n - c < nbp) ? n - c : nbp;

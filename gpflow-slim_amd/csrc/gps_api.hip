@@ -168,8 +168,6 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_rl2_max") == 0) { h->potrf_rl2_max = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_rl2_nb") == 0) { h->potrf_rl2_nb = ((int)value / GPS_TILE) * GPS_TILE; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
 

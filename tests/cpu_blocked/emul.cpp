@@ -11,7 +11,6 @@
 typedef int64_t i64;
 static const i64 T = GPS_TILE;
 
-static i64 g_rl2_max = 0, g_rl2_nb = 0;
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
 
 struct CpuOps {
@@ -89,8 +88,6 @@ struct CpuOps {
     return 0;
   }
   i64 rl_max() const { return g_rl_max; }
-  i64 rl2_max() const { return g_rl2_max; }
-  i64 rl2_nb() const { return g_rl2_nb; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -121,7 +118,14 @@ struct CpuOps {
 
 extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
-void emul_set_rl2(i64 mx, i64 nb) { g_rl2_max = mx; g_rl2_nb = nb; }
+// the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only
+int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rl(A, n, n, nb, 0, 0);
+  *info = ops.info;
+  return rc;
+}
 // A [n,n] in place -> L (lower valid); B [m,n]: X L^T = B ; B2 [m,n]: X L = B ; y [r][n]: L a = y
 int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, int* info) {
   CpuOps ops(n / T);

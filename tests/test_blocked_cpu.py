@@ -20,11 +20,10 @@ def emul():
     return lib
 
 
-@pytest.mark.parametrize("rl_max,rl2", [(0, (0, 0)), (256, (0, 0)), (1024, (0, 0)), (128, (1024, 256)), (256, (1024, 384))])
+@pytest.mark.parametrize("rl_max", [0, 256, 1024])
 @pytest.mark.parametrize("n,m,r", [(128, 128, 1), (256, 128, 2), (384, 256, 3), (640, 128, 1), (896, 128, 2)])
-def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, rl2):
+def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))      # diagonal blocks up to rl_max: right-looking sweep (potrf_rl)
-    emul.emul_set_rl2(ctypes.c_int64(rl2[0]), ctypes.c_int64(rl2[1]))     # ... and the panel sweep one level up
     rng = np.random.default_rng(n + m)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     B = rng.standard_normal((m, n)); B2 = B.copy(); y = rng.standard_normal((r, n))
@@ -43,7 +42,6 @@ def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, rl2):
 @pytest.mark.parametrize("rl_max", [0, 512])
 def test_blocked_recursion_reports_first_bad_pivot(emul, rl_max):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))
-    emul.emul_set_rl2(ctypes.c_int64(0), ctypes.c_int64(0))
     n = 384
     rng = np.random.default_rng(1)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
@@ -59,7 +57,6 @@ def test_blocked_recursion_reports_first_bad_pivot(emul, rl_max):
 def test_gradient_pieces_match_lapack(emul, n, r):
     """trsv_t_rec (L^T a = y), inv_t_rec (Y = L^-T) and lauum_rec (K^-1 = Y Y^T)."""
     emul.emul_set_rl_max(ctypes.c_int64(0))
-    emul.emul_set_rl2(ctypes.c_int64(0), ctypes.c_int64(0))
     rng = np.random.default_rng(n + r)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     A0 = A.copy()
@@ -74,3 +71,16 @@ def test_gradient_pieces_match_lapack(emul, n, r):
     assert np.abs(Y - Linv.T).max() <= 1e-12 * np.abs(Linv).max()
     ref = np.linalg.inv(A0)
     assert np.abs(np.tril(Kinv) - np.tril(ref)).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n,nb,rl_max", [(896, 256, 0), (896, 384, 256), (640, 128, 0)])
+def test_panel_sweep_matches_lapack(emul, n, nb, rl_max):
+    """potrf_rl with panels wider than one block (factored by potrf_rec, rows below solved by trsm_rec)."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    rng = np.random.default_rng(n + nb)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n); A0 = A.copy()
+    info = ctypes.c_int(0)
+    rc = emul.emul_potrf_rl(A.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int64(n), ctypes.c_int64(nb), ctypes.byref(info))
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A0, lower=True)
+    assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
