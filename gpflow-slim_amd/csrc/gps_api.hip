@@ -48,9 +48,7 @@ struct HipOps {
                                 (size_t)GPS_TILE * 8, GPS_TILE, hipMemcpyDeviceToDevice, h->stream));
     return GPS_OK;
   }
-  i64 rl_max() const { return h->potrf_rl_max; }
-  i64 rl2_max() const { return h->potrf_rl2_max; }
-  i64 rl2_nb() const { return h->potrf_rl2_nb; }   // diagonal blocks up to this size: right-looking panel sweep
+  i64 rl_max() const { return h->potrf_rl_max; }   // diagonal blocks up to this size: right-looking panel sweep
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     GPS_HIP(h, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)cols * 8, (size_t)rows, h->stream));
