@@ -43,15 +43,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p): hardware estimate + two Newton steps (full double accuracy; keeps the 16 serial pivots of a
-// diagonal block off the IEEE sqrt/divide sequences)
-__device__ __forceinline__ double rsqrt_nr(double p) {
-  double y = __builtin_amdgcn_rsq(p);
-  y = y * (1.5 - 0.5 * p * y * y);
-  y = y * (1.5 - 0.5 * p * y * y);
-  return y;
-}
-
 // whole 128x128 block -> LDS image; 16-byte loads, all 16 of a thread in flight at once (one memory round trip:
 // a lone workgroup draws ~40 GB/s, so the tile load is latency, not bandwidth); the upper triangle is loaded too:
 // it is never read before being overwritten
@@ -102,31 +93,46 @@ __device__ __forceinline__ void panel_step(double* a, double* scr, int* info, in
     const double v = a[rr * PS + o + c];
     r[c] = is_inv ? ((c == lane - 16) ? 1.0 : 0.0) : v;
   }
-  // Column j: pivot p = L_jj^2 broadcast, y = 1/sqrt(p) (hardware estimate + two Newton steps), scale the column,
-  // then r[k] -= r[j] * L_kj for k > j, L_kj broadcast from diagonal lane k.  Only the updates of columns j+1 and j+2
-  // are urgent: they take the v_readlane path (two readlanes + a dependent-SGPR wait per value).  For k >= j+3 the
-  // diagonal lanes publish the scaled column in an LDS scratch of this wave and every lane reads it back as
-  // broadcast ds_read_b128 (two values per read, no SGPR traffic); those updates are applied one column later, in
-  // the latency gaps of the next pivot's rsqrt / Newton chain.  (Updates of one register commute; r[k] is complete
-  // before pivot k because its LDS-path updates come from columns <= k-3, applied by the end of column k-2.)
-  // The order is pinned with sched_barrier: left alone, the compiler finishes every update of column j before it
-  // starts the next pivot, and the 16 chains (one rsqrt + 7 dependent fp64 operations each) run exposed.
+  // Column j: pivot p_j = L_jj^2, y_j = 1/sqrt(p_j), scale the column, then r[k] -= r[j] * L_kj for k > j (L_kj
+  // broadcast from diagonal lane k).  The 16 pivots are one dependent chain; everything else is kept off it:
+  //  * The next pivot does not wait for the vector update of column j+1.  With s = r[j] and d = r[j+1] of diagonal
+  //    lane j+1 read (v_readlane) BEFORE column j is scaled -- both are complete one column earlier --
+  //    p_{j+1} = d - (s y_j)^2 is two uniform operations after y_j (the same mul / fma the lanes execute, so it is
+  //    the value lane j+1 ends up with).
+  //  * 1/sqrt: hardware estimate y0 (2^-24) and ONE third-order step, e = 1 - p y0^2, y = y0 + y0 e (1/2 + 3/8 e)
+  //    (error 5/16 e^3 ~ 2^-70): four dependent operations instead of the six of two Newton steps.
+  //  * Only the updates of columns j+1 and j+2 take the v_readlane path.  For k >= j+3 the diagonal lanes publish the
+  //    scaled column in an LDS scratch of this wave and every lane reads it back as broadcast ds_read_b128 (two values
+  //    per read, no SGPR traffic); those updates are applied one column later.  (Updates of one register commute;
+  //    r[k] is complete before it is read for pivot k: its LDS-path updates come from columns <= k-3.)
+  //  The vector work is placed in the latency gaps of the pivot chain and the order pinned with sched_barrier: left
+  //  alone, the compiler finishes every update of column j before it starts the next pivot.
 #define PB_UPD(kk) do { if ((kk) < 16) { const double l_ = readlane_f64(r[j], (kk)); r[(kk)] -= r[j] * l_; } } while (0)
 #define PB_LUPD(kk) do { if (j >= 1 && (kk) < 16) r[(kk)] -= r[j - 1] * lq[(kk)]; } while (0)
 #define PB_FENCE() __builtin_amdgcn_sched_barrier(0)
   int bad = 0x7fffffff;
+  double p = readlane_f64(r[0], 0);            // pivot of the current column (uniform)
+  bad = !(p > 0.0) ? 0 : bad;
+  double y;                                    // its reciprocal square root
   {
-    const double p = readlane_f64(r[0], 0);
-    bad = !(p > 0.0) ? 0 : bad;
-    const double y = rsqrt_nr(p);
-    r[0] = (lane == 0) ? p * y : r[0] * y;       // rows below: x_j = (a_ij - sum_k<j x_k l_jk) / l_jj
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double t = p * y0;
+    const double e = __builtin_fma(-t, y0, 1.0);
+    y = __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
   }
+  double sd = readlane_f64(r[0], 1), dd = readlane_f64(r[1], 1);     // s, d of the next pivot
   double lq[16];                                  // L_k,j-1 (k >= j+2) of the column whose LDS-path updates are pending
 #pragma unroll
   for (int k = 0; k < 16; ++k) lq[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < 15; ++j) {
     double ln[16];
+    // ---- chain: l = s y_j
+    const double lj = sd * y;
+    r[j] = (lane == j) ? p * y : r[j] * y;       // rows below: x_j = (a_ij - sum_k<j x_k l_jk) / l_jj
+    PB_FENCE();
+    // ---- chain: p_{j+1}
+    const double pn = __builtin_fma(-lj, lj, dd);
     if (j + 3 < 16) {
       scr[lane] = r[j];          // slots 16..63 are never read: an unconditional store keeps the column loop one basic block
 #pragma unroll
@@ -136,39 +142,35 @@ __device__ __forceinline__ void panel_step(double* a, double* scr, int* info, in
       }
     }
     PB_FENCE();
+    // ---- chain: estimate
+    double yn = __builtin_amdgcn_rsq(pn);
+    PB_LUPD(j + 2);
     PB_UPD(j + 1);
     PB_FENCE();
-    const double p = readlane_f64(r[j + 1], j + 1);
-    bad = (!(p > 0.0) && bad == 0x7fffffff) ? j + 1 : bad;
-    const double hp = 0.5 * p;
-    double y = __builtin_amdgcn_rsq(p);
+    // ---- chain: t = p y0
+    const double t = pn * yn;
+    bad = (!(pn > 0.0) && bad == 0x7fffffff) ? j + 1 : bad;
     PB_UPD(j + 2);
     PB_FENCE();
-    double t = hp * y;
-    PB_LUPD(j + 2); PB_LUPD(j + 3);
+    // ---- chain: e = 1 - t y0
+    const double e = __builtin_fma(-t, yn, 1.0);
+    if (j + 2 < 16) { sd = readlane_f64(r[j + 1], j + 2); dd = readlane_f64(r[j + 2], j + 2); }
+    PB_LUPD(j + 3); PB_LUPD(j + 4); PB_LUPD(j + 5);
     PB_FENCE();
-    t = __builtin_fma(-y, t, 1.5);
-    PB_LUPD(j + 4); PB_LUPD(j + 5);
+    // ---- chain: q, y0 e
+    const double q = __builtin_fma(0.375, e, 0.5);
+    const double ye = yn * e;
+    PB_LUPD(j + 6); PB_LUPD(j + 7); PB_LUPD(j + 8); PB_LUPD(j + 9); PB_LUPD(j + 10);
     PB_FENCE();
-    y = y * t;
-    PB_LUPD(j + 6); PB_LUPD(j + 7);
+    // ---- chain: y_{j+1}
+    yn = __builtin_fma(ye, q, yn);
+    PB_LUPD(j + 11); PB_LUPD(j + 12); PB_LUPD(j + 13); PB_LUPD(j + 14); PB_LUPD(j + 15);
     PB_FENCE();
-    t = hp * y;
-    PB_LUPD(j + 8); PB_LUPD(j + 9);
-    PB_FENCE();
-    t = __builtin_fma(-y, t, 1.5);
-    PB_LUPD(j + 10); PB_LUPD(j + 11);
-    PB_FENCE();
-    y = y * t;
-    PB_LUPD(j + 12); PB_LUPD(j + 13);
-    PB_FENCE();
-    const double py = p * y;
-    PB_LUPD(j + 14); PB_LUPD(j + 15);
-    PB_FENCE();
-    r[j + 1] = (lane == j + 1) ? py : r[j + 1] * y;
+    y = yn; p = pn;
 #pragma unroll
     for (int k = j + 3; k < 16; ++k) lq[k] = ln[k];
   }
+  r[15] = (lane == 15) ? p * y : r[15] * y;
 #undef PB_UPD
 #undef PB_LUPD
 #undef PB_FENCE
