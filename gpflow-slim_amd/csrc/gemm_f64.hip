@@ -353,18 +353,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       return;
     }
     __threadfence();
+    // slice order outermost: all MI*NI*4 loads of one slice are in flight together (element by element, each sum
+    // was a chain of nsplit dependent loads: 365 us for 16 slices); per element the order of the additions is the same
     const double* all = g.ws + (i64)tail * g.nsplit * (BM * BN) + tid;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j) acc[0][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int sl = 0; sl < g.nsplit; ++sl) {
+      const double* src = all + (i64)sl * (BM * BN);
+      double v[MI][NI][4];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          double t = 0.0;
-          for (int sl = 0; sl < g.nsplit; ++sl)
-            t += __builtin_nontemporal_load(all + (i64)sl * (BM * BN) + ((i * NI + j) * 4 + rg) * 256);
-          acc[0][i][j][rg] = t;
-        }
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) v[i][j][rg] = __builtin_nontemporal_load(src + ((i * NI + j) * 4 + rg) * 256);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) acc[0][i][j][rg] += v[i][j][rg];
+    }
     if (tid == 0) g.cnt[tail] = 0;       // ready for the next launch on this stream
   }
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
@@ -445,7 +456,7 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     const int slots = 512;
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
     int ns = r > 0 ? slots / r : 1;
-    if (ns > 16) ns = 16;
+    if (ns > h->gemm_tail_max_slices) ns = h->gemm_tail_max_slices;
     while (ns > 1 && (g.K / BK_MIN) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
     if (nfull >= slots && ns > 1) {
       GPS_HIP(h, h->dGemmWs.ensure((size_t)r * ns * BM * BN * sizeof(double)));

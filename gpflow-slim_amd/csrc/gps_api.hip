@@ -166,6 +166,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_deep_slabs") == 0) { h->gemm_deep_slabs = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
+  if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_pairs") == 0) { h->potrf_rl_pairs = (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");

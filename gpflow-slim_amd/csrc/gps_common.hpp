@@ -68,6 +68,7 @@ struct gps_handle_s {
   int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
   int potrf_rl_pairs = 1;      // ... with the remainder updated once per pair of panels (K = 256)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
+  int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
