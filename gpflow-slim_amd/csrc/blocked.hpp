@@ -40,7 +40,7 @@ struct Blocked {
   int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0) {
     if (n <= 0) return 0;
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
-    if (n <= ops.rl_max()) return ops.rl_pairs() ? potrf_rl_pairs(A, lda, n, blk0, row0) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
+    if (n <= ops.rl_max()) return ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = potrf_rec(A, lda, n1, blk0, row0);
     if (rc) return rc;
@@ -79,34 +79,32 @@ struct Blocked {
     return 0;
   }
 
-  // The 128-column sweep with the remainder updated once per PAIR of panels: after the first panel of a pair only the
-  // next block column is updated (m x 128, K = 128); after the second, one K = 256 update of the remainder with both
-  // panels (they are adjacent columns of the same rows).  Same number of launches per 128 columns as potrf_rl, but the
-  // remainder -- whose read-modify-write is what bounds the K = 128 update above ~2000 rows -- crosses HBM half as often.
-  int potrf_rl_pairs(double* A, i64 lda, i64 n, i64 blk0, i64 row0) {
+  // The 128-column sweep with the remainder updated once per GROUP of g panels: inside a group, after panel i only
+  // the next block column is updated, with all i+1 panels of the group so far (m x 128, K = 128 (i+1): they are
+  // adjacent columns of the same rows); after the last panel one K = 128 g update of the remainder.  Same number of
+  // launches per 128 columns as potrf_rl, but the remainder -- whose read-modify-write is what bounds the K = 128
+  // update above ~2000 rows -- crosses HBM once per group.
+  int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0) {
     const i64 T = GPS_TILE;
-    for (i64 c = 0; c < n; c += 2 * T) {
-      double* A00 = A + c * lda + c;
-      int rc = ops.potrf_base(A00, lda, blk0 + c / T, row0 + c);
-      if (rc) return rc;
-      const i64 m = n - c - T;                       // rows below the first block
-      if (m == 0) break;
-      double* B0 = A00 + T * lda;
-      rc = ops.trsm_base(blk0 + c / T, 0, B0, lda, m);
-      if (rc) return rc;
-      rc = ops.gemm(0, 0, m, T, T, B0, lda, B0, lda, B0 + T, lda);          // next block column only
-      if (rc) return rc;
-      double* A11 = B0 + T;
-      rc = ops.potrf_base(A11, lda, blk0 + c / T + 1, row0 + c + T);
-      if (rc) return rc;
-      const i64 m1 = m - T;                          // rows below the second block
-      if (m1 == 0) break;
-      double* B1 = A11 + T * lda;
-      rc = ops.trsm_base(blk0 + c / T + 1, 0, B1, lda, m1);
-      if (rc) return rc;
-      double* P = B0 + T * lda;                      // [m1, 256]: both panels, rows below the pair
-      rc = ops.gemm(0, 1, m1, m1, 2 * T, P, lda, P, lda, P + 2 * T, lda);
-      if (rc) return rc;
+    for (i64 c0 = 0; c0 < n; c0 += g * T) {
+      for (i64 i = 0; i < g; ++i) {
+        const i64 c = c0 + i * T;
+        if (c >= n) return 0;
+        double* Acc = A + c * lda + c;
+        int rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
+        if (rc) return rc;
+        const i64 m = n - c - T;                       // rows below this block
+        if (m == 0) return 0;
+        rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m);
+        if (rc) return rc;
+        double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
+        if (i + 1 < g) {
+          rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, A + (c + T) * lda + (c + T), lda);      // next block column
+        } else {
+          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, A + (c + T) * lda + (c + T), lda);            // remainder
+        }
+        if (rc) return rc;
+      }
     }
     return 0;
   }

@@ -49,7 +49,7 @@ struct HipOps {
     return GPS_OK;
   }
   i64 rl_max() const { return h->potrf_rl_max; }   // diagonal blocks up to this size: right-looking panel sweep
-  bool rl_pairs() const { return h->potrf_rl_pairs != 0; }
+  i64 rl_group() const { return h->potrf_rl_group; }
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     GPS_HIP(h, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)cols * 8, (size_t)rows, h->stream));
@@ -168,7 +168,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_rl_pairs") == 0) { h->potrf_rl_pairs = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
 

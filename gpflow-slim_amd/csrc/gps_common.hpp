@@ -66,7 +66,7 @@ struct gps_handle_s {
   int gemm_force_tb = 0;
   int gemm_deep_slabs = 1;     // 32x32 tiles use 64-deep K slabs, the 16/32 x 128 row panels 32-deep ones
   int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
-  int potrf_rl_pairs = 1;      // ... with the remainder updated once per pair of panels (K = 256)
+  int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)

@@ -11,7 +11,7 @@
 typedef int64_t i64;
 static const i64 T = GPS_TILE;
 
-static int g_rl_pairs = 0;
+static i64 g_rl_group = 1;
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
 
 struct CpuOps {
@@ -89,7 +89,7 @@ struct CpuOps {
     return 0;
   }
   i64 rl_max() const { return g_rl_max; }
-  bool rl_pairs() const { return g_rl_pairs != 0; }
+  i64 rl_group() const { return g_rl_group; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -120,7 +120,7 @@ struct CpuOps {
 
 extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
-void emul_set_rl_pairs(int v) { g_rl_pairs = v; }
+void emul_set_rl_group(i64 v) { g_rl_group = v; }
 // the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only
 int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
   CpuOps ops(n / T);

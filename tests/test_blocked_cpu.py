@@ -20,11 +20,11 @@ def emul():
     return lib
 
 
-@pytest.mark.parametrize("rl_max,pairs", [(0, 0), (256, 0), (1024, 0), (256, 1), (1024, 1)])
+@pytest.mark.parametrize("rl_max,group", [(0, 1), (256, 1), (1024, 1), (256, 2), (1024, 2), (1024, 3), (1024, 4)])
 @pytest.mark.parametrize("n,m,r", [(128, 128, 1), (256, 128, 2), (384, 256, 3), (640, 128, 1), (896, 128, 2)])
-def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, pairs):
+def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, group):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))      # diagonal blocks up to rl_max: right-looking sweep (potrf_rl)
-    emul.emul_set_rl_pairs(pairs)                     # ... updating the remainder once per pair of panels (potrf_rl_pairs)
+    emul.emul_set_rl_group(ctypes.c_int64(group))     # ... updating the remainder once per group of panels (potrf_rl_groups)
     rng = np.random.default_rng(n + m)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     B = rng.standard_normal((m, n)); B2 = B.copy(); y = rng.standard_normal((r, n))
@@ -40,10 +40,10 @@ def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, pairs):
     assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
 
 
-@pytest.mark.parametrize("rl_max,pairs", [(0, 0), (512, 0), (512, 1)])
-def test_blocked_recursion_reports_first_bad_pivot(emul, rl_max, pairs):
+@pytest.mark.parametrize("rl_max,group", [(0, 1), (512, 1), (512, 2), (512, 3)])
+def test_blocked_recursion_reports_first_bad_pivot(emul, rl_max, group):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))
-    emul.emul_set_rl_pairs(pairs)
+    emul.emul_set_rl_group(ctypes.c_int64(group))
     n = 384
     rng = np.random.default_rng(1)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
