@@ -247,7 +247,12 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "gemm_pipe"       1 (default): hand-scheduled K loop (sched_group_barrier) of the 128x128 and 64x64 tiles;
  *                     0: the compiler's instruction order
  *   "gemm_tail_split" 1 (default): the tiles of a partial last round of a 128x128 launch are cut into
- *                     K-slices over the idle workgroup slots; 0: one workgroup per tile          */
+ *                     K-slices over the idle workgroup slots; 0: one workgroup per tile
+ *   "gemm_tail_max_slices"  most K-slices per tile of that tail (default 16)
+ *   "gemm_deep_slabs" 1 (default): deeper K slabs for the latency-bound small tiles
+ *   "potrf_rl_max"    diagonal blocks of at most this many columns (default 4096) are factored by a right-looking
+ *                     sweep over 128-column panels instead of the recursion (tf.cholesky, models/gpr.py:70); 0: recursion only
+ *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)              */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------
