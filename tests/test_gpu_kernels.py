@@ -138,6 +138,44 @@ def test_potrf_reports_not_positive_definite(handle):
     assert "201" in str(e.value)          # LAPACK-style: first failing leading minor
 
 
+@pytest.mark.parametrize("pos", [0, 1, 15, 16, 17, 31, 47, 48, 63, 64, 100, 111, 112, 127, 128, 129, 255, 256, 383])
+def test_potrf_first_failing_minor_at_every_panel_position(handle, pos):
+    """The base kernel factors 16 columns per step with several waves doing the diagonal block redundantly and the rows
+    below in spare lanes; only one of them reports.  The first non-positive leading minor must come back whatever
+    step, wave or lane it falls in (positions inside each of the 16-column steps and across 128-blocks)."""
+    import gpflowSlim
+    n = 384
+    rng = np.random.default_rng(pos)
+    G = rng.standard_normal((n, n + 5))
+    A = G @ G.T + np.eye(n)
+    # make the leading minor of order pos+1 the first singular/indefinite one: Schur complement pivot -> negative
+    L = np.linalg.cholesky(A)
+    A[pos, pos] -= 1.5 * L[pos, pos] ** 2
+    with pytest.raises(gpflowSlim.NotPositiveDefiniteError) as e:
+        handle.potrf(A)
+    assert "order %d " % (pos + 1) in str(e.value), str(e.value)
+
+
+@pytest.mark.parametrize("n", [640, 2048, 4224])
+def test_potrf_sweep_and_recursion_agree(handle, n):
+    """Diagonal blocks up to 4096 columns are factored by the right-looking sweep (groups of 1, 2 or 3 panels per
+    remainder update), larger ones by the recursion; "potrf_rl_max" = 0 forces the recursion everywhere.  Same
+    factor to rounding, whatever the schedule."""
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 3))
+    A = G @ G.T + 0.5 * np.eye(n)
+    ref = np.linalg.cholesky(A)
+    try:
+        for opts in ({"potrf_rl_max": 0}, {"potrf_rl_max": 4096, "potrf_rl_group": 1}, {"potrf_rl_max": 4096, "potrf_rl_group": 2},
+                     {"potrf_rl_max": 1024, "potrf_rl_group": 3}):
+            for k, v in opts.items():
+                handle.set_option(k, v)
+            L = handle.potrf(A)
+            assert np.abs(L - ref).max() <= 1e-10 * np.abs(ref).max(), opts
+    finally:
+        handle.set_option("potrf_rl_max", 4096); handle.set_option("potrf_rl_group", 2)
+
+
 @pytest.mark.parametrize("n,nrhs", [(1, 1), (7, 3), (128, 1), (200, 5), (513, 130), (1024, 1000)])
 @pytest.mark.parametrize("trans", [False, True])
 def test_trsm_lower(handle, n, nrhs, trans):
