@@ -10,7 +10,7 @@
 // (128 pivots), so the waves are specialised and everything that is not on the chain runs in its shadow:
 //
 //   phase A(g)  PANEL waves: each holds the 16 rows of the diagonal block g in lanes 0..15 (every panel wave factors
-//               it, redundantly, in registers: v_readlane broadcasts, hardware rsqrt + two Newton steps, no barrier)
+//               it, redundantly, in registers: v_readlane broadcasts, hardware rsqrt + one third-order correction, no barrier)
 //               and rows below it in its other lanes -- those lanes execute the very same instruction stream, which
 //               for them IS the forward substitution x L_gg^T = b against the block, so the whole 16-column panel is
 //               finished when the diagonal block is.  Lanes 16..31 of wave 0 start from the rows of the identity
@@ -77,7 +77,7 @@ __device__ __forceinline__ double x_elem(const double* a, const double* dinv, in
 // ---- phase A, panel wave: 16 columns o..o+15.  Lanes 0..15: rows of the diagonal block.  Owner (wave 0): lanes
 // 16..31 rows of the identity (-> columns of the block's inverse), lanes 32..63 rows o+16 .. o+47; other panel waves:
 // lanes 16..63 rows xrow0 .. xrow0+47 (rows >= 128 are idle lanes).  Branch-free body (one basic block): the scheduler
-// can overlap column j's trailing updates with the rsqrt / Newton chain of column j+1.
+// can overlap column j's trailing updates with the rsqrt chain of column j+1.
 // The rows below go back to the image here; the diagonal block's rows and the inverse's columns stay in r[] (lanes
 // 0..31 of the owner) and are written by the caller AFTER the barrier that ends the phase: the other panel waves read
 // the same block.
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // masked-out elements go to a per-lane dummy slot instead of a divergent branch per element
         const int c = lane & 15;
         const bool lo = lane < 16, act = lane < 32;
-        double dc = r[0];                      // X[c][c] = 1 / L_cc (the pivot's Newton reciprocal square root)
+        double dc = r[0];                      // X[c][c] = 1 / L_cc (the pivot's refined reciprocal square root)
 #pragma unroll
         for (int k = 1; k < 16; ++k) dc = (k == c) ? r[k] : dc;
         if (act && !lo) dinv[o + c] = dc;
