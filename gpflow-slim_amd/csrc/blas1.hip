@@ -309,6 +309,28 @@ __global__ __launch_bounds__(256) void extract_kernel(const double* __restrict__
     dst[rr * ldd + c] = (lower_only && c > rr) ? 0.0 : src[rr * lds_ + c];
 }
 
+// Look-ahead hand-over: one wave.  Publishes *sig = sval (if sig), then waits until *flag >= val (if flag) -- bounded, so a
+// broken schedule shows up as a counted time-out (and a wrong result the caller rejects), never as a hung GPU.
+__global__ __launch_bounds__(64) void la_wait_kernel(unsigned long long* sig, unsigned long long sval,
+                                                     const unsigned long long* flag, unsigned long long val,
+                                                     unsigned long long* timeouts) {
+  if (threadIdx.x != 0) return;
+  if (sig) __hip_atomic_store(sig, sval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (!flag) return;
+  for (int it = 0; it < 4000000; ++it) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= val) return;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  atomicAdd(timeouts, 1ull);
+}
+
+int gps_launch_la_wait(gps_handle_t h, hipStream_t st, unsigned long long* sig, unsigned long long sval,
+                       const unsigned long long* flag, unsigned long long val, unsigned long long* timeouts) {
+  hipLaunchKernelGGL(la_wait_kernel, dim3(1), dim3(64), 0, st, sig, sval, flag, val, timeouts);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
 // ---------------------------------------------------------------------------------
 int gps_launch_trsv_base(gps_handle_t h, const double* LinvT_blk, double* y, i64 ldy, i64 r) {
   LaunchScope ls(h, KC_TRSV, 2.0 * 128 * 128 * r, 128.0 * 128 * 8);

@@ -86,27 +86,48 @@ struct Blocked {
   // update above ~2000 rows -- crosses HBM once per group.
   int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0) {
     const i64 T = GPS_TILE;
+    const bool la = (g >= 2) && ops.lookahead();
+    unsigned long long pending = 0;              // join ticket of a remainder update still running on the side stream
+    bool forked = false;                         // a hand-over has already happened in this sweep
     for (i64 c0 = 0; c0 < n; c0 += g * T) {
       for (i64 i = 0; i < g; ++i) {
         const i64 c = c0 + i * T;
-        if (c >= n) return 0;
+        if (c >= n) return pending ? ops.chain_join(pending) : 0;
         double* Acc = A + c * lda + c;
         int rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
         if (rc) return rc;
         const i64 m = n - c - T;                       // rows below this block
-        if (m == 0) return 0;
+        if (m == 0) return pending ? ops.chain_join(pending) : 0;
         rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m);
         if (rc) return rc;
         double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
+        double* Cn = A + (c + T) * lda + (c + T);      // the next block column / the remainder
         if (i + 1 < g) {
-          rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, A + (c + T) * lda + (c + T), lda);      // next block column
+          // (the next block column was last written by the remainder update of the previous group)
+          if (pending) { rc = ops.chain_join(pending); pending = 0; if (rc) return rc; }
+          rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, Cn, lda);      // next block column
+        } else if (la && m - T >= ops.lookahead_min_rows()) {
+          // look-ahead: the chain updates only the next block column; the rest of the remainder runs on the side stream
+          // beside the next group's first potrf_base / panel solve.  The chain's GEMM publishes the fork ticket when it
+          // starts (= the panel solve before it has completed); the join is awaited before the next group's first
+          // block-column update, the first launch that touches what the side stream writes.
+          const unsigned long long t = ops.la_fork();
+          rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
+          if (rc) return rc;
+          rc = ops.side_begin(t, !forked);
+          forked = true;
+          if (rc) return rc;
+          rc = ops.gemm(0, 1, m - T, m - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+          const int rc2 = ops.side_end(t);
+          if (rc || rc2) return rc ? rc : rc2;
+          pending = t;
         } else {
-          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, A + (c + T) * lda + (c + T), lda);            // remainder
+          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);            // remainder
         }
         if (rc) return rc;
       }
     }
-    return 0;
+    return pending ? ops.chain_join(pending) : 0;
   }
 
   // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)

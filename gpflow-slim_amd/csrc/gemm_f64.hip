@@ -54,6 +54,9 @@ struct GemmArgs {
   int nfull, nsplit;
   double* ws;         // [(ntiles - nfull) * nsplit][BM * BN] slice partials
   unsigned* cnt;      // [ntiles - nfull] arrival counters (left at 0)
+  // Look-ahead hand-over (blocked.hpp::potrf_rl_groups): the first workgroup publishes sig_val at sig_ptr when the
+  // kernel STARTS -- on an in-order stream that means "everything launched before this kernel has completed".
+  unsigned long long* sig_ptr; unsigned long long sig_val;
   long long* stamps;  // diagnostics (gps_diag_gemm_timeline): [blockIdx][6] = start, end, HW_ID, XCC_ID, K loop start, K loop end (100 MHz ticks); else null
 };
 
@@ -164,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     decode_tile<LOWER>(tile_id, g.Tm, g.Tn, tm, tn);
     bcol = (i64)tn * BN;
   }
+  if (g.sig_ptr && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(g.sig_ptr, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (g.stamps && threadIdx.x == 0) {
     long long* st = g.stamps + 6 * (long long)blockIdx.x;
     st[0] = (long long)wall_clock64();
@@ -452,7 +457,9 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
   g.ntiles = (int)nt;
   // tail split: 128x128 tiles only (512 resident slots on 256 CUs), never for the in-place or triangular-A forms
   g.nfull = g.ntiles; g.nsplit = 1; g.ws = nullptr; g.cnt = nullptr;
-  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256) {
+  // (not on the look-ahead side stream either: the slice work space is shared by all launches of the handle)
+  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256 &&
+      (h->side_stream == nullptr || h->stream != h->side_stream)) {
     const int slots = 512;
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
     int ns = r > 0 ? slots / r : 1;
@@ -499,6 +506,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
   g.stamps = h->gemm_stamps;
+  g.sig_ptr = h->next_sig_ptr; g.sig_val = h->next_sig_val; h->next_sig_ptr = nullptr;      // consumed by this launch
   g.cb_tiles = 0; g.cb_stride = 0;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
@@ -543,6 +551,7 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
   GemmArgs g;
   g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;
+  g.sig_ptr = nullptr; g.sig_val = 0;
   g.stamps = h->gemm_stamps;
   // needed 128x128 tiles: block b uses rows >= b*stride
   double t128 = 0.0;

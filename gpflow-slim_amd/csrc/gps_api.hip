@@ -50,6 +50,59 @@ struct HipOps {
   }
   i64 rl_max() const { return h->potrf_rl_max; }   // diagonal blocks up to this size: right-looking panel sweep
   i64 rl_group() const { return h->potrf_rl_group; }
+  // ---- look-ahead of the sweep (see blocked.hpp::potrf_rl_groups)
+  i64 lookahead_min_rows() const { return h->potrf_lookahead_min; }
+  bool lookahead() {
+    // never on an external stream (gps_set_stream): that may be the legacy default stream, which synchronises
+    // implicitly with a blocking side stream -- the hand-over would wait on itself
+    if (!h->potrf_lookahead || h->ext_stream) return false;
+    if (!h->side_stream) {
+      // The side stream leaves one CU per XCD alone (mask bit i = CU i/8 of XCD i%8): potrf_base needs a whole CU's LDS,
+      // and a GEMM that keeps refilling every CU with small workgroups would starve it until its own tail.
+      hipError_t e;
+      if (h->prop.multiProcessorCount == 256) {
+        const uint32_t mask[8] = {0xffffff00u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        e = hipExtStreamCreateWithCUMask(&h->side_stream, 8, mask);
+      } else {
+        e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+      }
+      if (e != hipSuccess) { h->side_stream = nullptr; return false; }
+      if (h->dLaFlags.ensure(64) != hipSuccess) return false;
+      if (hipMemset(h->dLaFlags.p, 0, 64) != hipSuccess) return false;
+      if (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess) return false;
+      h->la_ticket = 0;
+    }
+    return true;
+  }
+  unsigned long long* la_flags() const { return (unsigned long long*)h->dLaFlags.p; }
+  // fork: the NEXT GEMM launched on the chain publishes the ticket when it starts; the side stream waits for it
+  unsigned long long la_fork() {
+    const unsigned long long t = ++h->la_ticket;
+    h->next_sig_ptr = la_flags(); h->next_sig_val = t;
+    return t;
+  }
+  hipStream_t saved_stream = nullptr;
+  // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
+  // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
+  // its second GEMM workgroup (measured: every big launch 4-10 % slower).  An event keeps the queue parked instead;
+  // inside a sweep the waits are tens of microseconds and stay in-kernel.
+  int side_begin(unsigned long long t, bool first) {
+    if (first) {
+      GPS_HIP(h, hipEventRecord(h->ev_la, h->stream));
+      GPS_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_la, 0));
+    }
+    int rc = gps_launch_la_wait(h, h->side_stream, nullptr, 0, la_flags(), t, la_flags() + 2);
+    if (rc) return rc;
+    saved_stream = h->stream; h->stream = h->side_stream;
+    return GPS_OK;
+  }
+  int side_end(unsigned long long t) {       // publish the join ticket after the side work
+    h->stream = saved_stream; saved_stream = nullptr;
+    return gps_launch_la_wait(h, h->side_stream, la_flags() + 1, t, nullptr, 0, la_flags() + 2);
+  }
+  int chain_join(unsigned long long t) {
+    return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
+  }
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     GPS_HIP(h, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)cols * 8, (size_t)rows, h->stream));
@@ -59,9 +112,12 @@ struct HipOps {
 
 static int read_info(gps_handle_t h, int* d_info, int* info) {
   int v = 0;
+  unsigned long long la_timeouts = 0;
   GPS_HIP(h, hipMemcpyAsync(&v, d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (h->dLaFlags.p) GPS_HIP(h, hipMemcpyAsync(&la_timeouts, (unsigned long long*)h->dLaFlags.p + 2, 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (info) *info = (v == INT_MAX) ? 0 : v;
+  if (la_timeouts) return gps_fail(h, GPS_ERR_STATE, "look-ahead hand-over timed out (result invalid)");
   return GPS_OK;
 }
 
@@ -106,6 +162,9 @@ extern "C" int gps_destroy(gps_handle_t h) {
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
+  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+  h->dLaFlags.release();
+  if (h->ev_la) (void)hipEventDestroy(h->ev_la);
   delete h;
   return GPS_OK;
 }
@@ -168,6 +227,8 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
@@ -806,6 +867,14 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
   if (external) {                       // hip_stream may be NULL: the legacy default stream
     if (!h->ext_stream) { h->own_stream = h->stream; h->ext_stream = true; }
     h->stream = (hipStream_t)hip_stream;
+    // The look-ahead side stream comes from hipExtStreamCreateWithCUMask, which has no "non-blocking" flag: while it
+    // exists, every launch on the legacy default stream is ordered against it (measured: the block-column run on the
+    // default stream 2.6x slower).  It is not used with an external stream, so it goes; lookahead() re-creates it.
+    if (h->side_stream) {
+      (void)hipStreamSynchronize(h->side_stream);
+      (void)hipStreamDestroy(h->side_stream);
+      h->side_stream = nullptr;
+    }
   } else if (h->ext_stream) {
     h->stream = h->own_stream; h->ext_stream = false;
   }

@@ -66,6 +66,15 @@ struct gps_handle_s {
   int gemm_force_tb = 0;
   int gemm_deep_slabs = 1;     // 32x32 tiles use 64-deep K slabs, the 16/32 x 128 row panels 32-deep ones
   int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
+  // look-ahead of the sweep (potrf_rl_groups): the remainder update of a pair of panels runs on side_stream (one CU per
+  // XCD left free for potrf_base) and is handed over through two monotone device counters instead of events
+  int potrf_lookahead = 1;
+  int potrf_lookahead_min = 1024;              // rows of that remainder from which the hand-over pays
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_la = nullptr;
+  DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
+  unsigned long long la_ticket = 0;
+  unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   int gemm_tail_max_slices = 16;
@@ -197,6 +206,9 @@ int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           long long* d_stamps = nullptr);
 // blas1.hip
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
+// look-ahead hand-over kernels (blas1.hip): optional publish of *sig = sval, then wait (bounded) until *flag >= val
+int gps_launch_la_wait(gps_handle_t h, hipStream_t st, unsigned long long* sig, unsigned long long sval,
+                       const unsigned long long* flag, unsigned long long val, unsigned long long* timeouts);
 int gps_launch_gemv_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,
                         const double* y1, double* y2, i64 ldy, i64 r);
 int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i64 n1,

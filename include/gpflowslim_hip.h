@@ -252,7 +252,10 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "gemm_deep_slabs" 1 (default): deeper K slabs for the latency-bound small tiles
  *   "potrf_rl_max"    diagonal blocks of at most this many columns (default 4096) are factored by a right-looking
  *                     sweep over 128-column panels instead of the recursion (tf.cholesky, models/gpr.py:70); 0: recursion only
- *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)              */
+ *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)
+ *   "potrf_lookahead" 1 (default): that remainder update runs on a second stream beside the next potrf_base, handed over
+ *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
+ *                     from which it is used (default 1024)                                         */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------

@@ -12,6 +12,7 @@ typedef int64_t i64;
 static const i64 T = GPS_TILE;
 
 static i64 g_rl_group = 1;
+static int g_lookahead = 0;
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
 
 struct CpuOps {
@@ -90,6 +91,14 @@ struct CpuOps {
   }
   i64 rl_max() const { return g_rl_max; }
   i64 rl_group() const { return g_rl_group; }
+  // look-ahead hooks: the host emulation is sequential; the hooks check that forks, side sections and joins pair up
+  unsigned long long ticket = 0, open_side = 0, unjoined = 0;
+  bool lookahead() { return g_lookahead != 0; }
+  i64 lookahead_min_rows() const { return 128; }
+  unsigned long long la_fork() { return ++ticket; }
+  int side_begin(unsigned long long t, bool) { if (open_side || unjoined || t != ticket) return -7; open_side = t; return 0; }
+  int side_end(unsigned long long t) { if (open_side != t) return -8; open_side = 0; unjoined = t; return 0; }
+  int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -121,6 +130,7 @@ struct CpuOps {
 extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
+void emul_set_lookahead(int v) { g_lookahead = v; }
 // the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only
 int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
   CpuOps ops(n / T);
