@@ -42,12 +42,19 @@ struct Blocked {
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
     if (n <= ops.rl_max()) return ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
     const i64 n1 = split(n), n2 = n - n1;
-    int rc = potrf_rec(A, lda, n1, blk0, row0);
-    if (rc) return rc;
     double* A21 = A + n1 * lda;
     double* A22 = A21 + n1;
-    rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
-    if (rc) return rc;
+    int rc;
+    if (n1 > GPS_TILE && n1 <= ops.rl_max() && ops.rl_group() > 1 && ops.follower()) {
+      // A11 is factored by the sweep: the solve of A21 against it follows the sweep on the side stream
+      rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, n2);
+      if (rc) return rc;
+    } else {
+      rc = potrf_rec(A, lda, n1, blk0, row0);
+      if (rc) return rc;
+      rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
+      if (rc) return rc;
+    }
     rc = ops.gemm(/*op sub*/ 0, /*lower*/ 1, n2, n2, n1, A21, lda, A21, lda, A22, lda);
     if (rc) return rc;
     return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1);
@@ -84,20 +91,41 @@ struct Blocked {
   // adjacent columns of the same rows); after the last panel one K = 128 g update of the remainder.  Same number of
   // launches per 128 columns as potrf_rl, but the remainder -- whose read-modify-write is what bounds the K = 128
   // update above ~2000 rows -- crosses HBM once per group.
-  int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0) {
+  // Follower (FB != nullptr, look-ahead on): FB [fm, n] is the block below this diagonal block in the parent's
+  // recursion (its A21), which the parent would solve against L afterwards (trsm_rec).  Column block [c0, c0 + 128 g)
+  // of that solve needs nothing but the columns of L up to c0 + 128 g, which are final as soon as the group's last
+  // panel is solved -- so the solve follows the sweep group by group on the side stream (left-looking: one update with
+  // all previous columns, K = c0, then the 128 g-column solve), where it fills the GPU the latency-bound chain leaves
+  // idle.  What the side stream has not reached when the sweep ends is finished on the chain.
+  int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0, double* FB = nullptr, i64 ldfb = 0, i64 fm = 0) {
     const i64 T = GPS_TILE;
     const bool la = (g >= 2) && ops.lookahead();
+    const bool fol = la && FB != nullptr && fm > 0;
     unsigned long long pending = 0;              // join ticket of a remainder update still running on the side stream
     bool forked = false;                         // a hand-over has already happened in this sweep
+    i64 fdone = 0;                               // columns of the follower solve issued so far
+    auto follower_piece = [&](i64 c_lo, i64 c_hi) -> int {          // columns [c_lo, c_hi) of  X L^T = FB
+      int rc = 0;
+      if (c_lo > 0) rc = ops.gemm(0, 0, fm, c_hi - c_lo, c_lo, FB, ldfb, A + c_lo * lda, lda, FB + c_lo, ldfb);
+      if (rc) return rc;
+      return trsm_rec(A + c_lo * lda + c_lo, lda, c_hi - c_lo, blk0 + c_lo / T, FB + c_lo, ldfb, fm);
+    };
+    auto finish = [&]() -> int {
+      int rc = pending ? ops.chain_join(pending) : 0;
+      pending = 0;
+      if (rc || FB == nullptr) return rc;
+      if (fol && fdone > 0) { rc = ops.follower_join(); if (rc) return rc; }
+      return fdone < n ? follower_piece(fdone, n) : 0;               // the rest (all of it without look-ahead) on the chain
+    };
     for (i64 c0 = 0; c0 < n; c0 += g * T) {
       for (i64 i = 0; i < g; ++i) {
         const i64 c = c0 + i * T;
-        if (c >= n) return pending ? ops.chain_join(pending) : 0;
+        if (c >= n) return finish();
         double* Acc = A + c * lda + c;
         int rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
         if (rc) return rc;
         const i64 m = n - c - T;                       // rows below this block
-        if (m == 0) return pending ? ops.chain_join(pending) : 0;
+        if (m == 0) return finish();
         rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m);
         if (rc) return rc;
         double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
@@ -106,28 +134,38 @@ struct Blocked {
           // (the next block column was last written by the remainder update of the previous group)
           if (pending) { rc = ops.chain_join(pending); pending = 0; if (rc) return rc; }
           rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, Cn, lda);      // next block column
-        } else if (la && m - T >= ops.lookahead_min_rows()) {
-          // look-ahead: the chain updates only the next block column; the rest of the remainder runs on the side stream
-          // beside the next group's first potrf_base / panel solve.  The chain's GEMM publishes the fork ticket when it
-          // starts (= the panel solve before it has completed); the join is awaited before the next group's first
-          // block-column update, the first launch that touches what the side stream writes.
-          const unsigned long long t = ops.la_fork();
-          rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
           if (rc) return rc;
-          rc = ops.side_begin(t, !forked);
-          forked = true;
-          if (rc) return rc;
-          rc = ops.gemm(0, 1, m - T, m - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
-          const int rc2 = ops.side_end(t);
-          if (rc || rc2) return rc ? rc : rc2;
-          pending = t;
-        } else {
-          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);            // remainder
+          continue;
         }
+        // ---- last panel of the group
+        const bool split = la && m - T >= ops.lookahead_min_rows();
+        if (!split && !fol) {
+          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);            // remainder
+          if (rc) return rc;
+          continue;
+        }
+        // look-ahead.  The chain's next GEMM publishes the fork ticket when it starts (= the panel solve before it has
+        // completed).  split: the chain updates only the next block column, the rest of the remainder runs on the side
+        // stream beside the next group's first potrf_base / panel solve; its join is awaited before the next group's
+        // first block-column update, the first launch that touches what the side stream writes.
+        const unsigned long long t = ops.la_fork();
+        if (split) rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
+        else rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);
         if (rc) return rc;
+        rc = ops.side_open(t, !forked);
+        forked = true;
+        if (rc) return rc;
+        if (split) {
+          rc = ops.gemm(0, 1, m - T, m - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+          if (!rc) rc = ops.side_publish_join(t);
+          pending = t;
+        }
+        if (!rc && fol) { rc = follower_piece(fdone, c0 + g * T); fdone = c0 + g * T; if (!rc) rc = ops.follower_publish(); }
+        const int rc2 = ops.side_close();
+        if (rc || rc2) return rc ? rc : rc2;
       }
     }
-    return pending ? ops.chain_join(pending) : 0;
+    return finish();
   }
 
   // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)

@@ -70,7 +70,7 @@ struct HipOps {
       if (h->dLaFlags.ensure(64) != hipSuccess) return false;
       if (hipMemset(h->dLaFlags.p, 0, 64) != hipSuccess) return false;
       if (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess) return false;
-      h->la_ticket = 0;
+      h->la_ticket = 0; h->fol_ticket = 0;
     }
     return true;
   }
@@ -82,11 +82,12 @@ struct HipOps {
     return t;
   }
   hipStream_t saved_stream = nullptr;
+  bool follower() { return h->potrf_follower != 0 && lookahead(); }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
   // its second GEMM workgroup (measured: every big launch 4-10 % slower).  An event keeps the queue parked instead;
   // inside a sweep the waits are tens of microseconds and stay in-kernel.
-  int side_begin(unsigned long long t, bool first) {
+  int side_open(unsigned long long t, bool first) {
     if (first) {
       GPS_HIP(h, hipEventRecord(h->ev_la, h->stream));
       GPS_HIP(h, hipStreamWaitEvent(h->side_stream, h->ev_la, 0));
@@ -96,9 +97,16 @@ struct HipOps {
     saved_stream = h->stream; h->stream = h->side_stream;
     return GPS_OK;
   }
-  int side_end(unsigned long long t) {       // publish the join ticket after the side work
-    h->stream = saved_stream; saved_stream = nullptr;
+  int side_publish_join(unsigned long long t) {       // after the remainder update: the join ticket
     return gps_launch_la_wait(h, h->side_stream, la_flags() + 1, t, nullptr, 0, la_flags() + 2);
+  }
+  int side_close() { h->stream = saved_stream; saved_stream = nullptr; return GPS_OK; }
+  // follower solve: the side stream publishes a ticket after each piece; the chain waits for the last one
+  int follower_publish() {
+    return gps_launch_la_wait(h, h->side_stream, la_flags() + 3, ++h->fol_ticket, nullptr, 0, la_flags() + 2);
+  }
+  int follower_join() {
+    return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 3, h->fol_ticket, la_flags() + 2);
   }
   int chain_join(unsigned long long t) {
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
@@ -228,6 +236,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");

@@ -255,7 +255,9 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)
  *   "potrf_lookahead" 1 (default): that remainder update runs on a second stream beside the next potrf_base, handed over
  *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
- *                     from which it is used (default 1024)                                         */
+ *                     from which it is used (default 1024)
+ *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
+ *                     that second stream                                                          */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------

@@ -96,8 +96,13 @@ struct CpuOps {
   bool lookahead() { return g_lookahead != 0; }
   i64 lookahead_min_rows() const { return 128; }
   unsigned long long la_fork() { return ++ticket; }
-  int side_begin(unsigned long long t, bool) { if (open_side || unjoined || t != ticket) return -7; open_side = t; return 0; }
-  int side_end(unsigned long long t) { if (open_side != t) return -8; open_side = 0; unjoined = t; return 0; }
+  bool follower() { return g_lookahead != 0; }
+  unsigned long long fol_pub = 0;
+  int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }
+  int side_publish_join(unsigned long long t) { if (open_side != t || unjoined) return -8; unjoined = t; return 0; }
+  int side_close() { if (!open_side) return -10; open_side = 0; return 0; }
+  int follower_publish() { if (!open_side) return -11; ++fol_pub; return 0; }
+  int follower_join() { if (open_side || fol_pub == 0) return -12; return 0; }
   int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {

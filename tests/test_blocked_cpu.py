@@ -20,7 +20,7 @@ def emul():
     return lib
 
 
-@pytest.mark.parametrize("rl_max,group", [(0, 1), (256, 1), (1024, 1), (256, 2), (1024, 2), (1024, 3), (1024, 4), (1024, -2), (1024, -3)])
+@pytest.mark.parametrize("rl_max,group", [(0, 1), (256, 1), (1024, 1), (256, 2), (1024, 2), (1024, 3), (1024, 4), (1024, -2), (1024, -3), (256, -2), (384, -2), (512, -3)])
 @pytest.mark.parametrize("n,m,r", [(128, 128, 1), (256, 128, 2), (384, 256, 3), (640, 128, 1), (896, 128, 2)])
 def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, group):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))      # diagonal blocks up to rl_max: right-looking sweep (potrf_rl)
