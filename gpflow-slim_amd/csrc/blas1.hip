@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void la_wait_kernel(unsigned long long* sig, un
   if (threadIdx.x != 0) return;
   if (sig) __hip_atomic_store(sig, sval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (!flag) return;
-  for (int it = 0; it < 4000000; ++it) {
+  for (int it = 0; it < 200000000; ++it) {          // ~30 s: far beyond any legitimate wait, still not a hang
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= val) return;
     __builtin_amdgcn_s_sleep(4);
   }
