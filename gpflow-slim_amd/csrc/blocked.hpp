@@ -160,7 +160,10 @@ struct Blocked {
           if (!rc) rc = ops.side_publish_join(t);
           pending = t;
         }
-        if (!rc && fol) { rc = follower_piece(fdone, c0 + g * T); fdone = c0 + g * T; if (!rc) rc = ops.follower_publish(); }
+        if (!rc && fol && c0 + g * T - fdone >= ops.follower_cols()) {
+          rc = follower_piece(fdone, c0 + g * T); fdone = c0 + g * T;
+          if (!rc) rc = ops.follower_publish();
+        }
         const int rc2 = ops.side_close();
         if (rc || rc2) return rc ? rc : rc2;
       }

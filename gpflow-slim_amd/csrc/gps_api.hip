@@ -83,6 +83,7 @@ struct HipOps {
   }
   hipStream_t saved_stream = nullptr;
   bool follower() { return h->potrf_follower != 0 && lookahead(); }
+  i64 follower_cols() const { return h->potrf_follower_cols; }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
   // its second GEMM workgroup (measured: every big launch 4-10 % slower).  An event keeps the queue parked instead;
@@ -237,6 +238,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");

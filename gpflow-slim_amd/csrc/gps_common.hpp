@@ -74,6 +74,7 @@ struct gps_handle_s {
   hipEvent_t ev_la = nullptr;
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
+  int potrf_follower_cols = 512;               // ... in pieces of at least this many columns
   int potrf_follower = 1;                      // the parent's panel solve follows the sweep on the side stream (blocked.hpp)
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)

@@ -97,6 +97,7 @@ struct CpuOps {
   i64 lookahead_min_rows() const { return 128; }
   unsigned long long la_fork() { return ++ticket; }
   bool follower() { return g_lookahead != 0; }
+  i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
   unsigned long long fol_pub = 0;
   int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }
   int side_publish_join(unsigned long long t) { if (open_side != t || unjoined) return -8; unjoined = t; return 0; }
