@@ -20,12 +20,13 @@ def emul():
     return lib
 
 
-@pytest.mark.parametrize("rl_max,group", [(0, 1), (256, 1), (1024, 1), (256, 2), (1024, 2), (1024, 3), (1024, 4), (1024, -2), (1024, -3), (256, -2), (384, -2), (512, -3)])
+@pytest.mark.parametrize("rl_max,group", [(0, 1), (256, 1), (1024, 1), (256, 2), (1024, 2), (1024, 3), (1024, 4), (1024, -2), (1024, -3), (256, -2), (384, -2), (512, -3), (512, -12), (256, -12)])
 @pytest.mark.parametrize("n,m,r", [(128, 128, 1), (256, 128, 2), (384, 256, 3), (640, 128, 1), (896, 128, 2)])
 def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, group):
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))      # diagonal blocks up to rl_max: right-looking sweep (potrf_rl)
-    emul.emul_set_lookahead(1 if group < 0 else 0)    # negative group: with the look-ahead split of the remainder update
-    group = abs(group)
+    # negative group: with the look-ahead split of the remainder update and the follower solve (-12: in 512-column pieces)
+    emul.emul_set_lookahead(2 if group == -12 else (1 if group < 0 else 0))
+    group = 2 if group == -12 else abs(group)
     emul.emul_set_rl_group(ctypes.c_int64(group))     # ... updating the remainder once per group of panels (potrf_rl_groups)
     rng = np.random.default_rng(n + m)
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
