@@ -37,7 +37,13 @@ struct Blocked {
 
   // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
   // row0: global row of A's first row (for info reporting)
-  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0) {
+  // A piece of the PARENT's panel solve handed down to a child node: solve  X L^T = B  for the first dn columns of the
+  // child's matrix (B [dm, dn]: the parent's rows below, same columns).  The child issues it on the deferred stream as
+  // soon as those columns are final -- its own first half is done --, where it runs beside the child's second-half
+  // sweep, during which the GPU is otherwise mostly idle.  The parent then skips that part of its trsm_rec.
+  struct Deferred { double* B; i64 ldb, dm, dn; bool issued; };
+
+  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr) {
     if (n <= 0) return 0;
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
     if (n <= ops.rl_max()) return ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
@@ -49,10 +55,32 @@ struct Blocked {
       // A11 is factored by the sweep: the solve of A21 against it follows the sweep on the side stream
       rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, n2);
       if (rc) return rc;
+      if (dj && dj->dn == n1) {
+        // the first n1 columns are final: the parent's rows below can be solved against them from now on
+        rc = ops.deferred_open();
+        if (rc) return rc;
+        rc = trsm_rec(A, lda, n1, blk0, dj->B, dj->ldb, dj->dm);
+        const int rc2 = ops.deferred_close();
+        if (rc || rc2) return rc ? rc : rc2;
+        dj->issued = true;
+      }
     } else {
-      rc = potrf_rec(A, lda, n1, blk0, row0);
+      // a child whose own first half is a sweep can take the first part of this node's panel solve with it
+      const i64 n1a = split(n1);
+      Deferred job{A21, lda, n2, n1a, false};
+      const bool hand_down = n1 > ops.rl_max() && n1a > GPS_TILE && n1a <= ops.rl_max() && ops.rl_group() > 1 && ops.follower() && ops.deferred();
+      rc = potrf_rec(A, lda, n1, blk0, row0, hand_down ? &job : nullptr);
       if (rc) return rc;
-      rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
+      if (hand_down && job.issued) {
+        // trsm_rec(A, n1) = trsm_rec(first n1a columns) [done on the deferred stream] ; update ; trsm_rec(the others)
+        rc = ops.deferred_join();
+        if (rc) return rc;
+        rc = ops.gemm(0, 0, n2, n1 - n1a, n1a, A21, lda, A + n1a * lda, lda, A21 + n1a, lda);
+        if (rc) return rc;
+        rc = trsm_rec(A + n1a * lda + n1a, lda, n1 - n1a, blk0 + n1a / GPS_TILE, A21 + n1a, lda, n2);
+      } else {
+        rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
+      }
       if (rc) return rc;
     }
     rc = ops.gemm(/*op sub*/ 0, /*lower*/ 1, n2, n2, n1, A21, lda, A21, lda, A22, lda);

@@ -459,7 +459,7 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
   g.nfull = g.ntiles; g.nsplit = 1; g.ws = nullptr; g.cnt = nullptr;
   // (not on the look-ahead side stream either: the slice work space is shared by all launches of the handle)
   if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256 &&
-      (h->side_stream == nullptr || h->stream != h->side_stream)) {
+      (h->side_stream == nullptr || h->stream != h->side_stream) && (h->def_stream == nullptr || h->stream != h->def_stream)) {
     const int slots = 512;
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
     int ns = r > 0 ? slots / r : 1;

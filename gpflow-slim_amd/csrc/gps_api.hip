@@ -109,6 +109,40 @@ struct HipOps {
   int follower_join() {
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 3, h->fol_ticket, la_flags() + 2);
   }
+  // ---- deferred stream: big pieces of a parent's panel solve that run beside a child's sweep (coarse: events)
+  bool deferred() {
+    if (!h->potrf_deferred || !lookahead()) return false;
+    if (!h->def_stream) {
+      hipError_t e;
+      if (h->prop.multiProcessorCount == 256) {
+        const uint32_t mask[8] = {0xffffff00u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        e = hipExtStreamCreateWithCUMask(&h->def_stream, 8, mask);
+      } else {
+        e = hipStreamCreateWithFlags(&h->def_stream, hipStreamNonBlocking);
+      }
+      if (e != hipSuccess) { h->def_stream = nullptr; return false; }
+      if (hipEventCreateWithFlags(&h->ev_def_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_def_join, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return true;
+  }
+  hipStream_t saved_stream_d = nullptr;
+  int deferred_open() {
+    GPS_HIP(h, hipEventRecord(h->ev_def_fork, h->stream));
+    GPS_HIP(h, hipStreamWaitEvent(h->def_stream, h->ev_def_fork, 0));
+    saved_stream_d = h->stream; h->stream = h->def_stream;
+    return GPS_OK;
+  }
+  int deferred_close() {
+    hipError_t e = hipEventRecord(h->ev_def_join, h->def_stream);
+    h->stream = saved_stream_d; saved_stream_d = nullptr;
+    GPS_HIP(h, e);
+    return GPS_OK;
+  }
+  int deferred_join() {
+    GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_def_join, 0));
+    return GPS_OK;
+  }
   int chain_join(unsigned long long t) {
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
   }
@@ -172,6 +206,9 @@ extern "C" int gps_destroy(gps_handle_t h) {
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+  if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }
+  if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
+  if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
   h->dLaFlags.release();
   if (h->ev_la) (void)hipEventDestroy(h->ev_la);
   delete h;
@@ -238,6 +275,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
@@ -885,6 +923,11 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
       (void)hipStreamSynchronize(h->side_stream);
       (void)hipStreamDestroy(h->side_stream);
       h->side_stream = nullptr;
+    }
+    if (h->def_stream) {
+      (void)hipStreamSynchronize(h->def_stream);
+      (void)hipStreamDestroy(h->def_stream);
+      h->def_stream = nullptr;
     }
   } else if (h->ext_stream) {
     h->stream = h->own_stream; h->ext_stream = false;

@@ -71,6 +71,9 @@ struct gps_handle_s {
   int potrf_lookahead = 1;
   int potrf_lookahead_min = 1024;              // rows of that remainder from which the hand-over pays
   hipStream_t side_stream = nullptr;
+  hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
+  hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
+  int potrf_deferred = 1;
   hipEvent_t ev_la = nullptr;
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;

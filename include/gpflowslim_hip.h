@@ -257,7 +257,9 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
  *                     from which it is used (default 1024)
  *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
- *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512)  */
+ *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512)
+ *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
+ *                     child, which runs them on a third stream beside its second sweep              */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------

@@ -97,6 +97,11 @@ struct CpuOps {
   i64 lookahead_min_rows() const { return 128; }
   unsigned long long la_fork() { return ++ticket; }
   bool follower() { return g_lookahead != 0; }
+  int def_open = 0, def_unjoined = 0;
+  bool deferred() { return g_lookahead != 0; }
+  int deferred_open() { if (def_open || def_unjoined || open_side) return -13; def_open = 1; return 0; }
+  int deferred_close() { if (!def_open) return -14; def_open = 0; def_unjoined = 1; return 0; }
+  int deferred_join() { if (!def_unjoined) return -15; def_unjoined = 0; return 0; }
   i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
   unsigned long long fol_pub = 0;
   int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }

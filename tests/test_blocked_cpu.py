@@ -90,3 +90,25 @@ def test_panel_sweep_matches_lapack(emul, n, nb, rl_max):
     assert rc == 0 and info.value == 0
     L = sl.cholesky(A0, lower=True)
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
+
+
+@pytest.mark.parametrize("n,rl_max", [(1536, 384), (1280, 256), (2048, 512)])
+def test_deferred_piece_of_the_parent_solve(emul, n, rl_max):
+    """Nodes whose first half is itself a node with a swept first half hand the first part of their panel solve down
+    (blocked.hpp: Deferred): the child issues it once those columns are final, the parent skips it.  Index check with
+    the look-ahead hooks on (the emulation's hooks verify that every open / close / join pairs up)."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(1)
+    emul.emul_set_rl_group(ctypes.c_int64(2))
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+    B = rng.standard_normal((128, n)); B2 = B.copy(); y = rng.standard_normal((1, n))
+    A0, B0, y0 = A.copy(), B.copy(), y.copy()
+    info = ctypes.c_int(0)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A0, lower=True)
+    assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
+    assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
+    emul.emul_set_lookahead(0)
