@@ -35,14 +35,14 @@ struct Blocked {
 
   static i64 split(i64 n) { return ((n / GPS_TILE) / 2) * GPS_TILE; }   // n >= 256 -> 128 <= n1 < n
 
-  // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
-  // row0: global row of A's first row (for info reporting)
   // A piece of the PARENT's panel solve handed down to a child node: solve  X L^T = B  for the first dn columns of the
   // child's matrix (B [dm, dn]: the parent's rows below, same columns).  The child issues it on the deferred stream as
   // soon as those columns are final -- its own first half is done --, where it runs beside the child's second-half
   // sweep, during which the GPU is otherwise mostly idle.  The parent then skips that part of its trsm_rec.
   struct Deferred { double* B; i64 ldb, dm, dn; bool issued; };
 
+  // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
+  // row0: global row of A's first row (for info reporting)
   int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr) {
     if (n <= 0) return 0;
     if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
