@@ -130,7 +130,7 @@ struct Blocked {
     const bool la = (g >= 2) && ops.lookahead();
     const bool fol = la && FB != nullptr && fm > 0;
     unsigned long long pending = 0;              // join ticket of a remainder update still running on the side stream
-    bool forked = false;                         // a hand-over has already happened in this sweep
+    bool forked = false, fforked = false;        // a hand-over to the side / follower stream has already happened in this sweep
     i64 fdone = 0;                               // columns of the follower solve issued so far
     auto follower_piece = [&](i64 c_lo, i64 c_hi) -> int {          // columns [c_lo, c_hi) of  X L^T = FB
       int rc = 0;
@@ -176,24 +176,31 @@ struct Blocked {
         // completed).  split: the chain updates only the next block column, the rest of the remainder runs on the side
         // stream beside the next group's first potrf_base / panel solve; its join is awaited before the next group's
         // first block-column update, the first launch that touches what the side stream writes.
-        const unsigned long long t = ops.la_fork();
+        const unsigned long long t = ops.la_fork();      // (also when only the follower needs it)
         if (split) rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
         else rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);
         if (rc) return rc;
-        rc = ops.side_open(t, !forked);
-        forked = true;
-        if (rc) return rc;
         if (split) {
+          rc = ops.side_open(t, !forked);
+          forked = true;
+          if (rc) return rc;
           rc = ops.gemm(0, 1, m - T, m - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
           if (!rc) rc = ops.side_publish_join(t);
           pending = t;
+          const int rc2 = ops.side_close();
+          if (rc || rc2) return rc ? rc : rc2;
         }
-        if (!rc && fol && c0 + g * T - fdone >= ops.follower_cols()) {
+        // the follower's pieces are long (a K = c0 update of all its rows): on a stream of their own, or the next
+        // group's remainder update -- which the chain waits for -- would queue behind them
+        if (fol && c0 + g * T - fdone >= ops.follower_cols()) {
+          rc = ops.follower_open(t, !fforked);
+          fforked = true;
+          if (rc) return rc;
           rc = follower_piece(fdone, c0 + g * T); fdone = c0 + g * T;
           if (!rc) rc = ops.follower_publish();
+          const int rc2 = ops.follower_close();
+          if (rc || rc2) return rc ? rc : rc2;
         }
-        const int rc2 = ops.side_close();
-        if (rc || rc2) return rc ? rc : rc2;
       }
     }
     return finish();

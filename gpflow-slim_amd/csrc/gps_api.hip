@@ -82,7 +82,8 @@ struct HipOps {
     return t;
   }
   hipStream_t saved_stream = nullptr;
-  bool follower() { return h->potrf_follower != 0 && lookahead(); }
+  hipStream_t saved_stream_d = nullptr;
+  bool follower() { return h->potrf_follower != 0 && lookahead() && aux_stream(); }
   i64 follower_cols() const { return h->potrf_follower_cols; }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
@@ -102,16 +103,28 @@ struct HipOps {
     return gps_launch_la_wait(h, h->side_stream, la_flags() + 1, t, nullptr, 0, la_flags() + 2);
   }
   int side_close() { h->stream = saved_stream; saved_stream = nullptr; return GPS_OK; }
-  // follower solve: the side stream publishes a ticket after each piece; the chain waits for the last one
+  // follower solve: on the deferred stream (created by follower()); it waits for the same fork ticket as the side
+  // stream, publishes a ticket of its own after each piece, and the chain waits for the last one
+  int follower_open(unsigned long long t, bool first) {
+    if (first) {
+      GPS_HIP(h, hipEventRecord(h->ev_def_fork, h->stream));
+      GPS_HIP(h, hipStreamWaitEvent(h->def_stream, h->ev_def_fork, 0));
+    }
+    int rc = gps_launch_la_wait(h, h->def_stream, nullptr, 0, la_flags(), t, la_flags() + 2);
+    if (rc) return rc;
+    saved_stream_d = h->stream; h->stream = h->def_stream;
+    return GPS_OK;
+  }
+  int follower_close() { h->stream = saved_stream_d; saved_stream_d = nullptr; return GPS_OK; }
   int follower_publish() {
-    return gps_launch_la_wait(h, h->side_stream, la_flags() + 3, ++h->fol_ticket, nullptr, 0, la_flags() + 2);
+    return gps_launch_la_wait(h, h->def_stream, la_flags() + 3, ++h->fol_ticket, nullptr, 0, la_flags() + 2);
   }
   int follower_join() {
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 3, h->fol_ticket, la_flags() + 2);
   }
   // ---- deferred stream: big pieces of a parent's panel solve that run beside a child's sweep (coarse: events)
-  bool deferred() {
-    if (!h->potrf_deferred || !lookahead()) return false;
+  bool deferred() { return h->potrf_deferred != 0 && lookahead() && aux_stream(); }
+  bool aux_stream() {
     if (!h->def_stream) {
       hipError_t e;
       if (h->prop.multiProcessorCount == 256) {
@@ -126,7 +139,6 @@ struct HipOps {
     }
     return true;
   }
-  hipStream_t saved_stream_d = nullptr;
   int deferred_open() {
     GPS_HIP(h, hipEventRecord(h->ev_def_fork, h->stream));
     GPS_HIP(h, hipStreamWaitEvent(h->def_stream, h->ev_def_fork, 0));

@@ -107,8 +107,11 @@ struct CpuOps {
   int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }
   int side_publish_join(unsigned long long t) { if (open_side != t || unjoined) return -8; unjoined = t; return 0; }
   int side_close() { if (!open_side) return -10; open_side = 0; return 0; }
-  int follower_publish() { if (!open_side) return -11; ++fol_pub; return 0; }
-  int follower_join() { if (open_side || fol_pub == 0) return -12; return 0; }
+  int fol_open = 0;
+  int follower_open(unsigned long long t, bool) { if (fol_open || def_open || t != ticket) return -16; fol_open = 1; return 0; }
+  int follower_close() { if (!fol_open) return -17; fol_open = 0; return 0; }
+  int follower_publish() { if (!fol_open) return -11; ++fol_pub; return 0; }
+  int follower_join() { if (open_side || fol_open || fol_pub == 0) return -12; return 0; }
   int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
