@@ -57,11 +57,11 @@ struct HipOps {
     // implicitly with a blocking side stream -- the hand-over would wait on itself
     if (!h->potrf_lookahead || h->ext_stream) return false;
     if (!h->side_stream) {
-      // The side stream leaves one CU per XCD alone (mask bit i = CU i/8 of XCD i%8): potrf_base needs a whole CU's LDS,
-      // and a GEMM that keeps refilling every CU with small workgroups would starve it until its own tail.
+      // The side stream leaves some CUs alone (la_mask_word0; mask bit i = CU i/8 of XCD i%8): potrf_base needs a whole
+      // CU's LDS, and a GEMM that keeps refilling every CU with small workgroups would starve it until its own tail.
       hipError_t e;
       if (h->prop.multiProcessorCount == 256) {
-        const uint32_t mask[8] = {0xffffff00u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         e = hipExtStreamCreateWithCUMask(&h->side_stream, 8, mask);
       } else {
         e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
@@ -128,7 +128,7 @@ struct HipOps {
     if (!h->def_stream) {
       hipError_t e;
       if (h->prop.multiProcessorCount == 256) {
-        const uint32_t mask[8] = {0xffffff00u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         e = hipExtStreamCreateWithCUMask(&h->def_stream, 8, mask);
       } else {
         e = hipStreamCreateWithFlags(&h->def_stream, hipStreamNonBlocking);
@@ -288,6 +288,13 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
+  if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
+    if (h->la_mask_word0 == (uint32_t)value) return GPS_OK;
+    h->la_mask_word0 = (uint32_t)value;
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
+    if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); h->def_stream = nullptr; }
+    return GPS_OK;
+  }
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
