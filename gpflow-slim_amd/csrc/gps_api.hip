@@ -200,6 +200,8 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   for (int i = 0; i < 8; ++i) {
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   }
+  if (const char* m0 = getenv("GPS_LA_MASK0")) h->la_mask_word0 = (uint32_t)strtoul(m0, nullptr, 0);     // diagnostics
+  if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
   if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   *out = h;
   return GPS_OK;

@@ -74,12 +74,11 @@ struct gps_handle_s {
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
   int potrf_deferred = 1;
-  // CU mask word 0 of the side / deferred streams (bit i = CU i/8 of XCD i%8; CU c sits in shader engine c%4):
-  // 0xffffff00 keeps one CU per XCD free.  Keeping one per shader engine free (word 0 = 0, 32 CUs) measured 2 % better at
-  // N = 8192 (a potrf_base workgroup steered to another shader engine no longer waits there for resident GEMM
-  // workgroups), but with that mask the block-column run on the legacy default stream hangs right after the streams
-  // are torn down (tests/test_gpu_dist.py) -- not understood, so the proven mask stays.
-  uint32_t la_mask_word0 = 0xffffff00u;
+  // CU mask word 0 of the side / deferred streams (bit i = CU i/8 of XCD i%8; CU c sits in shader engine c%4): 0 keeps
+  // one CU per shader engine per XCD free (32 CUs).  With only one per XCD (0xffffff00) a potrf_base workgroup that the
+  // dispatcher steers to another shader engine waits there for resident GEMM workgroups to finish (60-110 us, about
+  // one call in ten); N = 8192: 5.90 -> 5.77 ms, N = 16384: 29.2 -> 28.8 ms, N = 32768 unchanged.
+  uint32_t la_mask_word0 = 0x00000000u;
   hipEvent_t ev_la = nullptr;
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
