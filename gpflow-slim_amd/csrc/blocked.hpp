@@ -19,7 +19,8 @@
 //
 // Every flop of the recursion lands in Ops::gemm (C -= A B^T / C = A B^T / C += A B^T / C = -A B^T) with K = half the
 // current block, i.e. long-K MFMA GEMMs; the 128x128 leaves use the explicit block inverses
-// produced by Ops::potrf_base.
+// produced by Ops::potrf_base -- as the solve itself, or (Ops decides; trsm_leaf.hip) as the preconditioner of one
+// refinement step against the diagonal block D of the factor, which every leaf call therefore also receives.
 #pragma once
 #include <cstdint>
 
@@ -154,7 +155,7 @@ struct Blocked {
         if (rc) return rc;
         const i64 m = n - c - T;                       // rows below this block
         if (m == 0) return finish();
-        rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m);
+        rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m, Acc, lda);
         if (rc) return rc;
         double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
         double* Cn = A + (c + T) * lda + (c + T);      // the next block column / the remainder
@@ -209,7 +210,7 @@ struct Blocked {
   // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)
   int trsm_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
-    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m);
+    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m, L, ldl);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = trsm_rec(L, ldl, n1, blk0, B, ldb, m);
     if (rc) return rc;
@@ -221,7 +222,7 @@ struct Blocked {
   // solve X L = B in place, given U = L^T (upper, row-major) and the transposed block inverses
   int trsm_rn_rec(const double* U, i64 ldu, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
-    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m);
+    if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m, U, ldu);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = trsm_rn_rec(U + n1 * ldu + n1, ldu, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
     if (rc) return rc;
@@ -234,7 +235,7 @@ struct Blocked {
   // solve L^T a = y in place (backward substitution), right-hand sides stored as rows y[q*ldy + i]
   int trsv_t_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* y, i64 ldy, i64 r) {
     if (n <= 0 || r <= 0) return 0;
-    if (n == GPS_TILE) return ops.trsv_t_base(blk0, y, ldy, r);
+    if (n == GPS_TILE) return ops.trsv_t_base(blk0, y, ldy, r, L, ldl);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = trsv_t_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, y + n1, ldy, r);
     if (rc) return rc;
@@ -282,7 +283,7 @@ struct Blocked {
   // solve L a = y in place for r right-hand sides stored as rows y[q*ldy + i]
   int trsv_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* y, i64 ldy, i64 r) {
     if (n <= 0 || r <= 0) return 0;
-    if (n == GPS_TILE) return ops.trsv_base(blk0, y, ldy, r);
+    if (n == GPS_TILE) return ops.trsv_base(blk0, y, ldy, r, L, ldl);
     const i64 n1 = split(n), n2 = n - n1;
     int rc = trsv_rec(L, ldl, n1, blk0, y, ldy, r);
     if (rc) return rc;

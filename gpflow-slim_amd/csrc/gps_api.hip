@@ -19,16 +19,19 @@ struct HipOps {
                                  factor);
   }
   // B[m,128] = B * Linv[blk]^T  (transposed == 0)   or   B * Linv[blk]  (transposed == 1)
-  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m) {
+  // D: the diagonal block the leaf solves against (lower block of L, or the upper block of U = L^T when transposed)
+  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
     const double* W = (transposed ? linvT : linv) + blk * GPS_TILE * GPS_TILE;
+    if (h->refine_now) return gps_launch_trsm_leaf_refine(h, B, ldb, m, W, D, ldd, transposed);
     return gps_launch_gemm_nt(h, /*op set*/ 1, 0, m, GPS_TILE, GPS_TILE, B, ldb, W, GPS_TILE, B, ldb);
   }
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B,
            i64 ldb, double* C, i64 ldc) {
     return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
   }
-  int trsv_base(i64 blk, double* y, i64 ldy, i64 r) {
+  int trsv_base(i64 blk, double* y, i64 ldy, i64 r, const double* D, i64 ldd) {
     if (!linvT) return gps_fail(h, GPS_ERR_STATE, "trsv needs the transposed block inverses");
+    if (h->refine_now) return gps_launch_trsv_leaf_refine(h, linvT + blk * GPS_TILE * GPS_TILE, D, ldd, y, ldy, r, 0);
     return gps_launch_trsv_base(h, linvT + blk * GPS_TILE * GPS_TILE, y, ldy, r);
   }
   int gemv_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y1, double* y2, i64 ldy,
@@ -36,7 +39,8 @@ struct HipOps {
     return gps_launch_gemv_sub(h, L21, ldl, n2, n1, y1, y2, ldy, r);
   }
   // ---- pieces of the gradient path
-  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r) {       // y = Linv^T y : the kernel wants M[c][i] = Linv[c][i]
+  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r, const double* D, i64 ldd) {       // y = Linv^T y : the kernel wants M[c][i] = Linv[c][i]
+    if (h->refine_now) return gps_launch_trsv_leaf_refine(h, linv + blk * GPS_TILE * GPS_TILE, D, ldd, y, ldy, r, 1);
     return gps_launch_trsv_base(h, linv + blk * GPS_TILE * GPS_TILE, y, ldy, r);
   }
   int gemv_t_sub(const double* L21, i64 ldl, i64 n2, i64 n1, const double* y2, double* y1, i64 ldy, i64 r) {
@@ -286,6 +290,8 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
+  if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
+  if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
@@ -371,6 +377,80 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
   return GPS_OK;
 }
 
+// one 128-column leaf  X L11^T = B  (upper: X L11 = B through U = L^T) on m rows, timed over `reps` launches:
+// mode 0 = product with the block inverse, 1 = refined (trsm_leaf.hip); resid_out = max |X T - B| / (|X| |T|)_max
+// of the last launch's first 128 rows (T = L11^T or L11), checked on the host
+extern "C" int gps_diag_trsm_leaf(gps_handle_t h, int64_t m, int mode, int upper, int reps, double* us_per_launch,
+                                  double* resid_out) {
+  if (!h || m <= 0 || m % GPS_TILE || reps <= 0 || !us_per_launch) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 T = GPS_TILE;
+  std::vector<double> L((size_t)T * T, 0.0), B((size_t)T * T), X((size_t)T * T);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0 - 0.5; };
+  for (i64 i = 0; i < T; ++i) for (i64 j = 0; j <= i; ++j) L[i * T + j] = (i == j) ? 1.0 + 0.5 * (rnd() + 0.5) : 0.4 * rnd();
+  for (auto& v : B) v = rnd();
+  GPS_HIP(h, h->dTmp.ensure((size_t)4 * T * T * 8));
+  GPS_HIP(h, h->dB.ensure((size_t)m * T * 8 * 2));
+  double* dL = h->dTmp.d(); double* dU = dL + T * T; double* dInv = dU + T * T; double* dInvT = dInv + T * T;
+  double* dBm = h->dB.d(); double* dB0 = dBm + m * T;
+  GPS_HIP(h, hipMemcpyAsync(dL, L.data(), (size_t)T * T * 8, hipMemcpyHostToDevice, h->stream));
+  for (i64 q = 0; q < m / T; ++q) GPS_HIP(h, hipMemcpyAsync(dB0 + q * T * T, B.data(), (size_t)T * T * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_transpose(h, dL, T, T, T, dU, T);
+  if (rc) return rc;
+  rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
+  if (rc) return rc;
+  rc = gps_launch_potrf_base(h, dL, T, dInv, dInvT, (int*)h->dInfo.p, 0, /*factor*/ 0);
+  if (rc) return rc;
+  HipOps ops{h, dInv, dInvT, (int*)h->dInfo.p};
+  const bool saved = h->refine_now;
+  h->refine_now = (mode != 0);
+  hipEvent_t e0, e1;
+  GPS_HIP(h, hipEventCreate(&e0)); GPS_HIP(h, hipEventCreate(&e1));
+  float ms = 0.f;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {            // pass 0 warms up
+    GPS_HIP(h, hipEventRecord(e0, h->stream));
+    for (int it = 0; it < reps && !rc; ++it) {
+      if (it == 0 || it == reps - 1) GPS_HIP(h, hipMemcpyAsync(dBm, dB0, (size_t)m * T * 8, hipMemcpyDeviceToDevice, h->stream));
+      rc = ops.trsm_base(0, upper, dBm, T, m, upper ? dU : dL, T);
+    }
+    GPS_HIP(h, hipEventRecord(e1, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    GPS_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+  }
+  if (!rc && mode != 0 && getenv("GPS_LEAF_STAMPS")) {      // one more launch with phase stamps of workgroup 0
+    long long* dS = (long long*)(dB0 + m * T) - 16;         // tail of the spare copy of B
+    long long hs[8] = {0};
+    GPS_HIP(h, hipMemsetAsync(dS, 0, sizeof(hs), h->stream));
+    h->leaf_stamps = dS;
+    rc = ops.trsm_base(0, upper, dBm, T, m, upper ? dU : dL, T);
+    h->leaf_stamps = nullptr;
+    GPS_HIP(h, hipMemcpyAsync(hs, dS, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    fprintf(stderr, "leaf m=%lld phases (us): load+stage %.2f | product1 %.2f | stage2 %.2f | product2 %.2f | stage3 %.2f | product3 %.2f | store %.2f\n",
+            (long long)m, (hs[1] - hs[0]) * 0.01, (hs[2] - hs[1]) * 0.01, (hs[3] - hs[2]) * 0.01, (hs[4] - hs[3]) * 0.01,
+            (hs[5] - hs[4]) * 0.01, (hs[6] - hs[5]) * 0.01, (hs[7] - hs[6]) * 0.01);
+  }
+  h->refine_now = saved;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  *us_per_launch = 1e3 * ms / reps;
+  if (resid_out) {
+    GPS_HIP(h, hipMemcpy(X.data(), dBm + (m - T) * T, (size_t)T * T * 8, hipMemcpyDeviceToHost));
+    double worst = 0.0, scale = 0.0;
+    for (i64 i = 0; i < T; ++i) for (i64 j = 0; j < T; ++j) {
+      double s = 0.0, a = 0.0;
+      for (i64 k = 0; k < T; ++k) {
+        const double tkj = upper ? ((k >= j) ? L[k * T + j] : 0.0) : ((k <= j) ? L[j * T + k] : 0.0);   // T[k][j]
+        s += X[i * T + k] * tkj; a += fabs(X[i * T + k] * tkj);
+      }
+      worst = fmax(worst, fabs(s - B[i * T + j])); scale = fmax(scale, a);
+    }
+    *resid_out = worst / scale;
+  }
+  return GPS_OK;
+}
+
 // ---- kernels.K ---------------------------------------------------------------------------------------
 extern "C" int gps_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X,
                         int64_t n, const double* X2, int64_t m, int64_t d_all, double diag_add,
@@ -412,6 +492,7 @@ extern "C" int gps_potrf(gps_handle_t h, const double* A, int64_t n, double* L_o
   if (info) *info = 0;
   if (n == 0) return GPS_OK;
   GPS_HIP(h, hipSetDevice(h->device));
+  h->refine_now = (h->leaf_refine != 0);
   const i64 np = gps_pad(n);
   GPS_HIP(h, h->dTmp2.ensure((size_t)n * n * 8));
   GPS_HIP(h, h->dTmp.ensure((size_t)np * np * 8));
@@ -438,6 +519,7 @@ extern "C" int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double
   if (!h || !L || !B || n < 0 || nrhs < 0) return gps_fail(h, GPS_ERR_ARG, "gps_trsm_lower: bad argument");
   if (n == 0 || nrhs == 0) return GPS_OK;
   GPS_HIP(h, hipSetDevice(h->device));
+  h->refine_now = (h->leaf_refine != 0);
   const i64 np = gps_pad(n), mp = gps_pad(nrhs);
   const size_t blk_bytes = (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
   // dTmp: L padded (and, for trans, U = L^T) ; dTmp2: staging ; dTmp3: inverses ; dB: B^T padded
@@ -499,6 +581,14 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   if (r < 0 || (r > 0 && !resid)) return gps_fail(h, GPS_ERR_ARG, "resid missing");
   const i64 n = h->n, np = h->npad;
   h->have_factor = false;
+  {
+    // leaves refined or not: K + noise I is well conditioned unless the noise is tiny against the prior variance
+    double kd = 0.0;
+    int rck = gps_launch_kdiag(h, prog, n_nodes, &kd);
+    if (rck) return rck;
+    h->refine_now = h->leaf_refine > 0 || (h->leaf_refine < 0 && !(noise_var >= h->leaf_refine_ratio * kd));
+    h->factor_refine = h->refine_now;
+  }
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
@@ -636,6 +726,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
   } else {
     if (!h->have_factor) return gps_fail(h, GPS_ERR_STATE, "no resident factor: call gps_gpr_lml first or pass refactor=1");
     if (r != h->r) return gps_fail(h, GPS_ERR_STATE, "resident alpha has a different number of outputs");
+    h->refine_now = h->factor_refine;
     GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
     GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
     GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
@@ -836,6 +927,7 @@ extern "C" int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int 
     return gps_fail(h, GPS_ERR_ARG, "gps_conditional: q_sqrt_ndim must be 2 or 3");
   GPS_HIP(h, hipSetDevice(h->device));
   h->have_factor = false;          // dK / dLinv / dAlpha are reused below
+  h->refine_now = (h->leaf_refine != 0);
   if (info) *info = 0;
   CondIn c;
   c.m = m; c.mp = gps_pad(m); c.n_new = n_new; c.nsp = gps_pad(n_new); c.k = k;
@@ -879,6 +971,7 @@ extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const dou
   GPS_HIP(h, hipSetDevice(h->device));
   h->have_factor = false;
   h->n = 0;
+  h->refine_now = (h->leaf_refine != 0);
   if (info) *info = 0;
   CondIn c;
   c.m = m; c.mp = gps_pad(m); c.n_new = n_new; c.nsp = gps_pad(n_new); c.k = k;
@@ -981,6 +1074,12 @@ extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n
   const i64 nblk = np / nb;
   h->have_factor = false;
   h->npad = np; h->dist_np = np; h->dist_nb = nb; h->dist_P = nparts; h->dist_rank = part; h->dist_r = r;
+  {
+    double kd = 0.0;
+    int rck = gps_launch_kdiag(h, prog, n_nodes, &kd);
+    if (rck) return rck;
+    h->factor_refine = h->leaf_refine > 0 || (h->leaf_refine < 0 && !(noise_var >= h->leaf_refine_ratio * kd));
+  }
   GPS_HIP(h, h->dK.ensure((size_t)np * np * 8));
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
@@ -1024,6 +1123,7 @@ extern "C" int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1)
   if (!h || h->dist_nb <= 0 || j < 0 || j * h->dist_nb >= h->dist_np)                                 \
     return gps_fail(h, GPS_ERR_ARG, "gps_dist_*: bad panel index or gps_dist_begin not called");      \
   GPS_HIP(h, hipSetDevice(h->device));                                                                \
+  h->refine_now = h->factor_refine;                                                                   \
   const i64 np = h->dist_np, nb = h->dist_nb;                                                         \
   const i64 rows = np - j * nb;                                                                       \
   const i64 blk0 = j * nb / GPS_TILE, nbb = nb / GPS_TILE;                                            \
@@ -1085,6 +1185,7 @@ extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t 
 extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   if (!h || !lml || h->dist_nb <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_dist_finish: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
+  h->refine_now = h->factor_refine;
   const i64 n = h->n, np = h->dist_np, r = h->dist_r;
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   double* linv = h->dLinv.d();
@@ -1135,6 +1236,7 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   GPS_HIP(h, hipSetDevice(h->device));
   if (info) *info = 0;
   h->have_factor = false; h->n = 0;                       // GPR resident buffers are reused below
+  h->refine_now = (h->leaf_refine != 0);
   const i64 mp = gps_pad(m), np = gps_pad(n);
   const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
   const double sigma2 = noise_var;

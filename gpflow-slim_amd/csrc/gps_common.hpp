@@ -87,8 +87,16 @@ struct gps_handle_s {
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
+  // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned
+  // (every jittered path: conditional / base_conditional / SGPR / FITC / host-matrix potrf + trsm; GPR when the noise
+  // variance is below leaf_refine_ratio x Kdiag), 0 = plain product with the block inverse, 1 = always refine
+  int leaf_refine = -1;
+  double leaf_refine_ratio = 1e-3;
+  bool refine_now = false;       // resolved at every API entry
+  bool factor_refine = false;    // what the resident GPR factor was built with (warm predict_f keeps it)
   int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
+  long long* leaf_stamps = nullptr;   // phase stamps of one refined leaf launch (gps_diag_trsm_leaf)
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
   // profiling
@@ -214,6 +222,11 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor,
                           long long* d_stamps = nullptr);
+// trsm_leaf.hip : leaves refined once against the diagonal block D of the factor
+int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const double* W, const double* D, i64 ldd,
+                                int upper);
+int gps_launch_trsv_leaf_refine(gps_handle_t h, const double* Wt, const double* D, i64 ldd, double* y, i64 ldy, i64 r,
+                                int upper);
 // blas1.hip
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
 // look-ahead hand-over kernels (blas1.hip): optional publish of *sig = sval, then wait (bounded) until *flag >= val

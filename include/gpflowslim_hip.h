@@ -286,6 +286,13 @@ int gps_diag_set_cu_mask(gps_handle_t h, const uint32_t* mask, int n_words);
 /* phase timestamps (us) of one 128-block potrf_base launch; out7[0] = shader clock in MHz */
 int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
 
+/* one 128-column leaf of the triangular solves on m rows (device-resident synthetic block), average microseconds per
+ * launch over `reps`: mode 0 = product with the explicit block inverse, 1 = refined against the factor's diagonal
+ * block (what tf.matrix_triangular_solve's substitution delivers, conditionals.py:87,100); upper: the X L = B form;
+ * resid_out: scaled residual of the solve, checked on the host                                                  */
+int gps_diag_trsm_leaf(gps_handle_t h, int64_t m, int mode, int upper, int reps, double* us_per_launch,
+                       double* resid_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,7 +67,7 @@ struct CpuOps {
           C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : (op == 2 ? C[i * ldc + j] + out[i * N + j] : (op == 3 ? -out[i * N + j] : out[i * N + j]));
     return 0;
   }
-  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r) {
+  int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r, const double* = nullptr, i64 = 0) {
     const double* W = linv.data() + blk * T * T;
     for (i64 q = 0; q < r; ++q) {
       double tmp[GPS_TILE];
@@ -118,11 +118,11 @@ struct CpuOps {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
     return 0;
   }
-  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m) {
+  int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* = nullptr, i64 = 0) {
     const double* W = (transposed ? linvT.data() : linv.data()) + blk * T * T;
     return gemm(1, 0, m, T, T, B, ldb, W, T, B, ldb);
   }
-  int trsv_base(i64 blk, double* y, i64 ldy, i64 r) {
+  int trsv_base(i64 blk, double* y, i64 ldy, i64 r, const double* = nullptr, i64 = 0) {
     const double* W = linv.data() + blk * T * T;
     for (i64 q = 0; q < r; ++q) {
       double tmp[GPS_TILE];
