@@ -209,6 +209,27 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
   }
 }
 
+// SVGP, Gaussian likelihood (likelihoods.py:186-188): partial[b] += sum over this block's points of
+//   (yres[i][q] - fmean[i][q])^2 + base[i] + extra[i]      (fvar = base + extra, conditionals.py:96,107-118)
+// One writer per slot and launches of one stream are ordered, so the k per-latent launches add up reproducibly.
+__global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ fmean, const double* __restrict__ yres,
+                                                     int k, int q, const double* __restrict__ base,
+                                                     const double* __restrict__ extra, i64 n,
+                                                     double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s = 0.0;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double e = yres[i * k + q] - fmean[i * k + q];
+    s += e * e + base[i] + (extra ? extra[i] : 0.0);
+  }
+  s = wave_sum(s);
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ void fill_info_kernel(int* p, int v) { *p = v; }
 
 // var[i] = kdiag - sumsq[i]
@@ -394,6 +415,15 @@ int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64
   LaunchScope ls(h, KC_REDUCE, 2.0 * n_new * npad * (r + 1), (double)n_new * npad * 8.0);
   hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)n_new), dim3(256), 0, h->stream, At, ldat, npad,
                      alpha, ldy, (int)r, mean, sumsq);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
+                      const double* extra, i64 n, double* partial64) {
+  if (n <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_REDUCE, 4.0 * n, 32.0 * n);
+  hipLaunchKernelGGL(varexp_kernel, dim3(64), dim3(256), 0, h->stream, fmean, yres, (int)k, q, base, extra, n, partial64);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

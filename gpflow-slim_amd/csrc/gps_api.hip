@@ -795,9 +795,70 @@ struct CondIn {
   const double* dKnnDiag; double knn_const; double* dKnnFull /* [nsp,nsp], overwritten */;
 };
 
+// SVGP mode of conditional_tail (gps_svgp_elbo): instead of returning fmean / fvar, reduce them on the device to the
+// Gaussian variational expectations (likelihoods.py:186-188) and evaluate KL[q(u) || p(u)] (kullback_leiblers.py:26-105)
+// from the SAME factor Lm = chol(Kuu + jitter I) the conditional has just built (the reference factors it twice:
+// conditionals.py:84 and kullback_leiblers.py:51).
+struct SvgpAcc {
+  const double* yres;      // host [n, k] = Y - mean_function(X)
+  double noise_var;
+  double sq_sum = 0.0;     // sum_{i,q} (yres - fmean)^2 + fvar
+  double kl = 0.0;
+};
+
+// tr(Sigma_p^-1 Sigma_q) pieces of the KL for p = N(0, L L^T)                      kullback_leiblers.py:83-94
+//   diag q_sqrt [m, k]:   sum_j diag(K^-1)_j sum_q q_sqrt[j][q]^2 ,  diag(K^-1)_j = sum_i (L^-1)[i][j]^2 : L^-T by one
+//                         triangular solve against the identity (dWork [mp, mp]), row sums of squares, no K^-1 formed
+//   full  q_sqrt [m,m,k]: sum (L^-1 L_q)^2 per latent: dLqT [mp, mp] holds L_q^T on entry (overwritten)
+static int kl_diag_kinv(gps_handle_t h, Blocked<HipOps>& bl, const double* L, i64 mp, i64 m, double* dWork,
+                        std::vector<double>& kinv_diag) {
+  int rc = gps_launch_pad_copy(h, dWork, mp, 0, 0, dWork, mp, mp, mp, /*identity*/ 1, 0.0);
+  if (rc) return rc;
+  rc = bl.trsm_rec(L, mp, mp, 0, dWork, mp, mp);                  // X L^T = I  ->  X = L^-T (upper triangular)
+  if (rc) return rc;
+  GPS_HIP(h, h->dTmp3.ensure((size_t)mp * 8));
+  rc = gps_launch_rowdot(h, dWork, mp, m, mp, nullptr, mp, 0, nullptr, h->dTmp3.d());
+  if (rc) return rc;
+  kinv_diag.resize((size_t)m);
+  GPS_HIP(h, hipMemcpyAsync(kinv_diag.data(), h->dTmp3.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+static int kl_full_one(gps_handle_t h, Blocked<HipOps>& bl, const double* L, i64 mp, i64 m, double* dLqT, double* out) {
+  int rc = bl.trsm_rec(L, mp, mp, 0, dLqT, mp, mp);               // X L^T = L_q^T  ->  X = (L^-1 L_q)^T
+  if (rc) return rc;
+  GPS_HIP(h, h->dScal.ensure(4096 + (size_t)mp * 8));
+  double* dss = h->dScal.d() + 512;
+  rc = gps_launch_rowdot(h, dLqT, mp, m, mp, nullptr, mp, 0, nullptr, dss);
+  if (rc) return rc;
+  std::vector<double> ss((size_t)m);
+  GPS_HIP(h, hipMemcpyAsync(ss.data(), dss, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  double t = 0.0;
+  for (i64 i = 0; i < m; ++i) t += ss[i];
+  *out = t;
+  return GPS_OK;
+}
+// everything of the KL that only needs the host copies of q_mu / q_sqrt                 kullback_leiblers.py:68-82
+static void kl_host_terms(const double* q_sqrt, int ndim, i64 m, i64 k, double* logdet_qcov, double* trace_white) {
+  double ld = 0.0, tw = 0.0;
+  if (ndim == 2) {
+    for (i64 i = 0; i < m * k; ++i) { ld += log(q_sqrt[i] * q_sqrt[i]); tw += q_sqrt[i] * q_sqrt[i]; }
+  } else {
+    for (i64 q = 0; q < k; ++q)                                    // C-ABI layout [k][m][m]
+      for (i64 a = 0; a < m; ++a)
+        for (i64 b = 0; b <= a; ++b) {                             // lower triangle only (tf.matrix_band_part, :64)
+          const double v = q_sqrt[((size_t)q * m + a) * m + b];
+          tw += v * v;
+          if (a == b) ld += log(v * v);
+        }
+  }
+  *logdet_qcov = ld; *trace_white = tw;
+}
+
 static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const double* q_sqrt,
                             int q_sqrt_ndim, int white, int full_cov, double* fmean_out,
-                            double* fvar_out, int* info) {
+                            double* fvar_out, int* info, SvgpAcc* sv = nullptr) {
   const i64 m = c.m, mp = c.mp, n_new = c.n_new, nsp = c.nsp, k = c.k;
   int* d_info = (int*)h->dInfo.p;
   int rc = gps_launch_fill_info(h, d_info, INT_MAX);
@@ -821,12 +882,19 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
     rc = bl.trsv_rec(c.Kmm, mp, mp, 0, h->dAlpha.d(), mp, k);
     if (rc) return rc;
   }
+  double kl_hp[2 * 64];
+  if (sv) {
+    // sum log diag Lm and the Mahalanobis term sum (Lm^-1 q_mu)^2 (white: sum q_mu^2)    kullback_leiblers.py:68-69,98-103
+    rc = gps_launch_lml_reduce(h, c.Kmm, mp, m, h->dAlpha.d(), mp, k, h->dScal.d());
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(kl_hp, h->dScal.p, sizeof(kl_hp), hipMemcpyDeviceToHost, h->stream));
+  }
   GPS_HIP(h, h->dMean.ensure((size_t)(n_new * k + n_new) * 8));
   double* dmean = h->dMean.d();
   double* dss = dmean + n_new * k;
   rc = gps_launch_rowdot(h, c.Bt, mp, n_new, mp, h->dAlpha.d(), mp, k, dmean, dss);
   if (rc) return rc;
-  GPS_HIP(h, hipMemcpyAsync(fmean_out, dmean, (size_t)n_new * k * 8, hipMemcpyDeviceToHost, h->stream));
+  if (!sv) GPS_HIP(h, hipMemcpyAsync(fmean_out, dmean, (size_t)n_new * k * 8, hipMemcpyDeviceToHost, h->stream));
 
   // base variance (shared by all k)                                  conditionals.py:90-96
   if (!full_cov) {
@@ -839,7 +907,14 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
   }
 
   std::vector<double> base;        // host copies for the final assembly
-  if (!full_cov) {
+  double* dYres = nullptr;         // SVGP mode: [n_new, k] on the device, after the k + 1 variance vectors
+  if (sv) {
+    if (full_cov || !q_sqrt) return gps_fail(h, GPS_ERR_ARG, "svgp: needs q_sqrt and marginal variances");
+    GPS_HIP(h, h->dS1.ensure((size_t)n_new * k * 8 + 64 * 8));
+    dYres = h->dS1.d();
+    GPS_HIP(h, hipMemcpyAsync(dYres, sv->yres, (size_t)n_new * k * 8, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipMemsetAsync(dYres + (size_t)n_new * k, 0, 64 * 8, h->stream));
+  } else if (!full_cov) {
     base.resize(n_new);
     GPS_HIP(h, hipMemcpyAsync(base.data(), h->dVar.p, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
   } else {
@@ -870,7 +945,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
     rc = bl.trsm_rn_rec(h->dTmp.d(), mp, mp, 0, c.Bt, mp, nsp);
     if (rc) return rc;
   }
-  std::vector<double> extra(per);
+  std::vector<double> extra(sv ? 0 : per);
   GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));                 // LTA^T [nsp, mp]
   double* dLTA = h->dTmp3.d();
   for (i64 q = 0; q < k; ++q) {
@@ -894,7 +969,20 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
       rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
       if (rc) return rc;
     }
-    if (!full_cov) {
+    if (sv) {
+      rc = gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
+      if (rc) return rc;
+      // sum_i (yres - fmean)^2 + fvar for this latent, fvar = base + extra           likelihoods.py:186-188
+      rc = gps_launch_varexp(h, dmean, dYres, k, (int)q, h->dVar.d(), dss, n_new, dYres + (size_t)n_new * k);
+      if (rc) return rc;
+      if (!white && q_sqrt_ndim == 3) {
+        // tr(Kuu^-1 S_q) from the L_q^T that is already on the device (dLTA no longer needs it)
+        double t = 0.0;
+        rc = kl_full_one(h, bl, c.Kmm, mp, m, h->dTmp2.d(), &t);
+        if (rc) return rc;
+        sv->kl += t;                                                    // (trace term, completed below)
+      }
+    } else if (!full_cov) {
       rc = gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
       if (rc) return rc;
       GPS_HIP(h, hipMemcpyAsync(extra.data(), dss, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
@@ -912,6 +1000,33 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
       double* o = fvar_out + q * per;
       for (size_t e = 0; e < per; ++e) o[e] = base[e] + extra[e];
     }
+  }
+  if (sv) {
+    double part[64];
+    GPS_HIP(h, hipMemcpyAsync(part, dYres + (size_t)n_new * k, sizeof(part), hipMemcpyDeviceToHost, h->stream));
+    rc = read_info(h, d_info, info);
+    if (rc) return rc;
+    for (int b = 0; b < 64; ++b) sv->sq_sum += part[b];
+    // KL[q || p]                                                           kullback_leiblers.py:68-105
+    double slog = 0.0, mahal = 0.0, logdet_q = 0.0, trace = 0.0;
+    for (int b = 0; b < 64; ++b) { slog += kl_hp[2 * b]; mahal += kl_hp[2 * b + 1]; }
+    kl_host_terms(q_sqrt, q_sqrt_ndim, m, k, &logdet_q, &trace);
+    if (!white) {
+      if (q_sqrt_ndim == 2) {
+        std::vector<double> kd;
+        GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+        rc = kl_diag_kinv(h, bl, c.Kmm, mp, m, h->dTmp.d(), kd);
+        if (rc) return rc;
+        trace = 0.0;
+        for (i64 j = 0; j < m; ++j) { double sq = 0.0; for (i64 q = 0; q < k; ++q) sq += q_sqrt[j * k + q] * q_sqrt[j * k + q]; trace += kd[j] * sq; }
+      } else {
+        trace = sv->kl;                                                    // accumulated in the loop above
+      }
+    }
+    double twoKL = mahal - (double)(m * k) - logdet_q + trace;
+    if (!white) twoKL += (double)k * 2.0 * slog;
+    sv->kl = 0.5 * twoKL;
+    return GPS_OK;
   }
   return read_info(h, d_info, info);
 }
@@ -1008,6 +1123,124 @@ extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const dou
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+}
+
+// ---- SVGP bound: models/svgp.py:108-125 for the Gaussian likelihood ----------------------------------------------
+// elbo = scale * sum_{i,q} E_q[log N(y | f, sigma^2)] - KL[q(u) || p(u)] ; Kuu / Kuf and everything O(M^2 N) stay in HBM
+extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
+                             const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
+                             double noise_var, double scale, double* elbo, double* kl_out, double* var_exp_sum,
+                             int* info) {
+  if (!h || !Z || !X || !yres || !q_mu || !q_sqrt || !elbo || m <= 0 || n <= 0 || k <= 0 || d_all <= 0 || !(noise_var > 0.0))
+    return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: bad argument");
+  if (q_sqrt_ndim != 2 && q_sqrt_ndim != 3) return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: q_sqrt_ndim must be 2 or 3");
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->have_factor = false; h->n = 0;
+  h->refine_now = (h->leaf_refine != 0);
+  if (info) *info = 0;
+  CondIn c;
+  c.m = m; c.mp = gps_pad(m); c.n_new = n; c.nsp = gps_pad(n); c.k = k;
+  const size_t blk_bytes = (size_t)(c.mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, h->dX.ensure((size_t)m * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dX.p, Z, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dXnew.ensure((size_t)n * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dK.ensure((size_t)c.mp * c.mp * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dB.ensure((size_t)c.nsp * c.mp * 8));
+  c.Kmm = h->dK.d(); c.Bt = h->dB.d(); c.linv = h->dLinv.d(); c.linvT = h->dLinv.d() + blk_bytes / 8;
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), m, nullptr, m, d_all, jitter, c.Kmm, c.mp, c.mp, c.mp, 1, 1);
+  if (rc) return rc;
+  rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n, h->dX.d(), m, d_all, 0.0, c.Bt, c.mp, c.nsp, c.mp, 0, 0);
+  if (rc) return rc;
+  c.dKnnDiag = nullptr; c.dKnnFull = nullptr; c.knn_const = 0.0;
+  rc = gps_launch_kdiag(h, prog, n_nodes, &c.knn_const);
+  if (rc) return rc;
+  SvgpAcc sv; sv.yres = yres; sv.noise_var = noise_var;
+  int linfo = 0;
+  rc = conditional_tail(h, c, q_mu, q_sqrt, q_sqrt_ndim, white, 0, nullptr, nullptr, &linfo, &sv);
+  if (info) *info = linfo;
+  if (rc || linfo) return rc;
+  // likelihoods.py:186-188 summed over all points and latents
+  const double ve = (double)n * (double)k * (-0.5 * log(2.0 * M_PI) - 0.5 * log(noise_var)) - 0.5 * sv.sq_sum / noise_var;
+  if (var_exp_sum) *var_exp_sum = ve;
+  if (kl_out) *kl_out = sv.kl;
+  *elbo = ve * scale - sv.kl;
+  return GPS_OK;
+}
+
+// ---- KL[q || p], q = N(q_mu, q_sqrt q_sqrt^T), p = N(0, K) or N(0, I): kullback_leiblers.py:26-105 -------------------
+// K host [m, m] or NULL; q_mu host [m, k]; q_sqrt host [m, k] (ndim 2) or [k, m, m] (ndim 3, as gps_conditional).
+extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const double* q_mu, int64_t k,
+                            const double* q_sqrt, int q_sqrt_ndim, double* kl_out, int* info) {
+  if (!h || !q_mu || !q_sqrt || !kl_out || m <= 0 || k <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_gauss_kl: bad argument");
+  if (q_sqrt_ndim != 2 && q_sqrt_ndim != 3) return gps_fail(h, GPS_ERR_ARG, "gps_gauss_kl: q_sqrt_ndim must be 2 or 3");
+  if (info) *info = 0;
+  double logdet_q = 0.0, trace = 0.0, mahal = 0.0, slog = 0.0;
+  kl_host_terms(q_sqrt, q_sqrt_ndim, m, k, &logdet_q, &trace);
+  if (!K) {                                            // p = N(0, I): nothing to factor
+    for (i64 i = 0; i < m * k; ++i) mahal += q_mu[i] * q_mu[i];
+    *kl_out = 0.5 * (mahal - (double)(m * k) - logdet_q + trace);
+    return GPS_OK;
+  }
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->refine_now = (h->leaf_refine != 0);
+  const i64 mp = gps_pad(m);
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  // dS2: Lp ; dS4: block inverses ; dS3: alpha ; dTmp / dTmp2: work
+  GPS_HIP(h, h->dS2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dS4.ensure(2 * blk_bytes));
+  GPS_HIP(h, h->dS3.ensure((size_t)k * mp * 8));
+  GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, K, (size_t)m * m * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_pad_copy(h, h->dTmp.d(), m, m, m, h->dS2.d(), mp, mp, mp, 1, 0.0);
+  if (rc) return rc;
+  int* d_info = (int*)h->dInfo.p;
+  rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  HipOps ops{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, d_info};
+  Blocked<HipOps> bl(ops);
+  rc = bl.potrf_rec(h->dS2.d(), mp, mp, 0, 0);                                       // Lp          :51
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, q_mu, (size_t)m * k * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(h->dS3.p, 0, (size_t)k * mp * 8, h->stream));
+  rc = gps_launch_transpose(h, h->dTmp2.d(), k, m, k, h->dS3.d(), mp);
+  if (rc) return rc;
+  rc = bl.trsv_rec(h->dS2.d(), mp, mp, 0, h->dS3.d(), mp, k);                          // alpha       :52
+  if (rc) return rc;
+  rc = gps_launch_lml_reduce(h, h->dS2.d(), mp, m, h->dS3.d(), mp, k, h->dScal.d());
+  if (rc) return rc;
+  double hp[2 * 64];
+  GPS_HIP(h, hipMemcpyAsync(hp, h->dScal.p, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  int linfo = 0;
+  rc = read_info(h, d_info, &linfo);
+  if (rc) return rc;
+  if (info) *info = linfo;
+  if (linfo) return GPS_OK;
+  for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; mahal += hp[2 * b + 1]; }
+  if (q_sqrt_ndim == 2) {
+    std::vector<double> kd;
+    rc = kl_diag_kinv(h, bl, h->dS2.d(), mp, m, h->dTmp.d(), kd);
+    if (rc) return rc;
+    trace = 0.0;
+    for (i64 j = 0; j < m; ++j) { double sq = 0.0; for (i64 q = 0; q < k; ++q) sq += q_sqrt[j * k + q] * q_sqrt[j * k + q]; trace += kd[j] * sq; }
+  } else {
+    trace = 0.0;
+    std::vector<double> LT((size_t)mp * mp);
+    for (i64 q = 0; q < k; ++q) {
+      std::fill(LT.begin(), LT.end(), 0.0);
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = q_sqrt[((size_t)q * m + a) * m + b];
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      double t = 0.0;
+      rc = kl_full_one(h, bl, h->dS2.d(), mp, m, h->dTmp2.d(), &t);
+      if (rc) return rc;
+      trace += t;
+    }
+  }
+  *kl_out = 0.5 * (mahal - (double)(m * k) - logdet_q + trace + (double)k * 2.0 * slog);
+  return GPS_OK;
 }
 
 

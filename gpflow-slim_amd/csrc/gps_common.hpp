@@ -241,6 +241,8 @@ int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
 int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
                       const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq);
 int gps_launch_fill_info(gps_handle_t h, int* d_info, int value);
+int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
+                      const double* extra, i64 n, double* partial64);
 int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                          double* dst, i64 ldd);
 int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,

@@ -64,6 +64,11 @@ _SIGNATURES = {
     "gps_base_conditional": [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p, _i64, _i64, _c_double_p,
                              _i64, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                              _c_double_p, _c_int_p],
+    "gps_svgp_elbo": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64, ctypes.c_double,
+                      _c_double_p, _i64, _c_double_p, _c_double_p, _i64, _c_double_p, ctypes.c_int, ctypes.c_int,
+                      ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_int_p],
+    "gps_gauss_kl": [ctypes.c_void_p, _c_double_p, _i64, _c_double_p, _i64, _c_double_p, ctypes.c_int, _c_double_p,
+                     _c_int_p],
     "gps_sgpr": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
                  ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int, _c_double_p,
                  _c_double_p, _c_double_p, _c_int_p],
@@ -406,7 +411,10 @@ class Handle(object):
     def gpr_lml_grad(self, prog, noise_var, resid):
         """(lml, grad_slots, grad_noise, K_y^-1 resid)  -- see gps_gpr_lml_grad in the header."""
         resid = _f64(resid)
-        n, r = resid.shape
+        shape = getattr(self, "resident_shape", None)
+        _need(shape is not None and resid.ndim == 2 and resid.shape[0] == shape[0] and resid.shape[1] > 0,
+              "Y must have one row per row of X")
+        n, r = shape[0], resid.shape[1]          # the C side reads and writes n = rows of the resident X
         lml = ctypes.c_double(0)
         info = ctypes.c_int(0)
         nslots = ctypes.c_int(0)
@@ -531,6 +539,52 @@ class Handle(object):
         if full_cov:
             fvar = np.ascontiguousarray(np.transpose(fvar, (1, 2, 0)))     # [n,n,k]  conditionals.py:119
         return fmean, fvar
+
+    def svgp_elbo(self, prog, Z, X, yres, q_mu, q_sqrt, jitter, noise_var, white=True, scale=1.0):
+        """(elbo, kl, sum of variational expectations) of models/svgp.py:108-125 for the Gaussian likelihood."""
+        Z, X, yres, q_mu = _f64(Z), _f64(X), _f64(yres), _f64(q_mu)
+        _need(Z.ndim == 2 and X.ndim == 2 and Z.shape[1] == X.shape[1], "Z [M, D] and X [N, D] must share D")
+        m, d = Z.shape
+        n = X.shape[0]
+        _need(q_mu.ndim == 2 and q_mu.shape[0] == m, "q_mu must be [M, K]")
+        k = q_mu.shape[1]
+        _need(yres.shape == (n, k), "Y - mean must be [N, K] with K = number of latent functions")
+        _need(m > 0 and n > 0 and k > 0, "empty SVGP problem")
+        q, qnd = self._prep_q_sqrt(q_sqrt)
+        _need(q is not None, "SVGP needs q_sqrt")
+        self._check_q_sqrt(q, qnd, m, k)
+        elbo, kl, ve = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        self.resident_token = None
+        self.factor_key = None
+        self._check(self._lib.gps_svgp_elbo(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(X), n,
+                                            _ptr(yres), _ptr(q_mu), k, _ptr(q), qnd, 1 if white else 0,
+                                            float(noise_var), float(scale), ctypes.byref(elbo), ctypes.byref(kl),
+                                            ctypes.byref(ve), ctypes.byref(info)), "gps_svgp_elbo")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("Kuu + jitter*I is not positive definite (leading minor of order %d)" % info.value)
+        return elbo.value, kl.value, ve.value
+
+    def gauss_kl(self, q_mu, q_sqrt, K=None):
+        """kullback_leiblers.py:26-105"""
+        q_mu = _f64(q_mu)
+        _need(q_mu.ndim == 2, "q_mu must be [M, K]")
+        m, k = q_mu.shape
+        q, qnd = self._prep_q_sqrt(q_sqrt)
+        _need(q is not None, "gauss_kl needs q_sqrt")
+        self._check_q_sqrt(q, qnd, m, k)
+        if m == 0 or k == 0:
+            return 0.0
+        if K is not None:
+            K = _f64(K)
+            _need(K.shape == (m, m), "K must be [M, M]")
+        out = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        self._check(self._lib.gps_gauss_kl(self._h, _ptr(K) if K is not None else None, m, _ptr(q_mu), k, _ptr(q),
+                                           qnd, ctypes.byref(out), ctypes.byref(info)), "gps_gauss_kl")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("K is not positive definite (leading minor of order %d)" % info.value)
+        return out.value
 
     def base_conditional(self, Kmn, Kmm, Knn, f, q_sqrt=None, white=False, full_cov=False):
         Kmn, Kmm, Knn, f = _f64(Kmn), _f64(Kmm), _f64(Knn), _f64(f)

@@ -1,14 +1,17 @@
 """Sparse variational GP (Hensman et al. 2015) on top of the device conditional.
 
-Mirrors gpflowSlim/models/svgp.py:30-130 for the Gaussian likelihood: ELBO = sum of variational
-expectations (rescaled for mini-batches) - KL[q(u) || p(u)].  Kuu's Cholesky and the Kuf solve
-(BASELINE config 5: "Kuu potrf + Kuf trsm") run in gps_conditional; the prior KL in
-kullback_leiblers.gauss_kl.
+Mirrors gpflowSlim/models/svgp.py:30-130: ELBO = sum of variational expectations (rescaled for
+mini-batches) - KL[q(u) || p(u)].  With the Gaussian likelihood the whole bound is one device call
+(gps_svgp_elbo: Kuu potrf + Kuf trsm of BASELINE config 5, the q_sqrt products, the reduction of the
+expectations and the KL on the same factor); any other likelihood object with a
+``variational_expectations`` goes through conditional() + gauss_kl() like the reference.
 """
 import numpy as np
 
+from .. import _backend as be
 from .. import features
 from .. import kullback_leiblers
+from .. import likelihoods
 from .. import transforms
 from .._settings import settings
 from ..params import Parameter
@@ -55,10 +58,18 @@ class SVGP(GPModel):
 
     def _build_likelihood(self):
         """models/svgp.py:108-125"""
+        scale = float(self.num_data) / float(self.X.shape[0])
+        if type(self.likelihood) is likelihoods.Gaussian:
+            yres = self.Y - self.mean_function(self.X)
+            yres = np.ascontiguousarray(np.broadcast_to(yres, self.Y.shape))
+            elbo, _, _ = be.get_handle().svgp_elbo(self.kern._program(self.X.shape[1]), self.feature.Z, self.X, yres,
+                                                   self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
+                                                   float(np.squeeze(self.likelihood.variance)), white=self.whiten,
+                                                   scale=scale)
+            return elbo
         KL = self.build_prior_KL()
         fmean, fvar = self._build_predict(self.X, full_cov=False)
         var_exp = self.likelihood.variational_expectations(fmean, fvar, self.Y)
-        scale = float(self.num_data) / float(self.X.shape[0])
         return float(np.sum(var_exp) * scale - KL)
 
     def _build_predict(self, Xnew, full_cov=False):

@@ -173,6 +173,28 @@ int gps_base_conditional(gps_handle_t h, const double* Kmn, const double* Kmm,
                          int white, int full_cov,
                          double* fmean_out, double* fvar_out, int* info);
 
+/* ---- SVGP bound (Hensman et al. 2015) with the Gaussian likelihood: models.SVGP._build_likelihood
+ * (models/svgp.py:108-125) = scale * sum variational_expectations (likelihoods.py:186-188) over the conditional
+ * q(f) = conditional(X, Z, kern, q_mu, q_sqrt, white) (conditionals.py:24-121, features.py:74-81)
+ * - gauss_kl(q_mu, q_sqrt, Kuu + jitter I or None) (kullback_leiblers.py:26-105, models/svgp.py:101-106).
+ * One Cholesky of Kuu serves the conditional and the KL; Kuu, Kuf^T [n, m] and the q_sqrt products never leave HBM.
+ * Z host [m, d]; X host [n, d]; yres host [n, k] = Y - mean_function(X); q_mu host [m, k]; q_sqrt host [m, k]
+ * (ndim 2) or [k, m, m] (ndim 3, lower triangles used); scale = num_data / n (models/svgp.py:123).
+ * Outputs: *elbo; optional *kl, *var_exp_sum (unscaled).                                                     */
+int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                  const double* Z, int64_t m, int64_t d_all, double jitter,
+                  const double* X, int64_t n, const double* yres,
+                  const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim,
+                  int white, double noise_var, double scale,
+                  double* elbo, double* kl, double* var_exp_sum, int* info);
+
+/* gauss_kl(q_mu, q_sqrt, K) (kullback_leiblers.py:26-105): KL[N(q_mu, q_sqrt q_sqrt^T) || N(0, K)], summed over
+ * the k independent columns; K host [m, m] or NULL (p = N(0, I)).  tf.cholesky(K) (:51), alpha = Lp^-1 q_mu (:52),
+ * tr(K^-1 S_q) through Lp^-T (diagonal q_sqrt: row sums of squares of Lp^-T instead of forming K^-1, :84-90) or
+ * through Lp^-1 L_q per latent (:92-94) run on the device.  q_sqrt layouts as in gps_svgp_elbo.                 */
+int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const double* q_mu, int64_t k,
+                 const double* q_sqrt, int q_sqrt_ndim, double* kl, int* info);
+
 /* ---- SGPR (sparse GP regression, Titsias 2009) -------------------------------------------------
  * models/sgpr.py:121-153 (_build_likelihood: the collapsed bound) and :155-189 (_build_predict).
  * Z host [m, d] inducing inputs, X host [n, d], resid host [n, r] = Y - mean_function(X).

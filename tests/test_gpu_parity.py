@@ -310,60 +310,128 @@ def test_full_size_config4_invariances(handle):
     assert rel(smu, rmu) <= RTOL and rel(svar, rvar) <= RTOL
 
 
-def test_full_size_config5_conditional_consistency(handle):
-    """BASELINE configs[4] shape: conditional() with M = 4096 inducing points at N = 250 000 test points (a quarter
-    of the 10^6 of the config, to keep the host arrays small): test points are independent, so any slice of the big
-    call equals a small call on that slice, which in turn is checked against the oracle."""
-    import gpflowSlim as gpf
-    M, N, d = 4096, 250000, 8
-    rng = np.random.default_rng(1)
-    X = rng.standard_normal((N, d)); Z = X[:M].copy()
-    f = rng.standard_normal((M, 2))
-    ls = np.sqrt(d) * np.ones(d)
-    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
-    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d}
-    idx = np.sort(rng.choice(N, 300, replace=False))
-    tol = solve_tol(orc.K(spec, Z) + 1e-6 * np.eye(M))
-    for white in (True, False):
-        mu, var = gpf.conditionals.conditional(X, Z, kern, f, white=white)
-        assert mu.shape == (N, 2) and var.shape == (N, 2)
-        smu, svar = gpf.conditionals.conditional(X[idx], Z, kern, f, white=white)
-        # different tile shapes -> different summation order, amplified by cond(Kuu + 1e-6 I)
-        assert rel(mu[idx], smu) <= tol and np.abs(var[idx] - svar).max() <= tol
-        rmu, rvar = orc.conditional(X[idx], Z, spec, f, white=white)
-        assert rel(smu, rmu) <= tol and np.abs(svar - rvar).max() <= tol, (tol, rel(smu, rmu), np.abs(svar - rvar).max())
-        assert var.min() > -1e-6 and var.max() <= 1.0 + 1e-9
-
-
-@pytest.mark.parametrize("whiten", [True, False])
-@pytest.mark.parametrize("q_diag", [False, True])
-def test_svgp_bound_parity(handle, whiten, q_diag):
-    """models/svgp.py:101-130 (SVGP ELBO, Gaussian likelihood, mini-batch rescale) vs the oracle."""
-    import gpflowSlim as gpf
-    rng = np.random.default_rng(21)
-    n, m_, d, k = 400, 60, 3, 2
+def _svgp_case(gpf, rng, n, m_, d, k, q_diag, whiten, num_data):
     X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, k))) + 0.1 * rng.standard_normal((n, k))
     Z = X[:m_].copy()
     kern, spec = make_kernel(gpf, "rbf_ard", d)
-    lik = gpf.likelihoods.Gaussian(0.3)
-    m = gpf.models.SVGP(X, Y, kern, lik, Z=Z, q_diag=q_diag, whiten=whiten, num_data=4 * n)
+    m = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.3), Z=Z, q_diag=q_diag, whiten=whiten, num_data=num_data)
     q_mu = rng.standard_normal((m_, k)) * 0.3
     m._q_mu.assign(q_mu)
     if q_diag:
         q_sqrt = np.abs(rng.standard_normal((m_, k))) * 0.4 + 0.2
     else:
-        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * 0.05 + np.eye(m_) * 0.5).transpose(1, 2, 0).copy()
+        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * (0.5 / m_) + np.eye(m_) * 0.5).transpose(1, 2, 0).copy()
     m._q_sqrt.assign(q_sqrt)
     assert np.allclose(m.q_sqrt, q_sqrt, rtol=1e-14, atol=1e-300)
+    return m, spec, X, Y, Z, q_mu
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+@pytest.mark.parametrize("q_diag", [False, True])
+@pytest.mark.parametrize("m_", [60, 512])
+def test_svgp_bound_parity(handle, whiten, q_diag, m_):
+    """models/svgp.py:101-130 (SVGP ELBO, Gaussian likelihood, mini-batch rescale) vs the oracle: the fused device
+    bound (gps_svgp_elbo), the reference's composition conditional() + variational_expectations + gauss_kl() through
+    the same API, and the KL on its own (gps_gauss_kl)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(21 + m_)
+    n, d, k = 700, 3, 2
+    m, spec, X, Y, Z, q_mu = _svgp_case(gpf, rng, n, m_, d, k, q_diag, whiten, 4 * n)
+    q_sqrt = np.asarray(m.q_sqrt)
+    Kuu = orc.K(spec, Z) + 1e-6 * np.eye(m_)
+    tol = solve_tol(Kuu)
     got = m.compute_log_likelihood()
-    ref = orc.svgp_elbo(spec, X, Y, Z, q_mu, np.asarray(m.q_sqrt), orc.constrained(0.3), whiten=whiten, num_data=4 * n)
-    assert abs(got - ref) <= 1e-7 * abs(ref)
+    ref = orc.svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, orc.constrained(0.3), whiten=whiten, num_data=4 * n)
+    assert abs(got - ref) <= tol * abs(ref), (tol, abs(got - ref) / abs(ref))
     kl = m.build_prior_KL()
-    Kp = None if whiten else orc.K(spec, Z) + 1e-6 * np.eye(m_)
-    assert abs(kl - orc.gauss_kl(q_mu, np.asarray(m.q_sqrt), Kp)) <= 1e-7 * abs(kl)
+    rkl = orc.gauss_kl(q_mu, q_sqrt, None if whiten else Kuu)
+    assert abs(kl - rkl) <= tol * abs(rkl), (tol, kl, rkl)
+    # the reference's own composition (what a non-Gaussian likelihood object goes through)
+    fmean, fvar = m._build_predict(X)
+    composed = float(np.sum(m.likelihood.variational_expectations(fmean, fvar, Y)) * 4.0 - kl)
+    assert abs(got - composed) <= tol * abs(ref)
     mu, var = m.predict_f(X[:50])
-    rmu, rvar = orc.conditional(X[:50], Z, spec, q_mu, q_sqrt=np.asarray(m.q_sqrt), white=whiten)
-    assert rel(mu, rmu) <= 1e-7 and rel(var, rvar) <= 1e-7
+    rmu, rvar = orc.conditional(X[:50], Z, spec, q_mu, q_sqrt=q_sqrt, white=whiten)
+    assert rel(mu, rmu) <= tol and rel(var, rvar) <= tol
+
+
+@pytest.mark.parametrize("m_,k", [(1, 1), (127, 3), (300, 2)])
+def test_gauss_kl_parity(handle, m_, k):
+    """kullback_leiblers.py:26-105 through gps_gauss_kl: white / K, diagonal / full q_sqrt (upper triangles ignored)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(70 + m_)
+    Zp = rng.standard_normal((m_, 2))
+    spec = {"type": "rbf", "variance": 1.3, "lengthscales": np.array([0.9, 1.4]), "input_dim": 2}
+    K = orc.K(spec, Zp) + 1e-3 * np.eye(m_)
+    q_mu = rng.standard_normal((m_, k))
+    for q_sqrt in (np.abs(rng.standard_normal((m_, k))) + 0.1,
+                   rng.standard_normal((m_, m_, k)) * 0.2 + np.eye(m_)[:, :, None]):      # upper triangle: garbage on purpose
+        for Kp in (None, K):
+            got = gpf.kullback_leiblers.gauss_kl(q_mu, q_sqrt, Kp)
+            ref = orc.gauss_kl(q_mu, q_sqrt, Kp)
+            tol = RTOL if Kp is None else solve_tol(K)
+            assert abs(got - ref) <= tol * max(1.0, abs(ref)), (q_sqrt.ndim, Kp is None, got, ref)
+    with pytest.raises(gpf.NotPositiveDefiniteError):
+        gpf.kullback_leiblers.gauss_kl(q_mu, np.ones((m_, k)), -np.eye(m_))
+
+
+def test_full_size_config5_svgp_and_conditional(handle):
+    """BASELINE configs[4] at its stated size: M = 4096 inducing points, N = 10^6 points, RBF-ARD, D = 8.
+    (i) conditional() over all 10^6 points: any slice of the big call equals a small call on that slice, which equals
+    the oracle; (ii) SVGP.compute_log_likelihood() at the same size (full lower-triangular q_sqrt, whitened, the
+    reference's defaults): the bound is a sum over points minus one KL, so the variational expectations of the two
+    halves add up to those of the whole, the KL equals the oracle's, and a 300-point sub-model equals the oracle's
+    bound."""
+    import gpflowSlim as gpf
+    M, N, d = 4096, 1000000, 8
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, d)); Z = X[:M].copy()
+    w = rng.standard_normal((d, 1)) / np.sqrt(d)
+    Y = np.sin(X @ w) + 0.1 * rng.standard_normal((N, 1))
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d}
+    Kuu = orc.K(spec, Z) + 1e-6 * np.eye(M)
+    tol = solve_tol(Kuu)
+    idx = np.sort(rng.choice(N, 300, replace=False))
+    f = rng.standard_normal((M, 1))
+    for white in (True, False):
+        mu, var = gpf.conditionals.conditional(X, Z, kern, f, white=white)
+        assert mu.shape == (N, 1) and var.shape == (N, 1)
+        smu, svar = gpf.conditionals.conditional(X[idx], Z, kern, f, white=white)
+        assert rel(mu[idx], smu) <= tol and np.abs(var[idx] - svar).max() <= tol
+        rmu, rvar = orc.conditional(X[idx], Z, spec, f, white=white)
+        assert rel(smu, rmu) <= tol and np.abs(svar - rvar).max() <= tol, (tol, rel(smu, rmu), np.abs(svar - rvar).max())
+        assert var.min() > -tol and var.max() <= 1.0 + 1e-9
+    del mu, var
+    # ---- SVGP
+    q_mu = rng.standard_normal((M, 1)) * 0.3
+    q_sqrt = (np.tril(rng.standard_normal((M, M))) * (0.5 / M) + 0.5 * np.eye(M))[:, :, None]
+    noise = orc.constrained(0.1)
+    m = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.1), Z=Z, whiten=True)
+    m._q_mu.assign(q_mu); m._q_sqrt.assign(q_sqrt)
+    qs = np.asarray(m.q_sqrt)
+    elbo = m.compute_log_likelihood()
+    prog = kern._program(d)
+    half = N // 2
+    parts = [handle.svgp_elbo(prog, Z, X[a:b], Y[a:b], q_mu, qs, 1e-6, noise, white=True) for a, b in ((0, half), (half, N))]
+    e_all, kl_all, ve_all = handle.svgp_elbo(prog, Z, X, Y, q_mu, qs, 1e-6, noise, white=True)
+    assert e_all == elbo
+    assert abs((parts[0][2] + parts[1][2]) - ve_all) <= 1e-9 * abs(ve_all)
+    assert parts[0][1] == kl_all and parts[1][1] == kl_all                      # same factor, same KL, bit for bit
+    rkl = orc.gauss_kl(q_mu, qs, None)
+    assert abs(kl_all - rkl) <= RTOL * abs(rkl)
+    sub = orc.svgp_elbo(spec, X[idx], Y[idx], Z, q_mu, qs, noise, whiten=True)
+    got = handle.svgp_elbo(prog, Z, X[idx], Y[idx], q_mu, qs, 1e-6, noise, white=True)[0]
+    assert abs(got - sub) <= tol * abs(sub), (tol, got, sub)
+    # unwhitened, diagonal q_sqrt: the KL goes through the factor (log|Kuu|, Lp^-1 q_mu, diag(Kuu^-1))
+    qd = np.abs(rng.standard_normal((M, 1))) * 0.4 + 0.2
+    e2, kl2, ve2 = handle.svgp_elbo(prog, Z, X[:half], Y[:half], q_mu, qd, 1e-6, noise, white=False)
+    rkl2 = orc.gauss_kl(q_mu, qd, Kuu)
+    assert abs(kl2 - rkl2) <= tol * abs(rkl2), (tol, kl2, rkl2)
+    sub2 = orc.svgp_elbo(spec, X[idx], Y[idx], Z, q_mu, qd, noise, whiten=False)
+    got2 = handle.svgp_elbo(prog, Z, X[idx], Y[idx], q_mu, qd, 1e-6, noise, white=False)[0]
+    assert abs(got2 - sub2) <= tol * abs(sub2), (tol, got2, sub2)
 
 
 def test_predict_f_samples_moments(handle):
