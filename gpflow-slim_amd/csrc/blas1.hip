@@ -232,6 +232,18 @@ __global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ 
 
 __global__ void fill_info_kernel(int* p, int v) { *p = v; }
 
+// block-column distributed factorisation: fold the 64 fixed-order partials of lml_reduce_kernel and the info word of
+// the owner into the tail of the panel message (and the owner's own per-panel table)
+__global__ void dist_tail_kernel(const double* __restrict__ part, const int* __restrict__ info, double* __restrict__ t0,
+                                 double* __restrict__ t1) {
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < 64; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+  const int v = *info;
+  const double iv = (v == 0x7fffffff) ? 0.0 : (double)v;
+  t0[0] = a; t0[1] = b; t0[2] = iv; t0[3] = 0.0;
+  t1[0] = a; t1[1] = b; t1[2] = iv; t1[3] = 0.0;
+}
+
 // var[i] = kdiag - sumsq[i]
 __global__ void var_finish_kernel(double* __restrict__ var, const double* __restrict__ kdiag,
                                   double kconst, const double* __restrict__ sumsq, i64 n) {
@@ -424,6 +436,12 @@ int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i
   if (n <= 0) return GPS_OK;
   LaunchScope ls(h, KC_REDUCE, 4.0 * n, 32.0 * n);
   hipLaunchKernelGGL(varexp_kernel, dim3(64), dim3(256), 0, h->stream, fmean, yres, (int)k, q, base, extra, n, partial64);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own) {
+  hipLaunchKernelGGL(dist_tail_kernel, dim3(1), dim3(1), 0, h->stream, partials64x2, d_info, tail_msg, tail_own);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

@@ -220,7 +220,8 @@ extern "C" int gps_destroy(gps_handle_t h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
                     &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt};
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
+                    &h->dDistScal};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -1245,14 +1246,25 @@ extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const do
 
 
 // ---- block-column distributed factorisation ------------------------------------------------------
-// 1-D block-cyclic columns over P ranks.  Every rank holds the full [np, np] buffer, builds
-// and updates only the block columns it owns (c % P == rank), and receives every factored panel, so that
-// L ends up replicated (the solves / predictions that follow need no further exchange).  The library
-// only provides the per-step pieces; the exchange itself (one broadcast per panel: RCCL through
-// torch.distributed, or gloo in the CPU tests) is driven by gpflowSlim/distributed.py.
+// 1-D block-cyclic columns over P ranks.  Every rank holds an [np + 128, np] buffer, builds and updates
+// only the block columns it owns (c % P == rank) and receives every factored panel (kept in place, so that L ends up
+// replicated: warm predict_f needs no further exchange).
+//
+// Augmented rows ("alpha distributed"): rows np .. np+127 of the buffer hold (Y - m)^T (r real rows).  The
+// panel solve  X L_jj^T = B  and the trailing update treat them like any other rows below the diagonal block, which
+// is exactly the forward substitution: after panel j the augmented rows of block column j are alpha_j^T
+// (alpha = L^-1 (Y - m), densities.py:82).  So there is no forward-substitution pass over a replicated factor at the
+// end: the owner reduces  sum log L_ii  and  sum alpha^2  of its panel and ships them -- with its not-positive-definite
+// info word -- in the tail of the panel message; every rank adds the tails in panel order, so LML and info are
+// bit-identical on all ranks without a further collective.
+//
+// The library only provides the per-step pieces; the exchange itself (RCCL through torch.distributed, or gloo in the
+// CPU tests) and the two-lane schedule (chain: receive / urgent columns / factor / send; bulk: the rest of each
+// trailing update) are driven by gpflowSlim/distributed.py.
+#define DIST_TAIL 4          // doubles at the end of a panel message: sum log L_ii, sum alpha^2, info, (spare)
 static inline i64 dist_msg_doubles(gps_handle_t h, i64 j) {
-  const i64 rows = h->dist_np - j * h->dist_nb;
-  return rows * h->dist_nb + 2 * (h->dist_nb / GPS_TILE) * GPS_TILE * GPS_TILE;
+  const i64 rows = h->dist_np + GPS_TILE - j * h->dist_nb;
+  return rows * h->dist_nb + 2 * (h->dist_nb / GPS_TILE) * GPS_TILE * GPS_TILE + DIST_TAIL;
 }
 
 extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
@@ -1298,8 +1310,8 @@ extern "C" int gps_diag_set_cu_mask(gps_handle_t h, const uint32_t* mask, int n_
 extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
                               const double* resid, int64_t r, int nparts, int part, int64_t nb,
                               int64_t* n_panels, int64_t* msg_doubles_max) {
-  if (!h || nparts <= 0 || part < 0 || part >= nparts || nb <= 0 || nb % GPS_TILE || r < 0 || (r > 0 && !resid))
-    return gps_fail(h, GPS_ERR_ARG, "gps_dist_begin: bad argument");
+  if (!h || nparts <= 0 || part < 0 || part >= nparts || nb <= 0 || nb % GPS_TILE || r < 0 || r > GPS_TILE || (r > 0 && !resid))
+    return gps_fail(h, GPS_ERR_ARG, "gps_dist_begin: bad argument (at most 128 outputs)");
   if (h->n <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_gpr_set_data has not been called");
   GPS_HIP(h, hipSetDevice(h->device));
   const i64 n = h->n;
@@ -1313,15 +1325,17 @@ extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n
     if (rck) return rck;
     h->factor_refine = h->leaf_refine > 0 || (h->leaf_refine < 0 && !(noise_var >= h->leaf_refine_ratio * kd));
   }
-  GPS_HIP(h, h->dK.ensure((size_t)np * np * 8));
+  GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
+  GPS_HIP(h, h->dDistScal.ensure((size_t)nblk * DIST_TAIL * 8));
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  // augmented rows: (Y - m)^T, zero padded to 128 rows (all columns: owned or not, the bytes are few)
+  double* aug = h->dK.d() + np * np;
+  GPS_HIP(h, hipMemsetAsync(aug, 0, (size_t)GPS_TILE * np * 8, h->stream));
   if (r > 0) {
-    GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
     GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
-    GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)r * np * 8, h->stream));
-    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, h->dAlpha.d(), np);
+    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, aug, np);
     if (rc0) return rc0;
   }
   int prep = 1;
@@ -1352,20 +1366,30 @@ extern "C" int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1)
   return GPS_OK;
 }
 
+// second lane: gps_dist_update(..., lane = 1) launches on this stream instead of the handle's (no synchronisation
+// here: the caller orders the lanes with events); NULL: one lane
+extern "C" int gps_dist_set_bulk_stream(gps_handle_t h, void* hip_stream) {
+  if (!h) return GPS_ERR_ARG;
+  h->dist_bulk_stream = (hipStream_t)hip_stream;
+  h->dist_bulk_set = (hip_stream != nullptr);
+  return GPS_OK;
+}
+
 #define DIST_CHECK(h, j)                                                                              \
   if (!h || h->dist_nb <= 0 || j < 0 || j * h->dist_nb >= h->dist_np)                                 \
     return gps_fail(h, GPS_ERR_ARG, "gps_dist_*: bad panel index or gps_dist_begin not called");      \
   GPS_HIP(h, hipSetDevice(h->device));                                                                \
   h->refine_now = h->factor_refine;                                                                   \
   const i64 np = h->dist_np, nb = h->dist_nb;                                                         \
-  const i64 rows = np - j * nb;                                                                       \
+  const i64 rows = np + GPS_TILE - j * nb;              /* panel rows incl. the augmented ones */     \
   const i64 blk0 = j * nb / GPS_TILE, nbb = nb / GPS_TILE;                                            \
   double* const panel = h->dK.d() + j * nb * np + j * nb;                                             \
   double* const linv = h->dLinv.d();                                                                  \
   double* const linvT = linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE;                                 \
   (void)rows; (void)blk0; (void)nbb; (void)panel; (void)linvT;
 
-// owner of panel j: factor it in place (diagonal nb x nb block + rows below) and pack the message
+// owner of panel j: factor it in place (diagonal nb x nb block + rows below, augmented rows included), reduce its
+// share of log-det / sum alpha^2, and pack the message
 extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
   DIST_CHECK(h, j)
   if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
@@ -1379,13 +1403,21 @@ extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
   rc = gps_launch_extract(h, panel, np, rows, nb, msg, nb, 0);
   if (rc) return rc;
   const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
+  double* tail = msg + rows * nb + 2 * nbb * GPS_TILE * GPS_TILE;
   GPS_HIP(h, hipMemcpyAsync(msg + rows * nb, linv + blk0 * GPS_TILE * GPS_TILE, ib, hipMemcpyDeviceToDevice, h->stream));
   GPS_HIP(h, hipMemcpyAsync(msg + rows * nb + nbb * GPS_TILE * GPS_TILE, linvT + blk0 * GPS_TILE * GPS_TILE, ib,
                             hipMemcpyDeviceToDevice, h->stream));
+  // this panel's share of  sum log L_ii  and  sum alpha^2  (the augmented rows of this block column are alpha^T now),
+  // folded with the info word into the message tail -- and into this rank's own per-panel table
+  const double* aug = h->dK.d() + np * np + j * nb;
+  rc = gps_launch_lml_reduce(h, panel, np, nb, aug, np, h->dist_r, h->dScal.d());
+  if (rc) return rc;
+  rc = gps_launch_dist_tail(h, h->dScal.d(), (const int*)h->dInfo.p, tail, h->dDistScal.d() + j * DIST_TAIL);
+  if (rc) return rc;
   return GPS_OK;
 }
 
-// every other rank: copy the received panel (and its block inverses) into place
+// every other rank: copy the received panel (and its block inverses, and its scalars) into place
 extern "C" int gps_dist_unpack(gps_handle_t h, int64_t j, int buf) {
   DIST_CHECK(h, j)
   if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
@@ -1396,11 +1428,14 @@ extern "C" int gps_dist_unpack(gps_handle_t h, int64_t j, int buf) {
   GPS_HIP(h, hipMemcpyAsync(linv + blk0 * GPS_TILE * GPS_TILE, msg + rows * nb, ib, hipMemcpyDeviceToDevice, h->stream));
   GPS_HIP(h, hipMemcpyAsync(linvT + blk0 * GPS_TILE * GPS_TILE, msg + rows * nb + nbb * GPS_TILE * GPS_TILE, ib,
                             hipMemcpyDeviceToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h->dDistScal.d() + j * DIST_TAIL, msg + rows * nb + 2 * nbb * GPS_TILE * GPS_TILE, DIST_TAIL * 8,
+                            hipMemcpyDeviceToDevice, h->stream));
   return GPS_OK;
 }
 
 // apply panel j to the owned block columns c in [c_lo, c_hi), c > j:  A[c*nb:, c] -= L[c*nb:, j] L[c, j]^T
-extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi) {
+// (rows down to and including the augmented ones).  lane 1: on the bulk stream (gps_dist_set_bulk_stream).
+extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi, int lane) {
   DIST_CHECK(h, j)
   const i64 nblk = np / nb;
   if (c_lo <= j) c_lo = j + 1;
@@ -1411,36 +1446,39 @@ extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t 
   const i64 count = (c_hi - 1 - first) / h->dist_P + 1;
   const double* Lc = h->dK.d() + first * nb * np + j * nb;          // rows first*nb.. of panel j
   double* C = h->dK.d() + first * nb * np + first * nb;
-  return gps_launch_gemm_nt_cyclic(h, np - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, np, C, np);
+  hipStream_t saved = h->stream;
+  if (lane == 1 && h->dist_bulk_set) h->stream = h->dist_bulk_stream;
+  const int rc = gps_launch_gemm_nt_cyclic(h, np + GPS_TILE - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, np, C, np);
+  h->stream = saved;
+  return rc;
 }
 
-// after the last panel: alpha = L^-1 resid on the replicated factor, reductions, info
+// after the last panel: add the per-panel scalars in panel order (identical on every rank), info = first failing pivot
 extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   if (!h || !lml || h->dist_nb <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_dist_finish: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
   h->refine_now = h->factor_refine;
-  const i64 n = h->n, np = h->dist_np, r = h->dist_r;
+  const i64 n = h->n, np = h->dist_np, r = h->dist_r, nblk = np / h->dist_nb;
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
-  double* linv = h->dLinv.d();
-  HipOps ops{h, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
-  Blocked<HipOps> bl(ops);
-  int rc = 0;
+  // alpha [r][np] for warm predict_f: the augmented rows of the (replicated) factor
   if (r > 0) {
-    rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);
-    if (rc) return rc;
+    GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dAlpha.p, h->dK.d() + np * np, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
   }
-  double* part = h->dScal.d();
-  rc = gps_launch_lml_reduce(h, h->dK.d(), np, n, h->dAlpha.d(), np, r, part);
-  if (rc) return rc;
+  std::vector<double> tails((size_t)nblk * DIST_TAIL);
+  GPS_HIP(h, hipMemcpyAsync(tails.data(), h->dDistScal.p, tails.size() * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
-  double hp[2 * 64];
-  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
-  int linfo = 0;
-  rc = read_info(h, (int*)h->dInfo.p, &linfo);
+  int own = 0;
+  int rc = read_info(h, (int*)h->dInfo.p, &own);          // (also surfaces look-ahead time-outs of this rank's panels)
   if (rc) return rc;
-  if (info) *info = linfo;
   double slog = 0.0, ssq = 0.0;
-  for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; ssq += hp[2 * b + 1]; }
+  int linfo = 0;
+  for (i64 j = 0; j < nblk; ++j) {
+    slog += tails[j * DIST_TAIL]; ssq += tails[j * DIST_TAIL + 1];
+    const int pj = (int)tails[j * DIST_TAIL + 2];
+    if (pj > 0 && (linfo == 0 || pj < linfo)) linfo = pj;
+  }
+  if (info) *info = linfo;
   *lml = -0.5 * (double)n * (double)r * log(2.0 * M_PI) - (double)r * slog - 0.5 * ssq;
   h->r = r;
   h->have_factor = (linfo == 0);

@@ -131,6 +131,8 @@ struct gps_handle_s {
   int dist_P = 0, dist_rank = 0;
   i64 dist_nb = 0, dist_np = 0, dist_r = 0;
   double* dist_comm[2] = {nullptr, nullptr};
+  hipStream_t dist_bulk_stream = nullptr; bool dist_bulk_set = false;   // second lane of the distributed schedule
+  DevBuf dDistScal;                 // [n_panels][4] per-panel sum log L_ii, sum alpha^2, info
 
   DevBuf dA;        // [r][npad]  K_y^-1 (Y - m)                         (gradient path)
   DevBuf dY;        // [npad, npad]  L^-T                                 (gradient path)
@@ -241,6 +243,7 @@ int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
 int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
                       const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq);
 int gps_launch_fill_info(gps_handle_t h, int* d_info, int value);
+int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64);
 int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,

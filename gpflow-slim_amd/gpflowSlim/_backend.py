@@ -89,7 +89,8 @@ _SIGNATURES = {
     "gps_dist_set_comm": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     "gps_dist_panel_factor": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_unpack": [ctypes.c_void_p, _i64, ctypes.c_int],
-    "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64],
+    "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64, ctypes.c_int],
+    "gps_dist_set_bulk_stream": [ctypes.c_void_p, ctypes.c_void_p],
     "gps_dist_finish": [ctypes.c_void_p, _c_double_p, _c_int_p],
     "gps_diag_potrf_base_stamps": [ctypes.c_void_p, ctypes.c_int, _c_double_p],
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
@@ -289,8 +290,12 @@ class Handle(object):
     def dist_unpack(self, j, buf):
         self._check(self._lib.gps_dist_unpack(self._h, int(j), int(buf)), "gps_dist_unpack")
 
-    def dist_update(self, j, c_lo, c_hi):
-        self._check(self._lib.gps_dist_update(self._h, int(j), int(c_lo), int(c_hi)), "gps_dist_update")
+    def dist_update(self, j, c_lo, c_hi, lane=0):
+        self._check(self._lib.gps_dist_update(self._h, int(j), int(c_lo), int(c_hi), int(lane)), "gps_dist_update")
+
+    def dist_set_bulk_stream(self, hip_stream):
+        self._check(self._lib.gps_dist_set_bulk_stream(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None),
+                    "gps_dist_set_bulk_stream")
 
     def dist_finish(self):
         lml = ctypes.c_double(0)

@@ -2,18 +2,37 @@
 
 There is no reference counterpart (GPflow-Slim is single-device); the oracle for this
 module is the single-GPU result.  Partitioning: rank g owns block columns c with
-c % P == g (width nb); per panel j the owner factors it (diagonal block + rows below), the panel is
-broadcast (root = owner; RCCL over xGMI through torch.distributed, backend "nccl"), and every rank
-applies it to the block columns it owns.  Look-ahead of one panel: the owner of panel j+1 updates and
-factors that column first and starts its broadcast while everybody (itself included) is still
-applying panel j, so panel work and the exchange hide under the trailing update.  Every rank keeps
-each received panel, so L ends up replicated and alpha / predictions need no further exchange.
+c % P == g (width nb); per panel t the owner factors it (diagonal block + rows below, with (Y - m)^T
+riding along as augmented rows so that alpha = L^-1 (Y - m) falls out block by block), the panel is
+exchanged (root = owner), and every rank applies it to the block columns it owns.
 
-`block_column_schedule` is written against two small interfaces so that exactly the same schedule
-runs (a) on GPUs: `HipPanelOps` (C ABI gps_dist_*) + `TorchComm`, and (b) in the CPU tests:
-an emulation of the per-step pieces with numpy + the gloo backend (tests/test_dist_cpu.py).
+Schedule (`block_column_schedule`), two lanes per rank:
+
+* CHAIN lane -- the critical path.  For panel p, as soon as it is in place: update the next block column
+  with it, factor that column if this rank owns it and start its exchange; then update the other "urgent"
+  columns p+2 .. p+D; then receive panel p+1.
+* BULK lane -- everything else of the trailing update of panel p (columns > p+D), one launch per panel.
+
+Column c therefore takes panels 0 .. c-D-1 on the BULK lane and c-D .. c-1 on the CHAIN lane; the first
+CHAIN update of a column waits for the last BULK update that touches it (panel c-D-1), BULK(p) waits
+for panel p to be in place.  With depth D >= 2 the chain never waits for the bulk update of the panel it
+has just received, so a step costs max(chain, bulk) instead of their sum.  D = 1 is the classic
+one-panel look-ahead on two lanes; D = 0 is the plain right-looking order on one lane.
+
+Exchange (`TorchComm.exchange`): RCCL over xGMI through torch.distributed.  xGMI is a full mesh of
+point-to-point links, so a ring / tree broadcast of the whole panel is bound by one link; instead the
+root scatters the message in P equal chunks (all of its links carry 1/P of the panel at once) and an
+all-gather completes it (every link again carries 1/P): 2 S / (P b) per panel instead of S / b.
+gloo (CPU tests; CUDA tensors only support broadcast there) falls back to one broadcast.
+
+`block_column_schedule` is written against small interfaces so that exactly the same schedule runs
+(a) on GPUs: `HipPanelOps` (C ABI gps_dist_*, torch streams / events) + `TorchComm`, and (b) in the CPU
+tests: a numpy emulation with a vector-clock race detector over the two lanes + gloo
+(tests/test_dist_cpu.py).
 """
 import numpy as np
+
+CHAIN, BULK = 0, 1
 
 
 class _Done(object):
@@ -21,64 +40,122 @@ class _Done(object):
         return True
 
 
-def block_column_schedule(ops, comm, n_panels, lookahead=True):
-    """Run the factorisation.  `ops`: panel_factor(j, buf), message(j, buf) -> buffer object for comm,
-    unpack(j, buf), update(j, c_lo, c_hi).  `comm`: rank, world, broadcast(buffer, src, async_op) ->
-    object with wait()."""
+def block_column_schedule(ops, comm, n_panels, lookahead=2):
+    """Run the factorisation.
+
+    `ops`: panel_factor(t, buf), message(t, buf) -> buffer object for comm, unpack(t, buf),
+    update(p, c_lo, c_hi, lane), record(lane) -> token, wait(lane, token), and the context manager
+    comm_lane() under which collectives are issued.  `comm`: rank, world, exchange(buffer, src) ->
+    object with wait().  `lookahead`: depth D (bool accepted: True = 2, False = 0)."""
     P, rank = comm.world, comm.rank
-    owner = lambda j: j % P
+    D = 2 if lookahead is True else (0 if lookahead is False else int(lookahead))
+    owner = lambda t: t % P
+    two_lanes = D >= 1
+    bulk_lane = BULK if two_lanes else CHAIN
+    bulk_done = {}                      # panel -> token recorded after its BULK update
+
+    def exchange(t, buf):
+        with ops.comm_lane():
+            return comm.exchange(ops.message(t, buf), owner(t))
+
+    def receive(t, buf, handle):
+        with ops.comm_lane():
+            handle.wait()
+        if rank != owner(t):
+            ops.unpack(t, buf)
 
     if rank == owner(0):
         ops.panel_factor(0, 0)
-    comm.broadcast(ops.message(0, 0), owner(0), False).wait()
-    if rank != owner(0):
-        ops.unpack(0, 0)
+    receive(0, 0, exchange(0, 0))
 
-    for j in range(n_panels):
-        nxt = j + 1
-        if nxt >= n_panels:
-            break
-        buf = nxt % 2
-        if lookahead:
-            if rank == owner(nxt):
-                ops.update(j, nxt, nxt + 1)            # the next panel's column first ...
-                ops.panel_factor(nxt, buf)              # ... factor it ...
-            work = comm.broadcast(ops.message(nxt, buf), owner(nxt), True)   # ... and ship it while
-            ops.update(j, nxt + 1, n_panels)            # everybody applies panel j to the rest
-            work.wait()
-        else:
-            ops.update(j, nxt, n_panels)
+    for p in range(n_panels - 1):
+        # panel p is in place (CHAIN lane)
+        nxt, buf = p + 1, (p + 1) % 2
+        if D == 0:
+            ops.update(p, nxt, n_panels, CHAIN)
             if rank == owner(nxt):
                 ops.panel_factor(nxt, buf)
-            comm.broadcast(ops.message(nxt, buf), owner(nxt), False).wait()
-        if rank != owner(nxt):
-            ops.unpack(nxt, buf)
+            receive(nxt, buf, exchange(nxt, buf))
+            continue
+        in_place = ops.record(CHAIN)
+        last_urgent = min(p + D, n_panels - 1)
+
+        def urgent(c):
+            # first CHAIN update of column c = p + D: the BULK updates of panels <= p - 1 may still be running on it
+            if c == p + D and (p - 1) in bulk_done:
+                ops.wait(CHAIN, bulk_done.pop(p - 1))
+            ops.update(p, c, c + 1, CHAIN)
+
+        urgent(nxt)
+        if rank == owner(nxt):
+            ops.panel_factor(nxt, buf)
+        handle = exchange(nxt, buf)                       # in flight while ...
+        for c in range(nxt + 1, last_urgent + 1):         # ... the other urgent columns
+            urgent(c)
+        if last_urgent + 1 < n_panels:                     # ... and the bulk of the update run
+            ops.wait(BULK, in_place)
+            ops.update(p, last_urgent + 1, n_panels, BULK)
+            bulk_done[p] = ops.record(BULK)
+        receive(nxt, buf, handle)
+    for tok in bulk_done.values():                         # (nothing is left to do there; join for the caller)
+        ops.wait(CHAIN, tok)
 
 
 # ---- GPU side -------------------------------------------------------------------------------------
 class TorchComm(object):
     """torch.distributed (backend "nccl" = RCCL on ROCm, or "gloo") behind the tiny comm interface."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, mode=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        # "scatter_allgather" needs scatter / all_gather_into_tensor on the tensors' device: RCCL, or gloo on CPU tensors
+        self.mode = mode or ("scatter_allgather" if self.backend == "nccl" else "broadcast")
+        self.bytes_sent = 0            # payload bytes this rank put on the wire (diagnostics for bench.py)
+        self.exchanges = 0
 
+    def exchange(self, tensor, src):
+        """Make `tensor` (complete on rank `src`) complete on every rank; returns an object with wait()."""
+        if self.world == 1:
+            return _Done()
+        dist, P = self._dist, self.world
+        self.exchanges += 1
+        n = tensor.numel()
+        if self.mode == "broadcast" or n < 2 * P:
+            if self.rank == src:
+                self.bytes_sent += 8 * n * (P - 1)
+            w = dist.broadcast(tensor, src=src, group=self.group, async_op=True)
+            return w if w is not None else _Done()
+        # scatter + all-gather on P equal chunks (the ragged end of the message goes by a small broadcast)
+        chunk = n // P
+        body = tensor[: chunk * P]
+        mine = body[self.rank * chunk:(self.rank + 1) * chunk]
+        parts = [body[i * chunk:(i + 1) * chunk] for i in range(P)] if self.rank == src else None
+        self.bytes_sent += 8 * chunk * (P - 1) * (2 if self.rank == src else 1)
+        works = [dist.scatter(mine, scatter_list=parts, src=src, group=self.group, async_op=True)]
+        if self.backend != "nccl":
+            works[-1].wait()          # gloo runs queued work on a thread pool: keep the two phases ordered
+        works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
+        if chunk * P < n:
+            works.append(dist.broadcast(tensor[chunk * P:], src=src, group=self.group, async_op=True))
+        return _Works(works)
+
+    # kept for callers of the round-1 interface
     def broadcast(self, tensor, src, async_op):
         if self.world == 1:
             return _Done()
         w = self._dist.broadcast(tensor, src=src, group=self.group, async_op=async_op)
         return w if w is not None else _Done()
 
-
     def all_gather_rows(self, local, counts):
         """Concatenate per-rank row blocks `local` [counts[rank], c] (numpy, host) on every rank."""
         if self.world == 1:
             return local
         import torch
-        dev = "cuda" if self._dist.get_backend(self.group) == "nccl" else "cpu"
+        dev = "cuda" if self.backend == "nccl" else "cpu"
         c = local.shape[1]
         mx = max(counts)
         pad = np.zeros((mx, c))
@@ -89,8 +166,23 @@ class TorchComm(object):
         return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, counts)], axis=0)
 
 
+class _Works(object):
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
 class SingleComm(object):
     rank, world = 0, 1
+    bytes_sent = 0
+    exchanges = 0
+
+    def exchange(self, tensor, src):
+        return _Done()
 
     def broadcast(self, tensor, src, async_op):
         return _Done()
@@ -100,60 +192,97 @@ class SingleComm(object):
 
 
 class HipPanelOps(object):
-    """Per-step pieces on one GPU through the C ABI; comm buffers are torch tensors (device memory
-    plumbing only), library kernels run on torch's current stream so that they are ordered with the
-    collectives."""
+    """Per-step pieces on one GPU through the C ABI.  Comm buffers are torch tensors and the two lanes are torch
+    streams (device-memory / stream plumbing only): the CHAIN lane -- a high-priority stream on which the library's
+    kernels and the collectives are ordered -- and the BULK lane for the trailing updates.  Use as a context manager:
+    leaving it always gives the handle its own stream back."""
 
-    def __init__(self, handle, prog, noise_var, resid, nparts, part, nb):
+    def __init__(self, handle, prog, noise_var, resid, nparts, part, nb, two_lanes=True):
         import torch
         self.h = handle
         self.torch = torch
-        handle.set_stream(torch.cuda.current_stream().cuda_stream, True)
-        self.n_panels, mx = handle.dist_begin(prog, noise_var, resid, nparts, part, nb)
-        self.bufs = [torch.empty(mx, dtype=torch.float64, device="cuda") for _ in range(2)]
-        handle.dist_set_comm(self.bufs[0].data_ptr(), self.bufs[1].data_ptr())
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        self.chain = torch.cuda.Stream(priority=hi)
+        self.bulk = torch.cuda.Stream(priority=lo) if two_lanes else self.chain
+        self._installed = False
+        try:
+            self.chain.wait_stream(torch.cuda.current_stream())
+            handle.set_stream(self.chain.cuda_stream, True)
+            self._installed = True
+            handle.dist_set_bulk_stream(self.bulk.cuda_stream if two_lanes else 0)
+            self.n_panels, mx = handle.dist_begin(prog, noise_var, resid, nparts, part, nb)
+            mx = -(-mx // max(nparts, 1)) * max(nparts, 1)          # room for equal chunks
+            with torch.cuda.stream(self.chain):
+                self.bufs = [torch.empty(mx, dtype=torch.float64, device="cuda") for _ in range(2)]
+            handle.dist_set_comm(self.bufs[0].data_ptr(), self.bufs[1].data_ptr())
+        except Exception:
+            self.close()
+            raise
 
-    def panel_factor(self, j, buf):
-        self.h.dist_panel_factor(j, buf)
+    def __enter__(self):
+        return self
 
-    def message(self, j, buf):
-        return self.bufs[buf][: self.h.dist_msg_doubles(j)]
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
-    def unpack(self, j, buf):
-        self.h.dist_unpack(j, buf)
+    def close(self):
+        if self._installed:
+            self._installed = False
+            self.torch.cuda.current_stream().wait_stream(self.chain)
+            try:
+                self.h.dist_set_bulk_stream(0)
+            finally:
+                self.h.set_stream(0, False)
 
-    def update(self, j, c_lo, c_hi):
-        self.h.dist_update(j, c_lo, c_hi)
+    def comm_lane(self):
+        return self.torch.cuda.stream(self.chain)
+
+    def panel_factor(self, t, buf):
+        self.h.dist_panel_factor(t, buf)
+
+    def message(self, t, buf):
+        return self.bufs[buf][: self.h.dist_msg_doubles(t)]
+
+    def unpack(self, t, buf):
+        self.h.dist_unpack(t, buf)
+
+    def update(self, p, c_lo, c_hi, lane):
+        self.h.dist_update(p, c_lo, c_hi, lane)
+
+    def record(self, lane):
+        ev = self.torch.cuda.Event()
+        ev.record(self.chain if lane == CHAIN else self.bulk)
+        return ev
+
+    def wait(self, lane, token):
+        (self.chain if lane == CHAIN else self.bulk).wait_event(token)
 
     def finish(self):
-        try:
-            return self.h.dist_finish()
-        finally:
-            self.h.set_stream(0, False)
+        return self.h.dist_finish()
 
 
-def gpr_lml_distributed(model, comm=None, nb=512, lookahead=True):
+def _default_comm():
+    try:
+        import torch.distributed as dist
+        return TorchComm() if dist.is_available() and dist.is_initialized() else SingleComm()
+    except ImportError:
+        return SingleComm()
+
+
+def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2):
     """Log-marginal likelihood of a gpflowSlim.models.GPR with the covariance factorised across the
     ranks of `comm` (default: the default torch.distributed group, or a single rank).  Every rank must
-    call this with the same model state; every rank returns the same value."""
-    from . import _backend as be
-    if comm is None:
-        try:
-            import torch.distributed as dist
-            comm = TorchComm() if dist.is_available() and dist.is_initialized() else SingleComm()
-        except ImportError:
-            comm = SingleComm()
+    call this with the same model state; every rank returns the same value (bit for bit), or every rank
+    raises NotPositiveDefiniteError."""
+    comm = comm or _default_comm()
     h = model._handle()
     prog = model.kern._program(model.X.shape[1])
     model._factor_key = None
-    ops = HipPanelOps(h, prog, float(np.squeeze(model.likelihood.variance)), model._resid(), comm.world,
-                      comm.rank, nb)
-    try:
+    with HipPanelOps(h, prog, float(np.squeeze(model.likelihood.variance)), model._resid(), comm.world, comm.rank,
+                     nb, two_lanes=bool(lookahead)) as ops:
         block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
-    except Exception:
-        h.set_stream(0, False)
-        raise
-    lml = ops.finish()
+        lml = ops.finish()
     model._factor_key = model._state_key()      # L and alpha are resident (replicated) on every rank
     return lml
 
@@ -164,12 +293,7 @@ def predict_f_distributed(model, Xnew, comm=None):
     exchange in the solve -- only the final gather of the [N*, R] outputs).  Every rank passes the same
     Xnew and gets the full (mean, var) back.  Requires a resident factor (call gpr_lml_distributed or
     compute_log_likelihood first); models/gpr.py:119-131 per shard."""
-    if comm is None:
-        try:
-            import torch.distributed as dist
-            comm = TorchComm() if dist.is_available() and dist.is_initialized() else SingleComm()
-        except ImportError:
-            comm = SingleComm()
+    comm = comm or _default_comm()
     Xnew = np.ascontiguousarray(Xnew, dtype=np.float64)
     n_new = Xnew.shape[0]
     bounds = [(n_new * r) // comm.world for r in range(comm.world + 1)]

@@ -238,29 +238,37 @@ int gps_last_stage_ms(gps_handle_t h, double* out5);
 /* ---- multi-GPU: 1-D block-cyclic column Cholesky, one process per GPU ------------------------
  * No reference counterpart (the reference is single-device); the oracle is the single-GPU result.
  * Rank `part` of `nparts` owns block columns c with c % nparts == part (width nb, multiple of 128),
- * builds and updates only those, and receives every factored panel so that L ends up replicated.
- * The library supplies the per-step pieces; the caller moves the panel message (one broadcast per
- * panel over RCCL / xGMI, root = owner) between gps_dist_panel_factor and gps_dist_unpack:
+ * builds and updates only those, and receives every factored panel so that L ends up replicated
+ * (warm predict_f afterwards needs no exchange).  (Y - m)^T rides along as augmented rows under K: the
+ * panel solves and trailing updates turn them into alpha^T = (L^-1 (Y - m))^T block by block
+ * (densities.py:82), so no forward substitution over the replicated factor is needed; each panel message
+ * ends with that panel's  sum log L_ii,  sum alpha^2  and not-positive-definite info word, and every rank
+ * adds them in panel order: LML and info are bit-identical on all ranks.
+ * The library supplies the per-step pieces; the caller moves the panel message (RCCL / xGMI through
+ * torch.distributed: scatter + all-gather, root = owner) between gps_dist_panel_factor and gps_dist_unpack:
  *
- *   gps_dist_begin(...)                       build owned columns of K + noise I
+ *   gps_dist_begin(...)                       build owned columns of K + noise I, augmented rows
  *   for j in panels:  owner: gps_dist_panel_factor(j, buf)   -> message in comm buffer `buf`
- *                     broadcast(comm[buf][0 : gps_dist_msg_doubles(j)], root = j % nparts)
+ *                     exchange(comm[buf][0 : gps_dist_msg_doubles(j)], root = j % nparts)
  *                     others: gps_dist_unpack(j, buf)
- *                     all:    gps_dist_update(j, c_lo, c_hi)  (owned columns in [c_lo, c_hi), c > j)
- *   gps_dist_finish(&lml, &info)              alpha, log-det, sum alpha^2 on the replicated factor
+ *                     all:    gps_dist_update(j, c_lo, c_hi, lane)  (owned columns in [c_lo, c_hi), c > j)
+ *   gps_dist_finish(&lml, &info)              per-panel scalars added in panel order
  *
- * gps_set_stream(h, s, 1) installs the caller's HIP stream s (e.g. torch's current stream; NULL = the
- * legacy default stream) so that library kernels and the collective are ordered on one stream;
- * gps_set_stream(h, NULL, 0) restores the handle's own stream.                                      */
+ * Two lanes: everything runs on the handle's stream (gps_set_stream(h, s, 1) installs the caller's HIP
+ * stream s, e.g. a torch stream, so that library kernels and the collective are ordered on it;
+ * gps_set_stream(h, NULL, 0) restores the handle's own stream) except gps_dist_update(..., lane = 1),
+ * which launches on the stream given to gps_dist_set_bulk_stream: the schedule keeps the bulk of every
+ * trailing update there and orders the lanes with events (gpflowSlim/distributed.py).                */
 int gps_set_stream(gps_handle_t h, void* hip_stream, int external);
 int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
                    const double* resid, int64_t r, int nparts, int part, int64_t nb,
                    int64_t* n_panels, int64_t* msg_doubles_max);
 int gps_dist_msg_doubles(gps_handle_t h, int64_t j, int64_t* out);
 int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1);
+int gps_dist_set_bulk_stream(gps_handle_t h, void* hip_stream);
 int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf);
 int gps_dist_unpack(gps_handle_t h, int64_t j, int buf);
-int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi);
+int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi, int lane);
 int gps_dist_finish(gps_handle_t h, double* lml, int* info);
 
 /* tuning knobs (diagnostics; defaults are what bench.py measures):

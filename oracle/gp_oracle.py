@@ -506,6 +506,22 @@ def gpr_lml_timed(spec, X, Y, noise_var):
     return lml, {"kmat_s": t1 - t0, "potrf_s": t2 - t1, "trsv_s": t3 - t2, "total_s": t3 - t0}
 
 
+def rbf_K_inplace(spec, X):
+    """RBF K(X, X) with the passes of kernels.py:408-439 fused by hand (one matmul, then in-place numpy ops on the one
+    [N, N] buffer): the SURVEY 8(d) "in-place" CPU variant timed beside the unfused, one-op-per-TF-op build of K()."""
+    A = _slice(spec, X, None)[0] / spec["lengthscales"]
+    s = np.sum(A * A, axis=1)
+    Kb = A @ A.T
+    Kb *= -2.0
+    Kb += s[:, None]
+    Kb += s[None, :]
+    np.maximum(Kb, 0.0, out=Kb)
+    Kb *= -0.5
+    np.exp(Kb, out=Kb)
+    Kb *= spec["variance"]
+    return Kb
+
+
 def synthetic_gpr_data(n, d, n_new=0, seed=20240607):
     """SURVEY.md section 8(d) synthetic inputs."""
     rng = np.random.default_rng(seed)

@@ -1,7 +1,8 @@
 """world_size > 1 on CPU (gloo): the block-column schedule of gpflowSlim/distributed.py -- the SAME
 function the GPU path runs -- with the per-step pieces emulated in numpy/scipy (test infrastructure
-only) and the panel broadcast carried by torch.distributed/gloo.  Checks ownership, message sizes,
-look-ahead ordering and that every rank ends with the full factor."""
+only) and the panel exchange (scatter + all-gather, or broadcast) carried by torch.distributed/gloo.
+Checks ownership, message sizes, the event protocol between the two lanes (vector clocks), look-ahead
+depths and that every rank ends with the full factor."""
 import os
 import socket
 import sys
@@ -15,7 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class NumpyPanelOps(object):
     """Emulates gps_dist_* on the host: full [np, np] buffer per rank, only owned block columns are
-    initialised (everything else NaN, so any use of data that was never received shows up)."""
+    initialised (everything else NaN, so any use of data that was never received shows up).
+
+    The two lanes of the schedule are emulated sequentially, but every access is checked with vector
+    clocks: an operation on lane A that touches a region last written on lane B must have waited for a
+    token recorded on B after that write (ops.record / ops.wait) -- on the GPU the lanes are concurrent
+    streams, so an unordered pair is a data race even though it cannot misbehave here."""
 
     def __init__(self, A, nb, nparts, part):
         import torch
@@ -25,14 +31,61 @@ class NumpyPanelOps(object):
         self.M = np.full_like(A, np.nan)
         for c in range(part, self.n_panels, nparts):
             self.M[c * nb:, c * nb:(c + 1) * nb] = A[c * nb:, c * nb:(c + 1) * nb]
-        mx = self.np_ * nb
+        mx = -(-(self.np_ * nb) // nparts) * nparts
         self.bufs = [torch.full((mx,), float("nan"), dtype=torch.float64) for _ in range(2)]
         self.log = []
+        self.clock = [[0, 0], [0, 0]]            # clock[lane] = [events of lane 0 seen, events of lane 1 seen]
+        self.last_write = {}                     # region -> (lane, count)
+        self.last_reads = {}                     # region -> list of (lane, count) since the last write
+        self.max_lag = 0                         # how many panels the BULK lane was behind the CHAIN lane at most
+        self._bulk_panel = -1
 
+    # ---- lanes
+    def _tick(self, lane):
+        self.clock[lane][lane] += 1
+        return (lane, self.clock[lane][lane])
+
+    def _ordered(self, lane, ev):
+        return ev is None or ev[0] == lane or self.clock[lane][ev[0]] >= ev[1]
+
+    def _read(self, lane, region):
+        me = self._tick(lane)
+        assert self._ordered(lane, self.last_write.get(region)), ("read of %s on lane %d races with its writer" % (region, lane))
+        self.last_reads.setdefault(region, []).append(me)
+
+    def _write(self, lane, region):
+        me = self._tick(lane)
+        assert self._ordered(lane, self.last_write.get(region)), ("write of %s on lane %d races with the previous writer" % (region, lane))
+        for ev in self.last_reads.get(region, []):
+            assert self._ordered(lane, ev), ("write of %s on lane %d races with a reader" % (region, lane))
+        self.last_write[region] = me
+        self.last_reads[region] = []
+
+    def record(self, lane):
+        return (lane, self.clock[lane][lane], list(self.clock[lane]))
+
+    def wait(self, lane, token):
+        src, _, vc = token
+        for i in (0, 1):
+            self.clock[lane][i] = max(self.clock[lane][i], vc[i])
+
+    class _Nop(object):
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def comm_lane(self):
+        return self._Nop()
+
+    # ---- per-step pieces
     def panel_factor(self, j, buf):
         nb, s = self.nb, j * self.nb
         assert j % self.P == self.rank, "only the owner factors a panel"
+        self._write(0, ("col", j)); self._write(0, ("buf", buf))
         D = self.M[s:s + nb, s:s + nb]
+        assert not np.isnan(np.tril(D)).any(), "panel %d factored before all of its updates" % j
         L = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
         self.M[s:s + nb, s:s + nb] = L
         if s + nb < self.np_:
@@ -47,22 +100,26 @@ class NumpyPanelOps(object):
     def unpack(self, j, buf):
         nb, s = self.nb, j * self.nb
         assert j % self.P != self.rank
+        self._read(0, ("buf", buf)); self._write(0, ("col", j))
         rows = self.np_ - s
         self.M[s:, s:s + nb] = self.bufs[buf][: rows * nb].numpy().reshape(rows, nb)
         self.log.append(("unpack", j))
 
-    def update(self, j, c_lo, c_hi):
+    def update(self, j, c_lo, c_hi, lane=0):
         nb = self.nb
+        if lane == 1:
+            self._bulk_panel = j
         for c in range(max(c_lo, j + 1), min(c_hi, self.n_panels)):
             if c % self.P != self.rank:
                 continue
+            self._read(lane, ("col", j)); self._write(lane, ("col", c))
             Lc = self.M[c * nb:, j * nb:(j + 1) * nb]
             assert not np.isnan(Lc).any(), "panel %d used before it was received" % j
             self.M[c * nb:, c * nb:(c + 1) * nb] -= Lc @ Lc[:nb].T
-            self.log.append(("update", j, c))
+            self.log.append(("update", j, c, lane))
 
 
-def _worker(rank, world, port, n, nb, lookahead, q):
+def _worker(rank, world, port, n, nb, lookahead, mode, q):
     sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
     import torch.distributed as dist
     from gpflowSlim.distributed import TorchComm, block_column_schedule
@@ -72,11 +129,16 @@ def _worker(rank, world, port, n, nb, lookahead, q):
         G = rng.standard_normal((n, n))
         A = G @ G.T + n * np.eye(n)
         ops = NumpyPanelOps(A, nb, world, rank)
-        block_column_schedule(ops, TorchComm(), ops.n_panels, lookahead=lookahead)
+        comm = TorchComm(mode=mode)
+        block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
         L = np.linalg.cholesky(A)
         err = float(np.abs(np.tril(ops.M) - L).max())
         factored = [e[1] for e in ops.log if e[0] == "factor"]
-        q.put((rank, err, factored))
+        per_col = {}
+        for e in ops.log:
+            if e[0] == "update":
+                per_col.setdefault(e[2], []).append(e[1])
+        q.put((rank, err, factored, per_col, comm.bytes_sent))
     finally:
         dist.destroy_process_group()
 
@@ -85,13 +147,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("world,n,nb,lookahead", [(2, 96, 16, True), (2, 96, 16, False), (3, 112, 16, True), (2, 48, 48, True)])
-def test_block_column_schedule_gloo(world, n, nb, lookahead):
+@pytest.mark.parametrize("world,n,nb,lookahead,mode", [
+    (2, 96, 16, 2, "scatter_allgather"), (2, 96, 16, 0, "broadcast"), (2, 96, 16, 1, "broadcast"),
+    (3, 112, 16, 2, "scatter_allgather"), (3, 176, 16, 3, "scatter_allgather"), (2, 48, 48, True, "scatter_allgather"),
+    (3, 112, 16, 4, "broadcast")])
+def test_block_column_schedule_gloo(world, n, nb, lookahead, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, lookahead, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nb, lookahead, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -99,20 +164,54 @@ def test_block_column_schedule_gloo(world, n, nb, lookahead):
         p.join(timeout=60)
         assert p.exitcode == 0
     n_panels = n // nb
-    for rank, err, factored in res:
+    total_bytes = 0
+    for rank, err, factored, per_col, sent in res:
         assert err <= 1e-10, (rank, err)                       # every rank holds the whole factor
         assert factored == list(range(rank, n_panels, world))  # block-cyclic ownership
+        for c, panels in per_col.items():                      # every owned column took every earlier panel exactly once, in order
+            assert c % world == rank and panels == list(range(c)), (rank, c, panels)
+        total_bytes += sent
+    # payload on the wire: a broadcast delivers every panel to the P - 1 other ranks once; scatter + all-gather moves
+    # (P + 1) / P of that in total, but 1 / P of a panel per link and phase instead of a whole panel over one link
+    expect = sum((n - j * nb) * nb for j in range(n_panels)) * 8 * (world - 1)
+    if mode == "scatter_allgather":
+        expect = expect * (world + 1) / world
+    assert abs(total_bytes - expect) <= 8 * 2 * world * world * n_panels, (total_bytes, expect)
 
 
-def test_schedule_single_rank_matches_lapack():
+@pytest.mark.parametrize("lookahead", [0, 1, 2, 3, 7, True, False])
+def test_schedule_single_rank_matches_lapack(lookahead):
     sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
     from gpflowSlim.distributed import SingleComm, block_column_schedule
     rng = np.random.default_rng(5)
-    n, nb = 80, 16
+    n, nb = 96, 16
     G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
     ops = NumpyPanelOps(A, nb, 1, 0)
-    block_column_schedule(ops, SingleComm(), ops.n_panels)
+    block_column_schedule(ops, SingleComm(), ops.n_panels, lookahead=lookahead)
     assert np.abs(np.tril(ops.M) - np.linalg.cholesky(A)).max() <= 1e-10
+    lanes = {e[3] for e in ops.log if e[0] == "update"}
+    depth = 2 if lookahead is True else int(lookahead)
+    assert lanes == ({0} if depth == 0 or depth >= ops.n_panels - 1 else {0, 1})   # the bulk of the updates really is on the second lane
+
+
+def test_race_detector_catches_a_missing_wait():
+    """The vector-clock check of NumpyPanelOps is what validates the schedule's event protocol: drop the wait of the
+    first CHAIN update of a column on the last BULK update that touched it, and it must fire."""
+    sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
+    from gpflowSlim.distributed import SingleComm, block_column_schedule
+    rng = np.random.default_rng(5)
+    n, nb = 96, 16
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+
+    class Forgetful(NumpyPanelOps):
+        def wait(self, lane, token):
+            if lane == 0:
+                return                                   # the CHAIN lane never waits for the BULK lane
+            NumpyPanelOps.wait(self, lane, token)
+
+    ops = Forgetful(A, nb, 1, 0)
+    with pytest.raises(AssertionError, match="races"):
+        block_column_schedule(ops, SingleComm(), ops.n_panels, lookahead=2)
 
 
 def _gather_worker(rank, world, port, q):

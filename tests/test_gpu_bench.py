@@ -1,0 +1,64 @@
+"""bench.py end to end on the GPU box: the N = 1 line, and the N > 1 branch -- one block-column factorisation over all
+ranks per step -- with two processes sharing the one GPU of the box over gloo (RCCL refuses two ranks on one device;
+everything else is the production path: torch.distributed.run launch, TorchComm, HipPanelOps, the two-lane schedule)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+          "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_one_gpu_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--npoints", "4096",
+                        "--cpu-sample-n", "1024", "--num-new-throughput", "1024"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    assert COMMON <= set(out), sorted(COMMON - set(out))
+    assert out["n_gpus"] == 1 and out["unit"] == "evals/s" and out["dtype"] == "f64" and out["value"] > 0
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or rf["kernel_source_sha"]          # never a constant from other sources
+    assert rf["launch_counted"]["flops"] >= 4096 ** 3 / 3
+    for k in ("kmat", "trsv", "rowdot_predict_f"):
+        assert 0 < out["hbm_bound_kernels"][k]["gbs"] < 8000
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample_parity_rel_err"] <= 1e-8
+    assert out["predict_f_throughput"]["points_per_s"] > 0
+
+
+def test_bench_two_ranks_block_column_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
+           "--dist-timeout", "600"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    out = _last_json(p.stdout)
+    assert COMMON <= set(out), sorted(COMMON - set(out))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3 and out["value"] > 0
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-3 * out["value"]          # ONE evaluation of the whole job per step
+    dd = out["distributed"]
+    assert dd["rccl_ranks"] == 2 and dd["nb"] == 256 and dd["parity_rel_err_vs_one_gpu"] <= 1e-9
+    assert len(dd["stage_ms_per_rank_last_step"]) == 2
+    n_panels = 4096 // 256
+    rows = lambda j: 4096 + 128 - j * 256
+    payload = sum(rows(j) * 256 + 2 * 2 * 128 * 128 + 4 for j in range(n_panels)) * 8        # every panel to the one other rank
+    assert abs(dd["payload_bytes_per_eval_all_ranks"] - payload) <= 1e-6 * payload
+    assert "block-cyclic" in out["config"]["parallelism"]
+    assert out["independent_evals"]["scaling"] == "weak" and out["independent_evals"]["evals_per_s_all_gpus"] > 0
+    assert out["cpu_baseline"] is None                                                        # timed at N = 1 only
