@@ -350,8 +350,12 @@ __global__ __launch_bounds__(64) void la_wait_kernel(unsigned long long* sig, un
   if (threadIdx.x != 0) return;
   if (sig) __hip_atomic_store(sig, sval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (!flag) return;
-  for (int it = 0; it < 200000000; ++it) {          // ~30 s: far beyond any legitimate wait, still not a hang
+  // bounded by the 100 MHz wall clock: 1 s is four orders of magnitude beyond any legitimate hand-over wait (tens of
+  // microseconds), still not a hang; the evaluation is then re-run without look-ahead (gps_api.hip: with_la_retry)
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= val) return;
+    if (wall_clock64() - t0 > 100000000ull) break;
     __builtin_amdgcn_s_sleep(4);
   }
   atomicAdd(timeouts, 1ull);

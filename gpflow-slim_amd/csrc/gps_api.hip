@@ -71,9 +71,13 @@ struct HipOps {
         e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
       }
       if (e != hipSuccess) { h->side_stream = nullptr; return false; }
-      if (h->dLaFlags.ensure(64) != hipSuccess) return false;
-      if (hipMemset(h->dLaFlags.p, 0, 64) != hipSuccess) return false;
-      if (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess) return false;
+      // all or nothing: a half-initialised look-ahead (stream without flags / event) must not be used by the next call
+      if (h->dLaFlags.ensure(64) != hipSuccess || hipMemset(h->dLaFlags.p, 0, 64) != hipSuccess ||
+          (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(h->side_stream);
+        h->side_stream = nullptr;
+        return false;
+      }
       h->la_ticket = 0; h->fol_ticket = 0;
     }
     return true;
@@ -138,8 +142,13 @@ struct HipOps {
         e = hipStreamCreateWithFlags(&h->def_stream, hipStreamNonBlocking);
       }
       if (e != hipSuccess) { h->def_stream = nullptr; return false; }
-      if (hipEventCreateWithFlags(&h->ev_def_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&h->ev_def_join, hipEventDisableTiming) != hipSuccess) return false;
+      // (the events outlive the stream: it is re-created after every external-stream episode, they are not)
+      if ((!h->ev_def_fork && hipEventCreateWithFlags(&h->ev_def_fork, hipEventDisableTiming) != hipSuccess) ||
+          (!h->ev_def_join && hipEventCreateWithFlags(&h->ev_def_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(h->def_stream);
+        h->def_stream = nullptr;
+        return false;
+      }
     }
     return true;
   }
@@ -160,6 +169,9 @@ struct HipOps {
     return GPS_OK;
   }
   int chain_join(unsigned long long t) {
+    // diagnostics ("la_fault_inject" = k): the k-th join from now waits for a ticket that never comes, i.e. takes the
+    // time-out path of a missed hand-over (tests/test_gpu_kernels.py::test_lookahead_timeout_is_retried)
+    if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) t = ~0ull;
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
   }
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
@@ -176,8 +188,33 @@ static int read_info(gps_handle_t h, int* d_info, int* info) {
   if (h->dLaFlags.p) GPS_HIP(h, hipMemcpyAsync(&la_timeouts, (unsigned long long*)h->dLaFlags.p + 2, 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (info) *info = (v == INT_MAX) ? 0 : v;
-  if (la_timeouts) return gps_fail(h, GPS_ERR_STATE, "look-ahead hand-over timed out (result invalid)");
+  if (la_timeouts) {
+    // not sticky: the counter is cleared (stream-ordered) so that the handle is usable again; the entry point re-runs
+    // the evaluation once without look-ahead (with_la_retry)
+    (void)hipMemsetAsync((unsigned long long*)h->dLaFlags.p + 2, 0, 8, h->stream);
+    h->la_timed_out = true;
+    return gps_fail(h, GPS_ERR_STATE, "look-ahead hand-over timed out (result invalid)");
+  }
   return GPS_OK;
+}
+
+// A missed hand-over of the look-ahead (a bounded wait of la_wait_kernel that gave up) invalidates the evaluation, not
+// the handle: run the entry point's body again, once, with the look-ahead off -- same process, same handle, same
+// (host-owned, unchanged) inputs -- and count it.
+template <class F>
+static int with_la_retry(gps_handle_t h, F&& body) {
+  if (h) h->la_timed_out = false;
+  int rc = body();
+  if (h && rc == GPS_ERR_STATE && h->la_timed_out) {
+    h->la_timed_out = false;
+    h->la_retries++;
+    (void)hipDeviceSynchronize();
+    const int saved = h->potrf_lookahead;
+    h->potrf_lookahead = 0;
+    rc = body();
+    h->potrf_lookahead = saved;
+  }
+  return rc;
 }
 
 static int stage_time(gps_handle_t h, int a, int b, double* out) {
@@ -229,6 +266,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
   if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
   h->dLaFlags.release();
+  h->ring.release();
   if (h->ev_la) (void)hipEventDestroy(h->ev_la);
   delete h;
   return GPS_OK;
@@ -264,6 +302,11 @@ extern "C" int gps_profile_reset(gps_handle_t h) {
 extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launches, double* ms,
                                double* flops, double* bytes) {
   if (!h || !klass) return GPS_ERR_ARG;
+  if (strcmp(klass, "lookahead_retries") == 0) {      // evaluations re-run without look-ahead after a missed hand-over
+    if (launches) *launches = h->la_retries;
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   gps_profile_collect(h);
   for (int i = 0; i < KC_COUNT; ++i) {
@@ -295,6 +338,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
+  if (strcmp(key, "la_fault_inject") == 0) { h->la_fault_inject = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
@@ -489,6 +533,7 @@ extern "C" int gps_kmat(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
 
 // ---- tf.cholesky on a host matrix ----------------------------------------------------------------------
 extern "C" int gps_potrf(gps_handle_t h, const double* A, int64_t n, double* L_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !A || !L_out || n < 0) return gps_fail(h, GPS_ERR_ARG, "gps_potrf: bad argument");
   if (info) *info = 0;
   if (n == 0) return GPS_OK;
@@ -512,11 +557,13 @@ extern "C" int gps_potrf(gps_handle_t h, const double* A, int64_t n, double* L_o
   if (rc) return rc;
   GPS_HIP(h, hipMemcpyAsync(L_out, h->dTmp2.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, h->stream));
   return read_info(h, d_info, info);
+  });
 }
 
 // ---- tf.matrix_triangular_solve on host matrices ---------------------------------------------------------
 extern "C" int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double* B, int64_t nrhs,
                               int trans) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !L || !B || n < 0 || nrhs < 0) return gps_fail(h, GPS_ERR_ARG, "gps_trsm_lower: bad argument");
   if (n == 0 || nrhs == 0) return GPS_OK;
   GPS_HIP(h, hipSetDevice(h->device));
@@ -559,6 +606,7 @@ extern "C" int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double
   GPS_HIP(h, hipMemcpyAsync(B, h->dTmp2.p, (size_t)n * nrhs * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
+  });
 }
 
 // ---- GPR ------------------------------------------------------------------------------------------------
@@ -634,6 +682,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
 
 extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
                            const double* resid, int64_t r, double* lml, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !lml) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
   int linfo = 0;
@@ -658,6 +707,7 @@ extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   h->stage_ms[3] = 0.0;
   stage_time(h, 0, 3, &h->stage_ms[4]);
   return GPS_OK;
+  });
 }
 
 // LML and its gradient: d/d(kernel parameter slots), d/d(noise variance), d/d(resid) = -K_y^-1 resid ... see header
@@ -713,6 +763,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
                                double noise_var, const double* resid, int64_t r, const double* Xnew,
                                int64_t n_new, int full_cov, int refactor, double* mean_out,
                                double* var_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !Xnew || n_new <= 0 || !var_out || (r > 0 && !mean_out))
     return gps_fail(h, GPS_ERR_ARG, "gps_gpr_predict: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
@@ -783,6 +834,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
   stage_time(h, 3, 4, &h->stage_ms[3]);
   stage_time(h, 0, 4, &h->stage_ms[4]);
   return GPS_OK;
+  });
 }
 
 // ---- conditionals -------------------------------------------------------------------------------------
@@ -1037,6 +1089,7 @@ extern "C" int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int 
                                int64_t n_new, const double* f, int64_t k, const double* q_sqrt,
                                int q_sqrt_ndim, int white, int full_cov, double* fmean_out,
                                double* fvar_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !Z || !Xnew || !f || !fmean_out || !fvar_out || m <= 0 || n_new <= 0 || k <= 0 || d_all <= 0)
     return gps_fail(h, GPS_ERR_ARG, "gps_conditional: bad argument");
   if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
@@ -1074,12 +1127,14 @@ extern "C" int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int 
     if (rc) return rc;
   }
   return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+  });
 }
 
 extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const double* Kmm,
                                     const double* Knn, int64_t m, int64_t n_new, const double* f,
                                     int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
                                     int full_cov, double* fmean_out, double* fvar_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !Kmn || !Kmm || !Knn || !f || !fmean_out || !fvar_out || m <= 0 || n_new <= 0 || k <= 0)
     return gps_fail(h, GPS_ERR_ARG, "gps_base_conditional: bad argument");
   if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
@@ -1124,6 +1179,7 @@ extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const dou
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   return conditional_tail(h, c, f, q_sqrt, q_sqrt_ndim, white, full_cov, fmean_out, fvar_out, info);
+  });
 }
 
 // ---- SVGP bound: models/svgp.py:108-125 for the Gaussian likelihood ----------------------------------------------
@@ -1133,6 +1189,7 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
                              const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
                              double noise_var, double scale, double* elbo, double* kl_out, double* var_exp_sum,
                              int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !Z || !X || !yres || !q_mu || !q_sqrt || !elbo || m <= 0 || n <= 0 || k <= 0 || d_all <= 0 || !(noise_var > 0.0))
     return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: bad argument");
   if (q_sqrt_ndim != 2 && q_sqrt_ndim != 3) return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: q_sqrt_ndim must be 2 or 3");
@@ -1169,12 +1226,14 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
   if (kl_out) *kl_out = sv.kl;
   *elbo = ve * scale - sv.kl;
   return GPS_OK;
+  });
 }
 
 // ---- KL[q || p], q = N(q_mu, q_sqrt q_sqrt^T), p = N(0, K) or N(0, I): kullback_leiblers.py:26-105 -------------------
 // K host [m, m] or NULL; q_mu host [m, k]; q_sqrt host [m, k] (ndim 2) or [k, m, m] (ndim 3, as gps_conditional).
 extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const double* q_mu, int64_t k,
                             const double* q_sqrt, int q_sqrt_ndim, double* kl_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   if (!h || !q_mu || !q_sqrt || !kl_out || m <= 0 || k <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_gauss_kl: bad argument");
   if (q_sqrt_ndim != 2 && q_sqrt_ndim != 3) return gps_fail(h, GPS_ERR_ARG, "gps_gauss_kl: q_sqrt_ndim must be 2 or 3");
   if (info) *info = 0;
@@ -1242,6 +1301,7 @@ extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const do
   }
   *kl_out = 0.5 * (mahal - (double)(m * k) - logdet_q + trace + (double)k * 2.0 * slog);
   return GPS_OK;
+  });
 }
 
 
@@ -1685,16 +1745,20 @@ extern "C" int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
                         const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                         const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
                         double* bound_out, double* mean_out, double* var_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   return sparse_gpr_impl(h, 0, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, Xnew, n_new, full_cov,
                          bound_out, mean_out, var_out, info);
+  });
 }
 
 extern "C" int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                         const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                         const double* resid, int64_t r, const double* Xnew, int64_t n_new, int full_cov,
                         double* bound_out, double* mean_out, double* var_out, int* info) {
+  return with_la_retry(h, [&]() -> int {
   return sparse_gpr_impl(h, 1, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, Xnew, n_new, full_cov,
                          bound_out, mean_out, var_out, info);
+  });
 }
 
 extern "C" int gps_sparse_last_terms(gps_handle_t h, double* out5) {

@@ -41,6 +41,40 @@ struct DevBuf {
   double* d() const { return (double*)p; }
 };
 
+// ---- small host -> device uploads without a stream synchronisation --------------
+// Kernel programs, feature tables and network weights live in host vectors that die when the call returns; copying
+// them through a ring of pinned slots (one event per slot) lets the call return -- and the stream be captured -- without
+// waiting for the copy.
+struct PinnedRing {
+  static const int SLOTS = 8;
+  void* p[SLOTS] = {}; size_t cap[SLOTS] = {}; hipEvent_t ev[SLOTS] = {}; bool busy[SLOTS] = {}; int next = 0;
+  hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    const int i = next; next = (next + 1) % SLOTS;
+    hipError_t e;
+    if (busy[i]) { e = hipEventSynchronize(ev[i]); if (e != hipSuccess) return e; busy[i] = false; }
+    if (cap[i] < bytes) {
+      if (p[i]) { (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; }
+      const size_t want = (bytes + 4095) & ~(size_t)4095;
+      e = hipHostMalloc(&p[i], want, hipHostMallocDefault); if (e != hipSuccess) return e;
+      cap[i] = want;
+    }
+    if (!ev[i]) { e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (e != hipSuccess) return e; }
+    memcpy(p[i], src, bytes);
+    e = hipMemcpyAsync(dst, p[i], bytes, hipMemcpyHostToDevice, s); if (e != hipSuccess) return e;
+    e = hipEventRecord(ev[i], s); if (e != hipSuccess) return e;
+    busy[i] = true;
+    return hipSuccess;
+  }
+  void release() {
+    for (int i = 0; i < SLOTS; ++i) {
+      if (busy[i]) (void)hipEventSynchronize(ev[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      if (p[i]) (void)hipHostFree(p[i]);
+      p[i] = nullptr; ev[i] = nullptr; cap[i] = 0; busy[i] = false;
+    }
+  }
+};
+
 // ---- per-kernel-class accounting -------------------------------------------
 enum { KC_GEMM = 0, KC_POTRF_BASE, KC_KMAT, KC_TRSV, KC_REDUCE, KC_OTHER, KC_COUNT };
 static const char* const kc_names[KC_COUNT] = {"gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"};
@@ -82,6 +116,10 @@ struct gps_handle_s {
   hipEvent_t ev_la = nullptr;
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
+  int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
+  bool la_timed_out = false;                   // set by read_info when a hand-over wait gave up: the entry point re-runs without look-ahead
+  long long la_retries = 0;                    // evaluations re-run that way (gps_profile_get "lookahead_retries")
+  PinnedRing ring;
   int potrf_follower_cols = 512;               // ... in pieces of at least this many columns
   int potrf_follower = 1;                      // the parent's panel solve follows the sweep on the side stream (blocked.hpp)
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt

@@ -450,8 +450,7 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
   if (kc.has_nkn) {
     const size_t wbytes = kc.W.size() * 8;
     GPS_HIP(h, h->dNkn.ensure(wbytes + 64));
-    GPS_HIP(h, hipMemcpyAsync(h->dNkn.p, kc.W.data(), wbytes, hipMemcpyHostToDevice, h->stream));
-    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    GPS_HIP(h, h->ring.upload(h->dNkn.p, kc.W.data(), wbytes, h->stream));
     const int rows_f = kc.net.ftot + kc.net.nnorm;
     const size_t lds = ((size_t)2 * rows_f * KT + (size_t)kc.net.n_layers * NKN_W * (NKN_W + 1)) * 8;
     int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&nkn_tile_kernel), 160 * 1024);
@@ -526,9 +525,9 @@ static int run_prep(gps_handle_t h, const KCompiled& kc, const double* dX, i64 n
   GPS_HIP(h, feat.ensure((size_t)rows * npad * sizeof(double)));
   const size_t fb = (size_t)nfeat * sizeof(PrepFeat), nb = (size_t)nnorm * sizeof(PrepNorm);
   GPS_HIP(h, tables.ensure(fb + nb + 64));
-  if (fb) GPS_HIP(h, hipMemcpyAsync(tables.p, kc.feats.data(), fb, hipMemcpyHostToDevice, h->stream));
-  if (nb) GPS_HIP(h, hipMemcpyAsync((char*)tables.p + fb, kc.norms.data(), nb, hipMemcpyHostToDevice, h->stream));
-  GPS_HIP(h, hipStreamSynchronize(h->stream));   // host vectors may die after return
+  // (through pinned slots: the host vectors die after return, and the stream is not synchronised)
+  if (fb) GPS_HIP(h, h->ring.upload(tables.p, kc.feats.data(), fb, h->stream));
+  if (nb) GPS_HIP(h, h->ring.upload((char*)tables.p + fb, kc.norms.data(), nb, h->stream));
   LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * (double)(rows + d_all));
   hipLaunchKernelGGL(kmat_prep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream,
                      dX, n, d_all, npad, (const PrepFeat*)tables.p,

@@ -116,6 +116,7 @@ class TorchComm(object):
         self.mode = mode or ("scatter_allgather" if self.backend == "nccl" else "broadcast")
         self.bytes_sent = 0            # payload bytes this rank put on the wire (diagnostics for bench.py)
         self.exchanges = 0
+        self._scratch = None
 
     def exchange(self, tensor, src):
         """Make `tensor` (complete on rank `src`) complete on every rank; returns an object with wait()."""
@@ -133,9 +134,16 @@ class TorchComm(object):
         chunk = n // P
         body = tensor[: chunk * P]
         mine = body[self.rank * chunk:(self.rank + 1) * chunk]
-        parts = [body[i * chunk:(i + 1) * chunk] for i in range(P)] if self.rank == src else None
+        if self.rank == src:
+            # the root's own chunk is already where it belongs: let the scatter deliver it into a scratch chunk rather
+            # than onto itself
+            if self._scratch is None or self._scratch.numel() < chunk or self._scratch.device != tensor.device:
+                self._scratch = tensor.new_empty(chunk)
+            parts, landing = [body[i * chunk:(i + 1) * chunk] for i in range(P)], self._scratch[:chunk]
+        else:
+            parts, landing = None, mine
         self.bytes_sent += 8 * chunk * (P - 1) * (2 if self.rank == src else 1)
-        works = [dist.scatter(mine, scatter_list=parts, src=src, group=self.group, async_op=True)]
+        works = [dist.scatter(landing, scatter_list=parts, src=src, group=self.group, async_op=True)]
         if self.backend != "nccl":
             works[-1].wait()          # gloo runs queued work on a thread pool: keep the two phases ordered
         works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
@@ -201,6 +209,7 @@ class HipPanelOps(object):
         import torch
         self.h = handle
         self.torch = torch
+        self.nparts = max(int(nparts), 1)
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         self.chain = torch.cuda.Stream(priority=hi)
         self.bulk = torch.cuda.Stream(priority=lo) if two_lanes else self.chain
@@ -242,7 +251,8 @@ class HipPanelOps(object):
         self.h.dist_panel_factor(t, buf)
 
     def message(self, t, buf):
-        return self.bufs[buf][: self.h.dist_msg_doubles(t)]
+        n = self.h.dist_msg_doubles(t)
+        return self.bufs[buf][: -(-n // self.nparts) * self.nparts]      # whole chunks for the scatter + all-gather
 
     def unpack(self, t, buf):
         self.h.dist_unpack(t, buf)

@@ -57,7 +57,7 @@ def test_bench_two_ranks_block_column_gloo():
     assert len(dd["stage_ms_per_rank_last_step"]) == 2
     n_panels = 4096 // 256
     rows = lambda j: 4096 + 128 - j * 256
-    payload = sum(rows(j) * 256 + 2 * 2 * 128 * 128 + 4 for j in range(n_panels)) * 8        # every panel to the one other rank
+    payload = sum(-(-(rows(j) * 256 + 2 * 2 * 128 * 128 + 4) // 2) * 2 for j in range(n_panels)) * 8   # every panel to the one other rank
     assert abs(dd["payload_bytes_per_eval_all_ranks"] - payload) <= 1e-6 * payload
     assert "block-cyclic" in out["config"]["parallelism"]
     assert out["independent_evals"]["scaling"] == "weak" and out["independent_evals"]["evals_per_s_all_gpus"] > 0

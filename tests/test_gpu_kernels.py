@@ -186,3 +186,70 @@ def test_trsm_lower(handle, n, nrhs, trans):
     X = handle.trsm_lower(L, B, trans=trans)
     ref = sl.solve_triangular(L, B, lower=True, trans='T' if trans else 'N')
     assert np.abs(X - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_trsm_leaf_refined_residual(handle):
+    """csrc/trsm_leaf.hip: the refined 128-column leaf (three triangular MFMA products in one launch) solves
+    X L11^T = B and X L11 = B to a residual at rounding level for every row-tile size the launcher picks."""
+    for m in (128, 4096, 8192, 16384):
+        for upper in (False, True):
+            _, res = handle.diag_trsm_leaf(m, 1, upper, reps=2)
+            assert res <= 5e-16, (m, upper, res)
+    _, res0 = handle.diag_trsm_leaf(1024, 0, False, reps=2)
+    assert res0 <= 5e-15
+
+
+def test_lookahead_timeout_is_retried(handle):
+    """A missed hand-over of the look-ahead (here: injected -- the k-th join waits for a ticket that never comes and gives
+    up after its 1 s bound) must not surface as an error: the evaluation is re-run once without look-ahead on the same
+    handle, the result is the ordinary one, the event is counted, and the next evaluation uses the look-ahead again."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    n, d = 8192, 4
+    X, Y, _ = orc.synthetic_gpr_data(n, d, 0, seed=11)
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, lengthscales=1.5), obs_var=0.1)
+    ref = m.compute_log_likelihood()
+    handle.set_option("potrf_lookahead", 0)
+    try:
+        ref_plain = m.compute_log_likelihood()             # (other launch shapes: equal to rounding, not bit for bit)
+    finally:
+        handle.set_option("potrf_lookahead", 1)
+    assert abs(ref_plain - ref) <= 1e-12 * abs(ref)
+    before = handle.profile_get("lookahead_retries")["launches"]
+    handle.set_option("la_fault_inject", 3)
+    try:
+        got = m.compute_log_likelihood()
+    finally:
+        handle.set_option("la_fault_inject", 0)
+    assert got == ref_plain                                # what came back IS the evaluation without look-ahead
+    assert handle.profile_get("lookahead_retries")["launches"] == before + 1
+    assert m.compute_log_likelihood() == ref               # and the look-ahead is back on afterwards
+    assert handle.profile_get("lookahead_retries")["launches"] == before + 1
+
+
+def test_lookahead_stress_mixed_sizes_two_handles():
+    """1000 evaluations of mixed sizes, shuffled, alternating between two handles on the one device: not a single
+    hand-over time-out (every evaluation equals the first one of its size bit for bit, the retry counter stays 0)."""
+    import gpflowSlim as gpf
+    from gpflowSlim import _backend as be
+    rng = np.random.default_rng(5)
+    sizes = [300, 1100, 2048, 2500, 4096, 5000]
+    hs = [be.Handle(0), be.Handle(0)]
+    data, ref = {}, {}
+    kern = gpf.kernels.Matern32(3, variance=1.2, lengthscales=1.1)
+    prog = kern._program(3)
+    for n in sizes:
+        X = rng.standard_normal((n, 3))
+        data[n] = (X, np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1)))
+    order = rng.choice(sizes, 1000)
+    try:
+        for i, n in enumerate(order):
+            h = hs[i % 2]
+            X, Y = data[int(n)]
+            h.gpr_set_data(X, ("stress", int(n), i % 2))
+            v = h.gpr_lml(prog, 0.1, Y)
+            assert ref.setdefault(int(n), v) == v, (i, n, v, ref[int(n)])
+        assert all(h.profile_get("lookahead_retries")["launches"] == 0 for h in hs)
+    finally:
+        for h in hs:
+            h.close()
