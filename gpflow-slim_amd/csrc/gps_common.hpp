@@ -312,6 +312,11 @@ int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int
 int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                     double* grad_slots_host, double* grad_noise_host);
+// grad_general.hip : programs grad.hip does not take (more than 4 primitives, neural-kernel-network layers)
+int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int* n_slots);
+int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                            i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                            double* grad_slots_host, double* grad_noise_host);
 // diag.hip
 int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);
 int gps_run_gemm_timeline(gps_handle_t h, int op, int lower, i64 m, i64 n, i64 k, int reps, long long* stamps_out,

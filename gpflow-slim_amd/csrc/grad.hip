@@ -333,7 +333,18 @@ __global__ __launch_bounds__(256) void grad_kernel(GArgs a, GProg P) {
 // ---- host side ------------------------------------------------------------------------------------
 #define GRAD_BLOCKS 2048
 
+// programs this file's kernel does not take go to grad_general.hip
+static bool grad_needs_general(const gps_kern_node_t* prog, int n_nodes) {
+  int prims = 0;
+  for (int i = 0; i < n_nodes; ++i) {
+    if (prog[i].op >= GPS_K_NKN_LINROW) return true;
+    if (prog[i].op != GPS_K_ADD && prog[i].op != GPS_K_MUL) ++prims;
+  }
+  return prims > G_MAXP;
+}
+
 int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int* n_slots) {
+  if (grad_needs_general(prog, n_nodes)) return gps_grad_general_slots(h, prog, n_nodes, n_slots);
   int s = 0;
   for (int i = 0; i < n_nodes; ++i) {
     switch (prog[i].op) {
@@ -352,6 +363,8 @@ int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int
 int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                     double* grad_slots_host, double* grad_noise_host) {
+  if (grad_needs_general(prog, n_nodes))
+    return gps_launch_grad_general(h, prog, n_nodes, dX, n, d_all, npad, dKinv, ldk, dA, lda, r, grad_slots_host, grad_noise_host);
   GProg P;
   std::vector<GPrepFeat> feats;
   std::vector<double> ls_of_slot;          // lengthscale that divides a per-dim slot

@@ -100,7 +100,7 @@ class GPR(GPModel):
             if idx is None:
                 grads[id(param)] += g
             else:
-                grads[id(param)][idx] += g
+                grads[id(param)].reshape(-1)[idx] += g          # index into the flattened parameter
         grads[id(self.likelihood._variance)] += gnoise
         # mean function: d LML / d m(X) = K_y^-1 (Y - m) ; Zero has no parameters
         from ..mean_functions import Constant as _MConst, Linear as _MLin

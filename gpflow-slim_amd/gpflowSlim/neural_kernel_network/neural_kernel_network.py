@@ -31,4 +31,15 @@ class NeuralKernelNetwork(Kernel):
         return nodes + self._nknWrapper._nodes()
 
     def _grad_layout(self, d_all):
-        raise NotImplementedError("gradients of NeuralKernelNetwork are not available yet")
+        """Slot order of csrc/grad_general.hip: the primitives' slots, then per Linear layer and output o the row
+        W[o, :] and bias[o] (the parameters the reference trains through autodiff,
+        neural_kernel_network_wrapper.py:90-120)."""
+        out = []
+        for kern in self._primitive_kernels:
+            out.extend(kern._grad_layout(d_all))
+        for layer in self._nknWrapper._layers:
+            if hasattr(layer, "_weights"):
+                for o in range(layer.output_dim):
+                    out.extend((layer._weights, o * layer.input_dim + j) for j in range(layer.input_dim))
+                    out.append((layer._bias, o))
+        return out

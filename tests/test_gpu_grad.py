@@ -128,11 +128,135 @@ def test_gradient_too_many_primitives_is_a_loud_error(handle):
     import gpflowSlim as gpf
     d = 2
     k = gpf.kernels
-    kern = k.RBF(d) + k.Matern32(d) + k.Matern52(d) + k.Periodic(d) + k.Matern12(d)
+    kern = (k.RBF(d) + k.Matern32(d) + k.Matern52(d) + k.Periodic(d) + k.Matern12(d) + k.RBF(d, lengthscales=2.0)
+            + k.Matern32(d, lengthscales=0.5) + k.White(d) + k.Constant(d))
     X = np.random.default_rng(0).standard_normal((40, d)); Y = np.ones((40, 1))
     m = gpf.models.GPR(X, Y, kern)
-    with pytest.raises(RuntimeError, match="more than 4 primitive"):
+    with pytest.raises(RuntimeError, match="more than 8 primitive"):
         m.compute_log_likelihood_and_gradients()
+
+
+def _fd_check(m, grads, tol=1e-5, h=1e-5, max_per_param=6):
+    """central differences of the product's own LML through the unconstrained parameters"""
+    rng = np.random.default_rng(0)
+    for p, g in grads:
+        flat = np.atleast_1d(p.vf_val).ravel().copy()
+        gflat = np.atleast_1d(g).ravel()
+        idxs = range(flat.size) if flat.size <= max_per_param else rng.choice(flat.size, max_per_param, replace=False)
+        for i in idxs:
+            x0 = flat[i]
+            flat[i] = x0 + h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fp = m.compute_log_likelihood()
+            flat[i] = x0 - h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fm = m.compute_log_likelihood()
+            flat[i] = x0; p.assign_unconstrained(flat.reshape(p.vf_val.shape))
+            fd = (fp - fm) / (2 * h)
+            assert abs(gflat[i] - fd) <= tol * max(1.0, abs(fd)), (p.name, i, gflat[i], fd)
+
+
+def test_gradient_six_primitive_sum_product(handle):
+    """More than four primitives (csrc/grad_general.hip): oracle (central differences of the oracle's K) and finite
+    differences of the product's own LML."""
+    import gpflowSlim as gpf
+    d = 3
+    k = gpf.kernels
+    rng = np.random.default_rng(8)
+    n = 180
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, 1))) + 0.1 * rng.standard_normal((n, 1))
+    ls = np.linspace(0.8, 1.7, d)
+    kern = (k.RBF(d, variance=1.3, lengthscales=ls, ARD=True) * k.Periodic(d, period=2.5, variance=0.8, lengthscales=1.2)
+            + k.Matern52(d, variance=0.9, lengthscales=1.4) * k.Matern12(1, variance=0.7, lengthscales=2.0, active_dims=[1])
+            + k.Matern32(d, variance=1.1, lengthscales=1.3) + k.White(d, variance=0.2))
+    theta = np.concatenate([[c(1.3)], c(ls), [c(0.8), c(1.2), c(2.5)], [c(0.9), c(1.4)], [c(0.7), c(2.0)], [c(1.1), c(1.3)], [c(0.2)]])
+
+    def fn(t):
+        return {"type": "sum", "children": [
+            {"type": "product", "children": [{"type": "rbf", "variance": t[0], "lengthscales": t[1:1 + d], "input_dim": d},
+                                             {"type": "periodic", "variance": t[1 + d], "lengthscales": t[2 + d], "period": t[3 + d], "input_dim": d}]},
+            {"type": "product", "children": [{"type": "matern52", "variance": t[4 + d], "lengthscales": t[5 + d], "input_dim": d},
+                                             {"type": "matern12", "variance": t[6 + d], "lengthscales": t[7 + d], "input_dim": 1, "active_dims": [1]}]},
+            {"type": "matern32", "variance": t[8 + d], "lengthscales": t[9 + d], "input_dim": d},
+            {"type": "white", "variance": t[10 + d]}]}
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.15)
+    lml, grads = m.compute_log_likelihood_and_gradients()
+    ref_lml = orc.gpr_lml(fn(theta), X, Y, c(0.15))
+    assert abs(lml - ref_lml) <= 1e-8 * abs(ref_lml)
+    g_ref, gnoise_ref, _ = orc.gpr_lml_grad(fn, theta, X, Y, c(0.15))
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == g_ref.shape
+    assert np.abs(got - g_ref).max() <= 2e-6 * max(1.0, np.abs(g_ref).max()), (got, g_ref)
+    _fd_check(m, grads)
+
+
+def _nkn_model(gpf, d, act, n, seed):
+    from test_gpu_parity import _nkn_case
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, 1))) + 0.1 * rng.standard_normal((n, 1))
+    kern, spec = _nkn_case(gpf, d, act)
+    return gpf.models.GPR(X, Y, kern, obs_var=0.1), spec, X, Y
+
+
+@pytest.mark.parametrize("act", [False, True])
+def test_nkn_gradient_matches_oracle_and_finite_differences(handle, act):
+    """Neural Kernel Network (6 primitives -> Linear 6->8 -> Product(2) -> Linear 4->2 -> [exp] -> Linear 2->1): gradient
+    w.r.t. every Linear weight and bias (neural_kernel_network_wrapper.py:90-120 trains them through autodiff) and every
+    primitive parameter, against the oracle (1/2 tr(W dK) with dK by central differences of the oracle's own network
+    forward) and against finite differences of the product's LML."""
+    import copy
+    import gpflowSlim as gpf
+    d, n = 3, 160
+    m, spec, X, Y = _nkn_model(gpf, d, act, n, 31)
+    noise = c(0.1)
+    lml, grads = m.compute_log_likelihood_and_gradients()
+    assert abs(lml - orc.gpr_lml(spec, X, Y, noise)) <= 1e-8 * abs(lml)
+    # oracle: perturb the entries of the spec in kern.parameters order (wrapper parameters first, then the primitives')
+    wrapper = m.kern._nknWrapper
+    lin_idx = [i for i, l in enumerate(spec["layers"]) if l[0] == "linear"]
+    handles = []            # (getter / setter over a deep-copied spec) per scalar parameter, kern.parameters order
+    for li in lin_idx:
+        Wl, bl = spec["layers"][li][1], spec["layers"][li][2]
+        handles += [("W", li, idx) for idx in np.ndindex(Wl.shape)] + [("b", li, (o,)) for o in range(bl.size)]
+    for pi, ps in enumerate(spec["primitives"]):
+        handles.append(("pv", pi, None))
+        if "lengthscales" in ps:
+            handles += [("pl", pi, q) for q in range(np.atleast_1d(ps["lengthscales"]).size)]
+        if "period" in ps:
+            handles.append(("pp", pi, None))
+    theta = []
+    for kind, a, idx in handles:
+        if kind == "W": theta.append(spec["layers"][a][1][idx])
+        elif kind == "b": theta.append(spec["layers"][a][2][idx])
+        elif kind == "pv": theta.append(spec["primitives"][a]["variance"])
+        elif kind == "pl": theta.append(np.atleast_1d(spec["primitives"][a]["lengthscales"])[idx])
+        else: theta.append(spec["primitives"][a]["period"])
+    theta = np.array(theta, dtype=np.float64)
+
+    def fn(t):
+        sp_ = copy.deepcopy(spec)
+        layers = [list(l) for l in sp_["layers"]]
+        for (kind, a, idx), v in zip(handles, t):
+            if kind == "W": layers[a][1] = np.array(layers[a][1], dtype=np.float64); layers[a][1][idx] = v
+            elif kind == "b": layers[a][2] = np.array(layers[a][2], dtype=np.float64); layers[a][2][idx] = v
+            elif kind == "pv": sp_["primitives"][a]["variance"] = v
+            elif kind == "pl":
+                ls_ = np.array(np.atleast_1d(sp_["primitives"][a]["lengthscales"]), dtype=np.float64); ls_[idx] = v
+                sp_["primitives"][a]["lengthscales"] = ls_ if ls_.size > 1 else float(ls_[0])
+            else: sp_["primitives"][a]["period"] = v
+        sp_["layers"] = [tuple(l) for l in layers]
+        return sp_
+    g_ref, gnoise_ref, _ = orc.gpr_lml_grad(fn, theta, X, Y, noise)
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == g_ref.shape, (got.shape, g_ref.shape)
+    assert np.abs(got - g_ref).max() <= 2e-6 * max(1.0, np.abs(g_ref).max()), (np.abs(got - g_ref).max(), got, g_ref)
+    _fd_check(m, grads, max_per_param=4)
+
+
+def test_nkn_gpr_fit_lowers_the_objective(handle):
+    """NeuralKernelNetwork + GPR.optimize(): the fit the reference's examples run (AdamOptimizer.minimize(objective),
+    examples/gpr.py:53-54) is possible on the analytic gradients."""
+    import gpflowSlim as gpf
+    m, spec, X, Y = _nkn_model(gpf, 3, False, 250, 7)
+    start = m.objective
+    final = m.optimize(max_iter=40)
+    assert final < start - 10.0, (start, final)
 
 
 @pytest.mark.gpu
