@@ -42,19 +42,54 @@ struct Blocked {
   // sweep, during which the GPU is otherwise mostly idle.  The parent then skips that part of its trsm_rec.
   struct Deferred { double* B; i64 ldb, dm, dn; bool issued; };
 
+  // The forward substitution of the likelihood (alpha = L^-1 (Y - m), densities.py:82) FOLLOWS the factorisation: as
+  // soon as a diagonal block is final its trsv_rec is issued on a stream of its own (Ops::y_*), as soon as the block
+  // below it is solved the gemv that carries alpha on into the rows below -- ~500 launch-latency-bound kernels that
+  // then run beside the GEMMs of the rest of the factorisation instead of after it.  y: right-hand sides of the
+  // current column range, [r][ldy], in place.
+  struct YFollow { double* y; i64 ldy, r; };
+
   // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
   // row0: global row of A's first row (for info reporting)
-  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr) {
+  // e: AUGMENTED rows -- e more rows stored directly below A (same leading dimension, a multiple of 128) that are not
+  //    factored but solved along:  on return they hold  E L^-T.  With E = (Y - m)^T this is alpha^T = (L^-1 (Y - m))^T
+  //    (densities.py:82): the forward substitution of the likelihood costs no pass of its own -- the rows ride through
+  //    the panel solves and trailing updates of the right spine of the recursion (where "the rows below" are contiguous
+  //    with them), as the e extra rows of a few GEMMs.
+  // issue  y[0:n] <- L^-1 y[0:n]  of a block that the calling stream has just finished
+  int y_block(const double* L, i64 ldl, i64 n, i64 blk0, const YFollow* yf) {
+    if (!yf) return 0;
+    int rc = ops.y_open();
+    if (rc) return rc;
+    rc = ops.y_prepare(blk0, n / GPS_TILE);          // (whatever the leaves of the substitution need of these blocks)
+    if (!rc) rc = trsv_rec(L, ldl, n, blk0, yf->y, yf->ldy, yf->r);
+    const int rc2 = ops.y_close();
+    return rc ? rc : rc2;
+  }
+
+  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr, i64 e = 0, const YFollow* yf = nullptr) {
     if (n <= 0) return 0;
-    if (n == GPS_TILE) return ops.potrf_base(A, lda, blk0, row0);
-    if (n <= ops.rl_max()) return ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0);
+    if (n == GPS_TILE) {
+      int rc = ops.potrf_base(A, lda, blk0, row0);
+      if (rc) return rc;
+      if (e > 0) { rc = ops.trsm_base(blk0, 0, A + GPS_TILE * lda, lda, e, A, lda); if (rc) return rc; }
+      return y_block(A, lda, n, blk0, yf);
+    }
+    if (n <= ops.rl_max()) {
+      int rc = ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0, nullptr, 0, 0, e) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0, e);
+      if (rc) return rc;
+      return y_block(A, lda, n, blk0, yf);
+    }
     const i64 n1 = split(n), n2 = n - n1;
+    const i64 m2 = n2 + e;                          // rows below A11: A21 and, under it, the augmented rows
     double* A21 = A + n1 * lda;
     double* A22 = A21 + n1;
     int rc;
     if (n1 > GPS_TILE && n1 <= ops.rl_max() && ops.rl_group() > 1 && ops.follower()) {
       // A11 is factored by the sweep: the solve of A21 against it follows the sweep on the side stream
-      rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, n2);
+      rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, m2);
+      if (rc) return rc;
+      rc = y_block(A, lda, n1, blk0, yf);
       if (rc) return rc;
       if (dj && dj->dn == n1) {
         // the first n1 columns are final: the parent's rows below can be solved against them from now on
@@ -68,25 +103,35 @@ struct Blocked {
     } else {
       // a child whose own first half is a sweep can take the first part of this node's panel solve with it
       const i64 n1a = split(n1);
-      Deferred job{A21, lda, n2, n1a, false};
+      Deferred job{A21, lda, m2, n1a, false};
       const bool hand_down = n1 > ops.rl_max() && n1a > GPS_TILE && n1a <= ops.rl_max() && ops.rl_group() > 1 && ops.follower() && ops.deferred();
-      rc = potrf_rec(A, lda, n1, blk0, row0, hand_down ? &job : nullptr);
+      rc = potrf_rec(A, lda, n1, blk0, row0, hand_down ? &job : nullptr, 0, yf);
       if (rc) return rc;
       if (hand_down && job.issued) {
         // trsm_rec(A, n1) = trsm_rec(first n1a columns) [done on the deferred stream] ; update ; trsm_rec(the others)
         rc = ops.deferred_join();
         if (rc) return rc;
-        rc = ops.gemm(0, 0, n2, n1 - n1a, n1a, A21, lda, A + n1a * lda, lda, A21 + n1a, lda);
+        rc = ops.gemm(0, 0, m2, n1 - n1a, n1a, A21, lda, A + n1a * lda, lda, A21 + n1a, lda);
         if (rc) return rc;
-        rc = trsm_rec(A + n1a * lda + n1a, lda, n1 - n1a, blk0 + n1a / GPS_TILE, A21 + n1a, lda, n2);
+        rc = trsm_rec(A + n1a * lda + n1a, lda, n1 - n1a, blk0 + n1a / GPS_TILE, A21 + n1a, lda, m2);
       } else {
-        rc = trsm_rec(A, lda, n1, blk0, A21, lda, n2);
+        rc = trsm_rec(A, lda, n1, blk0, A21, lda, m2);
       }
       if (rc) return rc;
     }
-    rc = ops.gemm(/*op sub*/ 0, /*lower*/ 1, n2, n2, n1, A21, lda, A21, lda, A22, lda);
+    YFollow y2{nullptr, 0, 0};
+    if (yf) {
+      // L21 is final (the calling stream's order): carry alpha_1 on into the rows below,  y2 -= L21 alpha_1
+      y2 = YFollow{yf->y + n1, yf->ldy, yf->r};
+      rc = ops.y_open();
+      if (rc) return rc;
+      rc = ops.gemv_sub(A21, lda, n2, n1, yf->y, y2.y, yf->ldy, yf->r);
+      const int rc2 = ops.y_close();
+      if (rc || rc2) return rc ? rc : rc2;
+    }
+    rc = ops.gemm(/*op sub*/ 0, /*lower (trapezoid when e > 0)*/ 1, m2, n2, n1, A21, lda, A21, lda, A22, lda);
     if (rc) return rc;
-    return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1);
+    return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1, nullptr, e, yf ? &y2 : nullptr);
   }
 
   // Right-looking sweep over nbp-column panels.
@@ -97,19 +142,20 @@ struct Blocked {
   //  so the sweep loses against the recursion once that traffic costs more than the launches saved.
   //  nbp > 128: the same sweep with panels factored by potrf_rec and solved by trsm_rec (measured on MI355X for
   //  blocks of 4096 .. 32768 columns in panels of 256 .. 4096: always behind the recursion; not used by potrf_rec).
-  int potrf_rl(double* A, i64 lda, i64 n, i64 nbp, i64 blk0, i64 row0) {
+  int potrf_rl(double* A, i64 lda, i64 n, i64 nbp, i64 blk0, i64 row0, i64 e = 0) {
     for (i64 c = 0; c < n; c += nbp) {
       const i64 w = (n - c < nbp) ? n - c : nbp;
       double* Ajj = A + c * lda + c;
       const i64 blk = blk0 + c / GPS_TILE;
       int rc = (w == GPS_TILE) ? ops.potrf_base(Ajj, lda, blk, row0 + c) : potrf_rec(Ajj, lda, w, blk, row0 + c);
       if (rc) return rc;
-      const i64 m = n - c - w;
+      const i64 sq = n - c - w, m = sq + e;           // square remainder; rows below incl. the augmented ones
       if (m == 0) break;
       double* B = Ajj + w * lda;                      // rows below the diagonal block
       rc = trsm_rec(Ajj, lda, w, blk, B, lda, m);
       if (rc) return rc;
-      rc = ops.gemm(0, 1, m, m, w, B, lda, B, lda, B + w, lda);
+      if (sq == 0) break;
+      rc = ops.gemm(0, 1, m, sq, w, B, lda, B, lda, B + w, lda);
       if (rc) return rc;
     }
     return 0;
@@ -126,7 +172,9 @@ struct Blocked {
   // panel is solved -- so the solve follows the sweep group by group on the side stream (left-looking: one update with
   // all previous columns, K = c0, then the 128 g-column solve), where it fills the GPU the latency-bound chain leaves
   // idle.  What the side stream has not reached when the sweep ends is finished on the chain.
-  int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0, double* FB = nullptr, i64 ldfb = 0, i64 fm = 0) {
+  // e: augmented rows directly below A (see potrf_rec): every "rows below" of the sweep simply has e rows more.
+  int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0, double* FB = nullptr, i64 ldfb = 0, i64 fm = 0,
+                      i64 e = 0) {
     const i64 T = GPS_TILE;
     const bool la = (g >= 2) && ops.lookahead();
     const bool fol = la && FB != nullptr && fm > 0;
@@ -153,10 +201,11 @@ struct Blocked {
         double* Acc = A + c * lda + c;
         int rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
         if (rc) return rc;
-        const i64 m = n - c - T;                       // rows below this block
+        const i64 sq = n - c - T, m = sq + e;          // columns right of this block ; rows below it
         if (m == 0) return finish();
         rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m, Acc, lda);
         if (rc) return rc;
+        if (sq == 0) return finish();
         double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
         double* Cn = A + (c + T) * lda + (c + T);      // the next block column / the remainder
         if (i + 1 < g) {
@@ -167,9 +216,9 @@ struct Blocked {
           continue;
         }
         // ---- last panel of the group
-        const bool split = la && m - T >= ops.lookahead_min_rows();
+        const bool split = la && sq - T >= ops.lookahead_min_rows();
         if (!split && !fol) {
-          rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);            // remainder
+          rc = ops.gemm(0, 1, m, sq, g * T, P, lda, P, lda, Cn, lda);           // remainder
           if (rc) return rc;
           continue;
         }
@@ -179,13 +228,13 @@ struct Blocked {
         // first block-column update, the first launch that touches what the side stream writes.
         const unsigned long long t = ops.la_fork();      // (also when only the follower needs it)
         if (split) rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
-        else rc = ops.gemm(0, 1, m, m, g * T, P, lda, P, lda, Cn, lda);
+        else rc = ops.gemm(0, 1, m, sq, g * T, P, lda, P, lda, Cn, lda);
         if (rc) return rc;
         if (split) {
           rc = ops.side_open(t, !forked);
           forked = true;
           if (rc) return rc;
-          rc = ops.gemm(0, 1, m - T, m - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+          rc = ops.gemm(0, 1, m - T, sq - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
           if (!rc) rc = ops.side_publish_join(t);
           pending = t;
           const int rc2 = ops.side_close();

@@ -84,15 +84,14 @@ __device__ __forceinline__ void decode_tile(int id, int Tm, int Tn, int& tm, int
       tm = rem / STRIP; tn = s * STRIP + rem % STRIP;
     }
   } else {
-    // lower triangle of a T x T tile grid, strip s covers columns [8s, 8s+w),
-    // rows 8s .. T-1; inside the diagonal super-block only tn <= tm.
-    const int T = Tm;
+    // lower trapezoid of a Tm x Tn tile grid (Tm >= Tn; Tm == Tn: the lower triangle), strip s covers columns
+    // [8s, 8s+w), rows 8s .. Tm-1; inside the diagonal super-block only tn <= tm.
     int s = 0, rem = id;
     for (;;) {
       const int c0 = s * STRIP;
-      const int w = min(STRIP, T - c0);
+      const int w = min(STRIP, Tn - c0);
       const int tri = w * (w + 1) / 2;           // diagonal super-block
-      const int cnt = tri + (T - c0 - w) * w;
+      const int cnt = tri + (Tm - c0 - w) * w;
       if (rem < cnt) {
         if (rem < tri) {
           // row rr (0..w-1) of the triangle has rr+1 tiles
@@ -432,7 +431,7 @@ static int launch_variant(gps_handle_t h, const GemmArgs& g) {
 
 template <int BM, int BN, int WGM, int PIPE, int BKT = 16>
 static int dispatch_ops(gps_handle_t h, int op, int lower, const GemmArgs& g) {
-  if (BM == BN && lower) {
+  if (BM == BN && lower) {      // (M > N: lower trapezoid -- the square's lower triangle plus all rows below it)
     if (op == 0) return launch_variant<BM, BN, WGM, true, 0, PIPE, BKT>(h, g);
     if (op == 2) return launch_variant<BM, BN, WGM, true, 2, PIPE, BKT>(h, g);
     if (op == 3) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: op 3 has no lower-triangle form");
@@ -447,7 +446,7 @@ static int dispatch_ops(gps_handle_t h, int op, int lower, const GemmArgs& g) {
 template <int BM, int BN, int WGM>
 static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64 N) {
   g.Tm = (int)(M / BM); g.Tn = (int)(N / BN);
-  i64 nt = lower ? (i64)g.Tm * (g.Tm + 1) / 2 : (i64)g.Tm * g.Tn;
+  i64 nt = lower ? (i64)g.Tn * (g.Tn + 1) / 2 + (i64)(g.Tm - g.Tn) * g.Tn : (i64)g.Tm * g.Tn;
   if (g.cb_tiles > 0) {                  // needed tiles of the lower-trapezoidal block-cyclic update
     const i64 q = g.cb_stride / BM, nblocks = g.Tn / g.cb_tiles;
     nt = 0;
@@ -485,7 +484,8 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
 
 // rowpanel != 0: C may alias A (in-place B <- B W^T with N == K == 128): every workgroup then owns
 // complete rows (BN = N = 128), so it has consumed all of its A rows before it stores.
-// lower: 0 = all of C, 1 = lower triangle of a square C only, 2 = all of C with A (M == K) upper triangular:
+// lower: 0 = all of C, 1 = lower triangle of a square C only -- or, with M > N, the lower trapezoid: that triangle plus
+// every row below it (the rows of right-hand sides that ride along under a factorisation) --, 2 = all of C with A (M == K) upper triangular:
 // the zero part of A is skipped (half the flops; used by the L^-T / K^-1 recursions of the gradient).
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
@@ -496,8 +496,8 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
     if (M != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: triangular A must be square");
     lower = 0;
   }
-  if (M % 128 || N % 128 || K % BK_MIN || (lower && M != N))
-    return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16");
+  if (M % 128 || N % 128 || K % BK_MIN || (lower && M < N))
+    return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16 (lower: M >= N)");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: operands must be 16-byte aligned with even leading dimension");
   const bool rowpanel = (C == A);
@@ -510,7 +510,8 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   g.cb_tiles = 0; g.cb_stride = 0;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
-  const double t128 = lower ? 0.5 * (double)(M / 128) * (double)(M / 128 + 1) : (double)(M / 128) * (double)(N / 128);
+  const double t128 = lower ? 0.5 * (double)(N / 128) * (double)(N / 128 + 1) + (double)((M - N) / 128) * (double)(N / 128)
+                            : (double)(M / 128) * (double)(N / 128);
   const double flops = triA ? 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)   // sum_i 2 (K - 128 i)
                             : 2.0 * t128 * 128.0 * 128.0 * (double)K;
   const double bytes = t128 * (((op == 0 || op == 2) ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +

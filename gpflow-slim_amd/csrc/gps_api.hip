@@ -12,11 +12,54 @@ struct HipOps {
   double* linvT;    // optional transposed inverses (same layout) or nullptr
   int* d_info;
   int factor = 1;   // 0: matrix already holds L, only build the inverses
+  bool store_T = true;   // potrf_base also stores the transposed inverse (false: produced later by transpose_blocks)
 
   int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
     return gps_launch_potrf_base(h, A, lda, linv + blk * GPS_TILE * GPS_TILE,
-                                 linvT ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
+                                 (linvT && store_T) ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
                                  factor);
+  }
+  // ---- forward substitution following the factorisation (blocked.hpp: YFollow): its own stream, ordered behind the
+  // calling stream by one event per section
+  hipStream_t saved_stream_y = nullptr;
+  bool y_follow() {
+    if (!h->trsv_follow || !lookahead()) return false;
+    if (!h->y_stream) {
+      hipError_t e;
+      if (h->prop.multiProcessorCount == 256) {
+        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        e = hipExtStreamCreateWithCUMask(&h->y_stream, 8, mask);
+      } else {
+        e = hipStreamCreateWithFlags(&h->y_stream, hipStreamNonBlocking);
+      }
+      if (e != hipSuccess) { h->y_stream = nullptr; return false; }
+      if (!h->ev_y_join && hipEventCreateWithFlags(&h->ev_y_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(h->y_stream); h->y_stream = nullptr; return false;
+      }
+    }
+    return true;
+  }
+  int y_open() {
+    if (h->y_event_next >= h->y_events.size()) {
+      hipEvent_t ev;
+      GPS_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->y_events.push_back(ev);
+    }
+    hipEvent_t ev = h->y_events[h->y_event_next++];
+    GPS_HIP(h, hipEventRecord(ev, h->stream));
+    GPS_HIP(h, hipStreamWaitEvent(h->y_stream, ev, 0));
+    saved_stream_y = h->stream; h->stream = h->y_stream;
+    return GPS_OK;
+  }
+  int y_close() { h->stream = saved_stream_y; saved_stream_y = nullptr; return GPS_OK; }
+  int y_prepare(i64 blk0, i64 nblk) {         // the vector leaves read the transposed block inverses
+    if (store_T || !linvT) return GPS_OK;
+    return gps_launch_transpose_blocks(h, linv + blk0 * GPS_TILE * GPS_TILE, linvT + blk0 * GPS_TILE * GPS_TILE, nblk);
+  }
+  int y_join() {                              // the calling stream waits for everything issued on the y stream
+    GPS_HIP(h, hipEventRecord(h->ev_y_join, h->y_stream));
+    GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_y_join, 0));
+    return GPS_OK;
   }
   // B[m,128] = B * Linv[blk]^T  (transposed == 0)   or   B * Linv[blk]  (transposed == 1)
   // D: the diagonal block the leaf solves against (lower block of L, or the upper block of U = L^T when transposed)
@@ -263,6 +306,9 @@ extern "C" int gps_destroy(gps_handle_t h) {
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }
+  if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); }
+  for (auto e : h->y_events) (void)hipEventDestroy(e);
+  if (h->ev_y_join) (void)hipEventDestroy(h->ev_y_join);
   if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
   if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
   h->dLaFlags.release();
@@ -334,6 +380,8 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
+  if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
+  if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
@@ -346,6 +394,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
     h->la_mask_word0 = (uint32_t)value;
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
     if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); h->def_stream = nullptr; }
+    if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); h->y_stream = nullptr; }
     return GPS_OK;
   }
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
@@ -617,7 +666,7 @@ extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int6
   h->n = n; h->d_all = d_all; h->npad = gps_pad(n);
   GPS_HIP(h, h->dX.ensure((size_t)n * d_all * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dX.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
-  GPS_HIP(h, h->dK.ensure((size_t)h->npad * h->npad * 8));
+  GPS_HIP(h, h->dK.ensure((size_t)(h->npad + GPS_TILE) * h->npad * 8));      // + the augmented rows of gpr_factor
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(h->npad / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
@@ -639,13 +688,25 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     h->factor_refine = h->refine_now;
   }
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  // Augmented rows (blocked.hpp::potrf_rec; option "gpr_aug_rows"): (Y - m)^T stored as 128 more rows under K rides
+  // through the factorisation, which leaves alpha^T = (L^-1 (Y - m))^T there (densities.py:82) -- no forward-substitution
+  // pass (~4 N / 128 launch-latency-bound kernels).  Same-process A/B on MI355X: N = 2048 / 4096 / 8192 / 12288:
+  // -9 / -10 / -4.4 / -3.8 %; from N = 16384 on it loses (+0.9 %, N = 32768 +1.6 %): the extra tile row breaks the
+  // power-of-two tile counts of the big launches, whose whole rounds of 512 workgroup slots matter more than the 3 ms
+  // of trsv.  Hence automatic (-1): on below 14000 points.  (The block-column multi-GPU path always uses it.)
+  // "trsv_follow" (also off): the forward substitution issued block by block behind the factorisation on a stream of
+  // its own -- measured far worse still (see gps_common.hpp).  Default: the recursive forward substitution afterwards.
+  const bool aug = r > 0 && r <= GPS_TILE && (h->gpr_aug_rows > 0 || (h->gpr_aug_rows < 0 && np < 14000));
+  GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
+  double* const dAug = h->dK.d() + np * np;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
     GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
-    GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)r * np * 8, h->stream));
-    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, h->dAlpha.d(), np);
+    double* dst = aug ? dAug : h->dAlpha.d();
+    GPS_HIP(h, hipMemsetAsync(dst, 0, (size_t)(aug ? GPS_TILE : r) * np * 8, h->stream));
+    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dst, np);
     if (rc0) return rc0;
   }
   int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np,
@@ -656,20 +717,28 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
+  bool followed = false;
   {
     // the factorisation itself only needs the block inverses; their transposes (for the vector solves) are produced
-    // by one batched launch afterwards rather than by 128 KB of extra stores on the critical path of every block
+    // by batched launches off the critical path rather than by 128 KB of extra stores in every potrf_base.
+    // (Option "trsv_follow": alpha = L^-1 (Y - m) follows the factorisation block by block on a stream of its own.)
     HipOps fops = ops;
-    fops.linvT = nullptr;
+    fops.store_T = false;
     Blocked<HipOps> fbl(fops);
-    rc = fbl.potrf_rec(h->dK.d(), np, np, 0, 0);
+    followed = !aug && r > 0 && fops.y_follow();
+    Blocked<HipOps>::YFollow yf{h->dAlpha.d(), np, r};
+    h->y_event_next = 0;
+    rc = fbl.potrf_rec(h->dK.d(), np, np, 0, 0, nullptr, aug ? (i64)GPS_TILE : 0, followed ? &yf : nullptr);
     if (rc) return rc;
-    rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
+    if (followed) rc = fops.y_join();
+    else rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
     if (rc) return rc;
   }
   Blocked<HipOps> bl(ops);
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
-  if (r > 0) {
+  if (aug) {
+    GPS_HIP(h, hipMemcpyAsync(h->dAlpha.p, dAug, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
+  } else if (r > 0 && !followed) {
     rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);
     if (rc) return rc;
   }
@@ -1347,6 +1416,11 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
       (void)hipStreamSynchronize(h->def_stream);
       (void)hipStreamDestroy(h->def_stream);
       h->def_stream = nullptr;
+    }
+    if (h->y_stream) {
+      (void)hipStreamSynchronize(h->y_stream);
+      (void)hipStreamDestroy(h->y_stream);
+      h->y_stream = nullptr;
     }
   } else if (h->ext_stream) {
     h->stream = h->own_stream; h->ext_stream = false;

@@ -108,6 +108,13 @@ struct gps_handle_s {
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
   int potrf_deferred = 1;
+  // forward substitution of gps_gpr_lml following the factorisation on a stream of its own (blocked.hpp: YFollow).
+  // Off: measured on MI355X, ~500 small kernels dribbling in beside the 128x128 GEMM rounds (which own every register of
+  // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).
+  int trsv_follow = 0;
+  hipStream_t y_stream = nullptr;
+  std::vector<hipEvent_t> y_events; size_t y_event_next = 0;
+  hipEvent_t ev_y_join = nullptr;
   // CU mask word 0 of the side / deferred streams (bit i = CU i/8 of XCD i%8; CU c sits in shader engine c%4): 0 keeps
   // one CU per shader engine per XCD free (32 CUs).  With only one per XCD (0xffffff00) a potrf_base workgroup that the
   // dispatcher steers to another shader engine waits there for resident GEMM workgroups to finish (60-110 us, about
@@ -128,6 +135,7 @@ struct gps_handle_s {
   // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned
   // (every jittered path: conditional / base_conditional / SGPR / FITC / host-matrix potrf + trsm; GPR when the noise
   // variance is below leaf_refine_ratio x Kdiag), 0 = plain product with the block inverse, 1 = always refine
+  int gpr_aug_rows = -1;         // gps_gpr_lml / predict: (Y - m)^T as augmented rows of the factorisation instead of a trsv pass (-1: below 14000 points)
   int leaf_refine = -1;
   double leaf_refine_ratio = 1e-3;
   bool refine_now = false;       // resolved at every API entry

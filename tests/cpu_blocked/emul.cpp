@@ -113,6 +113,11 @@ struct CpuOps {
   int follower_publish() { if (!fol_open) return -11; ++fol_pub; return 0; }
   int follower_join() { if (open_side || fol_open || fol_pub == 0) return -12; return 0; }
   int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
+  // forward substitution following the factorisation: sequential here; the hooks check pairing
+  int y_opened = 0, y_sections = 0;
+  int y_open() { if (y_opened || open_side || def_open || fol_open) return -21; y_opened = 1; ++y_sections; return 0; }
+  int y_close() { if (!y_opened) return -22; y_opened = 0; return 0; }
+  int y_prepare(i64, i64) { return y_opened ? 0 : -23; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -167,6 +172,23 @@ int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, i
   rc = bl.trsm_rn_rec(U.data(), n, n, 0, B2, n, m);
   if (rc) return rc;
   return bl.trsv_rec(A, n, n, 0, y, n, r);
+}
+// A [(n + e), n] in place: rows 0..n-1 SPD -> L, rows n..n+e-1 (e a multiple of 128) -> E L^-T  (augmented rows)
+int emul_potrf_aug(double* A, i64 n, i64 e, int* info) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, e);
+  *info = ops.info;
+  return rc;
+}
+// A [n, n] in place -> L, with y [r][n] -> L^-1 y issued block by block behind the factorisation (YFollow)
+int emul_potrf_yfollow(double* A, i64 n, double* y, i64 r, int* info, int* sections) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  Blocked<CpuOps>::YFollow yf{y, n, r};
+  int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, 0, &yf);
+  *info = ops.info; *sections = ops.y_sections;
+  return rc;
 }
 // A [n,n] SPD in place -> L ; yt [r][n]: L^T a = yt ; Kinv [n,n] (lower valid) = A^-1 ; Yout = L^-T
 int emul_grad_pieces(double* A, i64 n, double* yt, i64 r, double* Yout, double* Kinv) {

@@ -112,3 +112,48 @@ def test_deferred_piece_of_the_parent_solve(emul, n, rl_max):
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
     assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
     emul.emul_set_lookahead(0)
+
+
+@pytest.mark.parametrize("rl_max,group,la", [(0, 1, 0), (256, 1, 0), (512, 2, 0), (512, 2, 1), (256, 2, 2), (1024, 3, 0), (384, 2, 1)])
+@pytest.mark.parametrize("n,e", [(128, 128), (256, 128), (640, 128), (1152, 256), (1536, 128)])
+def test_augmented_rows_ride_through_the_factorisation(emul, n, e, rl_max, group, la):
+    """potrf_rec with e augmented rows stored under the matrix (the residual^T of gps_gpr_lml): on return the rows hold
+    E L^-T, i.e. the forward substitution came out of the panel solves and (trapezoidal) trailing updates -- in every
+    variant of the recursion (plain, sweeps, groups, look-ahead / follower / deferred hooks)."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(la)
+    emul.emul_set_rl_group(ctypes.c_int64(group))
+    rng = np.random.default_rng(n + e + rl_max)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+    E = rng.standard_normal((e, n))
+    M = np.ascontiguousarray(np.vstack([A, E]))
+    info = ctypes.c_int(0)
+    rc = emul.emul_potrf_aug(M.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int64(n), ctypes.c_int64(e), ctypes.byref(info))
+    emul.emul_set_lookahead(0)
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A, lower=True)
+    assert np.abs(np.tril(M[:n]) - L).max() <= 1e-12 * np.abs(L).max()
+    ref = sl.solve_triangular(L, E.T, lower=True).T                     # E L^-T
+    assert np.abs(M[n:] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("rl_max,group,la", [(0, 1, 0), (256, 1, 0), (512, 2, 0), (512, 2, 1), (256, 2, 2), (384, 2, 1)])
+@pytest.mark.parametrize("n,r", [(128, 1), (256, 2), (640, 1), (1152, 3), (1536, 1), (2048, 2)])
+def test_forward_substitution_follows_the_factorisation(emul, n, r, rl_max, group, la):
+    """potrf_rec with a YFollow: the solves L a = y are issued block by block as the factor becomes final (trsv_rec of a
+    finished diagonal block, gemv of a finished block below it) -- same result as a forward substitution afterwards."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(la)
+    emul.emul_set_rl_group(ctypes.c_int64(group))
+    rng = np.random.default_rng(n + r + rl_max)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n); A0 = A.copy()
+    y = rng.standard_normal((r, n)); y0 = y.copy()
+    info, sections = ctypes.c_int(0), ctypes.c_int(0)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = emul.emul_potrf_yfollow(p(A), ctypes.c_int64(n), p(y), ctypes.c_int64(r), ctypes.byref(info), ctypes.byref(sections))
+    emul.emul_set_lookahead(0)
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A0, lower=True)
+    assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
+    assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
+    assert sections.value >= 1
