@@ -213,6 +213,110 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
 }
 
 
+// ---- single stationary primitive: the program of RBF / Matern GPR (BASELINE configs 1-3, 5) -----------------------
+// The interpreter above keeps a four-deep register stack of 16 entries per thread (251 VGPRs, two waves per SIMD) and
+// walks the program node by node; for the one-node programs that carry the headline workloads that is all overhead, and
+// the kernel was VALU-latency-bound at 2.4 TB/s of stores (a store-only kernel with the same access pattern reaches
+// 5.2 TB/s, tools/store_bw.hip).  Same tile, same 4x4 patch, same epilogue -- no stack, no node loop, and the
+// exponential in line (arguments are <= 0: no overflow branch; rint reduction, degree-13 polynomial, v_ldexp_f64),
+// which brings the kernel under 128 VGPRs (four waves per SIMD).
+__device__ __forceinline__ double gps_exp_nonpos(double x) {        // exp(x) for x <= 0, <= 1 ulp-class error
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  // Taylor to degree 13 on |r| <= ln2 / 2 (remainder 4e-18), Horner in pairs
+  double p = 1.6059043836821613e-10;                // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);              // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);             // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);             // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);            // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);              // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);             // 1/7!
+  p = fma(p, r, 1.3888888888888889e-03);            // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);             // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);            // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);            // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);                          // k >= -1075: gradual underflow to 0 like exp()
+}
+
+template <int OP>
+__global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDev node) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;   // 128-granular: diagonal blocks stay full
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
+  double* nc_s = nr_s + KT;                                // [KT]
+  double* Fr_s = nc_s + KT;                                // [nf][KLS]
+  double* Fc_s = Fr_s + node.nf * KLS;                     // [nf][KLS]
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const i64 gi0 = (i64)ti * KT, gj0 = (i64)tj * KT;
+  for (int idx = tid; idx < node.nf * KT; idx += 256) {
+    const int f = idx >> 6, p = idx & 63;
+    Fr_s[f * KLS + p] = a.Fr[(i64)(node.f0 + f) * a.ldfr + gi0 + p];
+    Fc_s[f * KLS + p] = a.Fc[(i64)(node.f0 + f) * a.ldfc + gj0 + p];
+  }
+  if (tid < KT) {
+    nr_s[tid] = a.Fr[(i64)node.norm_row * a.ldfr + gi0 + tid];
+    nc_s[tid] = a.Fc[(i64)node.norm_row * a.ldfc + gj0 + tid];
+  }
+  __syncthreads();
+  double dot[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dot[e] = 0.0;
+  for (int f = 0; f < node.nf; ++f) {
+    const double2 r01 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4), r23 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4 + 2);
+    const double2 c01 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4), c23 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4 + 2);
+    const double fr[4] = {r01.x, r01.y, r23.x, r23.y}, fc[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dot[e] = fma(fr[e >> 2], fc[e & 3], dot[e]);
+  }
+  const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const i64 li = gi0 + ty * 4 + q;
+    const i64 gi = a.row_off + li;
+    const double ni = nr_s[ty * 4 + q];
+    double o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const i64 gj = a.col_off + gj0 + tx * 4 + c;
+      double r2 = -2.0 * dot[q * 4 + c] + (ni + nc_s[tx * 4 + c]);        // kernels.py:409-421, same op order as the interpreter
+      r2 = fmax(r2, 0.0);
+      double val;
+      if (OP == GPS_K_RBF) {
+        val = node.variance * gps_exp_nonpos(-r2 / 2.0);
+      } else {
+        const double r = sqrt(r2 + 1e-12);
+        if (OP == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
+        else if (OP == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
+        else if (OP == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
+        else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r);
+      }
+      if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
+      else if (a.sym && gi == gj) val += a.diag_add;
+      o[c] = val;
+    }
+    double* dst = a.K + li * a.ldk + gj0 + tx * 4;
+    *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+  }
+}
+
+template <int OP>
+static int launch_single(gps_handle_t h, const KmatArgs& a, const KNodeDev& node, i64 prow, i64 pcol, double tiles) {
+  const size_t lds = (size_t)(2 * KT + 2 * node.nf * KLS) * sizeof(double);
+  int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_single_kernel<OP>), (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double)));
+  if (rcl) return rcl;
+  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * node.nf + 30.0), tiles * KT * KT * 8.0);
+  hipLaunchKernelGGL(kmat_single_kernel<OP>, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream, a, node);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
 // ---- Neural Kernel Network epilogue ---------------------------------------------------------------
 // neural_kernel_network/neural_kernel_network.py:41-47 stacks the primitive kernel values of every
 // (i, j) entry into a vector and pushes it through Linear (positive weights) / Product / Activation
@@ -461,6 +565,17 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
                        a, kc.prog, kc.net, (const double*)h->dNkn.p);
     GPS_HIP(h, hipGetLastError());
     return GPS_OK;
+  }
+  if (kc.prog.n_nodes == 1 && kc.prog.nodes[0].norm_row >= 0 && h->kmat_fast) {      // one stationary primitive
+    const KNodeDev& nd = kc.prog.nodes[0];
+    switch (nd.op) {
+      case GPS_K_RBF: return launch_single<GPS_K_RBF>(h, a, nd, prow, pcol, tiles);
+      case GPS_K_MATERN12: return launch_single<GPS_K_MATERN12>(h, a, nd, prow, pcol, tiles);
+      case GPS_K_MATERN32: return launch_single<GPS_K_MATERN32>(h, a, nd, prow, pcol, tiles);
+      case GPS_K_MATERN52: return launch_single<GPS_K_MATERN52>(h, a, nd, prow, pcol, tiles);
+      case GPS_K_EXPONENTIAL: return launch_single<GPS_K_EXPONENTIAL>(h, a, nd, prow, pcol, tiles);
+      default: break;
+    }
   }
   int maxnf = 1;
   for (int i = 0; i < kc.prog.n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
