@@ -91,6 +91,11 @@ __device__ __forceinline__ void leaf_product(v4d (&acc)[MI][NI], const double* _
 
 // NT threads: 4 waves side by side own the mirrored column-block pairs; 64 rows use 8 waves (two wave rows), which
 // keeps every wave at <= 256 registers and gives each SIMD a second wave to cover LDS latency and the stage phases.
+// Barrier for data that is exchanged through LDS only: __syncthreads() also waits for every outstanding GLOBAL access
+// of the wave (vmcnt(0)) -- here that would be the operand prefetch that is meant to stay in flight behind the product,
+// and the parked X0 store.
+__device__ __forceinline__ void lf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int BM, int NT, bool UPPER>
 __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ldb, i64 m,
                                                               const double* __restrict__ W,
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
       }
       LF_STAMP(2 + 2 * pass);
       if (pass == 2) break;
-      __syncthreads();               // every wave is done with Pa and Wp
+      lf_lds_barrier();               // every wave is done with Pa and Wp
       // X0 is parked in the output rows (B itself lives on in `bc`) and comes back as the accumulator of pass 2 (its
       // own lanes wrote it: no fence needed).  Keeping it in registers instead costs the 64-row tile spills.
 #pragma unroll
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
       }
     }
     stage();
-    __syncthreads();
+    lf_lds_barrier();
     LF_STAMP(3 + 2 * pass);
     if (pass < 0) {
 #pragma unroll
