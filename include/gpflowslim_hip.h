@@ -128,7 +128,9 @@ int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
  * Periodic [d/d lengthscale, d/d period], White / Constant nothing more -- all w.r.t. the CONSTRAINED
  * values; the caller applies the transform's chain rule.  grad_noise = d/d noise_var.
  * kinv_resid (optional) host [n, r] = A = d LML / d resid (chain rule for mean-function parameters).
- * Programs with more than 4 primitive nodes return GPS_ERR_UNSUPPORTED.                             */
+ * Neural-Kernel-Network programs (GPS_K_NKN_*: neural_kernel_network_wrapper.py:90-173, whose Linear weights and biases the
+ * reference trains through autodiff): after the primitives' slots, for every Linear layer in network order and every
+ * output o: [d/d W[o][0 .. in-1], d/d bias[o]].  Programs with more than 8 primitive nodes return GPS_ERR_UNSUPPORTED. */
 int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                      double noise_var, const double* resid, int64_t r, double* lml,
                      double* grad_slots, int n_slots_cap, int* n_slots_out,
@@ -289,7 +291,21 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
  *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512)
  *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
- *                     child, which runs them on a third stream beside its second sweep              */
+ *                     child, which runs them on a third stream beside its second sweep
+ *   "leaf_refine"     -1 (default): the 128-column leaves of the triangular solves are refined once against the factor's
+ *                     diagonal block (X0 = B W^T; R = B - X0 L11^T; X = X0 + R W^T, W = inv(L11): the accuracy of
+ *                     tf.matrix_triangular_solve's substitution, conditionals.py:87,100) wherever the matrix may be ill
+ *                     conditioned: gps_conditional / gps_base_conditional / gps_svgp_elbo / gps_gauss_kl / gps_sgpr /
+ *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when noise_var <
+ *                     "leaf_refine_ratio" (default 1e-3) x Kdiag; 0: plain products with the block inverses; 1: always
+ *   "gpr_aug_rows"    -1 (default): below 14000 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
+ *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
+ *                     0 / 1: never / always
+ *   "trsv_follow"     0 (default) / 1: the forward substitution is issued block by block behind the factorisation on a
+ *                     stream of its own (measured slower: DESIGN.md section 6)
+ *   "kmat_fast"       1 (default): one-primitive stationary programs use the stack-free kernel-matrix kernel
+ *   "la_fault_inject" diagnostics: the k-th look-ahead join from now takes the time-out path (the evaluation is then
+ *                     re-run once without look-ahead; gps_profile_get(h, "lookahead_retries", &count, ...) counts it)  */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------
