@@ -412,7 +412,7 @@ int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_no
 int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n, i64 d_all,
                             i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                             double* grad_slots_host, double* grad_noise_host) {
-  static GGProg P;                        // (4 KB: keep it off the stack of the caller's thread; single-threaded per handle)
+  GGProg P;
   std::vector<GGFeat> feats;
   std::vector<double> ls_of_slot;
   std::vector<double> W((size_t)GG_MAXL * GG_W * (GG_W + 1), 0.0);

@@ -150,6 +150,27 @@ def test_gpr_mean_function_and_min_var(handle):
     assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
 
 
+@pytest.mark.parametrize("n,r", [(1, 1), (130, 1), (300, 3), (1000, 2)])
+def test_multivariate_normal_density(handle, n, r):
+    """densities.multivariate_normal (densities.py:73-95) on a caller-supplied factor: the triangular solve runs on the
+    device (gps_trsm_lower); matrix and vector arguments; entries above the diagonal of L are ignored like
+    tf.matrix_triangular_solve ignores them; gaussian() beside it."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + r)
+    G = rng.standard_normal((n, n)); K = G @ G.T / n + np.eye(n)
+    L = np.linalg.cholesky(K)
+    x = rng.standard_normal((n, r)); mu = rng.standard_normal((n, r))
+    ref = orc.multivariate_normal(x, mu, L)
+    got = gpf.densities.multivariate_normal(x, mu, L)
+    assert abs(got - ref) <= RTOL * abs(ref)
+    Lg = L + np.triu(rng.standard_normal((n, n)), 1)                 # garbage above the diagonal
+    assert abs(gpf.densities.multivariate_normal(x, mu, Lg) - ref) <= RTOL * abs(ref)
+    got1 = gpf.densities.multivariate_normal(x[:, 0], mu[:, 0], L)
+    assert abs(got1 - orc.multivariate_normal(x[:, :1], mu[:, :1], L)) <= RTOL * abs(got1)
+    v = np.abs(rng.standard_normal((n, r))) + 0.1
+    assert np.allclose(gpf.densities.gaussian(x, mu, v), orc.gaussian_density(x, mu, v), rtol=1e-14)
+
+
 def test_gpr_not_positive_definite_raises(handle):
     import gpflowSlim as gpf
     # duplicate points + (almost) no noise -> singular K: tf.cholesky would raise InvalidArgumentError
