@@ -353,3 +353,35 @@ def test_fitc_and_upper_bound_limits():
     upper = orc.sgpr_upper_bound(spec, X, Y, Z, s2)
     assert lower < lml < upper
     assert orc.sgpr_upper_bound(spec, X, Y, X, s2) == pytest.approx(lml, rel=1e-4)
+
+
+@pytest.mark.parametrize("name", ["rbf_ard_m40", "matern52_m130"])
+def test_oracle_reproduces_sparse_golden_fixtures(name):
+    import importlib.util
+    """tests/golden/sparse/*.npz (conditional, gauss_kl, SVGP / SGPR / FITC bounds): any drift of the oracle shows up here."""
+    here = os.path.join(GOLD, "sparse")
+    spec_mod = importlib.util.spec_from_file_location("make_golden_sparse", os.path.join(here, "make_golden_sparse.py"))
+    mg = importlib.util.module_from_spec(spec_mod)
+    spec_mod.loader.exec_module(mg)
+    g = np.load(os.path.join(here, name + ".npz"))
+    kind = mg.CASES[name][0]
+    spec = mg.spec_for(kind, g["X"].shape[1])
+    regen = mg.inputs(name)
+    for k in ("X", "Y", "Z", "Xs", "q_mu", "q_diag", "q_full"):
+        assert np.array_equal(regen[k], g[k]), k
+    noise = float(g["noise_var"])
+    m = g["Z"].shape[0]
+    Kuu = orc.K(spec, g["Z"]) + orc.JITTER * np.eye(m)
+    tol = max(1e-10, 4 * np.finfo(float).eps * float(g["cond_Kuu"]))       # a re-run on another BLAS may round differently
+    for white in (True, False):
+        for qn in ("q_diag", "q_full"):
+            tag = "%s_%s" % ("white" if white else "unwhite", qn)
+            mu, var = orc.conditional(g["Xs"], g["Z"], spec, g["q_mu"], q_sqrt=g[qn], white=white)
+            assert np.abs(mu - g["cond_mu_" + tag]).max() <= tol * max(1.0, np.abs(mu).max())
+            assert np.abs(var - g["cond_var_" + tag]).max() <= tol * max(1.0, np.abs(var).max())
+            kl = orc.gauss_kl(g["q_mu"], g[qn], None if white else Kuu)
+            assert abs(kl - float(g["kl_" + tag])) <= tol * abs(kl)
+            el = orc.svgp_elbo(spec, g["X"], g["Y"], g["Z"], g["q_mu"], g[qn], noise, whiten=white, num_data=3 * g["X"].shape[0])
+            assert abs(el - float(g["elbo_" + tag])) <= tol * abs(el)
+    assert abs(orc.sgpr_bound(spec, g["X"], g["Y"], g["Z"], noise) - float(g["sgpr_bound"])) <= tol * abs(float(g["sgpr_bound"]))
+    assert abs(orc.fitc_lml(spec, g["X"], g["Y"], g["Z"], noise) - float(g["fitc_lml"])) <= tol * abs(float(g["fitc_lml"]))
