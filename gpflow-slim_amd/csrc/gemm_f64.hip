@@ -36,7 +36,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define BK_MIN 16      // K must be a multiple of this (the slab depth of the square tiles)
+#ifndef STRIP
 #define STRIP 8        // tile columns per strip
+#endif
 
 struct GemmArgs {
   const double* A; const double* B; double* C;
