@@ -230,6 +230,43 @@ __global__ __launch_bounds__(256) void varexp_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---- SVGP gradient helpers (gps_svgp_elbo_grad) -----------------------------------------------------------------------
+// Et[q][i] = scale (yres[i][q] - fmean[i][q]) / noise  (i < n; 0 in the padding): d ELBO / d fmean, transposed
+__global__ __launch_bounds__(256) void svgp_et_kernel(const double* __restrict__ yres, const double* __restrict__ fmean, int k,
+                                                      i64 n, i64 npad, double coef, double* __restrict__ Et) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  for (int q = 0; q < k; ++q) Et[(i64)q * npad + i] = (i < n) ? coef * (yres[i * k + q] - fmean[i * k + q]) : 0.0;
+}
+// Abar[i][m] = coef[m] Bt[i][m] + sum_q Et[q][i] qmu[m][q]     ([rows, cols], cols = inducing points)
+__global__ __launch_bounds__(256) void svgp_abar_kernel(const double* __restrict__ Bt, i64 ld, i64 rows, i64 cols,
+                                                        const double* __restrict__ coef, const double* __restrict__ Et, i64 lde,
+                                                        const double* __restrict__ qmu, int k, double* __restrict__ Abar) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const double cf = coef[c];
+  double qm[8];
+  for (int q = 0; q < k && q < 8; ++q) qm[q] = qmu[c * k + q];
+  for (i64 rr = blockIdx.y; rr < rows; rr += gridDim.y) {
+    double v = cf * Bt[rr * ld + c];
+    for (int q = 0; q < k; ++q) v = fma(Et[(i64)q * lde + rr], (q < 8) ? qm[q] : qmu[c * k + q], v);
+    Abar[rr * ld + c] = v;
+  }
+}
+// in-place maps on an [n, n] matrix (every element is written by one thread and nobody reads what another one writes).
+// mode 0: mirror the lower triangle into the upper one (also Phi(A) + Phi(A)^T of the Cholesky adjoint, Murray 2016: Phi =
+// lower triangle with halved diagonal) ; 1: A <- -tril(A) ; 3: A <- triu(A)
+__global__ __launch_bounds__(256) void tri_map_kernel(double* __restrict__ A, i64 ld, i64 n, int mode) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  for (i64 rr = blockIdx.y; rr < n; rr += gridDim.y) {
+    if (mode == 0) { if (c > rr) A[rr * ld + c] = A[c * ld + rr]; }
+    else if (mode == 1) { A[rr * ld + c] = (c <= rr) ? -A[rr * ld + c] : 0.0; }
+    else if (mode == 3) { if (c < rr) A[rr * ld + c] = 0.0; }                    // keep the upper triangle only
+
+  }
+}
+
 __global__ void fill_info_kernel(int* p, int v) { *p = v; }
 
 // block-column distributed factorisation: fold the 64 fixed-order partials of lml_reduce_kernel and the info word of
@@ -446,6 +483,29 @@ int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i
 
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own) {
   hipLaunchKernelGGL(dist_tail_kernel, dim3(1), dim3(1), 0, h->stream, partials64x2, d_info, tail_msg, tail_own);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_svgp_et(gps_handle_t h, const double* yres, const double* fmean, i64 k, i64 n, i64 npad, double coef, double* Et) {
+  LaunchScope ls(h, KC_OTHER, 2.0 * n * k, 24.0 * n * k);
+  hipLaunchKernelGGL(svgp_et_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, yres, fmean, (int)k, n, npad, coef, Et);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+int gps_launch_svgp_abar(gps_handle_t h, const double* Bt, i64 ld, i64 rows, i64 cols, const double* coef, const double* Et, i64 lde,
+                         const double* qmu, i64 k, double* Abar) {
+  LaunchScope ls(h, KC_OTHER, 2.0 * rows * cols * (k + 1), 16.0 * rows * cols);
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(svgp_abar_kernel, grid, dim3(256), 0, h->stream, Bt, ld, rows, cols, coef, Et, lde, qmu, (int)k, Abar);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+int gps_launch_tri_map(gps_handle_t h, double* A, i64 ld, i64 n, int mode) {
+  if (n <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n < 32768 ? n : 32768));
+  hipLaunchKernelGGL(tri_map_kernel, grid, dim3(256), 0, h->stream, A, ld, n, mode);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

@@ -301,7 +301,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
                     &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal};
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -1297,6 +1297,221 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
   *elbo = ve * scale - sv.kl;
   return GPS_OK;
   });
+}
+
+// ---- gradient of the SVGP bound (whitened parametrisation, Gaussian likelihood) ------------------------------------------
+// What TF autodiff gives the reference's optimiser for models/svgp.py:108-125 (examples/svgp.py:159-161 minimises
+// `objective`): reverse mode at the matrix level, every O(M^2 N) product on the fp64 MFMA and resident in HBM.
+//   forward (gps_svgp_elbo): Lm = chol(Kuu + jitter I), A = Lm^-1 Kuf, mu = A^T q_mu,
+//                            var_q = Kdiag - colsum(A^2) + colsum((L_q^T A)^2)
+//   E  = scale (Y - mu) / s2                                             d ELBO / d mu
+//   g(q_mu) = A E - q_mu ;  g(L_q) = tril(-(scale/s2) (A A^T) L_q - L_q + diag(1 / L_q,ii))   (diagonal q_sqrt: elementwise)
+//   Abar = q_mu E^T + (scale/s2) (k I - sum_q L_q L_q^T) A                 d ELBO / d A
+//   Kuf_bar = Lm^-T Abar ;  Lm_bar = -tril(Kuf_bar A^T) ;  Kuu_bar = Lm^-T (Phi(Lm^T Lm_bar) + Phi(.)^T) Lm^-1 / 2   (Phi: tril, diagonal halved)
+//   d/d theta = <Kuf_bar, dKuf> + <Kuu_bar, dKuu> + kbar dKdiag            (gps_launch_kmat_vjp: the kernel-matrix VJP)
+// Restated and checked against finite differences in oracle/gp_oracle.py::svgp_elbo_grad.  The inducing inputs Z are
+// held fixed (their gradient is not computed); the unwhitened parametrisation is not differentiated.
+extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                                  int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
+                                  const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
+                                  double noise_var, double scale, double* elbo, double* grad_slots, int n_slots_cap,
+                                  int* n_slots_out, double* grad_noise, double* grad_q_mu, double* grad_q_sqrt,
+                                  double* grad_mean, int* info) {
+  if (!h || !elbo || !grad_slots || !grad_noise || !grad_q_mu || !grad_q_sqrt)
+    return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: bad argument");
+  if (!white) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_svgp_elbo_grad: only the whitened parametrisation is differentiated");
+  if (k > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_svgp_elbo_grad: at most 128 latent functions");
+  int ns = 0;
+  int rc = gps_grad_general_slots(h, prog, n_nodes, &ns);
+  if (rc) return rc;
+  if (n_slots_out) *n_slots_out = ns;
+  if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: grad_slots too small");
+  double kl = 0.0, ve = 0.0;
+  int linfo = 0;
+  rc = gps_svgp_elbo(h, prog, n_nodes, Z, m, d_all, jitter, X, n, yres, q_mu, k, q_sqrt, q_sqrt_ndim, white, noise_var, scale,
+                     elbo, &kl, &ve, &linfo);
+  if (info) *info = linfo;
+  if (rc || linfo) return rc;
+  // what the forward pass left on the device: dK = Lm [mp, mp], dLinv (+T), dB = A^T [nsp, mp], dX = Z, dXnew = X,
+  // dMean = fmean [n, k], dS1 = yres [n, k]
+  const i64 mp = gps_pad(m), nsp = gps_pad(n);
+  const double w = scale, s2 = noise_var;
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  HipOps ops{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  double* Lm = h->dK.d();
+  double* Bt = h->dB.d();
+  // sum ((y - mu)^2 + var) back out of the variational expectations (likelihoods.py:186-188)
+  const double c0 = -0.5 * log(2.0 * M_PI) - 0.5 * log(s2);
+  const double sq_sum = ((double)n * (double)k * c0 - ve) * 2.0 * s2;
+  *grad_noise = w * (-(double)n * (double)k / (2.0 * s2) + sq_sum / (2.0 * s2 * s2));
+
+  // E^T [k][nsp]
+  GPS_HIP(h, h->dA.ensure((size_t)k * nsp * 8));
+  double* Et = h->dA.d();
+  rc = gps_launch_svgp_et(h, h->dS1.d(), h->dMean.d(), k, n, nsp, w / s2, Et);
+  if (rc) return rc;
+  if (grad_mean) {                                       // d ELBO / d mean_function(X) = E   [n, k]
+    GPS_HIP(h, h->dTmp2.ensure((size_t)n * k * 8));
+    rc = gps_launch_transpose(h, Et, nsp, k, n, h->dTmp2.d(), k);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(grad_mean, h->dTmp2.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  // A = (A^T)^T [mp, nsp] ;  A E [m, k] and diag(A A^T) in one pass over A
+  GPS_HIP(h, h->dS2.ensure((size_t)mp * nsp * 8));
+  double* Am = h->dS2.d();
+  rc = gps_launch_transpose(h, Bt, mp, nsp, mp, Am, nsp);
+  if (rc) return rc;
+  GPS_HIP(h, h->dG4.ensure((size_t)(mp * k + 2 * mp) * 8));
+  double* dAE = h->dG4.d();
+  double* dDiag = dAE + (size_t)mp * k;
+  double* dCoef = dDiag + mp;
+  rc = gps_launch_rowdot(h, Am, nsp, m, nsp, Et, nsp, k, dAE, dDiag);
+  if (rc) return rc;
+  std::vector<double> hAE((size_t)m * k), hDiag((size_t)m);
+  GPS_HIP(h, hipMemcpyAsync(hAE.data(), dAE, hAE.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(hDiag.data(), dDiag, hDiag.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  for (i64 i = 0; i < m * k; ++i) grad_q_mu[i] = hAE[i] - q_mu[i];                          // (KL white: q_mu)
+
+  // Abar^T [nsp, mp] = coef (.) A^T + E q_mu^T  (- (w/s2) sum_q (A^T L_q) L_q^T for a full q_sqrt, below)
+  std::vector<double> coef((size_t)mp, 0.0), qmp((size_t)mp * k, 0.0);
+  for (i64 j = 0; j < m; ++j) {
+    double c = (double)k;
+    if (q_sqrt_ndim == 2) for (i64 q = 0; q < k; ++q) c -= q_sqrt[j * k + q] * q_sqrt[j * k + q];
+    coef[j] = (w / s2) * c;
+    for (i64 q = 0; q < k; ++q) qmp[j * k + q] = q_mu[j * k + q];
+  }
+  GPS_HIP(h, h->dG3.ensure((size_t)mp * k * 8 + 64));
+  GPS_HIP(h, h->ring.upload(dCoef, coef.data(), (size_t)mp * 8, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(h->dG3.p, qmp.data(), (size_t)mp * k * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  GPS_HIP(h, h->dY.ensure((size_t)nsp * mp * 8));
+  double* Abar = h->dY.d();
+  rc = gps_launch_svgp_abar(h, Bt, mp, nsp, mp, dCoef, Et, nsp, h->dG3.d(), k, Abar);
+  if (rc) return rc;
+
+  if (q_sqrt_ndim == 2) {
+    for (i64 j = 0; j < m; ++j)
+      for (i64 q = 0; q < k; ++q) {
+        const double sv = q_sqrt[j * k + q];
+        grad_q_sqrt[j * k + q] = -(w / s2) * hDiag[j] * sv - sv + 1.0 / sv;
+      }
+  } else {
+    // A A^T (lower by one long-K GEMM, mirrored) ; per latent: A^T L_q, the Abar update, (A A^T) L_q
+    GPS_HIP(h, h->dS3.ensure((size_t)mp * mp * 8));
+    double* AAT = h->dS3.d();
+    rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, nsp, Am, nsp, Am, nsp, AAT, mp);
+    if (rc) return rc;
+    rc = gps_launch_tri_map(h, AAT, mp, mp, 0);
+    if (rc) return rc;
+    GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));
+    GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+    std::vector<double> LT((size_t)mp * mp), Ls((size_t)mp * mp), G((size_t)mp * mp);
+    for (i64 q = 0; q < k; ++q) {
+      const double* Lq = q_sqrt + (size_t)q * m * m;                  // C-ABI layout [k][m][m]
+      std::fill(LT.begin(), LT.end(), 0.0); std::fill(Ls.begin(), Ls.end(), 0.0);
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) { LT[(size_t)b * mp + a] = Lq[a * m + b]; Ls[(size_t)a * mp + b] = (w / s2) * Lq[a * m + b]; }
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, Ls.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, Bt, mp, h->dTmp2.d(), mp, h->dTmp3.d(), mp);        // A^T L_q
+      if (rc) return rc;
+      rc = gps_launch_gemm_nt(h, 0, 0, nsp, mp, mp, h->dTmp3.d(), mp, h->dTmp.d(), mp, Abar, mp);        // Abar^T -= (w/s2) (A^T L_q) L_q^T
+      if (rc) return rc;
+      rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, AAT, mp, h->dTmp2.d(), mp, h->dG1.d(), mp);           // (A A^T) L_q
+      if (rc) return rc;
+      GPS_HIP(h, hipMemcpyAsync(G.data(), h->dG1.p, (size_t)mp * mp * 8, hipMemcpyDeviceToHost, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      double* gq = grad_q_sqrt + (size_t)q * m * m;
+      for (i64 a = 0; a < m; ++a)
+        for (i64 b = 0; b < m; ++b)
+          gq[a * m + b] = (b > a) ? 0.0 : (-(w / s2) * G[(size_t)a * mp + b] - Lq[a * m + b] + (a == b ? 1.0 / Lq[a * m + a] : 0.0));
+    }
+  }
+  // Kuf_bar^T = Abar^T Lm^-1  (X Lm = Abar^T through U = Lm^T), then Kuf_bar [mp, nsp]
+  GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+  double* U = h->dTmp.d();
+  rc = gps_launch_transpose(h, Lm, mp, mp, mp, U, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, U, mp, mp, 3);            // (above the diagonal blocks the factor's buffer was never written)
+  if (rc) return rc;
+  rc = bl.trsm_rn_rec(U, mp, mp, 0, Abar, mp, nsp);
+  if (rc) return rc;
+  GPS_HIP(h, h->dS1.ensure((size_t)mp * nsp * 8));
+  double* KufBar = h->dS1.d();
+  rc = gps_launch_transpose(h, Abar, mp, nsp, mp, KufBar, nsp);
+  if (rc) return rc;
+  // Lm_bar = -tril(Kuf_bar A^T)
+  GPS_HIP(h, h->dS3.ensure((size_t)mp * mp * 8));
+  double* LmBar = h->dS3.d();
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, nsp, KufBar, nsp, Am, nsp, LmBar, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, LmBar, mp, mp, 1);
+  if (rc) return rc;
+  // Cholesky adjoint: P = Lm^T Lm_bar ; Kuu_bar = Lm^-T (Phi(P) + Phi(P)^T) Lm^-1 / 2
+  GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
+  double* LmBarT = h->dG1.d();
+  double* P = h->dG2.d();
+  rc = gps_launch_transpose(h, LmBar, mp, mp, mp, LmBarT, mp);
+  if (rc) return rc;
+  rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, U, mp, LmBarT, mp, P, mp);               // P[i][j] = sum_k Lm[k][i] Lm_bar[k][j]
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, P, mp, mp, 0);               // Phi(P) + Phi(P)^T = the lower triangle of P mirrored (the 1/2 follows below)
+  if (rc) return rc;
+  rc = bl.trsm_rn_rec(U, mp, mp, 0, P, mp, mp);                                        // Y = Psym Lm^-1
+  if (rc) return rc;
+  rc = gps_launch_transpose(h, P, mp, mp, mp, LmBarT, mp);                             // Y^T
+  if (rc) return rc;
+  rc = bl.trsm_rn_rec(U, mp, mp, 0, LmBarT, mp, mp);                                   // Y^T Lm^-1 = (Lm^-T Y)^T = Kuu_bar (symmetric)
+  if (rc) return rc;
+  // contractions with the kernel derivatives
+  for (int sI = 0; sI < ns; ++sI) grad_slots[sI] = 0.0;
+  rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, nsp, 0, grad_slots);
+  if (rc) return rc;
+  {
+    std::vector<double> uu((size_t)ns, 0.0);
+    rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, LmBarT, mp, 0, uu.data());
+    if (rc) return rc;
+    for (int sI = 0; sI < ns; ++sI) grad_slots[sI] += 0.5 * uu[sI];
+  }
+  rc = gps_kdiag_vjp(h, prog, n_nodes, d_all, -w * (double)k * (double)n / (2.0 * s2), grad_slots);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// ---- vector-Jacobian product of kernels.K: grad_slots = sum_ij W[i][j] d k(X_i, X2_j) / d theta ---------------------------
+// (reverse-mode autodiff through kern.K(X, X2), kernels.py:408-439 / 1071-1084 / neural_kernel_network.py:41-47, for a
+// caller-supplied cotangent W host [n, m]; X2 == NULL: K(X, X), W [n, n] taken as given -- no symmetrisation.)
+extern "C" int gps_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X, int64_t n,
+                            const double* X2, int64_t m, int64_t d_all, const double* W, double* grad_slots,
+                            int n_slots_cap, int* n_slots_out) {
+  if (!h || !X || !W || !grad_slots || n <= 0 || d_all <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_kmat_vjp: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  if (!X2) m = n;
+  int ns = 0;
+  int rc = gps_grad_general_slots(h, prog, n_nodes, &ns);
+  if (rc) return rc;
+  if (n_slots_out) *n_slots_out = ns;
+  if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_kmat_vjp: grad_slots too small");
+  GPS_HIP(h, h->dXnew.ensure((size_t)n * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  const double* dX2 = nullptr;
+  if (X2) {
+    GPS_HIP(h, h->dTmp3.ensure((size_t)m * d_all * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, X2, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+    dX2 = h->dTmp3.d();
+  }
+  GPS_HIP(h, h->dTmp.ensure((size_t)n * m * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, W, (size_t)n * m * 8, hipMemcpyHostToDevice, h->stream));
+  rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dXnew.d(), n, dX2, m, d_all, h->dTmp.d(), m, 0, grad_slots);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
 }
 
 // ---- KL[q || p], q = N(q_mu, q_sqrt q_sqrt^T), p = N(0, K) or N(0, I): kullback_leiblers.py:26-105 -------------------

@@ -185,6 +185,7 @@ struct gps_handle_s {
   DevBuf dY;        // [npad, npad]  L^-T                                 (gradient path)
   DevBuf dKinv;     // [npad, npad]  K_y^-1, lower triangle               (gradient path)
   DevBuf dS1, dS2, dS3, dS4;   // SGPR work space (gps_sgpr)
+  DevBuf dG1, dG2, dG3, dG4;   // SVGP gradient work space (gps_svgp_elbo_grad)
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
@@ -290,6 +291,10 @@ int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
 int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
                       const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq);
 int gps_launch_fill_info(gps_handle_t h, int* d_info, int value);
+int gps_launch_svgp_et(gps_handle_t h, const double* yres, const double* fmean, i64 k, i64 n, i64 npad, double coef, double* Et);
+int gps_launch_svgp_abar(gps_handle_t h, const double* Bt, i64 ld, i64 rows, i64 cols, const double* coef, const double* Et, i64 lde,
+                         const double* qmu, i64 k, double* Abar);
+int gps_launch_tri_map(gps_handle_t h, double* A, i64 ld, i64 n, int mode);
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64);
@@ -326,6 +331,9 @@ int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_no
 int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                             i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                             double* grad_slots_host, double* grad_noise_host);
+int gps_kdiag_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all, double kbar, double* grad_slots_host);
+int gps_launch_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dXr, i64 nr, const double* dXc,
+                        i64 nc, i64 d_all, const double* Wd, i64 ldw, int accumulate, double* grad_slots_host);
 // diag.hip
 int gps_run_mfma_diag(gps_handle_t h, int waves_per_simd, double* tflops, int* layout_ok);
 int gps_run_gemm_timeline(gps_handle_t h, int op, int lower, i64 m, i64 n, i64 k, int reps, long long* stamps_out,

@@ -36,13 +36,19 @@ struct GGProg {
   GGLayer layers[GG_MAXL];
 };
 struct GGArgs {
-  const double* Ft; i64 ldf;
+  const double* Ft; i64 ldf;            // features of the row points
+  const double* Ftc; i64 ldfc;          // features of the column points (== Ft for K(X, X))
   const double* Kinv; i64 ldk;
   const double* A; i64 lda; int r;
   const double* Wnet;                   // [n_layers][GG_W][GG_W + 1] (last column = bias)
   i64 n, npad;
   double* partial;                      // [gridDim.x][GG_MAXSLOT + 1]  (last = noise)
-  int tiles;                            // tiles per side
+  int tiles;                            // tile rows
+  // rect != 0: the vector-Jacobian product of the kernel-matrix build for an arbitrary cotangent:
+  //   slots += sum_{i < nr, j < nc} Wd[i][j] d k(xr_i, xc_j) / d theta     (all tiles, weight 1 everywhere)
+  // same_points: rows and columns index the same point set (K(Z, Z)): White contributes on i == j
+  int rect, tiles_c, same_points;
+  const double* Wd; i64 ldw; i64 nr, nc;
 };
 
 __device__ __forceinline__ double gg_wave_sum(double v) {
@@ -77,14 +83,14 @@ __device__ __forceinline__ void gg_stage(const GGArgs& a, int f0, int nf, i64 gi
   for (int idx = tid; idx < nf * GG_T; idx += 256) {
     const int f = idx >> 5, pp = idx & 31;
     Fr_s[f * GG_T + pp] = a.Ft[(i64)(f0 + f) * a.ldf + gi0 + pp];
-    Fc_s[f * GG_T + pp] = a.Ft[(i64)(f0 + f) * a.ldf + gj0 + pp];
+    Fc_s[f * GG_T + pp] = a.Ftc[(i64)(f0 + f) * a.ldfc + gj0 + pp];
   }
   __syncthreads();
 }
 
 // value and (squared distance | periodic sum) of one primitive at the thread's four entries
 __device__ __forceinline__ void gg_prim(const GGNode& node, const double* Fr_s, const double* Fc_s, int ty, int tx, i64 gi0,
-                                        i64 gj0, double (&val)[GG_E], double (&rr)[GG_E]) {
+                                        i64 gj0, bool same_points, double (&val)[GG_E], double (&rr)[GG_E]) {
   if (node.op == GPS_K_CONSTANT) {
 #pragma unroll
     for (int e = 0; e < GG_E; ++e) { val[e] = node.variance; rr[e] = 0.0; }
@@ -94,7 +100,7 @@ __device__ __forceinline__ void gg_prim(const GGNode& node, const double* Fr_s, 
 #pragma unroll
     for (int e = 0; e < GG_E; ++e) {
       const i64 i = gi0 + ty * 2 + (e >> 1), j = gj0 + tx * 2 + (e & 1);
-      val[e] = (i == j) ? node.variance : 0.0; rr[e] = 0.0;
+      val[e] = (same_points && i == j) ? node.variance : 0.0; rr[e] = 0.0;
     }
     return;
   }
@@ -179,10 +185,11 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
   if (P.nkn) for (int s = tid; s < P.n_layers * GG_W * (GG_W + 1); s += 256) W_s[s] = a.Wnet[s];
   __syncthreads();
 
-  const i64 ntiles = (i64)a.tiles * a.tiles;
+  const bool same_points = a.rect ? (a.same_points != 0) : true;
+  const i64 ntiles = (i64)a.tiles * a.tiles_c;
   for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int ti = (int)(t / a.tiles), tj = (int)(t % a.tiles);
-    if (tj > ti) continue;
+    const int ti = (int)(t / a.tiles_c), tj = (int)(t % a.tiles_c);
+    if (!a.rect && tj > ti) continue;
     const i64 gi0 = (i64)ti * GG_T, gj0 = (i64)tj * GG_T;
     // ---- weights c_e W_e
     double w[GG_E];
@@ -191,7 +198,9 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
     for (int e = 0; e < GG_E; ++e) {
       const i64 i = gi0 + ty * 2 + (e >> 1), j = gj0 + tx * 2 + (e & 1);
       double val = 0.0;
-      if (i < a.n && j <= i) {
+      if (a.rect) {
+        if (i < a.nr && j < a.nc) val = a.Wd[i * a.ldw + j];
+      } else if (i < a.n && j <= i) {
         double s = 0.0;
         for (int q = 0; q < a.r; ++q) s += a.A[(i64)q * a.lda + i] * a.A[(i64)q * a.lda + j];
         val = s - (double)a.r * a.Kinv[i * a.ldk + j];
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
       }
       w[e] = val;
     }
-    if (ti == tj) {                                        // noise: d K_y / d sigma^2 = I
+    if (!a.rect && ti == tj) {                             // noise: d K_y / d sigma^2 = I
       dsum = gg_wave_sum(dsum);
       if (lane == 0) acc_s[wave][GG_MAXSLOT] += dsum;
     }
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
       if (node.prim < 0) continue;
       if (node.nf > 0) gg_stage(a, node.f0, (node.op == GPS_K_PERIODIC) ? 2 * node.ndims : node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
       double val[GG_E], rr[GG_E];
-      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, val, rr);
+      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, rr);
 #pragma unroll
       for (int p = 0; p < GG_MAXP; ++p)
         if (node.prim == p) {
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
       if (node.op == GPS_K_PERIODIC) {
         gg_stage(a, node.f0, 3 * node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
         double val[GG_E], S4[GG_E];
-        gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, val, S4);
+        gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, S4);
         const double l = node.ls0, l2 = l * l;
         double s = 0.0;                                    // d k / d l = k S / l^3
 #pragma unroll
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
       // stationary: Q_e = f dk/d(r2) ; d k / d l_d = Q * (-2 delta_d^2 / l_d)
       gg_stage(a, node.f0, node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
       double val[GG_E], q4[GG_E], Q[GG_E];
-      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, val, q4);
+      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, q4);
       const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
 #pragma unroll
       for (int e = 0; e < GG_E; ++e) {
@@ -409,13 +418,20 @@ int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   return GPS_OK;
 }
 
-int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n, i64 d_all,
-                            i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
-                            double* grad_slots_host, double* grad_noise_host) {
+// compiled form of a kernel program for gg_kernel
+struct GGBuilt {
   GGProg P;
   std::vector<GGFeat> feats;
   std::vector<double> ls_of_slot;
-  std::vector<double> W((size_t)GG_MAXL * GG_W * (GG_W + 1), 0.0);
+  std::vector<double> W;
+};
+
+static int gg_build(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all, GGBuilt& B) {
+  GGProg& P = B.P;
+  std::vector<GGFeat>& feats = B.feats;
+  std::vector<double>& ls_of_slot = B.ls_of_slot;
+  std::vector<double>& W = B.W;
+  W.assign((size_t)GG_MAXL * GG_W * (GG_W + 1), 0.0);
   memset(&P, 0, sizeof(P));
   int n_prim_nodes = 0;
   for (int i = 0; i < n_nodes; ++i) if (prog[i].op < GPS_K_NKN_LINROW) n_prim_nodes = i + 1;
@@ -492,29 +508,36 @@ int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_n
     if (width != 1) return gps_fail(h, GPS_ERR_ARG, "gradient: the network must end with one output");
   }
   if (P.n_slots > GG_MAXSLOT) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradient: too many parameters");
+  return GPS_OK;
+}
 
-  const int nfeat = (int)feats.size();
-  const size_t wbytes = W.size() * 8;
-  GPS_HIP(h, h->dFeat.ensure((size_t)(nfeat > 0 ? nfeat : 1) * npad * 8));
+// features of `n` points (padded to npad) into `feat`
+static int gg_features(gps_handle_t h, const GGBuilt& B, const double* dX, i64 n, i64 d_all, i64 npad, DevBuf& feat) {
+  const int nfeat = (int)B.feats.size();
+  GPS_HIP(h, feat.ensure((size_t)(nfeat > 0 ? nfeat : 1) * npad * 8));
+  if (nfeat == 0) return GPS_OK;
   GPS_HIP(h, h->dProg.ensure((size_t)nfeat * sizeof(GGFeat) + 64));
+  GPS_HIP(h, h->ring.upload(h->dProg.p, B.feats.data(), (size_t)nfeat * sizeof(GGFeat), h->stream));
+  LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * nfeat);
+  hipLaunchKernelGGL(gg_prep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
+                     (const GGFeat*)h->dProg.p, nfeat, feat.d(), npad);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+// launch + fold the fixed-order partials; slots: set (accumulate == 0) or added to
+static int gg_run(gps_handle_t h, const GGBuilt& B, GGArgs& a, double flops, double bytes, int accumulate,
+                  double* grad_slots_host, double* grad_noise_host) {
+  const GGProg& P = B.P;
+  const size_t wbytes = B.W.size() * 8;
   GPS_HIP(h, h->dNkn.ensure(wbytes + 64));
-  if (nfeat > 0) {
-    GPS_HIP(h, h->ring.upload(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GGFeat), h->stream));
-    LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * nfeat);
-    hipLaunchKernelGGL(gg_prep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
-                       (const GGFeat*)h->dProg.p, nfeat, h->dFeat.d(), npad);
-    GPS_HIP(h, hipGetLastError());
-  }
-  GPS_HIP(h, h->ring.upload(h->dNkn.p, W.data(), wbytes, h->stream));
-  GGArgs a;
-  a.Ft = h->dFeat.d(); a.ldf = npad; a.Kinv = dKinv; a.ldk = ldk; a.A = dA; a.lda = lda; a.r = (int)r;
+  GPS_HIP(h, h->ring.upload(h->dNkn.p, B.W.data(), wbytes, h->stream));
   a.Wnet = (const double*)h->dNkn.p;
-  a.n = n; a.npad = npad; a.tiles = (int)(npad / GG_T);
   const size_t pbytes = (size_t)GG_BLOCKS * (GG_MAXSLOT + 1) * 8;
   GPS_HIP(h, h->dTmp2.ensure(pbytes));
   a.partial = h->dTmp2.d();
   {
-    LaunchScope ls(h, KC_REDUCE, 0.5 * (double)npad * npad * (60.0 + 4.0 * nfeat + 40.0 * P.n_layers), 4.0 * (double)npad * npad);
+    LaunchScope ls(h, KC_REDUCE, flops, bytes);
     hipLaunchKernelGGL(gg_kernel, dim3(GG_BLOCKS), dim3(256), 0, h->stream, a, P);
     GPS_HIP(h, hipGetLastError());
   }
@@ -527,9 +550,77 @@ int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_n
     for (int b = 0; b < GG_BLOCKS; ++b) tot += part[(size_t)b * (GG_MAXSLOT + 1) + s];
     if (s == GG_MAXSLOT) { if (grad_noise_host) *grad_noise_host = tot; }
     else {
-      if (ls_of_slot[s] > 0.0) tot /= ls_of_slot[s];       // -2 delta^2 / l_d : delta is already x/l
-      grad_slots_host[s] = tot;
+      if (B.ls_of_slot[s] > 0.0) tot /= B.ls_of_slot[s];       // -2 delta^2 / l_d : delta is already x/l
+      if (accumulate) grad_slots_host[s] += tot; else grad_slots_host[s] = tot;
     }
+  }
+  return GPS_OK;
+}
+
+int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n, i64 d_all,
+                            i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                            double* grad_slots_host, double* grad_noise_host) {
+  GGBuilt B;
+  int rc = gg_build(h, prog, n_nodes, d_all, B);
+  if (rc) return rc;
+  rc = gg_features(h, B, dX, n, d_all, npad, h->dFeat);
+  if (rc) return rc;
+  GGArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Ft = h->dFeat.d(); a.ldf = npad; a.Ftc = a.Ft; a.ldfc = npad; a.Kinv = dKinv; a.ldk = ldk; a.A = dA; a.lda = lda; a.r = (int)r;
+  a.n = n; a.npad = npad; a.tiles = (int)(npad / GG_T); a.tiles_c = a.tiles; a.rect = 0; a.same_points = 1;
+  return gg_run(h, B, a, 0.5 * (double)npad * npad * (60.0 + 4.0 * B.feats.size() + 40.0 * B.P.n_layers), 4.0 * (double)npad * npad,
+                0, grad_slots_host, grad_noise_host);
+}
+
+// Vector-Jacobian product of the kernel-matrix build:  slots (+)= sum_{i < nr, j < nc} Wd[i][j] d k(xr_i, xc_j) / d theta
+// for a device-resident cotangent Wd [nr, nc] (leading dimension ldw) -- what reverse-mode autodiff through kern.K(X, X2)
+// (kernels.py:408-439, 1071-1084; neural_kernel_network.py:41-47) delivers.  dXc == nullptr: K(Xr, Xr) (White on i == j).
+int gps_launch_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dXr, i64 nr, const double* dXc,
+                        i64 nc, i64 d_all, const double* Wd, i64 ldw, int accumulate, double* grad_slots_host) {
+  GGBuilt B;
+  int rc = gg_build(h, prog, n_nodes, d_all, B);
+  if (rc) return rc;
+  const bool same = (dXc == nullptr);
+  if (same) { dXc = dXr; nc = nr; }
+  const i64 nrp = gps_pad(nr), ncp = gps_pad(nc);
+  rc = gg_features(h, B, dXr, nr, d_all, nrp, h->dFeat);
+  if (rc) return rc;
+  if (!same) { rc = gg_features(h, B, dXc, nc, d_all, ncp, h->dFeat2); if (rc) return rc; }
+  GGArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Ft = h->dFeat.d(); a.ldf = nrp;
+  a.Ftc = same ? h->dFeat.d() : h->dFeat2.d(); a.ldfc = same ? nrp : ncp;
+  a.n = nr; a.npad = nrp; a.tiles = (int)(nrp / GG_T); a.tiles_c = (int)(ncp / GG_T);
+  a.rect = 1; a.same_points = same ? 1 : 0; a.Wd = Wd; a.ldw = ldw; a.nr = nr; a.nc = nc;
+  return gg_run(h, B, a, (double)nrp * ncp * (60.0 + 4.0 * B.feats.size() + 40.0 * B.P.n_layers), 8.0 * (double)nrp * ncp,
+                accumulate, grad_slots_host, nullptr);
+}
+
+// d (sum_i kbar_i Kdiag_i) / d theta for the constant Kdiag of these programs (every primitive's Kdiag is its variance,
+// kernels.py:428-429, 803-804, 327-328; Sum / Product fold them, :1075-1076, 1083-1084): kbar = sum_i kbar_i; only the
+// variance slots receive anything.  Forward mode over the fold, one primitive at a time.
+int gps_kdiag_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all, double kbar, double* grad_slots_host) {
+  GGBuilt B;
+  int rc = gg_build(h, prog, n_nodes, d_all, B);
+  if (rc) return rc;
+  if (B.P.nkn) return gps_fail(h, GPS_ERR_UNSUPPORTED, "Kdiag gradient: neural-kernel-network programs are not supported here");
+  for (int p = 0; p < B.P.n_prims; ++p) {
+    double sv[GPS_MAX_STACK + 1], st[GPS_MAX_STACK + 1]; int sp = 0;
+    int slot = -1;
+    for (int nd = 0; nd < B.P.n_nodes; ++nd) {
+      const GGNode& g = B.P.nodes[nd];
+      if (g.op == GPS_K_ADD || g.op == GPS_K_MUL) {
+        const double b = sv[--sp], tb = st[sp], a = sv[--sp], ta = st[sp];
+        sv[sp] = (g.op == GPS_K_ADD) ? a + b : a * b;
+        st[sp] = (g.op == GPS_K_ADD) ? ta + tb : ta * b + a * tb;
+        ++sp;
+      } else {
+        sv[sp] = g.variance; st[sp] = (g.prim == p) ? 1.0 : 0.0; ++sp;
+        if (g.prim == p) slot = g.slot0;
+      }
+    }
+    if (slot >= 0) grad_slots_host[slot] += kbar * st[0];
   }
   return GPS_OK;
 }

@@ -67,6 +67,12 @@ _SIGNATURES = {
     "gps_svgp_elbo": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64, ctypes.c_double,
                       _c_double_p, _i64, _c_double_p, _c_double_p, _i64, _c_double_p, ctypes.c_int, ctypes.c_int,
                       ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_int_p],
+    "gps_svgp_elbo_grad": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64, ctypes.c_double,
+                           _c_double_p, _i64, _c_double_p, _c_double_p, _i64, _c_double_p, ctypes.c_int, ctypes.c_int,
+                           ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_int, _c_int_p, _c_double_p,
+                           _c_double_p, _c_double_p, _c_double_p, _c_int_p],
+    "gps_kmat_vjp": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
+                     _c_double_p, _c_double_p, ctypes.c_int, _c_int_p],
     "gps_gauss_kl": [ctypes.c_void_p, _c_double_p, _i64, _c_double_p, _i64, _c_double_p, ctypes.c_int, _c_double_p,
                      _c_int_p],
     "gps_sgpr": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
@@ -569,6 +575,58 @@ class Handle(object):
         if info.value > 0:
             raise NotPositiveDefiniteError("Kuu + jitter*I is not positive definite (leading minor of order %d)" % info.value)
         return elbo.value, kl.value, ve.value
+
+    def svgp_elbo_grad(self, prog, Z, X, yres, q_mu, q_sqrt, jitter, noise_var, white=True, scale=1.0):
+        """(elbo, grad_slots, grad_noise, grad_q_mu [M, K], grad_q_sqrt shaped like q_sqrt, d/d mean(X) [N, K]) -- gradients
+        w.r.t. the constrained values; whitened parametrisation only, Z fixed (gps_svgp_elbo_grad)."""
+        Z, X, yres, q_mu = _f64(Z), _f64(X), _f64(yres), _f64(q_mu)
+        _need(Z.ndim == 2 and X.ndim == 2 and Z.shape[1] == X.shape[1], "Z [M, D] and X [N, D] must share D")
+        m, d = Z.shape
+        n = X.shape[0]
+        _need(q_mu.ndim == 2 and q_mu.shape[0] == m, "q_mu must be [M, K]")
+        k = q_mu.shape[1]
+        _need(yres.shape == (n, k), "Y - mean must be [N, K] with K = number of latent functions")
+        _need(m > 0 and n > 0 and k > 0, "empty SVGP problem")
+        q, qnd = self._prep_q_sqrt(q_sqrt)
+        _need(q is not None, "SVGP needs q_sqrt")
+        self._check_q_sqrt(q, qnd, m, k)
+        if not white:
+            raise NotImplementedError("the gradient of the SVGP bound is available for the whitened parametrisation only")
+        elbo, gnoise = ctypes.c_double(0), ctypes.c_double(0)
+        info, nslots = ctypes.c_int(0), ctypes.c_int(0)
+        cap = 700
+        slots = np.zeros(cap)
+        g_qmu = np.zeros((m, k))
+        g_q = np.zeros_like(q)
+        g_mean = np.zeros((n, k))
+        self.resident_token = None
+        self.factor_key = None
+        self._check(self._lib.gps_svgp_elbo_grad(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(X), n, _ptr(yres),
+                                                 _ptr(q_mu), k, _ptr(q), qnd, 1, float(noise_var), float(scale),
+                                                 ctypes.byref(elbo), _ptr(slots), cap, ctypes.byref(nslots), ctypes.byref(gnoise),
+                                                 _ptr(g_qmu), _ptr(g_q), _ptr(g_mean), ctypes.byref(info)), "gps_svgp_elbo_grad")
+        if info.value > 0:
+            raise NotPositiveDefiniteError("Kuu + jitter*I is not positive definite (leading minor of order %d)" % info.value)
+        if qnd == 3:
+            g_q = np.ascontiguousarray(np.transpose(g_q, (1, 2, 0)))           # [k, m, m] -> [m, m, k]
+        return elbo.value, slots[:nslots.value].copy(), gnoise.value, g_qmu, g_q, g_mean
+
+    def kmat_vjp(self, prog, X, W, X2=None):
+        """sum_ij W[i, j] d k(X_i, X2_j) / d(kernel parameter slot): reverse mode through kern.K(X, X2)."""
+        X, W = _f64(X), _f64(W)
+        n, d = X.shape
+        m = n
+        if X2 is not None:
+            X2 = _f64(X2)
+            _need(X2.ndim == 2 and X2.shape[1] == d, "X2 must be [M, %d]" % d)
+            m = X2.shape[0]
+        _need(W.shape == (n, m), "W must be [N, M]")
+        cap = 700
+        slots = np.zeros(cap)
+        ns = ctypes.c_int(0)
+        self._check(self._lib.gps_kmat_vjp(self._h, prog, len(prog), _ptr(X), n, _ptr(X2) if X2 is not None else None, m, d,
+                                           _ptr(W), _ptr(slots), cap, ctypes.byref(ns)), "gps_kmat_vjp")
+        return slots[:ns.value].copy()
 
     def gauss_kl(self, q_mu, q_sqrt, K=None):
         """kullback_leiblers.py:26-105"""

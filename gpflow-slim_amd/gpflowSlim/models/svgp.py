@@ -72,6 +72,62 @@ class SVGP(GPModel):
         var_exp = self.likelihood.variational_expectations(fmean, fvar, self.Y)
         return float(np.sum(var_exp) * scale - KL)
 
+    def compute_log_likelihood_and_gradients(self):
+        """The bound and d bound / d(unconstrained parameter) for every parameter of the model -- what
+        `tf.gradients(objective, variables)` yields in the reference (examples/svgp.py:159-161) up to the sign of
+        `objective`.  Gaussian likelihood, whitened parametrisation; the inducing inputs are held fixed (zero gradient).
+        Returns (bound, [(Parameter, gradient array shaped like Parameter.unconstrained_tensor), ...])."""
+        if type(self.likelihood) is not likelihoods.Gaussian:
+            raise NotImplementedError("analytic gradients of the SVGP bound need the Gaussian likelihood")
+        d_all = self.X.shape[1]
+        prog = self.kern._program(d_all)
+        layout = self.kern._grad_layout(d_all)
+        scale = float(self.num_data) / float(self.X.shape[0])
+        yres = np.ascontiguousarray(np.broadcast_to(self.Y - self.mean_function(self.X), self.Y.shape))
+        elbo, slots, gnoise, g_qmu, g_qsqrt, g_mean = be.get_handle().svgp_elbo_grad(
+            prog, self.feature.Z, self.X, yres, self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
+            float(np.squeeze(self.likelihood.variance)), white=self.whiten, scale=scale)
+        if len(layout) != len(slots):
+            raise RuntimeError("gradient slot layout mismatch: %d vs %d" % (len(layout), len(slots)))
+        grads = {id(p): np.zeros_like(np.atleast_1d(p.vf_val), dtype=settings.float_type) for p in self.parameters}
+        for (param, idx), g in zip(layout, slots):
+            if param is None:
+                continue
+            if idx is None:
+                grads[id(param)] += g
+            else:
+                grads[id(param)].reshape(-1)[idx] += g
+        grads[id(self.likelihood._variance)] += gnoise
+        from ..mean_functions import Constant as _MConst, Linear as _MLin
+        mf = self.mean_function
+
+        def _fit(g, like):
+            like = np.atleast_1d(like)
+            return g.reshape(like.shape) if g.size == like.size else np.full(like.shape, np.sum(g))
+
+        if isinstance(mf, _MConst):
+            grads[id(mf.c)] = grads[id(mf.c)] + _fit(np.sum(g_mean, axis=0), mf.c.vf_val)
+        elif isinstance(mf, _MLin):
+            grads[id(mf.A)] = grads[id(mf.A)] + _fit(self.X.T @ g_mean, mf.A.vf_val)
+            grads[id(mf.b)] = grads[id(mf.b)] + _fit(np.sum(g_mean, axis=0), mf.b.vf_val)
+        out = []
+        for p in self.parameters:
+            if p is self._q_mu:
+                out.append((p, g_qmu.reshape(p.vf_val.shape)))
+            elif p is self._q_sqrt:
+                if self.q_diag:
+                    out.append((p, (g_qsqrt * p.transform.forward_grad(p.vf_val)).reshape(p.vf_val.shape)))
+                else:       # LowerTriangular: the free vector holds the lower-triangular entries, row-major per latent
+                    n_ind = g_qsqrt.shape[0]
+                    rows, cols = np.tril_indices(n_ind, 0)
+                    out.append((p, np.stack([g_qsqrt[rows, cols, q] for q in range(g_qsqrt.shape[2])]).reshape(p.vf_val.shape)))
+            elif p is getattr(self.feature, "_Z", None):
+                out.append((p, np.zeros_like(p.vf_val)))                       # inducing inputs: fixed
+            else:
+                g = grads[id(p)].reshape(np.atleast_1d(p.vf_val).shape) * np.atleast_1d(p.transform.forward_grad(p.vf_val))
+                out.append((p, g.reshape(p.vf_val.shape)))
+        return elbo, out
+
     def _build_predict(self, Xnew, full_cov=False):
         """models/svgp.py:127-130"""
         mu, var = features.conditional(self.feature, self.kern, Xnew, self.q_mu, q_sqrt=self.q_sqrt,

@@ -190,6 +190,29 @@ int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                   int white, double noise_var, double scale,
                   double* elbo, double* kl, double* var_exp_sum, int* info);
 
+/* The same bound AND its gradient -- what TF autodiff through models/svgp.py:108-125 supplies to the optimiser of
+ * examples/svgp.py:159-161 -- for the whitened parametrisation (white must be 1; the unwhitened one returns
+ * GPS_ERR_UNSUPPORTED) and with the inducing inputs Z held fixed:
+ *   grad_slots   d/d kernel parameters, slot layout of gps_gpr_lml_grad;  grad_noise  d/d noise_var;
+ *   grad_q_mu    host [m, k];  grad_q_sqrt  host, layout of q_sqrt ([m, k], or [k, m, m] with zeros above the diagonals);
+ *   grad_mean    (optional) host [n, k] = d/d mean_function(X)  (chain rule for mean-function parameters).
+ * All with respect to the CONSTRAINED values.                                                                    */
+int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                       const double* Z, int64_t m, int64_t d_all, double jitter,
+                       const double* X, int64_t n, const double* yres,
+                       const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim,
+                       int white, double noise_var, double scale,
+                       double* elbo, double* grad_slots, int n_slots_cap, int* n_slots_out, double* grad_noise,
+                       double* grad_q_mu, double* grad_q_sqrt, double* grad_mean, int* info);
+
+/* Vector-Jacobian product of the kernel-matrix build -- reverse-mode autodiff through kern.K(X, X2) (kernels.py:408-439,
+ * 1071-1084; neural_kernel_network.py:41-47):  grad_slots[s] = sum_ij W[i][j] d k(X_i, X2_j) / d theta_s  for a
+ * caller-supplied cotangent W host [n, m] (X2 == NULL: K(X, X), W [n, n] used as given).  Slot layout of
+ * gps_gpr_lml_grad.  The building block of gps_svgp_elbo_grad, exported for models assembled by the caller.      */
+int gps_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X, int64_t n,
+                 const double* X2, int64_t m, int64_t d_all, const double* W, double* grad_slots,
+                 int n_slots_cap, int* n_slots_out);
+
 /* gauss_kl(q_mu, q_sqrt, K) (kullback_leiblers.py:26-105): KL[N(q_mu, q_sqrt q_sqrt^T) || N(0, K)], summed over
  * the k independent columns; K host [m, m] or NULL (p = N(0, I)).  tf.cholesky(K) (:51), alpha = Lp^-1 q_mu (:52),
  * tr(K^-1 S_q) through Lp^-T (diagonal q_sqrt: row sums of squares of Lp^-T instead of forming K^-1, :84-90) or

@@ -489,6 +489,59 @@ def svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, noise_var, whiten=True, num_data=None
     return np.sum(var_exp) * scale - KL
 
 
+def _chol_adjoint(L, Lbar):
+    """Kbar (symmetric) with <Kbar, dK> = <Lbar, dL> for L = chol(K) and symmetric dK (Murray 2016, eq. 10)."""
+    P = np.tril(L.T @ np.tril(Lbar))
+    P[np.diag_indices_from(P)] *= 0.5
+    S = sl.solve_triangular(L, P + P.T, lower=True, trans='T')
+    S = sl.solve_triangular(L, S.T, lower=True, trans='T')
+    return 0.5 * S
+
+
+def svgp_elbo_grad(spec_fn, theta, X, Y, Z, q_mu, q_sqrt, noise_var, num_data=None, jitter=JITTER, rel_step=1e-6):
+    """Gradient of svgp_elbo (whitened parametrisation, models/svgp.py:101-130) -- what TF autodiff differentiates for
+    examples/svgp.py:159-161 -- w.r.t. the flat constrained kernel parameters `theta` (spec_fn(theta) -> spec), the noise
+    variance, q_mu and q_sqrt.  Reverse mode at the matrix level (A = Lm^-1 Kuf, Cholesky adjoint) with dK/dtheta by central
+    differences of the oracle's own K: independent of the product's derivative formulas.  Returns
+    (g_theta, g_noise, g_q_mu [M, K], g_q_sqrt like q_sqrt, dELBO/dmean(X) [N, K])."""
+    theta = np.asarray(theta, dtype=np.float64)
+    spec = spec_fn(theta)
+    M, N, k = Z.shape[0], X.shape[0], q_mu.shape[1]
+    w = float(num_data or N) / float(N)
+    Kuu = K(spec, Z) + jitter * np.eye(M)
+    Kuf = K(spec, Z, X)
+    kd = Kdiag(spec, X)
+    L = np.linalg.cholesky(Kuu)
+    A = sl.solve_triangular(L, Kuf, lower=True)
+    if q_sqrt.ndim == 3:
+        Lq = np.tril(np.transpose(q_sqrt, (2, 0, 1)))
+    else:
+        Lq = np.stack([np.diag(q_sqrt[:, q]) for q in range(k)])
+    mu = A.T @ q_mu
+    var = np.stack([kd - np.sum(A * A, 0) + np.sum((Lq[q].T @ A) ** 2, 0) for q in range(k)], 1)
+    E = w * (Y - mu) / noise_var
+    sq = np.sum((Y - mu) ** 2 + var)
+    g_noise = w * (-N * k / (2 * noise_var) + sq / (2 * noise_var ** 2))
+    g_qmu = A @ E - q_mu
+    AAT = A @ A.T
+    gL = np.stack([np.tril(-(w / noise_var) * AAT @ Lq[q] - Lq[q] + np.diag(1.0 / np.diag(Lq[q]))) for q in range(k)])
+    g_qsqrt = np.transpose(gL, (1, 2, 0)) if q_sqrt.ndim == 3 else np.stack([np.diag(gL[q]) for q in range(k)], 1)
+    Ssum = sum(Lq[q] @ Lq[q].T for q in range(k))
+    Abar = q_mu @ E.T + (w / noise_var) * (k * np.eye(M) - Ssum) @ A
+    Kuf_bar = sl.solve_triangular(L, Abar, lower=True, trans='T')
+    Kuu_bar = _chol_adjoint(L, -np.tril(Kuf_bar @ A.T))
+    kd_bar = -w * k / (2 * noise_var)
+    g = np.zeros_like(theta)
+    for p in range(theta.size):
+        h = rel_step * max(1.0, abs(theta[p]))
+        tp, tm = theta.copy(), theta.copy()
+        tp[p] += h; tm[p] -= h
+        sp, sm = spec_fn(tp), spec_fn(tm)
+        g[p] = (np.sum(Kuu_bar * (K(sp, Z) - K(sm, Z))) + np.sum(Kuf_bar * (K(sp, Z, X) - K(sm, Z, X)))
+                + kd_bar * np.sum(Kdiag(sp, X) - Kdiag(sm, X))) / (2 * h)
+    return g, g_noise, g_qmu, g_qsqrt, E
+
+
 # ---------------------------------------------------------------------------------------------
 # bench.py cpu_baseline leg: the same path with LAPACK dpotrf/dtrtrs (algorithm class of TF-CPU's
 # Eigen LLT / triangular solve), K built the unfused way the reference's TF graph does.

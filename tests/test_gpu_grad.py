@@ -288,3 +288,114 @@ def test_gpr_optimize_lbfgs_and_adam():
     s2 = m2.objective
     f2 = m2.optimize(max_iter=150, method="adam", learning_rate=0.05)
     assert f2 < s2 - 50.0
+
+
+@pytest.mark.parametrize("q_diag", [False, True])
+@pytest.mark.parametrize("kind,n,m_,d,k", [("rbf_ard", 300, 40, 3, 2), ("m52_plus_periodic", 500, 150, 2, 1), ("m32_ard", 260, 130, 2, 3)])
+def test_svgp_bound_gradient(handle, q_diag, kind, n, m_, d, k):
+    """Gradient of the SVGP bound (whitened, Gaussian likelihood; gps_svgp_elbo_grad) w.r.t. the kernel parameters, the
+    noise variance, q_mu and q_sqrt against the oracle's matrix-level reverse mode (dK by central differences of the
+    oracle's own K) and against finite differences of the product's own bound through the unconstrained parameters."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_ + k)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, k))) + 0.1 * rng.standard_normal((n, k))
+    Z = X[:m_].copy()
+    kern, theta, fn, _ = _cases(gpf, d)[kind]()
+    m = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.3), Z=Z, q_diag=q_diag, whiten=True, num_data=3 * n)
+    q_mu = rng.standard_normal((m_, k)) * 0.3
+    m._q_mu.assign(q_mu)
+    if q_diag:
+        q_sqrt = np.abs(rng.standard_normal((m_, k))) * 0.4 + 0.2
+    else:
+        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * (0.5 / m_) + np.eye(m_) * 0.5).transpose(1, 2, 0).copy()
+    m._q_sqrt.assign(q_sqrt)
+    noise = c(0.3)
+    bound, grads = m.compute_log_likelihood_and_gradients()
+    assert abs(bound - m.compute_log_likelihood()) <= 1e-12 * abs(bound)
+    g_ref, gn_ref, gq_ref, gs_ref, _ = orc.svgp_elbo_grad(fn, theta, X, Y, Z, q_mu, np.asarray(m.q_sqrt), noise, num_data=3 * n)
+    scale = max(1.0, np.abs(g_ref).max())
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == g_ref.shape
+    assert np.abs(got - g_ref).max() <= 5e-6 * scale, (got, g_ref)
+    by = {id(p): g for p, g in grads}
+    gn = float(by[id(m.likelihood._variance)] / m.likelihood._variance.transform.forward_grad(m.likelihood._variance.vf_val))
+    assert abs(gn - gn_ref) <= 1e-7 * max(1.0, abs(gn_ref))
+    assert np.abs(by[id(m._q_mu)] - gq_ref).max() <= 1e-7 * max(1.0, np.abs(gq_ref).max())
+    if q_diag:
+        gs = by[id(m._q_sqrt)] / m._q_sqrt.transform.forward_grad(m._q_sqrt.vf_val)
+        assert np.abs(gs - gs_ref).max() <= 1e-7 * max(1.0, np.abs(gs_ref).max())
+    else:
+        rows, cols = np.tril_indices(m_, 0)
+        ref_free = np.stack([gs_ref[rows, cols, q] for q in range(k)])
+        assert np.abs(by[id(m._q_sqrt)] - ref_free).max() <= 1e-7 * max(1.0, np.abs(ref_free).max())
+    # finite differences of the product's own bound (a few entries per parameter)
+    rng2 = np.random.default_rng(1)
+    for p, g in grads:
+        flat = np.atleast_1d(p.vf_val).ravel().copy()
+        gflat = np.atleast_1d(g).ravel()
+        for i in (range(flat.size) if flat.size <= 4 else rng2.choice(flat.size, 4, replace=False)):
+            h = 1e-5
+            x0 = flat[i]
+            flat[i] = x0 + h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fp = m.compute_log_likelihood()
+            flat[i] = x0 - h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fm = m.compute_log_likelihood()
+            flat[i] = x0; p.assign_unconstrained(flat.reshape(p.vf_val.shape))
+            fd = (fp - fm) / (2 * h)
+            assert abs(gflat[i] - fd) <= 2e-5 * max(1.0, abs(fd)), (p.name, i, gflat[i], fd)
+
+
+def test_svgp_optimize_raises_the_bound(handle):
+    """SVGP + Model.optimize(): the bound goes up on the analytic gradients (the fit of examples/svgp.py:159-161, with a
+    Gaussian likelihood) and ends close to the exact GPR evidence it bounds."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(3)
+    n, d, m_ = 400, 2, 60
+    X = rng.standard_normal((n, d)); Y = np.sin(2.0 * X[:, :1]) * np.cos(X[:, 1:2]) + 0.1 * rng.standard_normal((n, 1))
+    m = gpf.models.SVGP(X, Y, gpf.kernels.RBF(d, ARD=True), gpf.likelihoods.Gaussian(0.5), Z=X[:m_].copy(), whiten=True)
+    start = m.objective
+    final = m.optimize(max_iter=150)
+    assert final < start - 100.0, (start, final)
+    exact = gpf.models.GPR(X, Y, m.kern, obs_var=float(np.squeeze(m.likelihood.variance))).compute_log_likelihood()
+    assert -final <= exact + 1e-6 * abs(exact)             # a lower bound on the evidence at the same hyper-parameters
+    with pytest.raises(NotImplementedError):
+        gpf.models.SVGP(X, Y, gpf.kernels.RBF(d), gpf.likelihoods.Gaussian(0.5), Z=X[:m_].copy(), whiten=False).compute_log_likelihood_and_gradients()
+
+
+@pytest.mark.parametrize("n,m_", [(40, 300), (130, None), (257, 70)])
+def test_kernel_matrix_vjp(handle, n, m_):
+    """gps_kmat_vjp: sum_ij W_ij d k(X_i, X2_j) / d theta for an arbitrary cotangent W (reverse mode through kern.K) against
+    central differences of the oracle's K -- rectangular and square, sum / product programs and a White kernel (which only
+    contributes on the diagonal of K(X, X))."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n)
+    d = 3
+    for kind in ("rbf_ard", "rbf_times_periodic_plus_white", "m52_plus_periodic"):
+        kern, theta, fn, _ = _cases(gpf, d)[kind]()
+        X = rng.standard_normal((n, d)); X2 = None if m_ is None else rng.standard_normal((m_, d))
+        W = rng.standard_normal((n, m_ or n))
+        got = handle.kmat_vjp(kern._program(d), X, W, X2)
+        ref = np.zeros(theta.size)
+        saved, orc.SQUARE_DIST_MODE = orc.SQUARE_DIST_MODE, "diff"
+        try:
+            for p in range(theta.size):
+                hh = 1e-6 * max(1.0, abs(theta[p])); tp, tm = theta.copy(), theta.copy(); tp[p] += hh; tm[p] -= hh
+                ref[p] = np.sum(W * (orc.K(fn(tp), X, X2) - orc.K(fn(tm), X, X2))) / (2 * hh)
+        finally:
+            orc.SQUARE_DIST_MODE = saved
+        # slots: per primitive [variance, one per active dim | lengthscale, period]; isotropic kernels sum their dim slots
+        layout = kern._grad_layout(d)
+        acc = {}
+        order = []
+        for (param, idx), g in zip(layout, got):
+            if param is None:
+                continue
+            key = (id(param), idx)
+            if key not in acc:
+                acc[key] = 0.0; order.append(key)
+            acc[key] += g
+        flat = []
+        for p in kern.parameters:
+            size = np.atleast_1d(p.vf_val).size
+            flat += [acc.get((id(p), None), 0.0) if size == 1 else acc.get((id(p), i), 0.0) for i in range(size)]
+        flat = np.array(flat)
+        assert flat.shape == ref.shape, (kind, flat.shape, ref.shape)
+        assert np.abs(flat - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (kind, flat, ref)
