@@ -1309,8 +1309,8 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
 //   Abar = q_mu E^T + (scale/s2) (k I - sum_q L_q L_q^T) A                 d ELBO / d A
 //   Kuf_bar = Lm^-T Abar ;  Lm_bar = -tril(Kuf_bar A^T) ;  Kuu_bar = Lm^-T (Phi(Lm^T Lm_bar) + Phi(.)^T) Lm^-1 / 2   (Phi: tril, diagonal halved)
 //   d/d theta = <Kuf_bar, dKuf> + <Kuu_bar, dKuu> + kbar dKdiag            (gps_launch_kmat_vjp: the kernel-matrix VJP)
-// Restated and checked against finite differences in oracle/gp_oracle.py::svgp_elbo_grad.  The inducing inputs Z are
-// held fixed (their gradient is not computed); the unwhitened parametrisation is not differentiated.
+// (Checked in tests/test_gpu_grad.py against a CPU restatement and finite differences.)  The inducing inputs Z are held
+// fixed (their gradient is not computed); the unwhitened parametrisation is not differentiated.
 extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                                   int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
                                   const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
