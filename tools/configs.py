@@ -70,6 +70,11 @@ else:
     sv.compute_log_likelihood()
     ms, elbo = best(sv.compute_log_likelihood, 2)
     out["svgp_elbo_full_q_sqrt_whitened_ms"] = round(ms, 1); out["svgp_elbo"] = elbo
+    if "grad" in sys.argv:
+        sv.compute_log_likelihood_and_gradients()
+        ms, (b2, grads) = best(sv.compute_log_likelihood_and_gradients, 2)
+        out["svgp_elbo_plus_gradient_ms"] = round(ms, 1)
+        out["svgp_grad_norms"] = {p.name: float(np.abs(g).max()) for p, g in grads}
     idx = rng.choice(N, 200, replace=False)
     spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(np.sqrt(d) * np.ones(d)), "input_dim": d}
     rmu, rvar = orc.conditional(X[idx], Z, spec, f, white=False)
