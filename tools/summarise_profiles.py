@@ -14,7 +14,7 @@ sha = kernel_source_sha()
 
 def find(d, pat):
     hits = glob.glob(os.path.join(OUT, d, "**", pat), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None      # a directory may hold an earlier collection too
 
 
 def last_json(path):
