@@ -290,7 +290,7 @@ def main():
                          "trsv": ({"bytes": tb, "ms": round(tv["ms"], 3), "launches": tv["launches"],
                                    "gbs": round(tb / (tv["ms"] * 1e-3) / 1e9, 1),
                                    "frac_of_hbm_peak": round(tb / (tv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "recursive forward substitution, one pass over the lower triangle of L in ~4 N / 128 launch-latency-bound kernels"}
+                                   "note": "forward substitution as one wavefront launch over the 128-row blocks of L (trsv_wave.hip): one pass over the lower triangle, bounded by the block-to-block hand-over chain (N / 128 fabric round trips)"}
                                   if tv["ms"] > 0 else
                                   {"bytes": 0.0, "ms": 0.0, "launches": 0, "gbs": None, "frac_of_hbm_peak": None,
                                    "note": "no forward-substitution pass at this size: (Y - m)^T rides through the factorisation as augmented rows"}),

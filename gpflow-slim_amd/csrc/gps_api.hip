@@ -224,13 +224,41 @@ struct HipOps {
   }
 };
 
+// L a = y / L^T a = y for r right-hand sides (rows of y): one wavefront launch (trsv_wave.hip) unless the leaves are
+// to be refined against the diagonal blocks (jittered factors), where the recursive substitution with its refined
+// leaves stays.
+static int trsv_forward(gps_handle_t h, HipOps& ops, const double* L, i64 ldl, i64 n, double* y, i64 ldy, i64 r) {
+  if (h->trsv_wave && !h->refine_now && ops.linvT && n >= 2 * GPS_TILE)
+    return gps_launch_trsv_wave(h, L, ldl, n, ops.linvT, y, ldy, r, 0);
+  Blocked<HipOps> bl(ops);
+  return bl.trsv_rec(L, ldl, n, 0, y, ldy, r);
+}
+static int trsv_backward(gps_handle_t h, HipOps& ops, const double* L, i64 ldl, i64 n, double* y, i64 ldy, i64 r) {
+  if (h->trsv_wave && !h->refine_now && n >= 2 * GPS_TILE)
+    return gps_launch_trsv_wave(h, L, ldl, n, ops.linv, y, ldy, r, 1);
+  Blocked<HipOps> bl(ops);
+  return bl.trsv_t_rec(L, ldl, n, 0, y, ldy, r);
+}
+
 static int read_info(gps_handle_t h, int* d_info, int* info) {
   int v = 0;
   unsigned long long la_timeouts = 0;
   GPS_HIP(h, hipMemcpyAsync(&v, d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (h->dLaFlags.p) GPS_HIP(h, hipMemcpyAsync(&la_timeouts, (unsigned long long*)h->dLaFlags.p + 2, 8, hipMemcpyDeviceToHost, h->stream));
+  unsigned wave_gave_up = 0;
+  if (h->dWave.p && h->wave_ctl_clear) GPS_HIP(h, hipMemcpyAsync(&wave_gave_up, (unsigned*)h->dWave.p + 1, 4, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (info) *info = (v == INT_MAX) ? 0 : v;
+  if (wave_gave_up) {
+    // a bounded wait of the trsv wavefront gave up (never seen; the bound is there so that a scheduling surprise is an
+    // error, not a hung GPU): the result is poisoned -- switch the wavefront off for this handle and have the entry
+    // point run the evaluation again through the recursive substitution (with_la_retry)
+    (void)hipMemsetAsync((unsigned*)h->dWave.p + 1, 0, 4, h->stream);
+    h->trsv_wave = 0;
+    h->wave_fallbacks++;
+    h->la_timed_out = true;
+    return gps_fail(h, GPS_ERR_STATE, "trsv wavefront timed out (result invalid)");
+  }
   if (la_timeouts) {
     // not sticky: the counter is cleared (stream-ordered) so that the handle is usable again; the entry point re-runs
     // the evaluation once without look-ahead (with_la_retry)
@@ -301,7 +329,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
                     &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4};
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -353,6 +381,11 @@ extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launc
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
     return GPS_OK;
   }
+  if (strcmp(klass, "trsv_wave_fallbacks") == 0) {    // wavefront substitutions that gave up (handle fell back to the recursive one)
+    if (launches) *launches = (int64_t)h->wave_fallbacks;
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   gps_profile_collect(h);
   for (int i = 0; i < KC_COUNT; ++i) {
@@ -382,6 +415,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "kmat_fast") == 0) { h->kmat_fast = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
+  if (strcmp(key, "trsv_wave") == 0) { h->trsv_wave = (int)value; return GPS_OK; }
   if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }
@@ -694,10 +728,12 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // pass (~4 N / 128 launch-latency-bound kernels).  Same-process A/B on MI355X: N = 2048 / 4096 / 8192 / 12288:
   // -9 / -10 / -4.4 / -3.8 %; from N = 16384 on it loses (+0.9 %, N = 32768 +1.6 %): the extra tile row breaks the
   // power-of-two tile counts of the big launches, whose whole rounds of 512 workgroup slots matter more than the 3 ms
-  // of trsv.  Hence automatic (-1): on below 14000 points.  (The block-column multi-GPU path always uses it.)
-  // "trsv_follow" (also off): the forward substitution issued block by block behind the factorisation on a stream of
-  // its own -- measured far worse still (see gps_common.hpp).  Default: the recursive forward substitution afterwards.
-  const bool aug = r > 0 && r <= GPS_TILE && (h->gpr_aug_rows > 0 || (h->gpr_aug_rows < 0 && np < 14000));
+  // of trsv.  Against the one-launch wavefront substitution (trsv_wave.hip: 0.28 ms at N = 8192, 1.2 ms at 32768, where the
+  // recursive one took 0.62 / 3.2 ms) the augmented rows still win up to N = 4096 (-3 %), lose from 8192 on (+1.5 %) and
+  // tie at 12288.  Hence automatic (-1): on below 6200 points.  (The block-column multi-GPU path always uses it.)
+  // "trsv_follow" (also off): the recursive substitution issued block by block behind the factorisation on a stream of
+  // its own -- measured far worse still (see gps_common.hpp).
+  const bool aug = r > 0 && r <= GPS_TILE && (h->gpr_aug_rows > 0 || (h->gpr_aug_rows < 0 && np < 6200));
   GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
   double* const dAug = h->dK.d() + np * np;
   // residual, transposed to [r][np] and zero padded
@@ -740,7 +776,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   if (aug) {
     GPS_HIP(h, hipMemcpyAsync(h->dAlpha.p, dAug, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
   } else if (r > 0 && !followed) {
-    rc = bl.trsv_rec(h->dK.d(), np, np, 0, h->dAlpha.d(), np, r);
+    rc = trsv_forward(h, ops, h->dK.d(), np, np, h->dAlpha.d(), np, r);
     if (rc) return rc;
   }
   h->r = r;
@@ -805,7 +841,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   // A = K_y^-1 resid = L^-T (L^-1 resid)
   GPS_HIP(h, h->dA.ensure((size_t)r * np * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dA.p, h->dAlpha.p, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
-  rc = bl.trsv_t_rec(h->dK.d(), np, np, 0, h->dA.d(), np, r);
+  rc = trsv_backward(h, ops, h->dK.d(), np, np, h->dA.d(), np, r);
   if (rc) return rc;
   // K_y^-1 = L^-T L^-1
   GPS_HIP(h, h->dY.ensure((size_t)np * np * 8));

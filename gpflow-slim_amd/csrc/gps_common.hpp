@@ -112,6 +112,9 @@ struct gps_handle_s {
   // Off: measured on MI355X, ~500 small kernels dribbling in beside the 128x128 GEMM rounds (which own every register of
   // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).
   int trsv_follow = 0;
+  int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp
+  bool wave_ctl_clear = false;
+  unsigned long long wave_fallbacks = 0;
   hipStream_t y_stream = nullptr;
   std::vector<hipEvent_t> y_events; size_t y_event_next = 0;
   hipEvent_t ev_y_join = nullptr;
@@ -135,7 +138,7 @@ struct gps_handle_s {
   // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned
   // (every jittered path: conditional / base_conditional / SGPR / FITC / host-matrix potrf + trsm; GPR when the noise
   // variance is below leaf_refine_ratio x Kdiag), 0 = plain product with the block inverse, 1 = always refine
-  int gpr_aug_rows = -1;         // gps_gpr_lml / predict: (Y - m)^T as augmented rows of the factorisation instead of a trsv pass (-1: below 14000 points)
+  int gpr_aug_rows = -1;         // gps_gpr_lml / predict: (Y - m)^T as augmented rows of the factorisation instead of a trsv pass (-1: below 6200 points)
   int leaf_refine = -1;
   double leaf_refine_ratio = 1e-3;
   bool refine_now = false;       // resolved at every API entry
@@ -168,6 +171,7 @@ struct gps_handle_s {
   DevBuf dFeat2;    // feature workspace (cols / Xnew)
   DevBuf dProg;     // device copy of the kernel program
   DevBuf dNkn;      // neural-kernel-network layer weights
+  DevBuf dWave;     // trsv wavefront: [0] ticket, [1] give-ups, +256 B: exchange buffer [2][npad]
   DevBuf dScal;     // small scalar outputs: [0]=sum log diag, [1]=sum alpha^2, ...
   DevBuf dInfo;     // int info word
   DevBuf dXnew;     // [n_new, d_all]
@@ -277,6 +281,9 @@ int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const
                                 int upper);
 int gps_launch_trsv_leaf_refine(gps_handle_t h, const double* Wt, const double* D, i64 ldd, double* y, i64 ldy, i64 r,
                                 int upper);
+// trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
+int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
+                         int trans);
 // blas1.hip
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
 // look-ahead hand-over kernels (blas1.hip): optional publish of *sig = sval, then wait (bounded) until *flag >= val

@@ -321,9 +321,12 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     conditioned: gps_conditional / gps_base_conditional / gps_svgp_elbo / gps_gauss_kl / gps_sgpr /
  *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when noise_var <
  *                     "leaf_refine_ratio" (default 1e-3) x Kdiag; 0: plain products with the block inverses; 1: always
- *   "gpr_aug_rows"    -1 (default): below 14000 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
+ *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always
+ *   "trsv_wave"       1 (default): L a = y and L^T a = y of the GPR entry points run as ONE wavefront launch over the
+ *                     128-row blocks (trsv_wave.hip: 1.2 ms at N = 32768); 0: recursive substitution (4 N / 128 launches,
+ *                     3.2 ms).  Refined leaves (jittered factors) always take the recursive one.
  *   "trsv_follow"     0 (default) / 1: the forward substitution is issued block by block behind the factorisation on a
  *                     stream of its own (measured slower: DESIGN.md section 6)
  *   "kmat_fast"       1 (default): one-primitive stationary programs use the stack-free kernel-matrix kernel

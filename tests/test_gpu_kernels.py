@@ -253,3 +253,34 @@ def test_lookahead_stress_mixed_sizes_two_handles():
     finally:
         for h in hs:
             h.close()
+
+
+@pytest.mark.parametrize("n,r", [(256, 1), (300, 2), (1000, 1), (2500, 3), (4096, 1), (6000, 5)])
+def test_trsv_wavefront_equals_recursive_substitution(handle, n, r):
+    """L a = y and L^T a = y as one wavefront launch (trsv_wave.hip) against the recursive substitution of blocked.hpp
+    (same factor, same block inverses: the two differ only in summation order) and against the oracle."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    rng = np.random.default_rng(n + r)
+    d = 3
+    X = rng.standard_normal((n, d)); Y = rng.standard_normal((n, r))
+    kern = gpf.kernels.Matern32(d, variance=1.3, lengthscales=0.9)
+    spec = {"type": "matern32", "variance": orc.constrained(1.3), "lengthscales": orc.constrained(0.9), "input_dim": d}
+    prog = kern._program(d)
+    handle.gpr_set_data(X, ("wave", n, r))
+    res = {}
+    try:
+        handle.set_option("gpr_aug_rows", 0)
+        for wave in (1, 0):
+            handle.set_option("trsv_wave", wave)
+            res[wave] = handle.gpr_lml_grad(prog, 0.2, Y)
+    finally:
+        handle.set_option("trsv_wave", 1); handle.set_option("gpr_aug_rows", -1)
+    ref = orc.gpr_lml(spec, X, Y, 0.2)
+    assert abs(res[1][0] - ref) <= 1e-9 * abs(ref)
+    assert abs(res[1][0] - res[0][0]) <= 1e-12 * abs(ref)
+    kinv = np.linalg.solve(orc.K(spec, X) + 0.2 * np.eye(n), Y)
+    assert np.abs(res[1][3] - kinv).max() <= 1e-9 * np.abs(kinv).max()                 # backward wavefront
+    assert np.abs(res[1][3] - res[0][3]).max() <= 1e-12 * np.abs(kinv).max()
+    assert np.abs(res[1][1] - res[0][1]).max() <= 1e-10 * max(1.0, np.abs(res[0][1]).max())
+    assert handle.profile_get("trsv_wave_fallbacks")["launches"] == 0
