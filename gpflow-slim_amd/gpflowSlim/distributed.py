@@ -117,6 +117,31 @@ class TorchComm(object):
         self.bytes_sent = 0            # payload bytes this rank put on the wire (diagnostics for bench.py)
         self.exchanges = 0
         self._scratch = None
+        if self.mode == "scatter_allgather" and self.world > 1 and mode is None:
+            self._probe()
+
+    def _probe(self):
+        """One tiny scatter + all-gather before the first panel: a collective library that lacks one of the two
+        operations for device tensors raises on every rank alike, and all ranks then agree (all-reduce MIN of a flag) to
+        exchange panels by plain broadcast instead of failing in the middle of a factorisation."""
+        import torch
+        dist, P = self._dist, self.world
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        ok = 1
+        try:
+            t = torch.arange(2 * P, dtype=torch.float64, device=dev) if self.rank == 0 else torch.zeros(2 * P, dtype=torch.float64, device=dev)
+            self._scatter_allgather(t, 0, 2).wait()
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            if not bool((t == torch.arange(2 * P, dtype=torch.float64, device=dev)).all()):
+                ok = 0
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            self.mode = "broadcast"
+        self.bytes_sent, self.exchanges = 0, 0
 
     def exchange(self, tensor, src):
         """Make `tensor` (complete on rank `src`) complete on every rank; returns an object with wait()."""
@@ -130,8 +155,11 @@ class TorchComm(object):
                 self.bytes_sent += 8 * n * (P - 1)
             w = dist.broadcast(tensor, src=src, group=self.group, async_op=True)
             return w if w is not None else _Done()
+        return self._scatter_allgather(tensor, src, n // P)
+
+    def _scatter_allgather(self, tensor, src, chunk):
         # scatter + all-gather on P equal chunks (the ragged end of the message goes by a small broadcast)
-        chunk = n // P
+        dist, P, n = self._dist, self.world, tensor.numel()
         body = tensor[: chunk * P]
         mine = body[self.rank * chunk:(self.rank + 1) * chunk]
         if self.rank == src:

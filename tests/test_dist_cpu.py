@@ -130,6 +130,15 @@ def _worker(rank, world, port, n, nb, lookahead, mode, q):
         A = G @ G.T + n * np.eye(n)
         ops = NumpyPanelOps(A, nb, world, rank)
         comm = TorchComm(mode=mode)
+        if mode == "scatter_allgather":
+            # the start-up probe the RCCL path runs (one tiny scatter + all-gather, all ranks agree on the outcome)
+            comm._probe()
+            assert comm.mode == "scatter_allgather" and comm.bytes_sent == 0
+            real = comm._scatter_allgather
+            comm._scatter_allgather = lambda *a: (_ for _ in ()).throw(RuntimeError("no scatter here"))
+            comm._probe()
+            assert comm.mode == "broadcast"                     # every rank fell back together
+            comm._scatter_allgather, comm.mode = real, "scatter_allgather"
         block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
         L = np.linalg.cholesky(A)
         err = float(np.abs(np.tril(ops.M) - L).max())
