@@ -1346,7 +1346,65 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
 //   Kuf_bar = Lm^-T Abar ;  Lm_bar = -tril(Kuf_bar A^T) ;  Kuu_bar = Lm^-T (Phi(Lm^T Lm_bar) + Phi(.)^T) Lm^-1 / 2   (Phi: tril, diagonal halved)
 //   d/d theta = <Kuf_bar, dKuf> + <Kuu_bar, dKuu> + kbar dKdiag            (gps_launch_kmat_vjp: the kernel-matrix VJP)
 // (Checked in tests/test_gpu_grad.py against a CPU restatement and finite differences.)  The inducing inputs Z are held
-// fixed (their gradient is not computed); the unwhitened parametrisation is not differentiated.
+// fixed (their gradient is not computed).
+// Unwhitened parametrisation (white == 0; examples/svgp.py:146 runs with whiten=False): the bound is the whitened one at
+//   m_w = Lm^-1 q_mu,  L_w,q = Lm^-1 L_q          (same predictive moments, KL invariant under the linear map),
+// so the whitened gradient (g_w, G_w) is computed at (m_w, L_w) and pulled back:
+//   g(q_mu) = Lm^-T g_w ;  g(L_q) = tril(Lm^-T G_w,q) ;  Lm_bar += -tril(g(q_mu) m_w^T + sum_q (Lm^-T G_w,q) L_w,q^T)
+// (the last term is the dependence of m_w, L_w on Lm; it joins Lm_bar before the Cholesky adjoint).
+static int svgp_whiten(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, i64 m, i64 d_all,
+                       double jitter, const double* q_mu, i64 k, const double* q_sqrt, int q_sqrt_ndim,
+                       std::vector<double>& mw, std::vector<double>& Lw, int* info) {
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->have_factor = false; h->n = 0;
+  h->refine_now = (h->leaf_refine != 0);
+  const i64 mp = gps_pad(m);
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, h->dX.ensure((size_t)m * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dX.p, Z, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dK.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dLinv.ensure(2 * blk_bytes));
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), m, nullptr, m, d_all, jitter, h->dK.d(), mp, mp, mp, 1, 1);
+  if (rc) return rc;
+  int* d_info = (int*)h->dInfo.p;
+  rc = gps_launch_fill_info(h, d_info, INT_MAX);
+  if (rc) return rc;
+  HipOps ops{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, d_info};
+  Blocked<HipOps> bl(ops);
+  rc = bl.potrf_rec(h->dK.d(), mp, mp, 0, 0);
+  if (rc) return rc;
+  rc = read_info(h, d_info, info);
+  if (rc || (info && *info)) return rc;
+  // m_w^T = (Lm^-1 q_mu)^T : right-hand sides as rows
+  std::vector<double> buf((size_t)GPS_TILE * mp, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < k; ++q) buf[(size_t)q * mp + j] = q_mu[j * k + q];
+  GPS_HIP(h, h->dG3.ensure(buf.size() * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dG3.p, buf.data(), buf.size() * 8, hipMemcpyHostToDevice, h->stream));
+  rc = bl.trsm_rec(h->dK.d(), mp, mp, 0, h->dG3.d(), mp, GPS_TILE);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(buf.data(), h->dG3.p, buf.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  mw.assign((size_t)m * k, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < k; ++q) mw[j * k + q] = buf[(size_t)q * mp + j];
+  // L_w,q^T = (Lm^-1 L_q)^T
+  Lw.assign((size_t)k * m * m, 0.0);
+  std::vector<double> LT((size_t)mp * mp);
+  GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+  for (i64 q = 0; q < k; ++q) {
+    std::fill(LT.begin(), LT.end(), 0.0);
+    if (q_sqrt_ndim == 2) { for (i64 a = 0; a < m; ++a) LT[(size_t)a * mp + a] = q_sqrt[a * k + q]; }
+    else { const double* Lq = q_sqrt + (size_t)q * m * m; for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = Lq[a * m + b]; }
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), LT.size() * 8, hipMemcpyHostToDevice, h->stream));
+    rc = bl.trsm_rec(h->dK.d(), mp, mp, 0, h->dTmp2.d(), mp, mp);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(LT.data(), h->dTmp2.p, LT.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    double* out = Lw.data() + (size_t)q * m * m;
+    for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) out[a * m + b] = LT[(size_t)b * mp + a];
+  }
+  return GPS_OK;
+}
+
 extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                                   int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
                                   const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
@@ -1355,8 +1413,9 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
                                   double* grad_mean, int* info) {
   if (!h || !elbo || !grad_slots || !grad_noise || !grad_q_mu || !grad_q_sqrt)
     return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: bad argument");
-  if (!white) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_svgp_elbo_grad: only the whitened parametrisation is differentiated");
   if (k > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_svgp_elbo_grad: at most 128 latent functions");
+  if (!Z || !q_mu || !q_sqrt || m <= 0 || k <= 0 || (q_sqrt_ndim != 2 && q_sqrt_ndim != 3))
+    return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: bad argument");
   int ns = 0;
   int rc = gps_grad_general_slots(h, prog, n_nodes, &ns);
   if (rc) return rc;
@@ -1364,7 +1423,20 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
   if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: grad_slots too small");
   double kl = 0.0, ve = 0.0;
   int linfo = 0;
-  rc = gps_svgp_elbo(h, prog, n_nodes, Z, m, d_all, jitter, X, n, yres, q_mu, k, q_sqrt, q_sqrt_ndim, white, noise_var, scale,
+  // unwhitened: differentiate the whitened bound at (m_w, L_w) and pull the result back (see above)
+  const bool unwhite = !white;
+  const double* const q_mu_in = q_mu; const double* const q_sqrt_in = q_sqrt; const int ndim_in = q_sqrt_ndim;
+  double* const grad_q_sqrt_out = grad_q_sqrt;
+  std::vector<double> mw_h, Lw_h, gw_tmp;
+  if (unwhite) {
+    rc = svgp_whiten(h, prog, n_nodes, Z, m, d_all, jitter, q_mu, k, q_sqrt, q_sqrt_ndim, mw_h, Lw_h, &linfo);
+    if (info) *info = linfo;
+    if (rc || linfo) return rc;
+    q_mu = mw_h.data(); q_sqrt = Lw_h.data(); q_sqrt_ndim = 3;
+    if (ndim_in == 2) { gw_tmp.assign((size_t)k * m * m, 0.0); grad_q_sqrt = gw_tmp.data(); }
+  }
+  (void)q_mu_in; (void)q_sqrt_in;
+  rc = gps_svgp_elbo(h, prog, n_nodes, Z, m, d_all, jitter, X, n, yres, q_mu, k, q_sqrt, q_sqrt_ndim, 1, noise_var, scale,
                      elbo, &kl, &ve, &linfo);
   if (info) *info = linfo;
   if (rc || linfo) return rc;
@@ -1485,6 +1557,60 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
   double* LmBar = h->dS3.d();
   rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, nsp, KufBar, nsp, Am, nsp, LmBar, mp);
   if (rc) return rc;
+  if (unwhite) {
+    // pull-back of (g_w, G_w) through m_w = Lm^-1 q_mu, L_w = Lm^-1 L_q; their dependence on Lm joins Lm_bar (still
+    // un-negated here: Lm_bar = -tril(Kuf_bar A^T + g(q_mu) m_w^T + sum_q (Lm^-T G_w,q) L_w,q^T))
+    std::vector<double> buf((size_t)GPS_TILE * mp, 0.0);
+    for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < k; ++q) buf[(size_t)q * mp + j] = grad_q_mu[j * k + q];
+    GPS_HIP(h, h->dG3.ensure(buf.size() * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dG3.p, buf.data(), buf.size() * 8, hipMemcpyHostToDevice, h->stream));
+    rc = bl.trsm_rn_rec(U, mp, mp, 0, h->dG3.d(), mp, GPS_TILE);                       // rows: g_w^T Lm^-1 = (Lm^-T g_w)^T
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(buf.data(), h->dG3.p, buf.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<double> ga((size_t)mp * GPS_TILE, 0.0), mb((size_t)mp * GPS_TILE, 0.0);
+    for (i64 j = 0; j < m; ++j)
+      for (i64 q = 0; q < k; ++q) {
+        const double g = buf[(size_t)q * mp + j];
+        grad_q_mu[j * k + q] = g;
+        ga[(size_t)j * GPS_TILE + q] = g;
+        mb[(size_t)j * GPS_TILE + q] = q_mu[j * k + q];
+      }
+    GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dG1.p, ga.data(), ga.size() * 8, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipMemcpyAsync(h->dG2.p, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, h->stream));
+    rc = gps_launch_gemm_nt(h, 2, 1, mp, mp, GPS_TILE, h->dG1.d(), GPS_TILE, h->dG2.d(), GPS_TILE, LmBar, mp);   // += g(q_mu) m_w^T
+    if (rc) return rc;
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<double> T((size_t)mp * mp);
+    for (i64 q = 0; q < k; ++q) {
+      const double* Gw = grad_q_sqrt + (size_t)q * m * m;              // whitened gradient, lower triangular [m][m]
+      const double* Lwq = q_sqrt + (size_t)q * m * m;
+      std::fill(T.begin(), T.end(), 0.0);
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) T[(size_t)b * mp + a] = Gw[a * m + b];      // G_w^T
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, T.data(), T.size() * 8, hipMemcpyHostToDevice, h->stream));
+      rc = bl.trsm_rn_rec(U, mp, mp, 0, h->dTmp2.d(), mp, mp);                          // (Lm^-T G_w)^T
+      if (rc) return rc;
+      rc = gps_launch_transpose(h, h->dTmp2.d(), mp, mp, mp, h->dG1.d(), mp);          // Lm^-T G_w
+      if (rc) return rc;
+      GPS_HIP(h, hipMemcpyAsync(T.data(), h->dG1.p, T.size() * 8, hipMemcpyDeviceToHost, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      if (ndim_in == 2) {
+        for (i64 a = 0; a < m; ++a) grad_q_sqrt_out[a * k + q] = T[(size_t)a * mp + a];
+      } else {
+        double* gq = grad_q_sqrt_out + (size_t)q * m * m;
+        for (i64 a = 0; a < m; ++a) for (i64 b = 0; b < m; ++b) gq[a * m + b] = (b <= a) ? T[(size_t)a * mp + b] : 0.0;
+      }
+      std::fill(T.begin(), T.end(), 0.0);
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) T[(size_t)a * mp + b] = Lwq[a * m + b];
+      GPS_HIP(h, hipMemcpyAsync(h->dG2.p, T.data(), T.size() * 8, hipMemcpyHostToDevice, h->stream));
+      rc = gps_launch_gemm_nt(h, 2, 1, mp, mp, mp, h->dG1.d(), mp, h->dG2.d(), mp, LmBar, mp);               // += (Lm^-T G_w) L_w^T
+      if (rc) return rc;
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+    }
+  }
   rc = gps_launch_tri_map(h, LmBar, mp, mp, 1);
   if (rc) return rc;
   // Cholesky adjoint: P = Lm^T Lm_bar ; Kuu_bar = Lm^-T (Phi(P) + Phi(P)^T) Lm^-1 / 2

@@ -578,7 +578,7 @@ class Handle(object):
 
     def svgp_elbo_grad(self, prog, Z, X, yres, q_mu, q_sqrt, jitter, noise_var, white=True, scale=1.0):
         """(elbo, grad_slots, grad_noise, grad_q_mu [M, K], grad_q_sqrt shaped like q_sqrt, d/d mean(X) [N, K]) -- gradients
-        w.r.t. the constrained values; whitened parametrisation only, Z fixed (gps_svgp_elbo_grad)."""
+        w.r.t. the constrained values, either parametrisation, Z fixed (gps_svgp_elbo_grad)."""
         Z, X, yres, q_mu = _f64(Z), _f64(X), _f64(yres), _f64(q_mu)
         _need(Z.ndim == 2 and X.ndim == 2 and Z.shape[1] == X.shape[1], "Z [M, D] and X [N, D] must share D")
         m, d = Z.shape
@@ -590,8 +590,6 @@ class Handle(object):
         q, qnd = self._prep_q_sqrt(q_sqrt)
         _need(q is not None, "SVGP needs q_sqrt")
         self._check_q_sqrt(q, qnd, m, k)
-        if not white:
-            raise NotImplementedError("the gradient of the SVGP bound is available for the whitened parametrisation only")
         elbo, gnoise = ctypes.c_double(0), ctypes.c_double(0)
         info, nslots = ctypes.c_int(0), ctypes.c_int(0)
         cap = 700
@@ -602,7 +600,7 @@ class Handle(object):
         self.resident_token = None
         self.factor_key = None
         self._check(self._lib.gps_svgp_elbo_grad(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(X), n, _ptr(yres),
-                                                 _ptr(q_mu), k, _ptr(q), qnd, 1, float(noise_var), float(scale),
+                                                 _ptr(q_mu), k, _ptr(q), qnd, 1 if white else 0, float(noise_var), float(scale),
                                                  ctypes.byref(elbo), _ptr(slots), cap, ctypes.byref(nslots), ctypes.byref(gnoise),
                                                  _ptr(g_qmu), _ptr(g_q), _ptr(g_mean), ctypes.byref(info)), "gps_svgp_elbo_grad")
         if info.value > 0:

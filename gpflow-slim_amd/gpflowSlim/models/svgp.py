@@ -75,7 +75,7 @@ class SVGP(GPModel):
     def compute_log_likelihood_and_gradients(self):
         """The bound and d bound / d(unconstrained parameter) for every parameter of the model -- what
         `tf.gradients(objective, variables)` yields in the reference (examples/svgp.py:159-161) up to the sign of
-        `objective`.  Gaussian likelihood, whitened parametrisation; the inducing inputs are held fixed (zero gradient).
+        `objective`.  Gaussian likelihood, whitened or not; the inducing inputs are held fixed (zero gradient).
         Returns (bound, [(Parameter, gradient array shaped like Parameter.unconstrained_tensor), ...])."""
         if type(self.likelihood) is not likelihoods.Gaussian:
             raise NotImplementedError("analytic gradients of the SVGP bound need the Gaussian likelihood")

@@ -342,6 +342,95 @@ def test_svgp_bound_gradient(handle, q_diag, kind, n, m_, d, k):
             fd = (fp - fm) / (2 * h)
             assert abs(gflat[i] - fd) <= 2e-5 * max(1.0, abs(fd)), (p.name, i, gflat[i], fd)
 
+@pytest.mark.parametrize("q_diag", [False, True])
+@pytest.mark.parametrize("kind,n,m_,d,k", [("rbf_ard", 300, 40, 3, 2), ("m32_ard", 260, 130, 2, 1)])
+def test_svgp_bound_gradient_unwhitened(handle, q_diag, kind, n, m_, d, k):
+    """whiten=False (what examples/svgp.py:146 runs): the gradient of the bound -- the whitened gradient at
+    (Lm^-1 q_mu, Lm^-1 L_q) pulled back, gps_svgp_elbo_grad white == 0 -- against central differences of the ORACLE's
+    unwhitened bound in the constrained parameters, and of the product's own bound in the unconstrained ones."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_ + k + 7)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, k))) + 0.1 * rng.standard_normal((n, k))
+    Z = X[:m_].copy()
+    kern, theta, fn, _ = _cases(gpf, d)[kind]()
+    m = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.3), Z=Z, q_diag=q_diag, whiten=False, num_data=3 * n)
+    q_mu = rng.standard_normal((m_, k)) * 0.3
+    m._q_mu.assign(q_mu)
+    if q_diag:
+        q_sqrt = np.abs(rng.standard_normal((m_, k))) * 0.4 + 0.2
+    else:
+        q_sqrt = np.tril(rng.standard_normal((k, m_, m_)) * (0.5 / m_) + np.eye(m_) * 0.5).transpose(1, 2, 0).copy()
+    m._q_sqrt.assign(q_sqrt)
+    q_sqrt = np.asarray(m.q_sqrt).copy()
+    noise = c(0.3)
+    bound, grads = m.compute_log_likelihood_and_gradients()
+    ref_bound = orc.svgp_elbo(fn(theta), X, Y, Z, q_mu, q_sqrt, noise, whiten=False, num_data=3 * n)
+    assert abs(bound - ref_bound) <= 1e-8 * abs(ref_bound)
+    assert abs(bound - m.compute_log_likelihood()) <= 1e-9 * abs(bound)         # (forward of the gradient call: whitened form)
+    by = {id(p): g for p, g in grads}
+
+    def f(th=theta, nz=noise, qm=q_mu, qs=q_sqrt):
+        return orc.svgp_elbo(fn(th), X, Y, Z, qm, qs, nz, whiten=False, num_data=3 * n)
+
+    def cd(make, x0, hrel=1e-6):
+        h = hrel * max(1.0, abs(x0))
+        return (make(x0 + h) - make(x0 - h)) / (2 * h)
+
+    # kernel parameters (constrained)
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == theta.shape
+    for i in range(theta.size):
+        def mk(v, i=i):
+            th = theta.copy(); th[i] = v
+            return f(th=th)
+        fd = cd(mk, theta[i])
+        assert abs(got[i] - fd) <= 2e-5 * max(1.0, abs(fd)), ("theta", i, got[i], fd)
+    gn = float(by[id(m.likelihood._variance)] / m.likelihood._variance.transform.forward_grad(m.likelihood._variance.vf_val))
+    fd = cd(lambda v: f(nz=v), noise)
+    assert abs(gn - fd) <= 2e-5 * max(1.0, abs(fd))
+    rng2 = np.random.default_rng(2)
+    gq = by[id(m._q_mu)]
+    for _ in range(4):
+        a, q = int(rng2.integers(m_)), int(rng2.integers(k))
+        def mk(v, a=a, q=q):
+            qm = q_mu.copy(); qm[a, q] = v
+            return f(qm=qm)
+        fd = cd(mk, q_mu[a, q])
+        assert abs(gq[a, q] - fd) <= 2e-5 * max(1.0, abs(fd)), ("q_mu", a, q, gq[a, q], fd)
+    if q_diag:
+        gs = by[id(m._q_sqrt)] / m._q_sqrt.transform.forward_grad(m._q_sqrt.vf_val)
+        for _ in range(4):
+            a, q = int(rng2.integers(m_)), int(rng2.integers(k))
+            def mk(v, a=a, q=q):
+                qs = q_sqrt.copy(); qs[a, q] = v
+                return f(qs=qs)
+            fd = cd(mk, q_sqrt[a, q])
+            assert abs(gs[a, q] - fd) <= 2e-5 * max(1.0, abs(fd)), ("q_sqrt", a, q, gs[a, q], fd)
+    else:
+        rows, cols = np.tril_indices(m_, 0)
+        gfree = by[id(m._q_sqrt)].reshape(k, -1)
+        for _ in range(6):
+            t, q = int(rng2.integers(rows.size)), int(rng2.integers(k))
+            a, b = int(rows[t]), int(cols[t])
+            def mk(v, a=a, b=b, q=q):
+                qs = q_sqrt.copy(); qs[a, b, q] = v
+                return f(qs=qs)
+            fd = cd(mk, q_sqrt[a, b, q])
+            assert abs(gfree[q, t] - fd) <= 2e-5 * max(1.0, abs(fd)), ("q_sqrt", a, b, q, gfree[q, t], fd)
+    # finite differences of the product's own (unwhitened) bound through the unconstrained parameters
+    for p, g in grads:
+        flat = np.atleast_1d(p.vf_val).ravel().copy()
+        gflat = np.atleast_1d(g).ravel()
+        for i in (range(flat.size) if flat.size <= 3 else rng2.choice(flat.size, 3, replace=False)):
+            h = 1e-5
+            x0 = flat[i]
+            flat[i] = x0 + h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fp = m.compute_log_likelihood()
+            flat[i] = x0 - h; p.assign_unconstrained(flat.reshape(p.vf_val.shape)); fm = m.compute_log_likelihood()
+            flat[i] = x0; p.assign_unconstrained(flat.reshape(p.vf_val.shape))
+            fd = (fp - fm) / (2 * h)
+            assert abs(gflat[i] - fd) <= 5e-5 * max(1.0, abs(fd)), (p.name, i, gflat[i], fd)
+
+
 
 def test_svgp_optimize_raises_the_bound(handle):
     """SVGP + Model.optimize(): the bound goes up on the analytic gradients (the fit of examples/svgp.py:159-161, with a
@@ -356,8 +445,13 @@ def test_svgp_optimize_raises_the_bound(handle):
     assert final < start - 100.0, (start, final)
     exact = gpf.models.GPR(X, Y, m.kern, obs_var=float(np.squeeze(m.likelihood.variance))).compute_log_likelihood()
     assert -final <= exact + 1e-6 * abs(exact)             # a lower bound on the evidence at the same hyper-parameters
-    with pytest.raises(NotImplementedError):
-        gpf.models.SVGP(X, Y, gpf.kernels.RBF(d), gpf.likelihoods.Gaussian(0.5), Z=X[:m_].copy(), whiten=False).compute_log_likelihood_and_gradients()
+    # the configuration of examples/svgp.py:146 (whiten=False) trains too and bounds the same evidence
+    m2 = gpf.models.SVGP(X, Y, gpf.kernels.RBF(d, ARD=True), gpf.likelihoods.Gaussian(0.5), Z=X[:m_].copy(), whiten=False)
+    start2 = m2.objective
+    final2 = m2.optimize(max_iter=150)
+    assert final2 < start2 - 100.0, (start2, final2)
+    exact2 = gpf.models.GPR(X, Y, m2.kern, obs_var=float(np.squeeze(m2.likelihood.variance))).compute_log_likelihood()
+    assert -final2 <= exact2 + 1e-6 * abs(exact2)
 
 
 @pytest.mark.parametrize("n,m_", [(40, 300), (130, None), (257, 70)])
