@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--dist-nb", type=int, default=512, help="block-column width of the distributed run")
     ap.add_argument("--dist-lookahead", type=int, default=2, help="look-ahead depth of the distributed schedule")
     ap.add_argument("--dist-timeout", type=float, default=600.0, help="watchdog (s) around the distributed run")
+    ap.add_argument("--no-dist-autotune", action="store_true", help="N > 1: keep --dist-nb / --dist-lookahead and the default exchange instead of choosing by measurement during warm-up")
     ap.add_argument("--independent-steps", type=int, default=2, help="N > 1: steps of the independent-evaluations side measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -145,7 +146,28 @@ def main():
         timer.daemon = True
         timer.start()
         comm = TorchComm()
-        for i in range(max(args.warmup, 1)):                 # (the first call also sets the communicator up)
+        tune = None
+        set_step(-1, False)
+        gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)      # (also sets the communicator up)
+        if not args.no_dist_autotune:
+            # untimed: pick the panel exchange and the panel width by measurement on this node (all ranks agree through
+            # max-over-ranks times); the timed steps below then run one fixed configuration
+            tune = {"exchange_s": comm.autotune() if args.backend == "nccl" else {}, "candidates_ms": {}}
+            best = None
+            for nb_c, la_c in ((args.dist_nb, args.dist_lookahead), (2 * args.dist_nb, args.dist_lookahead), (args.dist_nb // 2, args.dist_lookahead)):
+                if nb_c < 128 or nb_c % 128 or n // nb_c < 2 * world:
+                    continue
+                sync(); tc = time.perf_counter()
+                gpr_lml_distributed(model, comm, nb=nb_c, lookahead=la_c)
+                sync()
+                dt = max_over_ranks(time.perf_counter() - tc)
+                tune["candidates_ms"]["nb=%d,lookahead=%d" % (nb_c, la_c)] = round(1e3 * dt, 3)
+                if best is None or dt < best[0]:
+                    best = (dt, nb_c, la_c)
+            if best is not None:
+                args.dist_nb, args.dist_lookahead = best[1], best[2]
+            tune["chosen"] = {"nb": args.dist_nb, "lookahead": args.dist_lookahead, "exchange": comm.mode}
+        for i in range(args.warmup):
             set_step(-1 - i, False)
             gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)
         sync()
@@ -174,7 +196,7 @@ def main():
                                 "backend": args.backend, "rccl_ranks": dist.get_world_size(), "rccl_version": rccl,
                                 "stage_ms_per_rank_last_step": per_rank,
                                 "payload_bytes_per_eval_all_ranks": float(sent.item()) / args.steps,
-                                "lml_last_step": lml}
+                                "lml_last_step": lml, "autotune": tune}
     elapsed = max_over_ranks(elapsed)
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.steps / elapsed                     # whole-job evaluations / s (N > 1: ONE evaluation per step)

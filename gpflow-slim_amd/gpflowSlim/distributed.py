@@ -143,6 +143,44 @@ class TorchComm(object):
             self.mode = "broadcast"
         self.bytes_sent, self.exchanges = 0, 0
 
+    def autotune(self, doubles=1 << 22, reps=3):
+        """Pick the panel exchange by measurement: time `reps` exchanges of a `doubles`-long message (default 32 MB, the
+        order of a panel) as one broadcast and as scatter + all-gather, take the maximum over ranks of each, keep the
+        faster.  Collective; every rank ends with the same mode.  Returns {mode: seconds per exchange}."""
+        if self.world == 1:
+            return {}
+        import time
+        import torch
+        dist, P = self._dist, self.world
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        n = (int(doubles) // P) * P
+        buf = torch.zeros(n, dtype=torch.float64, device=dev)
+        sync = torch.cuda.synchronize if dev == "cuda" else (lambda: None)
+        times = {}
+        keep = self.mode
+        for mode in ("broadcast", "scatter_allgather"):
+            ok, dt = 1, float("inf")
+            try:
+                self.mode = mode
+                self.exchange(buf, 0).wait()                     # (first use of an operation sets it up)
+                sync(); dist.barrier(group=self.group); sync()
+                t0 = time.perf_counter()
+                for i in range(reps):
+                    self.exchange(buf, i % P).wait()
+                sync()
+                dt = (time.perf_counter() - t0) / reps
+            except Exception:
+                ok = 0
+            res = torch.tensor([float(ok), dt if ok else 1e30], dtype=torch.float64, device=dev)
+            agree = res.clone()
+            dist.all_reduce(agree[:1], op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(agree[1:], op=dist.ReduceOp.MAX, group=self.group)
+            if float(agree[0].item()) > 0.5:
+                times[mode] = float(agree[1].item())
+        self.mode = min(times, key=times.get) if times else keep
+        self.bytes_sent, self.exchanges = 0, 0
+        return times
+
     def exchange(self, tensor, src):
         """Make `tensor` (complete on rank `src`) complete on every rank; returns an object with wait()."""
         if self.world == 1:

@@ -47,11 +47,12 @@ def test_bench_two_ranks_block_column_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
-           "--dist-timeout", "600"]
+           "--dist-timeout", "600", "--no-dist-autotune"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
     assert COMMON <= set(out), sorted(COMMON - set(out))
+    assert out["distributed"]["autotune"] is None
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3 and out["value"] > 0
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-3 * out["value"]          # ONE evaluation of the whole job per step
     dd = out["distributed"]
@@ -64,3 +65,24 @@ def test_bench_two_ranks_block_column_gloo():
     assert "block-cyclic" in out["config"]["parallelism"]
     assert out["independent_evals"]["scaling"] == "weak" and out["independent_evals"]["evals_per_s_all_gpus"] > 0
     assert out["cpu_baseline"] is None                                                        # timed at N = 1 only
+
+
+def test_bench_two_ranks_autotuned_panel_width():
+    """The default N > 1 run picks the panel width (and, under RCCL, the exchange) by measurement during warm-up: the
+    timed steps run the chosen configuration and the line says which."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
+           "--dist-timeout", "600", "--independent-steps", "0", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    out = _last_json(p.stdout)
+    dd = out["distributed"]
+    tune = dd["autotune"]
+    assert set(tune["candidates_ms"]) == {"nb=256,lookahead=2", "nb=512,lookahead=2", "nb=128,lookahead=2"}
+    best = min(tune["candidates_ms"], key=tune["candidates_ms"].get)
+    assert "nb=%d," % dd["nb"] in best and tune["chosen"]["nb"] == dd["nb"] and tune["exchange_s"] == {}
+    assert dd["parity_rel_err_vs_one_gpu"] <= 1e-9 and out["value"] > 0
+    assert "nb=%d" % dd["nb"] in out["config"]["parallelism"]
