@@ -319,6 +319,34 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   return GPS_OK;
 }
 
+// every growable device buffer of the handle (the small fixed ones -- info word, look-ahead flags, pinned ring -- stay)
+static void release_work_buffers(gps_handle_t h, bool all) {
+  DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
+                    &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave};
+  for (DevBuf* b : bufs) b->release();
+  h->wave_ctl_clear = false;
+  if (all) { h->dInfo.release(); h->dScal.release(); }      // (allocated by gps_create; every reduction writes there)
+}
+
+// Hand the handle's device memory back to the allocator (K / L of a large problem is N^2 x 8 bytes and stays allocated
+// for re-use otherwise).  The resident data set and factor are gone afterwards: gps_gpr_set_data again before the next
+// GPR call.  Streams, events and options are kept.
+extern "C" int gps_release_buffers(gps_handle_t h) {
+  if (!h) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->side_stream) GPS_HIP(h, hipStreamSynchronize(h->side_stream));
+  if (h->def_stream) GPS_HIP(h, hipStreamSynchronize(h->def_stream));
+  if (h->y_stream) GPS_HIP(h, hipStreamSynchronize(h->y_stream));
+  gps_profile_collect(h);
+  release_work_buffers(h, false);
+  h->have_factor = false; h->n = 0; h->npad = 0; h->r = 0;
+  h->dist_np = 0; h->dist_nb = 0;          // (a distributed factorisation must start over with gps_dist_begin)
+  return GPS_OK;
+}
+
 extern "C" int gps_destroy(gps_handle_t h) {
   if (!h) return GPS_OK;
   (void)hipSetDevice(h->device);
@@ -326,11 +354,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   gps_profile_collect(h);
   for (auto e : h->evt_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 8; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg, &h->dScal,
-                    &h->dInfo, &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave};
-  for (DevBuf* b : bufs) b->release();
+  release_work_buffers(h, true);
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }

@@ -45,6 +45,7 @@ def lib_path():
 _SIGNATURES = {
     "gps_create": [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)],
     "gps_destroy": [ctypes.c_void_p],
+    "gps_release_buffers": [ctypes.c_void_p],
     "gps_device_info": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, _c_int_p, ctypes.POINTER(_i64),
                         ctypes.c_char_p, ctypes.c_int],
     "gps_kmat": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64,
@@ -263,6 +264,13 @@ class Handle(object):
         out = np.zeros(5)
         self._check(self._lib.gps_last_stage_ms(self._h, _ptr(out)), "gps_last_stage_ms")
         return dict(zip(["kmat", "potrf", "trsv", "predict", "total"], out.tolist()))
+
+    def release_buffers(self):
+        """Give the device buffers back (the resident data set and factor are dropped with them)."""
+        self._check(self._lib.gps_release_buffers(self._h), "gps_release_buffers")
+        self.resident_token = None
+        self.factor_key = None
+        self.resident_shape = None
 
     def set_option(self, key, value):
         self._check(self._lib.gps_set_option(self._h, key.encode(), float(value)), "gps_set_option")

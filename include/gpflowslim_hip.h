@@ -78,6 +78,10 @@ typedef struct gps_handle_s* gps_handle_t;
 /* ---- life cycle ------------------------------------------------------- */
 int  gps_create(int device_id, gps_handle_t* out);
 int  gps_destroy(gps_handle_t h);
+/* Give the handle's device buffers back (K / L of a large problem is N^2 x 8 bytes and is otherwise kept for re-use);
+ * the resident data set and factor are dropped -- call gps_gpr_set_data again.  Streams and options stay.  No
+ * reference counterpart: TensorFlow's allocator owns the reference's device memory.                              */
+int  gps_release_buffers(gps_handle_t h);
 const char* gps_last_error(gps_handle_t h);
 /* name: >=256 bytes.  Returns CU count, HBM bytes, and the gfx arch string. */
 int  gps_device_info(gps_handle_t h, char* name, int name_len, int* n_cu,

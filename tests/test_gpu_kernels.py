@@ -284,3 +284,27 @@ def test_trsv_wavefront_equals_recursive_substitution(handle, n, r):
     assert np.abs(res[1][3] - res[0][3]).max() <= 1e-12 * np.abs(kinv).max()
     assert np.abs(res[1][1] - res[0][1]).max() <= 1e-10 * max(1.0, np.abs(res[0][1]).max())
     assert handle.profile_get("trsv_wave_fallbacks")["launches"] == 0
+
+
+def test_release_buffers_gives_memory_back_and_the_handle_stays_usable(handle):
+    import torch
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    n, d = 6000, 3
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 10, seed=5)
+    kern = gpf.kernels.RBF(d, variance=1.1, lengthscales=1.3)
+    spec = {"type": "rbf", "variance": orc.constrained(1.1), "lengthscales": orc.constrained(1.3), "input_dim": d}
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    ref = orc.gpr_lml(spec, X, Y, orc.constrained(0.1))
+    assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    handle.release_buffers()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 - free0 >= 6016 * 6016 * 8                    # at least K / L came back
+    # the model notices that its data set is no longer resident and uploads it again; warm predict_f is refused a stale factor
+    m.reuse_factor = True
+    mu, var = m.predict_f(Xs)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
+    assert np.abs(mu - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var - rvar).max() <= 1e-8 * np.abs(rvar).max()
+    assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)

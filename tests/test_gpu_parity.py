@@ -263,6 +263,50 @@ def test_full_size_block_separable(handle):
         assert rel(mu[40 * k:40 * (k + 1)], rmu) <= RTOL and rel(var[40 * k:40 * (k + 1)], rvar) <= RTOL
 
 
+def test_maximum_size_block_separable(handle):
+    """N = 131072 on one GPU (K: 137 GB of the 288 GB HBM; every index beyond 2^32 elements): 128 exactly independent
+    clusters of 1024 points, interleaved in memory, so the factorisation is a dense N x N one and
+    LML(X, Y) = sum of the clusters' oracle LMLs.  (tools/big_n.py runs the same check at N = 180224 = 260 GB:
+    profiles/r02_big_n.json.)"""
+    import torch
+    import gpflowSlim as gpf
+    if torch.cuda.mem_get_info()[0] < 150e9:
+        pytest.skip("needs 150 GB of free HBM")
+    rng = np.random.default_rng(131072)
+    nc, per, d = 128, 1024, 8
+    ls = np.sqrt(d) * np.ones(d)
+    Xc = [rng.standard_normal((per, d)) for _ in range(nc)]
+    w = rng.standard_normal((d, 1)) / np.sqrt(d)
+    Yc = [np.sin(x @ w) + 0.1 * rng.standard_normal((per, 1)) for x in Xc]
+
+    def shift(c):
+        o = np.zeros((1, d))
+        o[0, 0], o[0, 1], o[0, 2] = 60.0 * ls[0] * (c % 6), 60.0 * ls[1] * ((c // 6) % 6), 60.0 * ls[2] * (c // 36)
+        return o
+
+    order = rng.permutation(nc * per)
+    X = np.concatenate([x + shift(c) for c, x in enumerate(Xc)])[order]
+    Y = np.concatenate(Yc)[order]
+    kern = gpf.kernels.RBF(d, variance=1.3, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.3), "lengthscales": orc.constrained(ls), "input_dim": d}
+    noise = orc.constrained(0.1)
+    ref = sum(orc.gpr_lml(spec, x, y, noise) for x, y in zip(Xc, Yc))
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    try:
+        lml = m.compute_log_likelihood()
+        assert abs(lml - ref) <= 1e-9 * abs(ref)
+        st = handle.last_stage_ms()
+        assert (131072.0 ** 3 / 3) / (st["potrf"] * 1e-3) > 55e12               # (71 TFLOP/s measured; not a tight gate)
+        m.reuse_factor = True
+        c = 77
+        Xs = rng.standard_normal((24, d)) + shift(c)
+        mu, var = m.predict_f(Xs)
+        rmu, rvar = orc.gpr_predict(spec, Xc[c], Yc[c], noise, Xs - shift(c))
+        assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+    finally:
+        handle.release_buffers()            # 138 GB back to the allocator for the tests that follow
+
+
 def test_full_size_dense_invariances(handle):
     """N = 32768, D = 8, dense covariance (the bench workload): the LML does not depend on the order of the data
     (a different factorisation of a permuted matrix), the posterior mean is linear in Y and the posterior variance
