@@ -317,6 +317,124 @@ static int launch_single(gps_handle_t h, const KmatArgs& a, const KNodeDev& node
   return GPS_OK;
 }
 
+// ---- left-deep chains: p0 (p_i op_i)*  -- Sum / Product of a few primitives (BASELINE config 4: Matern-5/2 + Periodic) --
+// kernels.py:1071-1084 folds its operands left to right, so the RPN program of a Sum / Product of primitives is
+// "p0 p1 op p2 op ...": at no point more than one intermediate value is alive.  The interpreter nevertheless carries its
+// four-deep stack with run-time pushes and pops (251 VGPRs, two waves per SIMD, 0.85 TB/s on config 4); here the one
+// running value is an accumulator, the primitives use the in-line exponential of the single-primitive kernel (every
+// argument is <= 0 up to rounding), and the kernel fits four waves per SIMD.  Same tile, staging, formulas and operand
+// order (older op newer) as kmat_tile_kernel.
+__global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev P) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
+  double* nc_s = nr_s + KT;                                // [KT]
+  double* Fr_s = nc_s + KT;                                // [a.maxnf][KLS]
+  double* Fc_s = Fr_s + a.maxnf * KLS;                     // [a.maxnf][KLS]
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const i64 gi0 = (i64)ti * KT, gj0 = (i64)tj * KT;
+  double acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+  for (int nd = 0; nd < P.n_nodes; nd += (nd == 0 ? 1 : 2)) {
+    const KNodeDev node = P.nodes[nd];
+    const int op = (nd == 0) ? -1 : P.nodes[nd + 1].op;
+    double v[16];
+    if (node.op == GPS_K_CONSTANT) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = node.variance;
+    } else if (node.op == GPS_K_WHITE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const i64 gi = a.row_off + gi0 + ty * 4 + (e >> 2), gj = a.col_off + gj0 + tx * 4 + (e & 3);
+        v[e] = (a.sym && gi == gj) ? node.variance : 0.0;
+      }
+    } else {
+      __syncthreads();
+      for (int idx = tid; idx < node.nf * KT; idx += 256) {
+        const int f = idx >> 6, p = idx & 63;
+        Fr_s[f * KLS + p] = a.Fr[(i64)(node.f0 + f) * a.ldfr + gi0 + p];
+        Fc_s[f * KLS + p] = a.Fc[(i64)(node.f0 + f) * a.ldfc + gj0 + p];
+      }
+      if (node.norm_row >= 0 && tid < KT) {
+        nr_s[tid] = a.Fr[(i64)node.norm_row * a.ldfr + gi0 + tid];
+        nc_s[tid] = a.Fc[(i64)node.norm_row * a.ldfc + gj0 + tid];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = 0.0;               // the dot products
+      for (int f = 0; f < node.nf; ++f) {
+        const double2 r01 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4), r23 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4 + 2);
+        const double2 c01 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4), c23 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4 + 2);
+        const double fr[4] = {r01.x, r01.y, r23.x, r23.y}, fc[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fma(fr[e >> 2], fc[e & 3], v[e]);
+      }
+      if (node.op == GPS_K_PERIODIC) {
+        const double half_d = 0.5 * (double)(node.nf / 2);
+        const double l2 = node.c0 * node.c0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const double rs = (half_d - 0.5 * v[e]) / l2;        // kernels.py:605-610 in cos / sin feature form
+          v[e] = node.variance * gps_exp_nonpos(-0.5 * rs);
+        }
+      } else {
+        const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const double ni = nr_s[ty * 4 + (e >> 2)], nj = nc_s[tx * 4 + (e & 3)];
+          double r2 = -2.0 * v[e] + (ni + nj);
+          r2 = fmax(r2, 0.0);
+          double val;
+          if (node.op == GPS_K_RBF) {
+            val = node.variance * gps_exp_nonpos(-r2 / 2.0);
+          } else {
+            const double r = sqrt(r2 + 1e-12);
+            if (node.op == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
+            else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
+            else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
+            else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r);
+          }
+          v[e] = val;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = (op < 0) ? v[e] : ((op == GPS_K_ADD) ? (acc[e] + v[e]) : (acc[e] * v[e]));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const i64 li = gi0 + ty * 4 + q;
+    const i64 gi = a.row_off + li;
+    double o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const i64 gj = a.col_off + gj0 + tx * 4 + c;
+      double val = acc[q * 4 + c];
+      if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
+      else if (a.sym && gi == gj) val += a.diag_add;
+      o[c] = val;
+    }
+    double* dst = a.K + li * a.ldk + gj0 + tx * 4;
+    *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+  }
+}
+
+// p0 (p_i op_i)* with op in {ADD, MUL}
+static bool is_left_deep_chain(const KProgDev& P) {
+  if (P.n_nodes < 3 || (P.n_nodes & 1) == 0) return false;
+  auto prim = [](int op) { return op != GPS_K_ADD && op != GPS_K_MUL && op < GPS_K_NKN_LINROW; };
+  if (!prim(P.nodes[0].op)) return false;
+  for (int i = 1; i < P.n_nodes; i += 2) {
+    if (!prim(P.nodes[i].op)) return false;
+    if (P.nodes[i + 1].op != GPS_K_ADD && P.nodes[i + 1].op != GPS_K_MUL) return false;
+  }
+  return true;
+}
+
 // ---- Neural Kernel Network epilogue ---------------------------------------------------------------
 // neural_kernel_network/neural_kernel_network.py:41-47 stacks the primitive kernel values of every
 // (i, j) entry into a vector and pushes it through Linear (positive weights) / Product / Activation
@@ -581,6 +699,14 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
   for (int i = 0; i < kc.prog.n_nodes; ++i) if (kc.prog.nodes[i].nf > maxnf) maxnf = kc.prog.nodes[i].nf;
   a.maxnf = maxnf;
   const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLS) * sizeof(double);
+  if (h->kmat_fast && is_left_deep_chain(kc.prog)) {                                   // Sum / Product of primitives
+    int rcc = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_chain_kernel), (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double)));
+    if (rcc) return rcc;
+    LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0 * ((kc.prog.n_nodes + 1) / 2)), tiles * KT * KT * 8.0);
+    hipLaunchKernelGGL(kmat_chain_kernel, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream, a, kc.prog);
+    GPS_HIP(h, hipGetLastError());
+    return GPS_OK;
+  }
   int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_tile_kernel), (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double)));
   if (rcl) return rcl;
   LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0), tiles * KT * KT * 8.0);

@@ -334,7 +334,8 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     3.2 ms).  Refined leaves (jittered factors) always take the recursive one.
  *   "trsv_follow"     0 (default) / 1: the forward substitution is issued block by block behind the factorisation on a
  *                     stream of its own (measured slower: DESIGN.md section 6)
- *   "kmat_fast"       1 (default): one-primitive stationary programs use the stack-free kernel-matrix kernel
+ *   "kmat_fast"       1 (default): one-primitive stationary programs and Sum / Product chains of primitives (programs
+ *                     "p0 p1 op p2 op ...") use the stack-free kernel-matrix kernels; 0: the stack interpreter for all
  *   "la_fault_inject" diagnostics: the k-th look-ahead join from now takes the time-out path (the evaluation is then
  *                     re-run once without look-ahead; gps_profile_get(h, "lookahead_retries", &count, ...) counts it)  */
 int gps_set_option(gps_handle_t h, const char* key, double value);

@@ -308,3 +308,27 @@ def test_release_buffers_gives_memory_back_and_the_handle_stays_usable(handle):
     rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
     assert np.abs(mu - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var - rvar).max() <= 1e-8 * np.abs(rvar).max()
     assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
+
+
+@pytest.mark.parametrize("n,m", [(70, None), (300, 190), (1000, None)])
+def test_kernel_matrix_chain_kernel_equals_interpreter(handle, n, m):
+    """Sum / Product of primitives folded left to right (kmat_chain_kernel: one accumulator, in-line exponential) against
+    the stack interpreter on the same program: equal to rounding of the two exponentials."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n)
+    d = 5
+    X = rng.standard_normal((n, d)); X2 = None if m is None else rng.standard_normal((m, d))
+    ks = gpf.kernels
+    cases = [ks.Matern52(d, variance=1.2, lengthscales=np.linspace(0.8, 1.7, d), ARD=True) + ks.Periodic(d, variance=0.7, lengthscales=1.3, period=2.1),
+             ks.RBF(d, variance=0.9, lengthscales=1.1) * ks.Periodic(d, variance=1.1, lengthscales=0.9, period=1.7) + ks.White(d, variance=0.3) + ks.Constant(d, variance=0.25),
+             ks.Matern32(d, variance=1.0, lengthscales=0.7) * ks.Matern12(d, variance=2.0, lengthscales=1.9) * ks.Exponential(d, variance=0.5, lengthscales=1.2)]
+    for kern in cases:
+        out = {}
+        try:
+            for fast in (1, 0):
+                handle.set_option("kmat_fast", fast)
+                out[fast] = kern.K(X) if X2 is None else kern.K(X, X2)
+        finally:
+            handle.set_option("kmat_fast", 1)
+        assert out[1].shape == out[0].shape
+        assert np.abs(out[1] - out[0]).max() <= 4e-15 * np.abs(out[0]).max()
