@@ -472,6 +472,70 @@ int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64
   return GPS_OK;
 }
 
+// out[j] = sum_i A[i][j]^2 over the rows of A [rows, ld], j < cols (cols even up to padding: ld >= cols rounded up to 2).
+// Thread = two adjacent columns (16-byte loads along the row), workgroup = 512 columns, blockIdx.y = a slice of the
+// rows; slices > 1: partial sums [slices][cols] are folded in slice order by colsum_fold_kernel (no atomics).
+__global__ __launch_bounds__(256) void colsumsq_kernel(const double* __restrict__ A, i64 ld, i64 rows, i64 cols,
+                                                       double* __restrict__ out, i64 out_stride) {
+  const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (j >= cols) return;
+  const i64 per = (rows + gridDim.y - 1) / gridDim.y;
+  const i64 i0 = (i64)blockIdx.y * per, i1 = min(rows, i0 + per);
+  double s0 = 0.0, s1 = 0.0;
+  const double* p = A + i0 * ld + j;
+  i64 i = i0;
+  for (; i + 8 <= i1; i += 8) {
+    v2d v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const v2d*>(p + (i64)u * ld);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 = fma(v[u].x, v[u].x, s0); s1 = fma(v[u].y, v[u].y, s1); }
+    p += 8 * ld;
+  }
+  for (; i < i1; ++i) {
+    const v2d v = *reinterpret_cast<const v2d*>(p);
+    s0 = fma(v.x, v.x, s0); s1 = fma(v.y, v.y, s1);
+    p += ld;
+  }
+  double* o = out + (i64)blockIdx.y * out_stride + j;
+  o[0] = s0;
+  if (j + 1 < cols) o[1] = s1;
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restrict__ part, i64 stride, int slices, i64 cols,
+                                                          double* __restrict__ out) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  double s = 0.0;
+  for (int q = 0; q < slices; ++q) s += part[(i64)q * stride + j];
+  out[j] = s;
+}
+
+// sumsq[j] = sum_i A[i][j]^2 for A [rows, ld] row-major (the column form of rowdot's sum of squares: conditionals.py:109
+// on (L_q^T A) stored [M, N] instead of [N, M])
+int gps_launch_colsumsq(gps_handle_t h, const double* A, i64 ld, i64 rows, i64 cols, double* sumsq) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  if ((ld & 1) || ((uintptr_t)A & 15)) return gps_fail(h, GPS_ERR_ARG, "colsumsq: operand must be 16-byte aligned with even leading dimension");
+  const i64 gx = (cols + 511) / 512;
+  i64 slices = (2048 + gx - 1) / gx;                    // aim at ~2048 workgroups
+  if (slices > rows / 64) slices = rows / 64;
+  if (slices > 64) slices = 64;
+  if (slices < 1) slices = 1;
+  LaunchScope ls(h, KC_REDUCE, 2.0 * rows * cols, (double)rows * cols * 8.0);
+  if (slices == 1) {
+    hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)gx, 1), dim3(256), 0, h->stream, A, ld, rows, cols, sumsq, (i64)0);
+    GPS_HIP(h, hipGetLastError());
+    return GPS_OK;
+  }
+  GPS_HIP(h, h->dGemvWs.ensure((size_t)slices * cols * 8));
+  hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)gx, (unsigned)slices), dim3(256), 0, h->stream, A, ld, rows, cols,
+                     h->dGemvWs.d(), cols);
+  GPS_HIP(h, hipGetLastError());
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, h->stream, h->dGemvWs.d(), cols,
+                     (int)slices, cols, sumsq);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64) {
   if (n <= 0) return GPS_OK;

@@ -1131,6 +1131,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
   std::vector<double> extra(sv ? 0 : per);
   GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));                 // LTA^T [nsp, mp]
   double* dLTA = h->dTmp3.d();
+  bool lta_transposed = false;
   for (i64 q = 0; q < k; ++q) {
     if (q_sqrt_ndim == 2) {
       // LTA^T[i][j] = A^T[i][j] * q_sqrt[j][q] : one column-scaling pass          conditionals.py:107
@@ -1149,11 +1150,19 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
       for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = Lq[a * m + b];
       GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
       GPS_HIP(h, hipStreamSynchronize(h->stream));
-      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
+      if (!full_cov) {
+        // only the column sums of squares of L_q^T A are needed: form it as (L_q^T) A^T-transposed, [mp, nsp], with the
+        // upper-triangular L_q^T as the A operand -- the GEMM skips its zero half (half the flop of the product below)
+        lta_transposed = true;
+        rc = gps_launch_gemm_nt(h, 1, /*A upper triangular*/ 2, mp, nsp, mp, h->dTmp2.d(), mp, c.Bt, mp, dLTA, nsp);
+      } else {
+        rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, c.Bt, mp, h->dTmp2.d(), mp, dLTA, mp);
+      }
       if (rc) return rc;
     }
     if (sv) {
-      rc = gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
+      rc = lta_transposed ? gps_launch_colsumsq(h, dLTA, nsp, mp, n_new, dss)
+                          : gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
       if (rc) return rc;
       // sum_i (yres - fmean)^2 + fvar for this latent, fvar = base + extra           likelihoods.py:186-188
       rc = gps_launch_varexp(h, dmean, dYres, k, (int)q, h->dVar.d(), dss, n_new, dYres + (size_t)n_new * k);
@@ -1166,7 +1175,8 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
         sv->kl += t;                                                    // (trace term, completed below)
       }
     } else if (!full_cov) {
-      rc = gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
+      rc = lta_transposed ? gps_launch_colsumsq(h, dLTA, nsp, mp, n_new, dss)
+                          : gps_launch_rowdot(h, dLTA, mp, n_new, mp, nullptr, mp, 0, nullptr, dss);
       if (rc) return rc;
       GPS_HIP(h, hipMemcpyAsync(extra.data(), dss, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
       GPS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1530,7 +1540,8 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
         grad_q_sqrt[j * k + q] = -(w / s2) * hDiag[j] * sv - sv + 1.0 / sv;
       }
   } else {
-    // A A^T (lower by one long-K GEMM, mirrored) ; per latent: A^T L_q, the Abar update, (A A^T) L_q
+    // A A^T (lower by one long-K GEMM, mirrored) ; per latent: S += (w/s2) L_q L_q^T and (A A^T) L_q (both M^3) ; then ONE
+    // M^2 N product for all latents:  Abar^T -= A^T S   (S symmetric; instead of (A^T L_q) L_q^T per latent: 2k -> 1 products)
     GPS_HIP(h, h->dS3.ensure((size_t)mp * mp * 8));
     double* AAT = h->dS3.d();
     rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, nsp, Am, nsp, Am, nsp, AAT, mp);
@@ -1539,19 +1550,19 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
     if (rc) return rc;
     GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
-    GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));
     GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+    GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
+    double* Ssum = h->dG2.d();
+    const double rs = sqrt(w / s2);
     std::vector<double> LT((size_t)mp * mp), Ls((size_t)mp * mp), G((size_t)mp * mp);
     for (i64 q = 0; q < k; ++q) {
       const double* Lq = q_sqrt + (size_t)q * m * m;                  // C-ABI layout [k][m][m]
       std::fill(LT.begin(), LT.end(), 0.0); std::fill(Ls.begin(), Ls.end(), 0.0);
-      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) { LT[(size_t)b * mp + a] = Lq[a * m + b]; Ls[(size_t)a * mp + b] = (w / s2) * Lq[a * m + b]; }
+      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) { LT[(size_t)b * mp + a] = Lq[a * m + b]; Ls[(size_t)a * mp + b] = rs * Lq[a * m + b]; }
       GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
       GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, Ls.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
       GPS_HIP(h, hipStreamSynchronize(h->stream));
-      rc = gps_launch_gemm_nt(h, 1, 0, nsp, mp, mp, Bt, mp, h->dTmp2.d(), mp, h->dTmp3.d(), mp);        // A^T L_q
-      if (rc) return rc;
-      rc = gps_launch_gemm_nt(h, 0, 0, nsp, mp, mp, h->dTmp3.d(), mp, h->dTmp.d(), mp, Abar, mp);        // Abar^T -= (w/s2) (A^T L_q) L_q^T
+      rc = gps_launch_gemm_nt(h, q == 0 ? 1 : 2, 0, mp, mp, mp, h->dTmp.d(), mp, h->dTmp.d(), mp, Ssum, mp);    // S (+)= (w/s2) L_q L_q^T
       if (rc) return rc;
       rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, AAT, mp, h->dTmp2.d(), mp, h->dG1.d(), mp);           // (A A^T) L_q
       if (rc) return rc;
@@ -1562,6 +1573,8 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
         for (i64 b = 0; b < m; ++b)
           gq[a * m + b] = (b > a) ? 0.0 : (-(w / s2) * G[(size_t)a * mp + b] - Lq[a * m + b] + (a == b ? 1.0 / Lq[a * m + a] : 0.0));
     }
+    rc = gps_launch_gemm_nt(h, 0, 0, nsp, mp, mp, Bt, mp, Ssum, mp, Abar, mp);                           // Abar^T -= A^T S
+    if (rc) return rc;
   }
   // Kuf_bar^T = Abar^T Lm^-1  (X Lm = Abar^T through U = Lm^T), then Kuf_bar [mp, nsp]
   GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));

@@ -295,6 +295,7 @@ int gps_launch_gemv_t_sub(gps_handle_t h, const double* L21, i64 ldl, i64 n2, i6
                           const double* y2, double* y1, i64 ldy, i64 r);
 int gps_launch_lml_reduce(gps_handle_t h, const double* L, i64 ldl, i64 n,
                           const double* alpha, i64 ldy, i64 r, double* out2);
+int gps_launch_colsumsq(gps_handle_t h, const double* A, i64 ld, i64 rows, i64 cols, double* sumsq);
 int gps_launch_rowdot(gps_handle_t h, const double* At, i64 ldat, i64 n_new, i64 npad,
                       const double* alpha, i64 ldy, i64 r, double* mean, double* sumsq);
 int gps_launch_fill_info(gps_handle_t h, int* d_info, int value);
