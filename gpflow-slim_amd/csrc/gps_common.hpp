@@ -114,6 +114,7 @@ struct gps_handle_s {
   int trsv_follow = 0;
   int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp
   bool wave_ctl_clear = false;
+  void* wave_ctl_ptr = nullptr;
   unsigned long long wave_fallbacks = 0;
   hipStream_t y_stream = nullptr;
   std::vector<hipEvent_t> y_events; size_t y_event_next = 0;

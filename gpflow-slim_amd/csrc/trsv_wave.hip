@@ -242,9 +242,10 @@ int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const 
   GPS_HIP(h, h->dWave.ensure(256 + (size_t)2 * n * 8));
   unsigned* ctl = (unsigned*)h->dWave.p;
   u64* xch = (u64*)((char*)h->dWave.p + 256);
-  if (!h->wave_ctl_clear) {
+  if (!h->wave_ctl_clear || h->wave_ctl_ptr != (void*)ctl) {       // a (re)allocated buffer holds whatever the allocator handed out
     GPS_HIP(h, hipMemsetAsync(ctl, 0, 256, h->stream));
     h->wave_ctl_clear = true;
+    h->wave_ctl_ptr = (void*)ctl;
   }
   for (i64 r0 = 0; r0 < r; r0 += 2) {
     int rc;
