@@ -246,14 +246,14 @@ static int read_info(gps_handle_t h, int* d_info, int* info) {
   GPS_HIP(h, hipMemcpyAsync(&v, d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (h->dLaFlags.p) GPS_HIP(h, hipMemcpyAsync(&la_timeouts, (unsigned long long*)h->dLaFlags.p + 2, 8, hipMemcpyDeviceToHost, h->stream));
   unsigned wave_gave_up = 0;
-  if (h->dWave.p && h->wave_ctl_clear) GPS_HIP(h, hipMemcpyAsync(&wave_gave_up, (unsigned*)h->dWave.p + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  if (h->dWaveCtl.p) GPS_HIP(h, hipMemcpyAsync(&wave_gave_up, (unsigned*)h->dWaveCtl.p + 1, 4, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (info) *info = (v == INT_MAX) ? 0 : v;
   if (wave_gave_up) {
     // a bounded wait of the trsv wavefront gave up (never seen; the bound is there so that a scheduling surprise is an
     // error, not a hung GPU): the result is poisoned -- switch the wavefront off for this handle and have the entry
     // point run the evaluation again through the recursive substitution (with_la_retry)
-    (void)hipMemsetAsync((unsigned*)h->dWave.p + 1, 0, 4, h->stream);
+    (void)hipMemsetAsync((unsigned*)h->dWaveCtl.p + 1, 0, 4, h->stream);
     h->trsv_wave = 0;
     h->wave_fallbacks++;
     h->la_timed_out = true;
@@ -326,8 +326,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
                     &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave};
   for (DevBuf* b : bufs) b->release();
-  h->wave_ctl_clear = false;
-  if (all) { h->dInfo.release(); h->dScal.release(); }      // (allocated by gps_create; every reduction writes there)
+  if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
 }
 
 // Hand the handle's device memory back to the allocator (K / L of a large problem is N^2 x 8 bytes and stays allocated

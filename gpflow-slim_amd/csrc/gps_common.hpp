@@ -113,8 +113,6 @@ struct gps_handle_s {
   // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).
   int trsv_follow = 0;
   int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp
-  bool wave_ctl_clear = false;
-  void* wave_ctl_ptr = nullptr;
   unsigned long long wave_fallbacks = 0;
   hipStream_t y_stream = nullptr;
   std::vector<hipEvent_t> y_events; size_t y_event_next = 0;
@@ -172,7 +170,8 @@ struct gps_handle_s {
   DevBuf dFeat2;    // feature workspace (cols / Xnew)
   DevBuf dProg;     // device copy of the kernel program
   DevBuf dNkn;      // neural-kernel-network layer weights
-  DevBuf dWave;     // trsv wavefront: [0] ticket, [1] give-ups, +256 B: exchange buffer [2][npad]
+  DevBuf dWave;     // trsv wavefront: exchange buffer [2][npad]
+  DevBuf dWaveCtl;  // [0] ticket, [1] give-ups (persistent)
   DevBuf dScal;     // small scalar outputs: [0]=sum log diag, [1]=sum alpha^2, ...
   DevBuf dInfo;     // int info word
   DevBuf dXnew;     // [n_new, d_all]

@@ -239,14 +239,13 @@ int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const 
   if (n <= 0 || r <= 0) return GPS_OK;
   if (n % 128) return gps_fail(h, GPS_ERR_ARG, "trsv wavefront: n must be a multiple of 128");
   const int nblk = (int)(n / 128);
-  GPS_HIP(h, h->dWave.ensure(256 + (size_t)2 * n * 8));
-  unsigned* ctl = (unsigned*)h->dWave.p;
-  u64* xch = (u64*)((char*)h->dWave.p + 256);
-  if (!h->wave_ctl_clear || h->wave_ctl_ptr != (void*)ctl) {       // a (re)allocated buffer holds whatever the allocator handed out
-    GPS_HIP(h, hipMemsetAsync(ctl, 0, 256, h->stream));
-    h->wave_ctl_clear = true;
-    h->wave_ctl_ptr = (void*)ctl;
+  GPS_HIP(h, h->dWave.ensure((size_t)2 * n * 8));
+  if (!h->dWaveCtl.p) {                                 // control words: allocated and cleared once, persistent afterwards
+    GPS_HIP(h, h->dWaveCtl.ensure(256));
+    GPS_HIP(h, hipMemsetAsync(h->dWaveCtl.p, 0, 256, h->stream));
   }
+  unsigned* ctl = (unsigned*)h->dWaveCtl.p;
+  u64* xch = (u64*)h->dWave.p;
   for (i64 r0 = 0; r0 < r; r0 += 2) {
     int rc;
     if (r - r0 >= 2) rc = trans ? tw_launch<2, true>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl)
