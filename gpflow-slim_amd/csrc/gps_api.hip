@@ -439,6 +439,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "kmat_fast") == 0) { h->kmat_fast = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_wave") == 0) { h->trsv_wave = (int)value; return GPS_OK; }
+  if (strcmp(key, "leaf_persistent") == 0) { h->leaf_persistent = (int)value; return GPS_OK; }
   if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }

@@ -114,9 +114,12 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WGN, wc = wave % WGN;
   const int fr = lane & 15, fk = lane >> 4;
-  const i64 row_base = (i64)blockIdx.x * BM;
-  if (row_base >= m) return;
-  double* Bg = Bm + row_base * ldb;
+  // Persistent over row tiles: workgroup b takes tiles b, b + gridDim.x, ...  From the second tile on the operand W is
+  // still staged from the previous tile's last product and the tile's rows were fetched behind that product: a tile
+  // costs two operand stagings instead of three, no exposed load of its rows and no workgroup launch.
+  const i64 ntiles = m / BM;
+  if ((i64)blockIdx.x >= ntiles) return;
+  double* Bg = Bm + (i64)blockIdx.x * BM * ldb;
   // diagnostics (gps_diag_trsm_leaf): phase stamps of workgroup 0 in 100 MHz ticks
 #define LF_STAMP(q) do { if (stamps && blockIdx.x == 0 && tid == 0) stamps[q] = (long long)wall_clock64(); } while (0)
   LF_STAMP(0);
@@ -128,12 +131,13 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
   // kept part of the row do not load).  The values are only touched again in stage(), so the loads stay in flight
   // behind the product that runs meanwhile.
   v2d pre[NPRE];
+  int lane_v = lane, tid_v = tid;                            // re-laundered per tile (see the tile loop)
   auto fetch = [&](const double* __restrict__ S, i64 lds_) {
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
       const int j = NWV * u + wave, jb = (NWV * u) >> 4;
-      const bool keep = UPPER ? (2 * lane >= 16 * jb) : (2 * lane < 16 * (jb + 1));
-      pre[u] = keep ? *reinterpret_cast<const v2d*>(S + (i64)j * lds_ + 2 * lane) : (v2d){0.0, 0.0};
+      const bool keep = UPPER ? (2 * lane_v >= 16 * jb) : (2 * lane_v < 16 * (jb + 1));
+      pre[u] = keep ? *reinterpret_cast<const v2d*>(S + (i64)j * lds_ + 2 * lane_v) : (v2d){0.0, 0.0};
     }
   };
   // registers -> packed rows; entries beyond the diagonal are zeroed here (whatever the caller's matrix holds on
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
   auto stage = [&]() {
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
-      const int j = NWV * u + wave, jb = (NWV * u) >> 4, k = 2 * lane;
+      const int j = NWV * u + wave, jb = (NWV * u) >> 4, k = 2 * lane_v;
       v2d v = pre[u];
       if (UPPER) { if (k < j) v.x = 0.0; if (k + 1 < j) v.y = 0.0; }
       else { if (k > j) v.x = 0.0; if (k + 1 > j) v.y = 0.0; }
@@ -150,37 +154,60 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
     }
   };
   constexpr int NLB = BM * LF_N / 2 / NT;                    // 16-byte loads per thread of the B tile
-  {
-    v2d t[NLB];
+  v2d rows[NLB];                                             // a tile's rows on their way from HBM to Pa
+  auto fetch_rows = [&](const double* __restrict__ G) {
 #pragma unroll
     for (int u = 0; u < NLB; ++u) {
-      const int idx = u * NT + tid;
-      t[u] = *reinterpret_cast<const v2d*>(Bg + (i64)(idx >> 6) * ldb + (idx & 63) * 2);
+      const int idx = u * NT + tid_v;
+      rows[u] = *reinterpret_cast<const v2d*>(G + (i64)(idx >> 6) * ldb + (idx & 63) * 2);
     }
+  };
+  auto stage_rows = [&]() {
 #pragma unroll
     for (int u = 0; u < NLB; ++u) {
-      const int idx = u * NT + tid;
-      *reinterpret_cast<v2d*>(Pa + (idx >> 6) * LF_LS + (idx & 63) * 2) = t[u];
+      const int idx = u * NT + tid_v;
+      *reinterpret_cast<v2d*>(Pa + (idx >> 6) * LF_LS + (idx & 63) * 2) = rows[u];
     }
-  }
+  };
+  fetch_rows(Bg);
+  stage_rows();
 
   // accumulator map of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg
-  const int crow = wr * WTM + (lane >> 4), ccol = lane & 15;
+  int crow = wr * WTM + (lane >> 4), ccol = lane & 15;       // (laundered per tile with the other thread indices)
   double bc[MI][NI][4];                                      // B in accumulator layout
   const double* a_base = Pa + (wr * WTM + fr) * LF_LS + fk;
   v4d acc[MI][NI];
   // pass 0: X0 = B W^T (D on its way) ; pass 1: R = B - X0 D^T (W on its way again: L2-hot) ; pass 2: X = X0 + R W^T
   // (pass -1 only stages W)
 #pragma unroll 1
-  for (int pass = -1; pass < 3; ++pass) {
-    if (pass < 2) fetch((pass == 0) ? D : W, (pass == 0) ? ldd : (i64)LF_N);
+  for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const bool first = (tile == (i64)blockIdx.x);
+  Bg = Bm + tile * BM * ldb;
+  // (pointers and thread indices pass an opaque barrier per tile: hoisted out of the tile loop, the per-thread fetch /
+  // stage / store addresses cost ~100 registers for the whole loop, and the 64-row variant spills)
+  const double* Wt = W; const double* Dt = D;
+  asm volatile("" : "+s"(Wt), "+s"(Dt));
+  asm volatile("" : "+v"(lane_v), "+v"(tid_v), "+v"(crow), "+v"(ccol));
+  if (!first) {
+    // this tile's rows were fetched behind the previous tile's last product; W is still staged in Wp from it
+    lf_lds_barrier();                                        // every wave is done with Pa
+    stage_rows();
+    lf_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) bc[i][j][rg] = Pa[(crow + i * 16 + 4 * rg) * LF_LS + cb[j] * 16 + ccol];
+  }
+#pragma unroll 1
+  for (int pass = first ? -1 : 0; pass < 2; ++pass) {
+    fetch((pass == 0) ? Dt : Wt, (pass == 0) ? ldd : (i64)LF_N);
     if (pass >= 0) {
-      if (pass < 2) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-      }
+        for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
       switch (wc) {
         case 0: leaf_product<MI, NI, 0, UPPER>(acc, a_base, Wp, fr, fk); break;
         case 1: leaf_product<MI, NI, 1, UPPER>(acc, a_base, Wp, fr, fk); break;
@@ -188,7 +215,6 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
         default: leaf_product<MI, NI, 3, UPPER>(acc, a_base, Wp, fr, fk); break;
       }
       LF_STAMP(2 + 2 * pass);
-      if (pass == 2) break;
       lf_lds_barrier();               // every wave is done with Pa and Wp
       // X0 is parked in the output rows (B itself lives on in `bc`) and comes back as the accumulator of pass 2 (its
       // own lanes wrote it: no fence needed).  Keeping it in registers instead costs the 64-row tile spills.
@@ -227,6 +253,18 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
           for (int rg = 0; rg < 4; ++rg) bc[i][j][rg] = Pa[(crow + i * 16 + 4 * rg) * LF_LS + cb[j] * 16 + ccol];
     }
   }
+  // pass 2 (outside the loop: the rows fetched here stay in registers until the next tile stages them, and inside the
+  // loop the allocator would keep those registers reserved through every pass): X = X0 + R W^T
+  // (unconditional, so that the registers are dead from the staging at the top of a tile to here: the last tile of a
+  // workgroup fetches its own rows once more and drops them)
+  fetch_rows(Bm + ((tile + (i64)gridDim.x < ntiles) ? tile + (i64)gridDim.x : tile) * BM * ldb);     // behind the last product
+  switch (wc) {
+    case 0: leaf_product<MI, NI, 0, UPPER>(acc, a_base, Wp, fr, fk); break;
+    case 1: leaf_product<MI, NI, 1, UPPER>(acc, a_base, Wp, fr, fk); break;
+    case 2: leaf_product<MI, NI, 2, UPPER>(acc, a_base, Wp, fr, fk); break;
+    default: leaf_product<MI, NI, 3, UPPER>(acc, a_base, Wp, fr, fk); break;
+  }
+  LF_STAMP(6);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -234,6 +272,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) Bg[(i64)(crow + i * 16 + 4 * rg) * ldb + cb[j] * 16 + ccol] = acc[i][j][rg];
   LF_STAMP(7);
+  }
 }
 
 template <int BM, int NT, bool UPPER>
@@ -242,7 +281,11 @@ static int launch_leaf_u(gps_handle_t h, double* B, i64 ldb, i64 m, const double
   const size_t lds = (size_t)(BM * LF_LS + LF_WP_DOUBLES) * sizeof(double);
   int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_leaf_refine_kernel<BM, NT, UPPER>), (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER>), dim3((unsigned)(m / BM)), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
+  // one workgroup per CU fits (140 KB of LDS at BM = 64): more tiles than CUs are walked by the resident workgroups
+  i64 grid = m / BM;
+  const i64 cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
+  if (h->leaf_persistent && grid > cus) grid = cus;
+  hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER>), dim3((unsigned)grid), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
@@ -262,7 +305,7 @@ int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const
   LaunchScope ls(h, KC_GEMM, 3.0 * (9.0 / 16.0) * 2.0 * (double)m * 128.0 * 128.0, 16.0 * (double)m * 128.0 + 3.0 * 128.0 * 128.0 * 8.0);
   ls.tag[0] = m; ls.tag[1] = 128; ls.tag[2] = 128; ls.tag[3] = 1000 + upper;
   // latency-bound below ~one workgroup per CU: spread the rows; above, the 64-row tile has the densest MFMA stream
-  if (m / 64 >= 256) return launch_leaf<64, 512>(h, B, ldb, m, W, D, ldd, upper);
+  if (m / 64 >= 256 && h->leaf_persistent != 2) return launch_leaf<64, 512>(h, B, ldb, m, W, D, ldd, upper);
   if (m / 32 >= 256) return launch_leaf<32, 256>(h, B, ldb, m, W, D, ldd, upper);
   return launch_leaf<16, 256>(h, B, ldb, m, W, D, ldd, upper);
 }

@@ -329,6 +329,8 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always
+ *   "leaf_persistent" 1 (default): the refined solve leaves run as resident workgroups that walk the row tiles (long panels:
+ *                     -14 %); 0: one workgroup per 64-row tile
  *   "trsv_wave"       1 (default): L a = y and L^T a = y of the GPR entry points run as ONE wavefront launch over the
  *                     128-row blocks (trsv_wave.hip: 1.2 ms at N = 32768); 0: recursive substitution (4 N / 128 launches,
  *                     3.2 ms).  Refined leaves (jittered factors) always take the recursive one.
