@@ -96,7 +96,7 @@ __device__ __forceinline__ void leaf_product(v4d (&acc)[MI][NI], const double* _
 // and the parked X0 store.
 __device__ __forceinline__ void lf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BM, int NT, bool UPPER>
+template <int BM, int NT, bool UPPER, bool WALK>
 __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ldb, i64 m,
                                                               const double* __restrict__ W,
                                                               const double* __restrict__ D, i64 ldd,
@@ -176,11 +176,11 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
   int crow = wr * WTM + (lane >> 4), ccol = lane & 15;       // (laundered per tile with the other thread indices)
   double bc[MI][NI][4];                                      // B in accumulator layout
   const double* a_base = Pa + (wr * WTM + fr) * LF_LS + fk;
-  v4d acc[MI][NI];
+  v4d acc[MI][NI], x0[MI][NI];
   // pass 0: X0 = B W^T (D on its way) ; pass 1: R = B - X0 D^T (W on its way again: L2-hot) ; pass 2: X = X0 + R W^T
   // (pass -1 only stages W)
 #pragma unroll 1
-  for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (i64 tile = blockIdx.x; tile < ntiles; tile += (WALK ? (i64)gridDim.x : ntiles)) {       // WALK == false: one tile per workgroup
   const bool first = (tile == (i64)blockIdx.x);
   Bg = Bm + tile * BM * ldb;
   // (pointers and thread indices pass an opaque barrier per tile: hoisted out of the tile loop, the per-thread fetch /
@@ -223,8 +223,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           if (pass == 0) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) Bg[(i64)(crow + i * 16 + 4 * rg) * ldb + cb[j] * 16 + ccol] = acc[i][j][rg];
+            x0[i][j] = acc[i][j];
           } else {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] = bc[i][j][rg] - acc[i][j][rg];
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
 #pragma unroll
           for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] = Bg[(i64)(crow + i * 16 + 4 * rg) * ldb + cb[j] * 16 + ccol];
+            for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] = x0[i][j][rg];
       }
     }
     stage();
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(NT) void trsm_leaf_refine_kernel(double* Bm, i64 ld
   // loop the allocator would keep those registers reserved through every pass): X = X0 + R W^T
   // (unconditional, so that the registers are dead from the staging at the top of a tile to here: the last tile of a
   // workgroup fetches its own rows once more and drops them)
-  fetch_rows(Bm + ((tile + (i64)gridDim.x < ntiles) ? tile + (i64)gridDim.x : tile) * BM * ldb);     // behind the last product
+  if (WALK) fetch_rows(Bm + ((tile + (i64)gridDim.x < ntiles) ? tile + (i64)gridDim.x : tile) * BM * ldb);     // behind the last product
   switch (wc) {
     case 0: leaf_product<MI, NI, 0, UPPER>(acc, a_base, Wp, fr, fk); break;
     case 1: leaf_product<MI, NI, 1, UPPER>(acc, a_base, Wp, fr, fk); break;
@@ -279,13 +278,18 @@ template <int BM, int NT, bool UPPER>
 static int launch_leaf_u(gps_handle_t h, double* B, i64 ldb, i64 m, const double* W, const double* D, i64 ldd) {
   long long* stamps = h->leaf_stamps;
   const size_t lds = (size_t)(BM * LF_LS + LF_WP_DOUBLES) * sizeof(double);
-  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_leaf_refine_kernel<BM, NT, UPPER>), (int)lds);
-  if (rc) return rc;
   // one workgroup per CU fits (140 KB of LDS at BM = 64): more tiles than CUs are walked by the resident workgroups
-  i64 grid = m / BM;
+  const i64 ntiles = m / BM;
   const i64 cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
-  if (h->leaf_persistent && grid > cus) grid = cus;
-  hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER>), dim3((unsigned)grid), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
+  if (h->leaf_persistent && ntiles > cus) {
+    int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_leaf_refine_kernel<BM, NT, UPPER, true>), (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER, true>), dim3((unsigned)cus), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
+  } else {
+    int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_leaf_refine_kernel<BM, NT, UPPER, false>), (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER, false>), dim3((unsigned)ntiles), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
+  }
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
@@ -304,10 +308,12 @@ int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const
   // three triangular products: 3 x 9/16 of the dense 2 m 128^2
   LaunchScope ls(h, KC_GEMM, 3.0 * (9.0 / 16.0) * 2.0 * (double)m * 128.0 * 128.0, 16.0 * (double)m * 128.0 + 3.0 * 128.0 * 128.0 * 8.0);
   ls.tag[0] = m; ls.tag[1] = 128; ls.tag[2] = 128; ls.tag[3] = 1000 + upper;
-  // latency-bound below ~one workgroup per CU: spread the rows; above, the 64-row tile has the densest MFMA stream
-  if (m / 64 >= 256 && h->leaf_persistent != 2) return launch_leaf<64, 512>(h, B, ldb, m, W, D, ldd, upper);
-  if (m / 32 >= 256) return launch_leaf<32, 256>(h, B, ldb, m, W, D, ldd, upper);
-  return launch_leaf<16, 256>(h, B, ldb, m, W, D, ldd, upper);
+  // latency-bound up to one workgroup per CU: the smallest tile that still covers the rows in one round of workgroups;
+  // beyond, the 64-row tile has the densest MFMA stream (and its resident workgroups walk the tiles)
+  const i64 cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
+  if (m / 16 <= cus) return launch_leaf<16, 256>(h, B, ldb, m, W, D, ldd, upper);
+  if (m / 32 <= cus || h->leaf_persistent == 2) return launch_leaf<32, 256>(h, B, ldb, m, W, D, ldd, upper);
+  return launch_leaf<64, 512>(h, B, ldb, m, W, D, ldd, upper);
 }
 
 // ---- vector leaf:  y <- solution of  L11 a = y  (one workgroup per right-hand side), refined once
