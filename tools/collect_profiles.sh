@@ -8,14 +8,6 @@ OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 what=${1:-all}
-if [ "$what" = all ] || [ "$what" = stats ]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/prof_bench.log 2>&1 || exit 1
-  echo "bench stats done"
-  for c in 2 4 5; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg$c -- python3 $R/tools/configs.py $c > $OUT/prof_cfg$c.log 2>&1 || exit 1
-    echo "cfg$c stats done"
-  done
-fi
 if [ "$what" = all ] || [ "$what" = pmc ]; then
   # counter collection serialises the dispatches: a look-ahead hand-over could only time out (and the evaluation would
   # be re-run without it) -- switch it off up front
@@ -26,4 +18,14 @@ if [ "$what" = all ] || [ "$what" = pmc ]; then
   done
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_pmc_mfma -- python3 $R/tools/one_eval.py 32768 1 > $OUT/prof_pmc_mfma.log 2>&1 || exit 1
   echo "pmc mfma done"
+  # the bench below reports roofline.traffic only from a PMC summary of the same kernel sources: write it now (on this box)
+  (cd $R && python3 tools/summarise_profiles.py r02 > $OUT/summarise_on_box.log 2>&1) || true
+fi
+if [ "$what" = all ] || [ "$what" = stats ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/prof_bench.log 2>&1 || exit 1
+  echo "bench stats done"
+  for c in 2 4 5; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg$c -- python3 $R/tools/configs.py $c > $OUT/prof_cfg$c.log 2>&1 || exit 1
+    echo "cfg$c stats done"
+  done
 fi
