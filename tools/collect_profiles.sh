@@ -20,6 +20,7 @@ if [ "$what" = all ] || [ "$what" = pmc ]; then
   echo "pmc mfma done"
   # the bench below reports roofline.traffic only from a PMC summary of the same kernel sources: write it now (on this box)
   (cd $R && python3 tools/summarise_profiles.py r02 > $OUT/summarise_on_box.log 2>&1) || true
+  unset GPS_LOOKAHEAD
 fi
 if [ "$what" = all ] || [ "$what" = stats ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/prof_bench.log 2>&1 || exit 1
