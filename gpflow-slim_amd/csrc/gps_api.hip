@@ -1380,7 +1380,7 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
 //   Kuf_bar = Lm^-T Abar ;  Lm_bar = -tril(Kuf_bar A^T) ;  Kuu_bar = Lm^-T (Phi(Lm^T Lm_bar) + Phi(.)^T) Lm^-1 / 2   (Phi: tril, diagonal halved)
 //   d/d theta = <Kuf_bar, dKuf> + <Kuu_bar, dKuu> + kbar dKdiag            (gps_launch_kmat_vjp: the kernel-matrix VJP)
 // (Checked in tests/test_gpu_grad.py against a CPU restatement and finite differences.)  The inducing inputs Z are held
-// fixed (their gradient is not computed).
+// fixed unless the caller asks for grad_Z (gps_launch_kmat_input_vjp: the kernel-matrix build differentiated in its points).
 // Unwhitened parametrisation (white == 0; examples/svgp.py:146 runs with whiten=False): the bound is the whitened one at
 //   m_w = Lm^-1 q_mu,  L_w,q = Lm^-1 L_q          (same predictive moments, KL invariant under the linear map),
 // so the whitened gradient (g_w, G_w) is computed at (m_w, L_w) and pulled back:
@@ -1444,7 +1444,7 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
                                   const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
                                   double noise_var, double scale, double* elbo, double* grad_slots, int n_slots_cap,
                                   int* n_slots_out, double* grad_noise, double* grad_q_mu, double* grad_q_sqrt,
-                                  double* grad_mean, int* info) {
+                                  double* grad_mean, double* grad_Z, int* info) {
   if (!h || !elbo || !grad_slots || !grad_noise || !grad_q_mu || !grad_q_sqrt)
     return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo_grad: bad argument");
   if (k > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_svgp_elbo_grad: at most 128 latent functions");
@@ -1679,6 +1679,15 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
   }
   rc = gps_kdiag_vjp(h, prog, n_nodes, d_all, -w * (double)k * (double)n / (2.0 * s2), grad_slots);
   if (rc) return rc;
+  if (grad_Z) {
+    // inducing inputs: Z enters through Kuf = k(Z, X) (cotangent Kuf_bar) and Kuu = k(Z, Z) (cotangent Kuu_bar / 2 on the full
+    // symmetric matrix: both arguments move, which doubles the first-argument gradient); Kdiag and the jitter do not depend on Z
+    for (i64 i = 0; i < m * d_all; ++i) grad_Z[i] = 0.0;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, nsp, 1.0, grad_Z);
+    if (rc) return rc;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, LmBarT, mp, 1.0, grad_Z);
+    if (rc) return rc;
+  }
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
 }
@@ -1708,6 +1717,38 @@ extern "C" int gps_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_n
   GPS_HIP(h, h->dTmp.ensure((size_t)n * m * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, W, (size_t)n * m * 8, hipMemcpyHostToDevice, h->stream));
   rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dXnew.d(), n, dX2, m, d_all, h->dTmp.d(), m, 0, grad_slots);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
+// gradient of sum_ij W[i][j] k(X_i, X2_j) with respect to the points X (first argument): grad_X host [n, d_all].
+// X2 == NULL: k(X_i, X_j), BOTH arguments move (W [n, n] as given): grad = first-argument gradient of (W + W^T).
+extern "C" int gps_kmat_input_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X, int64_t n,
+                                  const double* X2, int64_t m, int64_t d_all, const double* W, double* grad_X) {
+  if (!h || !X || !W || !grad_X || n <= 0 || d_all <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_kmat_input_vjp: bad argument");
+  GPS_HIP(h, hipSetDevice(h->device));
+  if (!X2) m = n;
+  GPS_HIP(h, h->dXnew.ensure((size_t)n * d_all * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
+  const double* dX2 = nullptr;
+  if (X2) {
+    GPS_HIP(h, h->dTmp3.ensure((size_t)m * d_all * 8));
+    GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, X2, (size_t)m * d_all * 8, hipMemcpyHostToDevice, h->stream));
+    dX2 = h->dTmp3.d();
+  }
+  GPS_HIP(h, h->dTmp.ensure((size_t)n * m * 8));
+  std::vector<double> Ws;
+  const double* Wsrc = W;
+  if (!X2) {                                   // symmetrise: d/dx_i of sum_ij W_ij k(x_i, x_j) = sum_j (W_ij + W_ji) d1 k(x_i, x_j)
+    Ws.resize((size_t)n * n);
+    for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j < n; ++j) Ws[(size_t)i * n + j] = W[(size_t)i * n + j] + W[(size_t)j * n + i];
+    Wsrc = Ws.data();
+  }
+  GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, Wsrc, (size_t)n * m * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  for (int64_t i = 0; i < n * d_all; ++i) grad_X[i] = 0.0;
+  int rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dXnew.d(), n, dX2, m, d_all, h->dTmp.d(), m, 1.0, grad_X);
   if (rc) return rc;
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;

@@ -340,6 +340,9 @@ int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_no
 int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                             i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                             double* grad_slots_host, double* grad_noise_host);
+int gps_launch_kmat_input_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dXr, i64 nr,
+                              const double* dXc, i64 nc, i64 d_all, const double* Wd, i64 ldw, double factor,
+                              double* grad_X_host);
 int gps_kdiag_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 d_all, double kbar, double* grad_slots_host);
 int gps_launch_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dXr, i64 nr, const double* dXc,
                         i64 nc, i64 d_all, const double* Wd, i64 ldw, int accumulate, double* grad_slots_host);

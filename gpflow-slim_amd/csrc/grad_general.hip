@@ -173,66 +173,33 @@ __device__ __forceinline__ double gg_prog_tangent(const GGProg& P, const double 
   return st[0];
 }
 
-__global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
-  __shared__ double Fr_s[GG_MAXF * GG_T];
-  __shared__ double Fc_s[GG_MAXF * GG_T];
-  __shared__ double acc_s[4][GG_MAXSLOT + 1];
-  __shared__ double W_s[GG_MAXL * GG_W * (GG_W + 1)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = tid & 15, ty = tid >> 4;       // 16 x 16 threads ; 2 rows x 2 cols each
-  for (int s = tid; s < 4 * (GG_MAXSLOT + 1); s += 256) (&acc_s[0][0])[s] = 0.0;
-  if (P.nkn) for (int s = tid; s < P.n_layers * GG_W * (GG_W + 1); s += 256) W_s[s] = a.Wnet[s];
-  __syncthreads();
-
-  const bool same_points = a.rect ? (a.same_points != 0) : true;
-  const i64 ntiles = (i64)a.tiles * a.tiles_c;
-  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int ti = (int)(t / a.tiles_c), tj = (int)(t % a.tiles_c);
-    if (!a.rect && tj > ti) continue;
-    const i64 gi0 = (i64)ti * GG_T, gj0 = (i64)tj * GG_T;
-    // ---- weights c_e W_e
-    double w[GG_E];
-    double dsum = 0.0;
+// ---- pass 1: values of all primitives at the thread's four entries of tile (gi0, gj0)
+__device__ __forceinline__ void gg_values(const GGArgs& a, const GGProg& P, i64 gi0, i64 gj0, bool same_points, double* Fr_s,
+                                          double* Fc_s, int tid, int ty, int tx, double (&pv)[GG_MAXP][GG_E]) {
 #pragma unroll
-    for (int e = 0; e < GG_E; ++e) {
-      const i64 i = gi0 + ty * 2 + (e >> 1), j = gj0 + tx * 2 + (e & 1);
-      double val = 0.0;
-      if (a.rect) {
-        if (i < a.nr && j < a.nc) val = a.Wd[i * a.ldw + j];
-      } else if (i < a.n && j <= i) {
-        double s = 0.0;
-        for (int q = 0; q < a.r; ++q) s += a.A[(i64)q * a.lda + i] * a.A[(i64)q * a.lda + j];
-        val = s - (double)a.r * a.Kinv[i * a.ldk + j];
-        if (i == j) { val *= 0.5; dsum += val; }
-      }
-      w[e] = val;
-    }
-    if (!a.rect && ti == tj) {                             // noise: d K_y / d sigma^2 = I
-      dsum = gg_wave_sum(dsum);
-      if (lane == 0) acc_s[wave][GG_MAXSLOT] += dsum;
-    }
-    // ---- pass 1: primitive values
-    double pv[GG_MAXP][GG_E];
+  for (int p = 0; p < GG_MAXP; ++p)
+#pragma unroll
+    for (int e = 0; e < GG_E; ++e) pv[p][e] = 0.0;
+  for (int nd = 0; nd < P.n_nodes; ++nd) {
+    const GGNode node = P.nodes[nd];
+    if (node.prim < 0) continue;
+    if (node.nf > 0) gg_stage(a, node.f0, (node.op == GPS_K_PERIODIC) ? 2 * node.ndims : node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
+    double val[GG_E], rr[GG_E];
+    gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, rr);
 #pragma unroll
     for (int p = 0; p < GG_MAXP; ++p)
+      if (node.prim == p) {
 #pragma unroll
-      for (int e = 0; e < GG_E; ++e) pv[p][e] = 0.0;
-    for (int nd = 0; nd < P.n_nodes; ++nd) {
-      const GGNode node = P.nodes[nd];
-      if (node.prim < 0) continue;
-      if (node.nf > 0) gg_stage(a, node.f0, (node.op == GPS_K_PERIODIC) ? 2 * node.ndims : node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
-      double val[GG_E], rr[GG_E];
-      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, rr);
-#pragma unroll
-      for (int p = 0; p < GG_MAXP; ++p)
-        if (node.prim == p) {
-#pragma unroll
-          for (int e = 0; e < GG_E; ++e) pv[p][e] = val[e];
-        }
-    }
-    // ---- pass 2: adjoints  f[p][e] = c W d k / d prim_p ; network weights on the way
-    double fp[GG_MAXP][GG_E];
+        for (int e = 0; e < GG_E; ++e) pv[p][e] = val[e];
+      }
+  }
+}
+
+// ---- pass 2: adjoints  fp[p][e] = w_e d k / d prim_p ; ACCW: the network's weight / bias slots are accumulated on the way
+template <bool ACCW>
+__device__ __forceinline__ void gg_adjoints(const GGProg& P, const double* W_s, const double (&w)[GG_E],
+                                            const double (&pv)[GG_MAXP][GG_E], double (&fp)[GG_MAXP][GG_E],
+                                            double (*acc_s)[GG_MAXSLOT + 1], int lane, int wave) {
     if (!P.nkn) {
 #pragma unroll
       for (int e = 0; e < GG_E; ++e) {
@@ -290,12 +257,16 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
             for (int o = 0; o < ly.out_dim; ++o) {
               const double ao = adj[o];
               for (int j = 0; j < ly.in_dim; ++j) {
-                double g = gg_wave_sum(ao * act[L][j]);               // d / d W[o][j]
-                if (lane == 0) acc_s[wave][ly.slot0 + o * (ly.in_dim + 1) + j] += g;
+                if (ACCW) {
+                  double g = gg_wave_sum(ao * act[L][j]);             // d / d W[o][j]
+                  if (lane == 0) acc_s[wave][ly.slot0 + o * (ly.in_dim + 1) + j] += g;
+                }
                 nxt[j] = fma(Wl[o * (GG_W + 1) + j], ao, nxt[j]);
               }
-              double gb = gg_wave_sum(ao);                            // d / d bias[o]
-              if (lane == 0) acc_s[wave][ly.slot0 + o * (ly.in_dim + 1) + ly.in_dim] += gb;
+              if (ACCW) {
+                double gb = gg_wave_sum(ao);                          // d / d bias[o]
+                if (lane == 0) acc_s[wave][ly.slot0 + o * (ly.in_dim + 1) + ly.in_dim] += gb;
+              }
             }
           } else if (ly.type == 1) {
             for (int o = 0; o < ly.out_dim; ++o)
@@ -315,6 +286,51 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
           for (int u = 0; u < GG_E; ++u) if (u == e) fp[p][u] = adj[p];
       }
     }
+}
+
+__global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
+  __shared__ double Fr_s[GG_MAXF * GG_T];
+  __shared__ double Fc_s[GG_MAXF * GG_T];
+  __shared__ double acc_s[4][GG_MAXSLOT + 1];
+  __shared__ double W_s[GG_MAXL * GG_W * (GG_W + 1)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 15, ty = tid >> 4;       // 16 x 16 threads ; 2 rows x 2 cols each
+  for (int s = tid; s < 4 * (GG_MAXSLOT + 1); s += 256) (&acc_s[0][0])[s] = 0.0;
+  if (P.nkn) for (int s = tid; s < P.n_layers * GG_W * (GG_W + 1); s += 256) W_s[s] = a.Wnet[s];
+  __syncthreads();
+
+  const bool same_points = a.rect ? (a.same_points != 0) : true;
+  const i64 ntiles = (i64)a.tiles * a.tiles_c;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int ti = (int)(t / a.tiles_c), tj = (int)(t % a.tiles_c);
+    if (!a.rect && tj > ti) continue;
+    const i64 gi0 = (i64)ti * GG_T, gj0 = (i64)tj * GG_T;
+    // ---- weights c_e W_e
+    double w[GG_E];
+    double dsum = 0.0;
+#pragma unroll
+    for (int e = 0; e < GG_E; ++e) {
+      const i64 i = gi0 + ty * 2 + (e >> 1), j = gj0 + tx * 2 + (e & 1);
+      double val = 0.0;
+      if (a.rect) {
+        if (i < a.nr && j < a.nc) val = a.Wd[i * a.ldw + j];
+      } else if (i < a.n && j <= i) {
+        double s = 0.0;
+        for (int q = 0; q < a.r; ++q) s += a.A[(i64)q * a.lda + i] * a.A[(i64)q * a.lda + j];
+        val = s - (double)a.r * a.Kinv[i * a.ldk + j];
+        if (i == j) { val *= 0.5; dsum += val; }
+      }
+      w[e] = val;
+    }
+    if (!a.rect && ti == tj) {                             // noise: d K_y / d sigma^2 = I
+      dsum = gg_wave_sum(dsum);
+      if (lane == 0) acc_s[wave][GG_MAXSLOT] += dsum;
+    }
+    // ---- pass 1: primitive values ; pass 2: adjoints  fp[p][e] = c W d k / d prim_p (network weights on the way)
+    double pv[GG_MAXP][GG_E], fp[GG_MAXP][GG_E];
+    gg_values(a, P, gi0, gj0, same_points, Fr_s, Fc_s, tid, ty, tx, pv);
+    gg_adjoints<true>(P, W_s, w, pv, fp, acc_s, lane, wave);
     // ---- pass 3: the primitives' own parameters
     for (int nd = 0; nd < P.n_nodes; ++nd) {
       const GGNode node = P.nodes[nd];
@@ -393,6 +409,116 @@ __global__ __launch_bounds__(256) void gg_kernel(GGArgs a, GGProg P) {
   __syncthreads();
   for (int s = tid; s < GG_MAXSLOT + 1; s += 256)
     a.partial[(i64)blockIdx.x * (GG_MAXSLOT + 1) + s] = (acc_s[0][s] + acc_s[1][s]) + (acc_s[2][s] + acc_s[3][s]);
+}
+
+// ---- gradient with respect to the INPUT points of the first argument ------------------------------------------------
+//   G[i][d] = sum_j Wd[i][j] d k(xr_i, xc_j) / d xr_i[d]
+// -- what reverse-mode autodiff through kern.K(Z, X) hands to a trainable Z (features.py:65: the inducing inputs are a
+// Parameter; examples/svgp.py:161 minimises over every variable of the graph).  Same per-entry forward / reverse pass
+// through the program as gg_kernel; then, per primitive, the chain through its argument:
+//   stationary  r2 = sum_d (F_id - F_jd)^2, F = x / l :  d k / d x_id = (d k / d r2) 2 (F_id - F_jd) / l_d
+//   Periodic    S = sum_d sin^2((a_id - a_jd) / 2), a = 2 pi x / p :  d k / d x_id = -k / (2 l^2) (1/2) sin(a_id - a_jd) 2 pi / p
+// Workgroup (ti, slice) owns 32 rows and a slice of the column tiles; row sums over the 16 threads of a patch row by
+// shuffles, over the tiles in LDS; the slices' partial sums [slices][rows][d_all] are added in order on the host.
+struct GIArgs { const GGFeat* feats; double* part; int d_all; int slices; i64 rows_pad; };
+
+__global__ __launch_bounds__(256) void gg_input_kernel(GGArgs a, GGProg P, GIArgs gi) {
+  __shared__ double Fr_s[GG_MAXF * GG_T];
+  __shared__ double Fc_s[GG_MAXF * GG_T];
+  __shared__ double W_s[GG_MAXL * GG_W * (GG_W + 1)];
+  __shared__ double rowacc[GG_T][GPS_MAX_DIMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 15, ty = tid >> 4;
+  for (int s = tid; s < GG_T * GPS_MAX_DIMS; s += 256) (&rowacc[0][0])[s] = 0.0;
+  if (P.nkn) for (int s = tid; s < P.n_layers * GG_W * (GG_W + 1); s += 256) W_s[s] = a.Wnet[s];
+  __syncthreads();
+  const bool same_points = a.same_points != 0;
+  const int ti = blockIdx.x, slice = blockIdx.y;
+  const int per = (a.tiles_c + gi.slices - 1) / gi.slices;
+  const int tj0 = slice * per, tj1 = min(a.tiles_c, tj0 + per);
+  const i64 gi0 = (i64)ti * GG_T;
+  for (int tj = tj0; tj < tj1; ++tj) {
+    const i64 gj0 = (i64)tj * GG_T;
+    double w[GG_E];
+#pragma unroll
+    for (int e = 0; e < GG_E; ++e) {
+      const i64 i = gi0 + ty * 2 + (e >> 1), j = gj0 + tx * 2 + (e & 1);
+      w[e] = (i < a.nr && j < a.nc) ? a.Wd[i * a.ldw + j] : 0.0;
+    }
+    double pv[GG_MAXP][GG_E], fp[GG_MAXP][GG_E];
+    gg_values(a, P, gi0, gj0, same_points, Fr_s, Fc_s, tid, ty, tx, pv);
+    gg_adjoints<false>(P, W_s, w, pv, fp, nullptr, lane, wave);
+    for (int nd = 0; nd < P.n_nodes; ++nd) {
+      const GGNode node = P.nodes[nd];
+      if (node.prim < 0 || node.op == GPS_K_WHITE || node.op == GPS_K_CONSTANT) continue;
+      double f4[GG_E], k4[GG_E];
+#pragma unroll
+      for (int e = 0; e < GG_E; ++e) { f4[e] = 0.0; k4[e] = 0.0; }
+#pragma unroll
+      for (int p = 0; p < GG_MAXP; ++p)
+        if (node.prim == p) {
+#pragma unroll
+          for (int e = 0; e < GG_E; ++e) { f4[e] = fp[p][e]; k4[e] = pv[p][e]; }
+        }
+      double Q[GG_E];
+      if (node.op == GPS_K_PERIODIC) {
+        gg_stage(a, node.f0, 2 * node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
+        const double coef = -0.25 / (node.ls0 * node.ls0) * (2.0 * M_PI / node.period);
+#pragma unroll
+        for (int e = 0; e < GG_E; ++e) Q[e] = f4[e] * k4[e] * coef;
+        for (int d = 0; d < node.ndims; ++d) {
+          const double ci0 = Fr_s[(2 * d) * GG_T + ty * 2], si0 = Fr_s[(2 * d + 1) * GG_T + ty * 2];
+          const double ci1 = Fr_s[(2 * d) * GG_T + ty * 2 + 1], si1 = Fr_s[(2 * d + 1) * GG_T + ty * 2 + 1];
+          const double cj0 = Fc_s[(2 * d) * GG_T + tx * 2], sj0 = Fc_s[(2 * d + 1) * GG_T + tx * 2];
+          const double cj1 = Fc_s[(2 * d) * GG_T + tx * 2 + 1], sj1 = Fc_s[(2 * d + 1) * GG_T + tx * 2 + 1];
+          double s0 = Q[0] * (si0 * cj0 - ci0 * sj0) + Q[1] * (si0 * cj1 - ci0 * sj1);
+          double s1 = Q[2] * (si1 * cj0 - ci1 * sj0) + Q[3] * (si1 * cj1 - ci1 * sj1);
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+          if (tx == 0) {
+            const int dim = gi.feats[node.f0 + 2 * d].dim;
+            rowacc[ty * 2][dim] += s0; rowacc[ty * 2 + 1][dim] += s1;
+          }
+        }
+        continue;
+      }
+      gg_stage(a, node.f0, node.ndims, gi0, gj0, Fr_s, Fc_s, tid);
+      double val[GG_E], q4[GG_E];
+      gg_prim(node, Fr_s, Fc_s, ty, tx, gi0, gj0, same_points, val, q4);
+      const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+#pragma unroll
+      for (int e = 0; e < GG_E; ++e) {
+        const double k = k4[e];
+        double dk;
+        if (node.op == GPS_K_RBF) dk = -0.5 * k;
+        else {
+          const double rad = sqrt(q4[e] + 1e-12);
+          if (node.op == GPS_K_MATERN12) dk = -k / (2.0 * rad);
+          else if (node.op == GPS_K_EXPONENTIAL) dk = -k / (4.0 * rad);
+          else if (node.op == GPS_K_MATERN32) dk = -1.5 * node.variance * exp(-sq3 * rad);
+          else dk = -(5.0 / 6.0) * node.variance * (1.0 + sq5 * rad) * exp(-sq5 * rad);
+        }
+        Q[e] = 2.0 * f4[e] * dk;
+      }
+      for (int d = 0; d < node.ndims; ++d) {
+        const double r0 = Fr_s[d * GG_T + ty * 2], r1 = Fr_s[d * GG_T + ty * 2 + 1];
+        const double c0 = Fc_s[d * GG_T + tx * 2], c1 = Fc_s[d * GG_T + tx * 2 + 1];
+        double s0 = Q[0] * (r0 - c0) + Q[1] * (r0 - c1);
+        double s1 = Q[2] * (r1 - c0) + Q[3] * (r1 - c1);
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+        if (tx == 0) {
+          const GGFeat ft = gi.feats[node.f0 + d];
+          rowacc[ty * 2][ft.dim] += s0 / ft.param; rowacc[ty * 2 + 1][ft.dim] += s1 / ft.param;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < GG_T * gi.d_all; s += 256) {
+    const int r = s / gi.d_all, d = s - r * gi.d_all;
+    gi.part[((i64)slice * gi.rows_pad + gi0 + r) * gi.d_all + d] = rowacc[r][d];
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -622,5 +748,55 @@ int gps_kdiag_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 
     }
     if (slot >= 0) grad_slots_host[slot] += kbar * st[0];
   }
+  return GPS_OK;
+}
+
+// grad_X_host [nr, d_all] += factor * sum_j Wd[i][j] d k(xr_i, xc_j) / d xr_i  for a device-resident cotangent Wd [nr, nc];
+// dXc == nullptr: k(xr_i, xr_j) differentiated in its FIRST argument only (for a symmetric Wd the full gradient of
+// sum_ij Wd_ij k(x_i, x_j) with respect to x is twice that).
+int gps_launch_kmat_input_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dXr, i64 nr,
+                              const double* dXc, i64 nc, i64 d_all, const double* Wd, i64 ldw, double factor,
+                              double* grad_X_host) {
+  if (d_all > GPS_MAX_DIMS) return gps_fail(h, GPS_ERR_UNSUPPORTED, "input gradient: more input dimensions than GPS_MAX_DIMS");
+  GGBuilt B;
+  int rc = gg_build(h, prog, n_nodes, d_all, B);
+  if (rc) return rc;
+  const bool same = (dXc == nullptr);
+  if (same) { dXc = dXr; nc = nr; }
+  const i64 nrp = gps_pad(nr), ncp = gps_pad(nc);
+  if (!same) { rc = gg_features(h, B, dXc, nc, d_all, ncp, h->dFeat2); if (rc) return rc; }
+  rc = gg_features(h, B, dXr, nr, d_all, nrp, h->dFeat);            // (last: leaves the feature table in dProg)
+  if (rc) return rc;
+  GGArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Ft = h->dFeat.d(); a.ldf = nrp;
+  a.Ftc = same ? h->dFeat.d() : h->dFeat2.d(); a.ldfc = same ? nrp : ncp;
+  a.n = nr; a.npad = nrp; a.tiles = (int)(nrp / GG_T); a.tiles_c = (int)(ncp / GG_T);
+  a.rect = 1; a.same_points = same ? 1 : 0; a.Wd = Wd; a.ldw = ldw; a.nr = nr; a.nc = nc;
+  const size_t wbytes = B.W.size() * 8;
+  GPS_HIP(h, h->dNkn.ensure(wbytes + 64));
+  GPS_HIP(h, h->ring.upload(h->dNkn.p, B.W.data(), wbytes, h->stream));
+  a.Wnet = (const double*)h->dNkn.p;
+  GIArgs gi;
+  gi.feats = (const GGFeat*)h->dProg.p; gi.d_all = (int)d_all; gi.rows_pad = nrp;
+  int slices = 2048 / a.tiles; if (slices > a.tiles_c) slices = a.tiles_c; if (slices < 1) slices = 1; if (slices > 64) slices = 64;
+  gi.slices = slices;
+  const size_t pbytes = (size_t)slices * nrp * d_all * 8;
+  GPS_HIP(h, h->dTmp2.ensure(pbytes));
+  gi.part = h->dTmp2.d();
+  {
+    LaunchScope ls(h, KC_REDUCE, (double)nrp * ncp * (60.0 + 6.0 * B.feats.size() + 40.0 * B.P.n_layers), 8.0 * (double)nrp * ncp);
+    hipLaunchKernelGGL(gg_input_kernel, dim3((unsigned)a.tiles, (unsigned)slices), dim3(256), 0, h->stream, a, B.P, gi);
+    GPS_HIP(h, hipGetLastError());
+  }
+  std::vector<double> part((size_t)slices * nrp * d_all);
+  GPS_HIP(h, hipMemcpyAsync(part.data(), gi.part, pbytes, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  for (i64 i = 0; i < nr; ++i)
+    for (i64 d = 0; d < d_all; ++d) {
+      double tot = 0.0;
+      for (int q = 0; q < slices; ++q) tot += part[((size_t)q * nrp + i) * d_all + d];
+      grad_X_host[i * d_all + d] += factor * tot;
+    }
   return GPS_OK;
 }

@@ -71,9 +71,11 @@ _SIGNATURES = {
     "gps_svgp_elbo_grad": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _i64, ctypes.c_double,
                            _c_double_p, _i64, _c_double_p, _c_double_p, _i64, _c_double_p, ctypes.c_int, ctypes.c_int,
                            ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_int, _c_int_p, _c_double_p,
-                           _c_double_p, _c_double_p, _c_double_p, _c_int_p],
+                           _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_int_p],
     "gps_kmat_vjp": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
                      _c_double_p, _c_double_p, ctypes.c_int, _c_int_p],
+    "gps_kmat_input_vjp": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
+                           _c_double_p, _c_double_p],
     "gps_gauss_kl": [ctypes.c_void_p, _c_double_p, _i64, _c_double_p, _i64, _c_double_p, ctypes.c_int, _c_double_p,
                      _c_int_p],
     "gps_sgpr": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
@@ -584,9 +586,10 @@ class Handle(object):
             raise NotPositiveDefiniteError("Kuu + jitter*I is not positive definite (leading minor of order %d)" % info.value)
         return elbo.value, kl.value, ve.value
 
-    def svgp_elbo_grad(self, prog, Z, X, yres, q_mu, q_sqrt, jitter, noise_var, white=True, scale=1.0):
+    def svgp_elbo_grad(self, prog, Z, X, yres, q_mu, q_sqrt, jitter, noise_var, white=True, scale=1.0, want_grad_Z=False):
         """(elbo, grad_slots, grad_noise, grad_q_mu [M, K], grad_q_sqrt shaped like q_sqrt, d/d mean(X) [N, K]) -- gradients
-        w.r.t. the constrained values, either parametrisation, Z fixed (gps_svgp_elbo_grad)."""
+        w.r.t. the constrained values, either parametrisation (gps_svgp_elbo_grad); want_grad_Z: a seventh item, the gradient
+        with respect to the inducing inputs [M, D]."""
         Z, X, yres, q_mu = _f64(Z), _f64(X), _f64(yres), _f64(q_mu)
         _need(Z.ndim == 2 and X.ndim == 2 and Z.shape[1] == X.shape[1], "Z [M, D] and X [N, D] must share D")
         m, d = Z.shape
@@ -605,17 +608,39 @@ class Handle(object):
         g_qmu = np.zeros((m, k))
         g_q = np.zeros_like(q)
         g_mean = np.zeros((n, k))
+        g_Z = np.zeros((m, d))
         self.resident_token = None
         self.factor_key = None
         self._check(self._lib.gps_svgp_elbo_grad(self._h, prog, len(prog), _ptr(Z), m, d, float(jitter), _ptr(X), n, _ptr(yres),
                                                  _ptr(q_mu), k, _ptr(q), qnd, 1 if white else 0, float(noise_var), float(scale),
                                                  ctypes.byref(elbo), _ptr(slots), cap, ctypes.byref(nslots), ctypes.byref(gnoise),
-                                                 _ptr(g_qmu), _ptr(g_q), _ptr(g_mean), ctypes.byref(info)), "gps_svgp_elbo_grad")
+                                                 _ptr(g_qmu), _ptr(g_q), _ptr(g_mean), _ptr(g_Z) if want_grad_Z else None,
+                                                 ctypes.byref(info)), "gps_svgp_elbo_grad")
         if info.value > 0:
             raise NotPositiveDefiniteError("Kuu + jitter*I is not positive definite (leading minor of order %d)" % info.value)
         if qnd == 3:
             g_q = np.ascontiguousarray(np.transpose(g_q, (1, 2, 0)))           # [k, m, m] -> [m, m, k]
+        if want_grad_Z:
+            return elbo.value, slots[:nslots.value].copy(), gnoise.value, g_qmu, g_q, g_mean, g_Z
         return elbo.value, slots[:nslots.value].copy(), gnoise.value, g_qmu, g_q, g_mean
+
+    def kmat_input_vjp(self, prog, X, W, X2=None):
+        """d/dX sum_ij W[i, j] k(X_i, X2_j)  [N, D]: reverse mode through kern.K(X, X2) with respect to the points X
+        (X2 None: K(X, X), both arguments move)."""
+        X, W = _f64(X), _f64(W)
+        n, d = X.shape
+        m = n
+        if X2 is not None:
+            X2 = _f64(X2)
+            _need(X2.ndim == 2 and X2.shape[1] == d, "X2 must be [M, %d]" % d)
+            m = X2.shape[0]
+        _need(W.shape == (n, m), "W must be [N, M]")
+        g = np.zeros((n, d))
+        self.resident_token = None
+        self.factor_key = None
+        self._check(self._lib.gps_kmat_input_vjp(self._h, prog, len(prog), _ptr(X), n, _ptr(X2) if X2 is not None else None, m, d,
+                                                 _ptr(W), _ptr(g)), "gps_kmat_input_vjp")
+        return g
 
     def kmat_vjp(self, prog, X, W, X2=None):
         """sum_ij W[i, j] d k(X_i, X2_j) / d(kernel parameter slot): reverse mode through kern.K(X, X2)."""

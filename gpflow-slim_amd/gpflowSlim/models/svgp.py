@@ -20,7 +20,7 @@ from .model import GPModel
 
 class SVGP(GPModel):
     def __init__(self, X, Y, kern, likelihood, feat=None, mean_function=None, num_latent=None, q_diag=False,
-                 whiten=True, minibatch_size=None, Z=None, num_data=None, **kwargs):
+                 whiten=True, minibatch_size=None, Z=None, num_data=None, train_inducing=False, **kwargs):
         X = np.ascontiguousarray(X, dtype=settings.float_type)
         Y = np.ascontiguousarray(Y, dtype=settings.float_type)
         GPModel.__init__(self, X, Y, kern, likelihood, mean_function, **kwargs)
@@ -39,6 +39,12 @@ class SVGP(GPModel):
             self._q_sqrt = Parameter(q_sqrt, transform=transforms.LowerTriangular(num_inducing, self.num_latent),
                                      name='q_sqrt')
         self._parameters = self._parameters + [self._q_mu, self._q_sqrt]
+        # The reference keeps Z (a Parameter of the feature, features.py:65) out of `model.parameters`, but its example
+        # minimises the objective over every TF variable (examples/svgp.py:161), Z included.  train_inducing=True puts Z
+        # into `parameters`, so that `optimize()` moves it too.
+        self.train_inducing = bool(train_inducing)
+        if self.train_inducing and getattr(self.feature, "_Z", None) is not None:
+            self._parameters = self._parameters + [self.feature._Z]
 
     @property
     def q_mu(self):
@@ -75,7 +81,7 @@ class SVGP(GPModel):
     def compute_log_likelihood_and_gradients(self):
         """The bound and d bound / d(unconstrained parameter) for every parameter of the model -- what
         `tf.gradients(objective, variables)` yields in the reference (examples/svgp.py:159-161) up to the sign of
-        `objective`.  Gaussian likelihood, whitened or not; the inducing inputs are held fixed (zero gradient).
+        `objective`.  Gaussian likelihood, whitened or not; the inducing inputs move only with train_inducing=True.
         Returns (bound, [(Parameter, gradient array shaped like Parameter.unconstrained_tensor), ...])."""
         if type(self.likelihood) is not likelihoods.Gaussian:
             raise NotImplementedError("analytic gradients of the SVGP bound need the Gaussian likelihood")
@@ -84,9 +90,13 @@ class SVGP(GPModel):
         layout = self.kern._grad_layout(d_all)
         scale = float(self.num_data) / float(self.X.shape[0])
         yres = np.ascontiguousarray(np.broadcast_to(self.Y - self.mean_function(self.X), self.Y.shape))
-        elbo, slots, gnoise, g_qmu, g_qsqrt, g_mean = be.get_handle().svgp_elbo_grad(
+        zparam = getattr(self.feature, "_Z", None)
+        want_z = zparam is not None and any(p is zparam for p in self.parameters)
+        res = be.get_handle().svgp_elbo_grad(
             prog, self.feature.Z, self.X, yres, self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
-            float(np.squeeze(self.likelihood.variance)), white=self.whiten, scale=scale)
+            float(np.squeeze(self.likelihood.variance)), white=self.whiten, scale=scale, want_grad_Z=want_z)
+        elbo, slots, gnoise, g_qmu, g_qsqrt, g_mean = res[:6]
+        g_Z = res[6] if want_z else None
         if len(layout) != len(slots):
             raise RuntimeError("gradient slot layout mismatch: %d vs %d" % (len(layout), len(slots)))
         grads = {id(p): np.zeros_like(np.atleast_1d(p.vf_val), dtype=settings.float_type) for p in self.parameters}
@@ -121,8 +131,8 @@ class SVGP(GPModel):
                     n_ind = g_qsqrt.shape[0]
                     rows, cols = np.tril_indices(n_ind, 0)
                     out.append((p, np.stack([g_qsqrt[rows, cols, q] for q in range(g_qsqrt.shape[2])]).reshape(p.vf_val.shape)))
-            elif p is getattr(self.feature, "_Z", None):
-                out.append((p, np.zeros_like(p.vf_val)))                       # inducing inputs: fixed
+            elif p is zparam:
+                out.append((p, (g_Z * np.atleast_1d(p.transform.forward_grad(p.vf_val))).reshape(p.vf_val.shape)))
             else:
                 g = grads[id(p)].reshape(np.atleast_1d(p.vf_val).shape) * np.atleast_1d(p.transform.forward_grad(p.vf_val))
                 out.append((p, g.reshape(p.vf_val.shape)))

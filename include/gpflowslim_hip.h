@@ -200,7 +200,9 @@ int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
  * with the inducing inputs Z held fixed:
  *   grad_slots   d/d kernel parameters, slot layout of gps_gpr_lml_grad;  grad_noise  d/d noise_var;
  *   grad_q_mu    host [m, k];  grad_q_sqrt  host, layout of q_sqrt ([m, k], or [k, m, m] with zeros above the diagonals);
- *   grad_mean    (optional) host [n, k] = d/d mean_function(X)  (chain rule for mean-function parameters).
+ *   grad_mean    (optional) host [n, k] = d/d mean_function(X)  (chain rule for mean-function parameters);
+ *   grad_Z       (optional) host [m, d_all] = d/d inducing inputs (features.py:65 makes Z a Parameter and
+ *                examples/svgp.py:161 minimises over every variable of the graph, Z included).
  * All with respect to the CONSTRAINED values.                                                                    */
 int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                        const double* Z, int64_t m, int64_t d_all, double jitter,
@@ -208,7 +210,7 @@ int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                        const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim,
                        int white, double noise_var, double scale,
                        double* elbo, double* grad_slots, int n_slots_cap, int* n_slots_out, double* grad_noise,
-                       double* grad_q_mu, double* grad_q_sqrt, double* grad_mean, int* info);
+                       double* grad_q_mu, double* grad_q_sqrt, double* grad_mean, double* grad_Z, int* info);
 
 /* Vector-Jacobian product of the kernel-matrix build -- reverse-mode autodiff through kern.K(X, X2) (kernels.py:408-439,
  * 1071-1084; neural_kernel_network.py:41-47):  grad_slots[s] = sum_ij W[i][j] d k(X_i, X2_j) / d theta_s  for a
@@ -217,6 +219,11 @@ int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
 int gps_kmat_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X, int64_t n,
                  const double* X2, int64_t m, int64_t d_all, const double* W, double* grad_slots,
                  int n_slots_cap, int* n_slots_out);
+/* The same contraction differentiated in the POINTS: grad_X host [n, d_all] = d/dX sum_ij W[i][j] k(X_i, X2_j)
+ * (X2 == NULL: K(X, X), both arguments move).  Reverse mode through kern.K with respect to its first argument --
+ * what a trainable InducingPoints.Z receives (features.py:65, 74-81).                                             */
+int gps_kmat_input_vjp(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* X, int64_t n,
+                       const double* X2, int64_t m, int64_t d_all, const double* W, double* grad_X);
 
 /* gauss_kl(q_mu, q_sqrt, K) (kullback_leiblers.py:26-105): KL[N(q_mu, q_sqrt q_sqrt^T) || N(0, K)], summed over
  * the k independent columns; K host [m, m] or NULL (p = N(0, I)).  tf.cholesky(K) (:51), alpha = Lp^-1 q_mu (:52),

@@ -493,3 +493,104 @@ def test_kernel_matrix_vjp(handle, n, m_):
         flat = np.array(flat)
         assert flat.shape == ref.shape, (kind, flat.shape, ref.shape)
         assert np.abs(flat - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (kind, flat, ref)
+
+
+@pytest.mark.parametrize("n,m_", [(40, 300), (130, None), (257, 70)])
+def test_kernel_matrix_input_vjp(handle, n, m_):
+    """gps_kmat_input_vjp: d/dX sum_ij W_ij k(X_i, X2_j) -- reverse mode through kern.K with respect to its POINTS (what a
+    trainable InducingPoints.Z receives) -- against central differences of the oracle's K, entry by entry of X; rectangular
+    and square (both arguments move), Matern / RBF / Periodic / White / Constant in sums and products, and an NKN."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + 5)
+    d = 3
+    for kind in ("rbf_ard", "rbf_times_periodic_plus_white", "m52_plus_periodic", "m32_ard", "m12_iso"):
+        kern, theta, fn, _ = _cases(gpf, d)[kind]()
+        X = rng.standard_normal((n, d)); X2 = None if m_ is None else rng.standard_normal((m_, d))
+        W = rng.standard_normal((n, m_ or n))
+        got = handle.kmat_input_vjp(kern._program(d), X, W, X2)
+        assert got.shape == (n, d)
+        spec = fn(theta)
+        saved, orc.SQUARE_DIST_MODE = orc.SQUARE_DIST_MODE, "diff"
+        try:
+            worst = 0.0
+            for i in rng.choice(n, 6, replace=False):
+                for k in range(d):
+                    hh = 1e-6
+                    Xp, Xm = X.copy(), X.copy(); Xp[i, k] += hh; Xm[i, k] -= hh
+                    if X2 is None:
+                        fd = np.sum(W * (orc.K(spec, Xp) - orc.K(spec, Xm))) / (2 * hh)
+                    else:
+                        fd = np.sum(W * (orc.K(spec, Xp, X2) - orc.K(spec, Xm, X2))) / (2 * hh)
+                    worst = max(worst, abs(got[i, k] - fd) / max(1.0, abs(fd)))
+            # (Matern-1/2 has a kink at r = 0: the diagonal of K(X, X) contributes nothing in the product, one-sided slopes in
+            # a central difference cancel as well)
+            assert worst <= 5e-6, (kind, worst)
+        finally:
+            orc.SQUARE_DIST_MODE = saved
+
+
+@pytest.mark.parametrize("whiten,q_diag", [(True, False), (False, False), (True, True)])
+def test_svgp_inducing_input_gradient_and_training(handle, whiten, q_diag):
+    """train_inducing=True: Z is among the parameters (as every TF variable is for examples/svgp.py:161); its gradient
+    against central differences of the oracle's bound in single entries of Z, and optimize() moves Z and ends higher than
+    with Z fixed."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(17)
+    n, d, m_, k = 240, 2, 24, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, k)) * 1.5) + 0.1 * rng.standard_normal((n, k))
+    Z = X[:m_].copy() + 0.05 * rng.standard_normal((m_, d))
+    ls = np.array([0.9, 1.4])
+    kern = gpf.kernels.Matern52(d, variance=1.3, lengthscales=ls, ARD=True)
+    spec = {"type": "matern52", "variance": c(1.3), "lengthscales": c(ls), "input_dim": d}
+    m = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.2), Z=Z, q_diag=q_diag, whiten=whiten, num_data=2 * n,
+                        train_inducing=True)
+    q_mu = rng.standard_normal((m_, k)) * 0.3
+    m._q_mu.assign(q_mu)
+    if q_diag:
+        m._q_sqrt.assign(np.abs(rng.standard_normal((m_, k))) * 0.4 + 0.2)
+    else:
+        m._q_sqrt.assign(np.tril(rng.standard_normal((k, m_, m_)) * (0.5 / m_) + np.eye(m_) * 0.5).transpose(1, 2, 0).copy())
+    q_sqrt = np.asarray(m.q_sqrt).copy()
+    noise = c(0.2)
+    assert any(p is m.feature._Z for p in m.parameters)
+    bound, grads = m.compute_log_likelihood_and_gradients()
+    gz = {id(p): g for p, g in grads}[id(m.feature._Z)]
+    assert gz.shape == Z.shape
+    for _ in range(8):
+        a, b = int(rng.integers(m_)), int(rng.integers(d))
+        hh = 1e-6
+        Zp, Zm = Z.copy(), Z.copy(); Zp[a, b] += hh; Zm[a, b] -= hh
+        fp = orc.svgp_elbo(spec, X, Y, Zp, q_mu, q_sqrt, noise, whiten=whiten, num_data=2 * n)
+        fm = orc.svgp_elbo(spec, X, Y, Zm, q_mu, q_sqrt, noise, whiten=whiten, num_data=2 * n)
+        fd = (fp - fm) / (2 * hh)
+        assert abs(gz[a, b] - fd) <= 2e-5 * max(1.0, abs(fd)), (a, b, gz[a, b], fd)
+    # training: with Z free the bound ends at least as high as with Z fixed, and Z has moved
+    fixed = gpf.models.SVGP(X, Y, gpf.kernels.Matern52(d, variance=1.3, lengthscales=ls, ARD=True), gpf.likelihoods.Gaussian(0.2),
+                            Z=Z, q_diag=q_diag, whiten=whiten, num_data=2 * n)
+    f_fixed = fixed.optimize(max_iter=60)
+    f_free = m.optimize(max_iter=60)
+    assert np.abs(np.asarray(m.feature.Z) - Z).max() > 1e-3
+    assert f_free <= f_fixed + 1e-6 * abs(f_fixed)
+
+
+@pytest.mark.parametrize("act", [False, True])
+def test_kernel_matrix_input_vjp_through_a_neural_kernel_network(handle, act):
+    """The same input gradient through a Neural Kernel Network (the per-entry reverse pass through Linear / Product / exp
+    layers yields the adjoints of the primitive values; the chain into the points is the primitives' own)."""
+    import gpflowSlim as gpf
+    d, n = 3, 90
+    m, spec, X, _ = _nkn_model(gpf, d, act, n, 12)
+    rng = np.random.default_rng(3)
+    X2 = rng.standard_normal((55, d))
+    W = rng.standard_normal((n, 55))
+    got = handle.kmat_input_vjp(m.kern._program(d), X, W, X2)
+    saved, orc.SQUARE_DIST_MODE = orc.SQUARE_DIST_MODE, "diff"
+    try:
+        for i in rng.choice(n, 5, replace=False):
+            for k in range(d):
+                hh = 1e-6
+                Xp, Xm = X.copy(), X.copy(); Xp[i, k] += hh; Xm[i, k] -= hh
+                fd = np.sum(W * (orc.K(spec, Xp, X2) - orc.K(spec, Xm, X2))) / (2 * hh)
+                assert abs(got[i, k] - fd) <= 5e-6 * max(1.0, abs(fd)), (i, k, got[i, k], fd)
+    finally:
+        orc.SQUARE_DIST_MODE = saved

@@ -75,6 +75,12 @@ else:
         ms, (b2, grads) = best(sv.compute_log_likelihood_and_gradients, 2)
         out["svgp_elbo_plus_gradient_ms"] = round(ms, 1)
         out["svgp_grad_norms"] = {p.name: float(np.abs(g).max()) for p, g in grads}
+        svz = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.1), Z=Z, whiten=True, train_inducing=True)
+        svz._q_mu.assign(q_mu); svz._q_sqrt.assign(q_sqrt)
+        svz.compute_log_likelihood_and_gradients()
+        ms, (b3, gz) = best(svz.compute_log_likelihood_and_gradients, 2)
+        out["svgp_elbo_plus_gradient_incl_inducing_inputs_ms"] = round(ms, 1)
+        out["svgp_grad_Z_max"] = float(np.abs({id(p): g for p, g in gz}[id(svz.feature._Z)]).max())
     idx = rng.choice(N, 200, replace=False)
     spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(np.sqrt(d) * np.ones(d)), "input_dim": d}
     rmu, rvar = orc.conditional(X[idx], Z, spec, f, white=False)
