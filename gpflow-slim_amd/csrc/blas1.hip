@@ -565,6 +565,68 @@ int gps_launch_svgp_abar(gps_handle_t h, const double* Bt, i64 ld, i64 rows, i64
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
+// A <- alpha A + beta I on the leading [n_real, n_real] block of an [n, n] matrix, zero elsewhere
+__global__ __launch_bounds__(256) void axpby_eye_kernel(double* __restrict__ A, i64 ld, i64 n, i64 n_real, double alpha, double beta) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  for (i64 rr = blockIdx.y; rr < n; rr += gridDim.y)
+    A[rr * ld + c] = (rr < n_real && c < n_real) ? alpha * A[rr * ld + c] + (rr == c ? beta : 0.0) : 0.0;
+}
+// A[i][i] += coef / L[i][i], i < n
+__global__ __launch_bounds__(256) void diag_recip_add_kernel(double* __restrict__ A, i64 lda, const double* __restrict__ L, i64 ldl,
+                                                             i64 n, double coef) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * lda + i] += coef / L[i * ldl + i];
+}
+// part[2 b] = sum over the rows i = b (mod 64) of sum_{j <= i} A[i][j] B[i][j] ; part[2 b + 1] = their share of trace(A)
+__global__ __launch_bounds__(256) void tri_dot_kernel(const double* __restrict__ A, i64 lda, const double* __restrict__ B, i64 ldb,
+                                                      i64 n, double* __restrict__ part) {
+  __shared__ double red[2][4];
+  double s = 0.0, t = 0.0;
+  for (i64 i = blockIdx.x; i < n; i += gridDim.x) {
+    for (i64 j = threadIdx.x; j <= i; j += 256) s = fma(A[i * lda + j], B[i * ldb + j], s);
+    if (threadIdx.x == 0) t += A[i * lda + i];
+  }
+  s = wave_sum(s); t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+int gps_launch_axpby_eye(gps_handle_t h, double* A, i64 ld, i64 n, i64 n_real, double alpha, double beta) {
+  if (n <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n < 32768 ? n : 32768));
+  hipLaunchKernelGGL(axpby_eye_kernel, grid, dim3(256), 0, h->stream, A, ld, n, n_real, alpha, beta);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+int gps_launch_diag_recip_add(gps_handle_t h, double* A, i64 lda, const double* L, i64 ldl, i64 n, double coef) {
+  if (n <= 0) return GPS_OK;
+  hipLaunchKernelGGL(diag_recip_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A, lda, L, ldl, n, coef);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+// out2[0] = sum_{j <= i < n} A[i][j] B[i][j], out2[1] = trace(A)   (host values; synchronises the stream)
+int gps_tri_dot(gps_handle_t h, const double* A, i64 lda, const double* B, i64 ldb, i64 n, double* out2) {
+  out2[0] = out2[1] = 0.0;
+  if (n <= 0) return GPS_OK;
+  double* part = h->dScal.d();
+  {
+    LaunchScope ls(h, KC_REDUCE, (double)n * n, 8.0 * n * n);
+    hipLaunchKernelGGL(tri_dot_kernel, dim3(64), dim3(256), 0, h->stream, A, lda, B, ldb, n, part);
+    GPS_HIP(h, hipGetLastError());
+  }
+  double hp[128];
+  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  for (int b = 0; b < 64; ++b) { out2[0] += hp[2 * b]; out2[1] += hp[2 * b + 1]; }
+  return GPS_OK;
+}
+
 int gps_launch_tri_map(gps_handle_t h, double* A, i64 ld, i64 n, int mode) {
   if (n <= 0) return GPS_OK;
   LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);

@@ -1369,6 +1369,23 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
   });
 }
 
+// Cholesky adjoint on the device (Murray 2016, eq. 10):  for L = chol(K) and a lower-triangular cotangent Lbar, the symmetric
+// Kbar with <Kbar, dK> = <Lbar, dL> is  L^-T (Phi(P) + Phi(P)^T) L^-1 / 2,  P = L^T Lbar, Phi = lower triangle with halved
+// diagonal.  U = L^T (upper, row-major; `bl` carries L's block inverses).  out <- 2 Kbar (the callers fold the 1/2); P: scratch.
+static int chol_adjoint2(gps_handle_t h, Blocked<HipOps>& bl, const double* U, const double* Lbar, double* out, double* P, i64 mp) {
+  int rc = gps_launch_transpose(h, Lbar, mp, mp, mp, out, mp);
+  if (rc) return rc;
+  rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, U, mp, out, mp, P, mp);                 // P[i][j] = sum_k L[k][i] Lbar[k][j]
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, P, mp, mp, 0);               // Phi(P) + Phi(P)^T = the lower triangle of P mirrored
+  if (rc) return rc;
+  rc = bl.trsm_rn_rec(U, mp, mp, 0, P, mp, mp);                                        // Y = Psym L^-1
+  if (rc) return rc;
+  rc = gps_launch_transpose(h, P, mp, mp, mp, out, mp);                                // Y^T
+  if (rc) return rc;
+  return bl.trsm_rn_rec(U, mp, mp, 0, out, mp, mp);                                    // Y^T L^-1 = (L^-T Y)^T  (symmetric)
+}
+
 // ---- gradient of the SVGP bound (whitened parametrisation, Gaussian likelihood) ------------------------------------------
 // What TF autodiff gives the reference's optimiser for models/svgp.py:108-125 (examples/svgp.py:159-161 minimises
 // `objective`): reverse mode at the matrix level, every O(M^2 N) product on the fp64 MFMA and resident in HBM.
@@ -1650,22 +1667,11 @@ extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, i
   }
   rc = gps_launch_tri_map(h, LmBar, mp, mp, 1);
   if (rc) return rc;
-  // Cholesky adjoint: P = Lm^T Lm_bar ; Kuu_bar = Lm^-T (Phi(P) + Phi(P)^T) Lm^-1 / 2
+  // Cholesky adjoint: Kuu_bar = Lm^-T (Phi(P) + Phi(P)^T) Lm^-1 / 2, P = Lm^T Lm_bar   (chol_adjoint2 leaves twice that)
   GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
   GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
   double* LmBarT = h->dG1.d();
-  double* P = h->dG2.d();
-  rc = gps_launch_transpose(h, LmBar, mp, mp, mp, LmBarT, mp);
-  if (rc) return rc;
-  rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, U, mp, LmBarT, mp, P, mp);               // P[i][j] = sum_k Lm[k][i] Lm_bar[k][j]
-  if (rc) return rc;
-  rc = gps_launch_tri_map(h, P, mp, mp, 0);               // Phi(P) + Phi(P)^T = the lower triangle of P mirrored (the 1/2 follows below)
-  if (rc) return rc;
-  rc = bl.trsm_rn_rec(U, mp, mp, 0, P, mp, mp);                                        // Y = Psym Lm^-1
-  if (rc) return rc;
-  rc = gps_launch_transpose(h, P, mp, mp, mp, LmBarT, mp);                             // Y^T
-  if (rc) return rc;
-  rc = bl.trsm_rn_rec(U, mp, mp, 0, LmBarT, mp, mp);                                   // Y^T Lm^-1 = (Lm^-T Y)^T = Kuu_bar (symmetric)
+  rc = chol_adjoint2(h, bl, U, LmBar, LmBarT, h->dG2.d(), mp);
   if (rc) return rc;
   // contractions with the kernel derivatives
   for (int sI = 0; sI < ns; ++sI) grad_slots[sI] = 0.0;
@@ -2289,6 +2295,165 @@ extern "C" int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   return sparse_gpr_impl(h, 1, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, Xnew, n_new, full_cov,
                          bound_out, mean_out, var_out, info);
   });
+}
+
+// ---- gradient of the SGPR bound ----------------------------------------------------------------------------------
+// What TF autodiff through models/sgpr.py:121-153 supplies to the reference's optimiser (SGPR keeps Z among its parameters,
+// sgpr.py:118).  Reverse mode at the matrix level over what gps_sgpr leaves on the device, s = noise variance, R outputs:
+//   forward   L = chol(Kuu + jitter I), A = L^-1 Kuf, G = A A^T, B = I + G / s, LB = chol(B), v = A err, u = LB^-1 v, c = u / s
+//             F = const - R sum log diag LB - N R / 2 log s - |err|^2 / (2 s) + |c|^2 / 2 - R sum Kdiag / (2 s) + R tr(G) / (2 s)
+//   ubar = u / s^2 ; vbar = LB^-T ubar ; LB_bar = -tril(vbar u^T + R diag(1 / LB_ii)) ; B_bar = adjoint(LB, LB_bar)
+//   G_bar = B_bar / s + R / (2 s) I ; A_bar = 2 G_bar A + vbar err^T ; Kuf_bar = L^-T A_bar ; L_bar = -tril(Kuf_bar A^T)
+//   Kuu_bar = adjoint(L, L_bar) ; d/d theta = <Kuf_bar, dKuf> + <Kuu_bar, dKuu> - R N / (2 s) dKdiag   (kernel-matrix VJPs)
+//   d/d s = -|u|^2 / s^3 - <B_bar, G> / s^2 - R tr(G) / (2 s^2) - N R / (2 s) + |err|^2 / (2 s^2) + R N Kdiag / (2 s^2),
+//           <B_bar, G> = s (<LB_bar, LB> / 2 - tr B_bar)     (B = LB LB^T scales like LB^2; no second copy of G is kept)
+//   d/d mean(X) = err / s - A^T vbar ; d/d Z through k(Z, X) and k(Z, Z) (gps_launch_kmat_input_vjp).
+extern "C" int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  if (!h || !bound || !grad_slots || !grad_noise) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr_grad: bad argument");
+  if (r > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_sgpr_grad: at most 128 outputs");
+  int ns = 0;
+  int rc = gps_grad_general_slots(h, prog, n_nodes, &ns);
+  if (rc) return rc;
+  if (n_slots_out) *n_slots_out = ns;
+  if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr_grad: grad_slots too small");
+  int linfo = 0;
+  rc = gps_sgpr(h, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, nullptr, 0, 0, bound, nullptr, nullptr, &linfo);
+  if (info) *info = linfo;
+  if (rc || linfo) return rc;
+  // on the device: dK = L, dLinv ; dS1 = A^T [np, mp] ; dS2 = A [mp, np] ; dS3 = LB, dS4 its block inverses ;
+  // dAlpha = err^T [r][np], then u^T [r][mp] ; dX = Z ; dXnew = X
+  const i64 mp = gps_pad(m), np = gps_pad(n);
+  const double s = noise_var, R = (double)r, N = (double)n;
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  HipOps opsL{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, (int*)h->dInfo.p};
+  HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, (int*)h->dInfo.p};
+  Blocked<HipOps> blL(opsL), blB(opsB);
+  double* L = h->dK.d(); double* At = h->dS1.d(); double* A = h->dS2.d(); double* LB = h->dS3.d();
+  double* dErrT = h->dAlpha.d(); double* dUT = dErrT + (size_t)r * np;
+  const double kdiag = h->sparse_terms[3], trG = h->sparse_terms[1];
+  // u, then vbar^T = (LB^-T u / s^2)^T as rows
+  std::vector<double> hu((size_t)r * mp), hv((size_t)r * mp);
+  GPS_HIP(h, hipMemcpyAsync(hu.data(), dUT, hu.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  double u2 = 0.0;
+  for (size_t i = 0; i < hu.size(); ++i) { u2 += hu[i] * hu[i]; hv[i] = hu[i] / (s * s); }
+  GPS_HIP(h, h->dG3.ensure((size_t)(GPS_TILE + r) * mp * 8));
+  double* dVT = h->dG3.d();                                       // [r][mp]
+  GPS_HIP(h, hipMemcpyAsync(dVT, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, h->stream));
+  rc = blB.trsv_t_rec(LB, mp, mp, 0, dVT, mp, r);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(hv.data(), dVT, hv.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  // LB_bar = -tril(vbar u^T + R diag(1 / LB_ii))
+  GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp3.ensure((size_t)2 * mp * GPS_TILE * 8));
+  std::vector<double> va((size_t)mp * GPS_TILE, 0.0), ub((size_t)mp * GPS_TILE, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < r; ++q) { va[(size_t)j * GPS_TILE + q] = hv[(size_t)q * mp + j]; ub[(size_t)j * GPS_TILE + q] = hu[(size_t)q * mp + j]; }
+  double* dVa = h->dTmp3.d(); double* dUb = dVa + (size_t)mp * GPS_TILE;
+  GPS_HIP(h, hipMemcpyAsync(dVa, va.data(), va.size() * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(dUb, ub.data(), ub.size() * 8, hipMemcpyHostToDevice, h->stream));
+  double* LBbar = h->dG1.d();
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, GPS_TILE, dVa, GPS_TILE, dUb, GPS_TILE, LBbar, mp);
+  if (rc) return rc;
+  rc = gps_launch_diag_recip_add(h, LBbar, mp, LB, mp, m, R);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, LBbar, mp, mp, 1);
+  if (rc) return rc;
+  double dots[2];
+  rc = gps_tri_dot(h, LBbar, mp, LB, mp, m, dots);                 // <LB_bar, LB> over the lower triangle
+  if (rc) return rc;
+  const double lbar_dot_lb = dots[0];
+  // B_bar: U_B = LB^T, adjoint
+  double* U = h->dTmp.d();
+  rc = gps_launch_transpose(h, LB, mp, mp, mp, U, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, U, mp, mp, 3);
+  if (rc) return rc;
+  double* B2 = h->dG2.d();                                        // 2 B_bar
+  rc = chol_adjoint2(h, blB, U, LBbar, B2, h->dTmp2.d(), mp);
+  if (rc) return rc;
+  rc = gps_tri_dot(h, B2, mp, B2, mp, m, dots);
+  if (rc) return rc;
+  const double trBbar = 0.5 * dots[1];
+  const double Bbar_dot_G = s * (0.5 * lbar_dot_lb - trBbar);
+  *grad_noise = -u2 / (s * s * s) - Bbar_dot_G / (s * s) - 0.5 * R * trG / (s * s) - 0.5 * N * R / s + 0.5 * R * N * kdiag / (s * s);
+  {
+    double serr2 = 0.0;
+    for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
+    *grad_noise += 0.5 * serr2 / (s * s);
+  }
+  // 2 G_bar = (2 B_bar) / s + (R / s) I
+  rc = gps_launch_axpby_eye(h, B2, mp, mp, m, 1.0 / s, R / s);
+  if (rc) return rc;
+  // A_bar^T [np, mp] = err vbar^T + A^T (2 G_bar)
+  GPS_HIP(h, h->dY.ensure((size_t)np * mp * 8));
+  double* AbarT = h->dY.d();
+  std::vector<double> zero((size_t)mp, 0.0), vmk((size_t)mp * r, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < r; ++q) vmk[(size_t)j * r + q] = hv[(size_t)q * mp + j];
+  GPS_HIP(h, h->dG4.ensure((size_t)(mp + mp * r) * 8));
+  double* dZero = h->dG4.d(); double* dVmk = dZero + mp;
+  GPS_HIP(h, hipMemcpyAsync(dZero, zero.data(), (size_t)mp * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(dVmk, vmk.data(), vmk.size() * 8, hipMemcpyHostToDevice, h->stream));
+  rc = gps_launch_svgp_abar(h, At, mp, np, mp, dZero, dErrT, np, dVmk, r, AbarT);
+  if (rc) return rc;
+  rc = gps_launch_gemm_nt(h, 2, 0, np, mp, mp, At, mp, B2, mp, AbarT, mp);
+  if (rc) return rc;
+  if (grad_mean) {                                                // err / s - A^T vbar   [n, r]
+    GPS_HIP(h, h->dMean.ensure((size_t)(n * r + n) * 8));
+    rc = gps_launch_rowdot(h, At, mp, n, mp, dVT, mp, r, h->dMean.d(), h->dMean.d() + (size_t)n * r);
+    if (rc) return rc;
+    std::vector<double> av((size_t)n * r);
+    GPS_HIP(h, hipMemcpyAsync(av.data(), h->dMean.p, av.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    for (i64 i = 0; i < n * r; ++i) grad_mean[i] = resid[i] / s - av[i];
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));                    // (host vectors above are read by the copies)
+  // Kuf_bar^T = A_bar^T L^-1 ; Kuf_bar [mp, np]
+  rc = gps_launch_transpose(h, L, mp, mp, mp, U, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, U, mp, mp, 3);
+  if (rc) return rc;
+  rc = blL.trsm_rn_rec(U, mp, mp, 0, AbarT, mp, np);
+  if (rc) return rc;
+  GPS_HIP(h, h->dB.ensure((size_t)mp * np * 8));
+  double* KufBar = h->dB.d();
+  rc = gps_launch_transpose(h, AbarT, mp, np, mp, KufBar, np);
+  if (rc) return rc;
+  // L_bar = -tril(Kuf_bar A^T) ; Kuu_bar
+  double* Lbar = h->dG1.d();
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, KufBar, np, A, np, Lbar, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, Lbar, mp, mp, 1);
+  if (rc) return rc;
+  double* K2 = h->dG2.d();                                        // 2 Kuu_bar
+  rc = chol_adjoint2(h, blL, U, Lbar, K2, h->dTmp2.d(), mp);
+  if (rc) return rc;
+  for (int sI = 0; sI < ns; ++sI) grad_slots[sI] = 0.0;
+  rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 0, grad_slots);
+  if (rc) return rc;
+  {
+    std::vector<double> uu((size_t)ns, 0.0);
+    rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 0, uu.data());
+    if (rc) return rc;
+    for (int sI = 0; sI < ns; ++sI) grad_slots[sI] += 0.5 * uu[sI];
+  }
+  rc = gps_kdiag_vjp(h, prog, n_nodes, d_all, -0.5 * R * N / s, grad_slots);
+  if (rc) return rc;
+  if (grad_Z) {
+    for (i64 i = 0; i < m * d_all; ++i) grad_Z[i] = 0.0;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 1.0, grad_Z);
+    if (rc) return rc;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 1.0, grad_Z);
+    if (rc) return rc;
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
 }
 
 extern "C" int gps_sparse_last_terms(gps_handle_t h, double* out5) {

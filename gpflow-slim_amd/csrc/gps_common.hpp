@@ -304,6 +304,9 @@ int gps_launch_svgp_et(gps_handle_t h, const double* yres, const double* fmean, 
 int gps_launch_svgp_abar(gps_handle_t h, const double* Bt, i64 ld, i64 rows, i64 cols, const double* coef, const double* Et, i64 lde,
                          const double* qmu, i64 k, double* Abar);
 int gps_launch_tri_map(gps_handle_t h, double* A, i64 ld, i64 n, int mode);
+int gps_launch_axpby_eye(gps_handle_t h, double* A, i64 ld, i64 n, i64 n_real, double alpha, double beta);
+int gps_launch_diag_recip_add(gps_handle_t h, double* A, i64 lda, const double* L, i64 ldl, i64 n, double coef);
+int gps_tri_dot(gps_handle_t h, const double* A, i64 lda, const double* B, i64 ldb, i64 n, double* out2);
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64);

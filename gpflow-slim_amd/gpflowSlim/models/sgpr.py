@@ -64,6 +64,51 @@ class SGPR(GPModel, SGPRUpperMixin):
         bound, _, _ = self._call()
         return bound
 
+    def compute_log_likelihood_and_gradients(self):
+        """The collapsed bound and d bound / d(unconstrained parameter) for every parameter of the model (kernel, noise,
+        mean function, inducing inputs -- SGPR keeps Z among its parameters, models/sgpr.py:118): what TF autodiff through
+        models/sgpr.py:121-153 yields.  Returns (bound, [(Parameter, gradient shaped like its unconstrained value), ...])."""
+        d_all = self.X.shape[1]
+        prog = self.kern._program(d_all)
+        layout = self.kern._grad_layout(d_all)
+        err = np.ascontiguousarray(self.Y - self.mean_function(self.X))
+        zparam = getattr(self.feature, "_Z", None)
+        want_z = zparam is not None and any(p is zparam for p in self.parameters)
+        bound, slots, gnoise, g_mean, g_Z = be.get_handle().sgpr_grad(
+            prog, self.feature.Z, self.X, err, settings.numerics.jitter_level, float(np.squeeze(self.likelihood.variance)),
+            want_grad_Z=want_z)
+        if len(layout) != len(slots):
+            raise RuntimeError("gradient slot layout mismatch: %d vs %d" % (len(layout), len(slots)))
+        grads = {id(p): np.zeros_like(np.atleast_1d(p.vf_val), dtype=settings.float_type) for p in self.parameters}
+        for (param, idx), g in zip(layout, slots):
+            if param is None:
+                continue
+            if idx is None:
+                grads[id(param)] += g
+            else:
+                grads[id(param)].reshape(-1)[idx] += g
+        grads[id(self.likelihood._variance)] += gnoise
+        from ..mean_functions import Constant as _MConst, Linear as _MLin
+        mf = self.mean_function
+
+        def _fit(g, like):
+            like = np.atleast_1d(like)
+            return g.reshape(like.shape) if g.size == like.size else np.full(like.shape, np.sum(g))
+
+        if isinstance(mf, _MConst):
+            grads[id(mf.c)] = grads[id(mf.c)] + _fit(np.sum(g_mean, axis=0), mf.c.vf_val)
+        elif isinstance(mf, _MLin):
+            grads[id(mf.A)] = grads[id(mf.A)] + _fit(self.X.T @ g_mean, mf.A.vf_val)
+            grads[id(mf.b)] = grads[id(mf.b)] + _fit(np.sum(g_mean, axis=0), mf.b.vf_val)
+        out = []
+        for p in self.parameters:
+            if p is zparam:
+                out.append((p, (g_Z * np.atleast_1d(p.transform.forward_grad(p.vf_val))).reshape(p.vf_val.shape)))
+            else:
+                g = grads[id(p)].reshape(np.atleast_1d(p.vf_val).shape) * np.atleast_1d(p.transform.forward_grad(p.vf_val))
+                out.append((p, g.reshape(p.vf_val.shape)))
+        return bound, out
+
     def _build_predict(self, Xnew, full_cov=False):
         """models/sgpr.py:155-189"""
         Xnew = np.ascontiguousarray(Xnew, dtype=settings.float_type)

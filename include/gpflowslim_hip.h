@@ -243,6 +243,17 @@ int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
              const double* Xnew, int64_t n_new, int full_cov,
              double* bound_out, double* mean_out, double* var_out, int* info);
 
+/* The SGPR bound and its gradient -- what TF autodiff through models/sgpr.py:121-153 supplies to the optimiser (SGPR keeps the
+ * inducing inputs among its parameters, sgpr.py:118): grad_slots (kernel parameters, slot layout of gps_gpr_lml_grad),
+ * grad_noise, grad_mean (optional, host [n, r] = d/d mean_function(X)), grad_Z (optional, host [m, d_all]); all with respect
+ * to the constrained values.  Reverse mode at the matrix level (two Cholesky adjoints, kernel-matrix VJPs); every O(M^2 N)
+ * product on the fp64 MFMA, resident in HBM.                                                                      */
+int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                  const double* Z, int64_t m, const double* X, int64_t n, int64_t d_all,
+                  double jitter, double noise_var, const double* resid, int64_t r,
+                  double* bound, double* grad_slots, int n_slots_cap, int* n_slots_out, double* grad_noise,
+                  double* grad_mean, double* grad_Z, int* info);
+
 /* GP regression with the FITC approximation: models.GPRFITC._build_likelihood / _build_predict
  * (models/sgpr.py:229-318: Luu = chol(Kuu), V = Luu^-1 Kuf, nu = Kdiag - colsumsq(V) + sigma^2,
  * L = chol(I + (V/nu) V^T), gamma = L^-1 V (err/nu)).  Same arguments, layouts and outputs as gps_sgpr;

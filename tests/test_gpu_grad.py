@@ -594,3 +594,81 @@ def test_kernel_matrix_input_vjp_through_a_neural_kernel_network(handle, act):
                 assert abs(got[i, k] - fd) <= 5e-6 * max(1.0, abs(fd)), (i, k, got[i, k], fd)
     finally:
         orc.SQUARE_DIST_MODE = saved
+
+
+@pytest.mark.parametrize("kind,n,m_,d,r", [("rbf_ard", 300, 40, 3, 1), ("m52_plus_periodic", 420, 130, 2, 2), ("m32_ard", 260, 60, 2, 3)])
+def test_sgpr_bound_gradient(handle, kind, n, m_, d, r):
+    """Gradient of the SGPR collapsed bound (gps_sgpr_grad; models/sgpr.py:121-153 through TF autodiff in the reference) with
+    respect to the kernel parameters, the noise variance, a Linear mean function and the inducing inputs, against central
+    differences of the ORACLE's bound in the constrained parameters and of the product's own bound in the unconstrained
+    ones."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_ + r)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r)) + 0.3
+    Z = X[:m_].copy() + 0.05 * rng.standard_normal((m_, d))
+    kern, theta, fn, _ = _cases(gpf, d)[kind]()
+    Am = rng.standard_normal((d, r)) * 0.2; bm = rng.standard_normal(r) * 0.1
+    mf = gpf.mean_functions.Linear(Am.copy(), bm.copy())
+    m = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.25, mean_function=mf)
+    noise = c(0.25)
+    bound, grads = m.compute_log_likelihood_and_gradients()
+
+    def f(th=theta, nz=noise, ZZ=Z, AA=Am, bb=bm):
+        return orc.sgpr_bound(fn(th), X, Y, ZZ, nz, mean_X=X @ AA + bb)
+
+    ref_bound = f()
+    assert abs(bound - ref_bound) <= 1e-8 * abs(ref_bound)
+    assert abs(bound - m.compute_log_likelihood()) <= 1e-12 * abs(bound)
+    by = {id(p): g for p, g in grads}
+
+    def cd(make, x0, hrel=1e-6):
+        hh = hrel * max(1.0, abs(x0))
+        return (make(x0 + hh) - make(x0 - hh)) / (2 * hh)
+
+    got = _flat_constrained_grad(m, grads)
+    assert got.shape == theta.shape
+    for i in range(theta.size):
+        def mk(v, i=i):
+            th = theta.copy(); th[i] = v
+            return f(th=th)
+        fd = cd(mk, theta[i])
+        assert abs(got[i] - fd) <= 2e-5 * max(1.0, abs(fd)), ("theta", i, got[i], fd)
+    gn = float(by[id(m.likelihood._variance)] / m.likelihood._variance.transform.forward_grad(m.likelihood._variance.vf_val))
+    fd = cd(lambda v: f(nz=v), noise)
+    assert abs(gn - fd) <= 2e-5 * max(1.0, abs(fd)), (gn, fd)
+    gz = by[id(m.feature._Z)]
+    for _ in range(6):
+        a, b = int(rng.integers(m_)), int(rng.integers(d))
+        def mk(v, a=a, b=b):
+            ZZ = Z.copy(); ZZ[a, b] = v
+            return f(ZZ=ZZ)
+        fd = cd(mk, Z[a, b])
+        assert abs(gz[a, b] - fd) <= 2e-5 * max(1.0, abs(fd)), ("Z", a, b, gz[a, b], fd)
+    gA, gb = by[id(mf.A)], by[id(mf.b)]
+    for _ in range(3):
+        a, b = int(rng.integers(d)), int(rng.integers(r))
+        def mk(v, a=a, b=b):
+            AA = Am.copy(); AA[a, b] = v
+            return f(AA=AA)
+        fd = cd(mk, Am[a, b])
+        assert abs(np.reshape(gA, Am.shape)[a, b] - fd) <= 2e-5 * max(1.0, abs(fd)), ("A", a, b)
+    fd = cd(lambda v: f(bb=np.concatenate([[v], bm[1:]])), bm[0])
+    assert abs(np.ravel(gb)[0] - fd) <= 2e-5 * max(1.0, abs(fd))
+    _fd_check(m, grads)
+
+
+def test_sgpr_optimize_raises_the_bound(handle):
+    """SGPR + Model.optimize(): hyper-parameters, noise and inducing inputs move; the bound goes up and stays below the exact
+    evidence at the same hyper-parameters."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(8)
+    n, d, m_ = 500, 2, 30
+    X = rng.standard_normal((n, d)); Y = np.sin(2.0 * X[:, :1]) * np.cos(X[:, 1:2]) + 0.1 * rng.standard_normal((n, 1))
+    Z0 = X[:m_].copy()
+    m = gpf.models.SGPR(X, Y, gpf.kernels.RBF(d, ARD=True), Z=Z0, obs_var=0.5)
+    start = m.objective
+    final = m.optimize(max_iter=120)
+    assert final < start - 100.0, (start, final)
+    assert np.abs(np.asarray(m.feature.Z) - Z0).max() > 1e-3
+    exact = gpf.models.GPR(X, Y, m.kern, obs_var=float(np.squeeze(m.likelihood.variance))).compute_log_likelihood()
+    assert -final <= exact + 1e-6 * abs(exact)

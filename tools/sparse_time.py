@@ -20,4 +20,10 @@ for name, cls in (("sgpr", gpf.models.SGPR), ("fitc", gpf.models.GPRFITC)):
     cl = {k: h.profile_get(k) for k in ("gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other")}
     out[name] = {"bound": v, "ms": round(1e3 * (t1 - t0), 1), "classes_ms": {k: round(c["ms"], 1) for k, c in cl.items()},
                  "gemm_tflops": round(cl["gemm_f64"]["flops"] / max(cl["gemm_f64"]["ms"], 1e-9) / 1e9, 1)}
+model = gpf.models.SGPR(X, Y, gpf.kernels.RBF(d, lengthscales=np.sqrt(d) * np.ones(d), ARD=True), Z=Z)
+model.likelihood._variance.assign(0.1)
+model.compute_log_likelihood_and_gradients()
+t0 = time.perf_counter(); b, grads = model.compute_log_likelihood_and_gradients(); t1 = time.perf_counter()
+out["sgpr_bound_plus_gradient_ms"] = round(1e3 * (t1 - t0), 1)
+out["sgpr_grad_max"] = {p.name: float(np.abs(g).max()) for p, g in grads}
 print(json.dumps(out))
