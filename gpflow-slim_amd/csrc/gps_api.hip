@@ -2298,8 +2298,8 @@ extern "C" int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
 }
 
 // ---- gradient of the SGPR bound ----------------------------------------------------------------------------------
-// What TF autodiff through models/sgpr.py:121-153 supplies to the reference's optimiser (SGPR keeps Z among its parameters,
-// sgpr.py:118).  Reverse mode at the matrix level over what gps_sgpr leaves on the device, s = noise variance, R outputs:
+// What TF autodiff through models/sgpr.py:121-153 supplies to the reference's optimiser (Z is a Parameter, features.py:65,
+// and moves like every other variable).  Reverse mode at the matrix level over what gps_sgpr leaves on the device, s = noise variance, R outputs:
 //   forward   L = chol(Kuu + jitter I), A = L^-1 Kuf, G = A A^T, B = I + G / s, LB = chol(B), v = A err, u = LB^-1 v, c = u / s
 //             F = const - R sum log diag LB - N R / 2 log s - |err|^2 / (2 s) + |c|^2 / 2 - R sum Kdiag / (2 s) + R tr(G) / (2 s)
 //   ubar = u / s^2 ; vbar = LB^-T ubar ; LB_bar = -tril(vbar u^T + R diag(1 / LB_ii)) ; B_bar = adjoint(LB, LB_bar)

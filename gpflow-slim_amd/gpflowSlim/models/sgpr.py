@@ -66,7 +66,7 @@ class SGPR(GPModel, SGPRUpperMixin):
 
     def compute_log_likelihood_and_gradients(self):
         """The collapsed bound and d bound / d(unconstrained parameter) for every parameter of the model (kernel, noise,
-        mean function, inducing inputs -- SGPR keeps Z among its parameters, models/sgpr.py:118): what TF autodiff through
+        mean function, inducing inputs -- Z is a Parameter of the feature, features.py:65): what TF autodiff through
         models/sgpr.py:121-153 yields.  Returns (bound, [(Parameter, gradient shaped like its unconstrained value), ...])."""
         d_all = self.X.shape[1]
         prog = self.kern._program(d_all)

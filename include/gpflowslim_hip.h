@@ -244,7 +244,7 @@ int gps_sgpr(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
              double* bound_out, double* mean_out, double* var_out, int* info);
 
 /* The SGPR bound and its gradient -- what TF autodiff through models/sgpr.py:121-153 supplies to the optimiser (SGPR keeps the
- * inducing inputs among its parameters, sgpr.py:118): grad_slots (kernel parameters, slot layout of gps_gpr_lml_grad),
+ * inducing inputs trainable: features.py:65 makes Z a Parameter): grad_slots (kernel parameters, slot layout of gps_gpr_lml_grad),
  * grad_noise, grad_mean (optional, host [n, r] = d/d mean_function(X)), grad_Z (optional, host [m, d_all]); all with respect
  * to the constrained values.  Reverse mode at the matrix level (two Cholesky adjoints, kernel-matrix VJPs); every O(M^2 N)
  * product on the fp64 MFMA, resident in HBM.                                                                      */
