@@ -596,6 +596,44 @@ __global__ __launch_bounds__(256) void tri_dot_kernel(const double* __restrict__
   }
 }
 
+// out[i] = sum_j A[i][j] B[i][j]   (one wave per row, 16-byte loads; cols a multiple of 2)
+__global__ __launch_bounds__(256) void rowdot2_kernel(const double* __restrict__ A, i64 lda, const double* __restrict__ B, i64 ldb,
+                                                      i64 rows, i64 cols, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const i64 row = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const double* a = A + row * lda; const double* b = B + row * ldb;
+  double s = 0.0;
+  for (i64 k = 2 * lane; k < cols; k += 128) {
+    const v2d x = *reinterpret_cast<const v2d*>(a + k), y = *reinterpret_cast<const v2d*>(b + k);
+    s = fma(x.x, y.x, fma(x.y, y.y, s));
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+// X[i][:] = a[i] X[i][:] + b[i] Y[i][:]
+__global__ __launch_bounds__(256) void rows_axpby_kernel(double* __restrict__ X, i64 ldx, const double* __restrict__ Y, i64 ldy,
+                                                         i64 rows, i64 cols, const double* __restrict__ a, const double* __restrict__ b) {
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (i64 rr = blockIdx.y; rr < rows; rr += gridDim.y) X[rr * ldx + c] = a[rr] * X[rr * ldx + c] + b[rr] * Y[rr * ldy + c];
+}
+int gps_launch_rowdot2(gps_handle_t h, const double* A, i64 lda, const double* B, i64 ldb, i64 rows, i64 cols, double* out) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_REDUCE, 2.0 * rows * cols, 16.0 * rows * cols);
+  hipLaunchKernelGGL(rowdot2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, A, lda, B, ldb, rows, cols, out);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+int gps_launch_rows_axpby(gps_handle_t h, double* X, i64 ldx, const double* Y, i64 ldy, i64 rows, i64 cols, const double* a,
+                          const double* b) {
+  if (rows <= 0 || cols <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, 3.0 * rows * cols, 24.0 * rows * cols);
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(rows_axpby_kernel, grid, dim3(256), 0, h->stream, X, ldx, Y, ldy, rows, cols, a, b);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
 int gps_launch_axpby_eye(gps_handle_t h, double* A, i64 ld, i64 n, i64 n_real, double alpha, double beta) {
   if (n <= 0) return GPS_OK;
   LaunchScope ls(h, KC_OTHER, (double)n * n, 16.0 * n * n);

@@ -2297,6 +2297,57 @@ extern "C" int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   });
 }
 
+// common tail of the SGPR / FITC gradients: from A_bar^T [np, mp] (cotangent of A = L^-1 Kuf, transposed) to the kernel
+// parameters and the inducing inputs.  On the device: dK = L (blL: its block inverses), A [mp, np], dX = Z, dXnew = X.
+//   Kuf_bar = L^-T A_bar ; L_bar = -tril(Kuf_bar A^T) ; Kuu_bar = adjoint(L, L_bar) ; kernel-matrix VJPs ; Kdiag's share kbar
+static int sparse_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 m, i64 n, i64 d_all,
+                            Blocked<HipOps>& blL, double* AbarT, const double* A, double* U, double kdiag_bar, int ns,
+                            double* grad_slots, double* grad_Z) {
+  const i64 mp = gps_pad(m), np = gps_pad(n);
+  double* L = h->dK.d();
+  int rc;
+  // Kuf_bar^T = A_bar^T L^-1 ; Kuf_bar [mp, np]
+  rc = gps_launch_transpose(h, L, mp, mp, mp, U, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, U, mp, mp, 3);
+  if (rc) return rc;
+  rc = blL.trsm_rn_rec(U, mp, mp, 0, AbarT, mp, np);
+  if (rc) return rc;
+  GPS_HIP(h, h->dB.ensure((size_t)mp * np * 8));
+  double* KufBar = h->dB.d();
+  rc = gps_launch_transpose(h, AbarT, mp, np, mp, KufBar, np);
+  if (rc) return rc;
+  // L_bar = -tril(Kuf_bar A^T) ; Kuu_bar
+  double* Lbar = h->dG1.d();
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, KufBar, np, A, np, Lbar, mp);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, Lbar, mp, mp, 1);
+  if (rc) return rc;
+  double* K2 = h->dG2.d();                                        // 2 Kuu_bar
+  rc = chol_adjoint2(h, blL, U, Lbar, K2, h->dTmp2.d(), mp);
+  if (rc) return rc;
+  for (int sI = 0; sI < ns; ++sI) grad_slots[sI] = 0.0;
+  rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 0, grad_slots);
+  if (rc) return rc;
+  {
+    std::vector<double> uu((size_t)ns, 0.0);
+    rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 0, uu.data());
+    if (rc) return rc;
+    for (int sI = 0; sI < ns; ++sI) grad_slots[sI] += 0.5 * uu[sI];
+  }
+  rc = gps_kdiag_vjp(h, prog, n_nodes, d_all, kdiag_bar, grad_slots);
+  if (rc) return rc;
+  if (grad_Z) {
+    for (i64 i = 0; i < m * d_all; ++i) grad_Z[i] = 0.0;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 1.0, grad_Z);
+    if (rc) return rc;
+    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 1.0, grad_Z);
+    if (rc) return rc;
+  }
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  return GPS_OK;
+}
+
 // ---- gradient of the SGPR bound ----------------------------------------------------------------------------------
 // What TF autodiff through models/sgpr.py:121-153 supplies to the reference's optimiser (Z is a Parameter, features.py:65,
 // and moves like every other variable).  Reverse mode at the matrix level over what gps_sgpr leaves on the device, s = noise variance, R outputs:
@@ -2331,7 +2382,7 @@ extern "C" int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_
   HipOps opsL{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, (int*)h->dInfo.p};
   HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, (int*)h->dInfo.p};
   Blocked<HipOps> blL(opsL), blB(opsB);
-  double* L = h->dK.d(); double* At = h->dS1.d(); double* A = h->dS2.d(); double* LB = h->dS3.d();
+  double* At = h->dS1.d(); double* A = h->dS2.d(); double* LB = h->dS3.d();
   double* dErrT = h->dAlpha.d(); double* dUT = dErrT + (size_t)r * np;
   const double kdiag = h->sparse_terms[3], trG = h->sparse_terms[1];
   // u, then vbar^T = (LB^-T u / s^2)^T as rows
@@ -2414,46 +2465,133 @@ extern "C" int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_
     for (i64 i = 0; i < n * r; ++i) grad_mean[i] = resid[i] / s - av[i];
   }
   GPS_HIP(h, hipStreamSynchronize(h->stream));                    // (host vectors above are read by the copies)
-  // Kuf_bar^T = A_bar^T L^-1 ; Kuf_bar [mp, np]
-  rc = gps_launch_transpose(h, L, mp, mp, mp, U, mp);
+  return sparse_grad_tail(h, prog, n_nodes, m, n, d_all, blL, AbarT, A, U, -0.5 * R * N / s, ns, grad_slots, grad_Z);
+}
+
+// ---- gradient of the FITC log-likelihood (models/sgpr.py:229-290 under TF autodiff) ---------------------------------------
+//   forward   A = L^-1 Kuf, q_i = |a_i|^2, nu_i = Kdiag - q_i + s, w_i = nu_i^-1/2, Ah = A diag(w), B = I + Ah Ah^T, LB = chol(B),
+//             beta = err . w (rows), v = Ah beta, u = LB^-1 v,
+//             F = -|beta|^2 / 2 + |u|^2 / 2 - R (N / 2 log 2 pi + sum log nu / 2 + sum log diag LB)
+//   vbar = LB^-T u ; LB_bar = -tril(vbar u^T + R diag(1 / LB_ii)) ; B_bar = adjoint(LB, LB_bar)
+//   Ah_bar = 2 B_bar Ah + vbar beta^T ; beta_bar = Ah^T vbar - beta
+//   wbar_i = <Ah_bar[:, i], A[:, i]> + <beta_bar_i, err_i> ; nubar_i = -wbar_i nu_i^-3/2 / 2 - R / (2 nu_i)
+//   sbar = sum nubar ; Kdiag_bar = sum nubar ; A_bar[:, i] = w_i Ah_bar[:, i] - 2 nubar_i A[:, i] ; then the common tail.
+extern "C" int gps_fitc_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  if (!h || !bound || !grad_slots || !grad_noise) return gps_fail(h, GPS_ERR_ARG, "gps_fitc_grad: bad argument");
+  if (r > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_fitc_grad: at most 128 outputs");
+  int ns = 0;
+  int rc = gps_grad_general_slots(h, prog, n_nodes, &ns);
+  if (rc) return rc;
+  if (n_slots_out) *n_slots_out = ns;
+  if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_fitc_grad: grad_slots too small");
+  int linfo = 0;
+  rc = gps_fitc(h, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, nullptr, 0, 0, bound, nullptr, nullptr, &linfo);
+  if (info) *info = linfo;
+  if (rc || linfo) return rc;
+  // on the device: dK = L ; dS1 = Ah^T [np, mp] (rows scaled by w) ; dS2 = Ah [mp, np] ; dS3 = LB ; dS4 its block inverses ;
+  // dAlpha = beta^T [r][np], then u^T [r][mp] ; dTmp3 = w [np]
+  const i64 mp = gps_pad(m), np = gps_pad(n);
+  const double R = (double)r;
+  const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
+  HipOps opsL{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, (int*)h->dInfo.p};
+  HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, (int*)h->dInfo.p};
+  Blocked<HipOps> blL(opsL), blB(opsB);
+  double* Aht = h->dS1.d(); double* Ah = h->dS2.d(); double* LB = h->dS3.d();
+  double* dBetaT = h->dAlpha.d(); double* dUT = dBetaT + (size_t)r * np;
+  std::vector<double> w((size_t)np, 0.0), hu((size_t)r * mp), hv((size_t)r * mp);
+  GPS_HIP(h, hipMemcpyAsync(w.data(), h->dTmp3.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(hu.data(), dUT, hu.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  // the vector of weights moves to a buffer of its own (dTmp3 is scratch below)
+  GPS_HIP(h, h->dG4.ensure((size_t)(3 * np + mp + mp * r) * 8));
+  double* dW = h->dG4.d(); double* dCa = dW + np; double* dCb = dCa + np; double* dZero = dCb + np; double* dVmk = dZero + mp;
+  GPS_HIP(h, hipMemcpyAsync(dW, w.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
+  // vbar^T = (LB^-T u)^T
+  GPS_HIP(h, h->dG3.ensure((size_t)(GPS_TILE + r) * mp * 8));
+  double* dVT = h->dG3.d();
+  GPS_HIP(h, hipMemcpyAsync(dVT, hu.data(), hu.size() * 8, hipMemcpyHostToDevice, h->stream));
+  rc = blB.trsv_t_rec(LB, mp, mp, 0, dVT, mp, r);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(hv.data(), dVT, hv.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  // LB_bar, B_bar
+  GPS_HIP(h, h->dG1.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
+  GPS_HIP(h, h->dTmp3.ensure((size_t)2 * mp * GPS_TILE * 8));
+  std::vector<double> va((size_t)mp * GPS_TILE, 0.0), ub((size_t)mp * GPS_TILE, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < r; ++q) { va[(size_t)j * GPS_TILE + q] = hv[(size_t)q * mp + j]; ub[(size_t)j * GPS_TILE + q] = hu[(size_t)q * mp + j]; }
+  double* dVa = h->dTmp3.d(); double* dUb = dVa + (size_t)mp * GPS_TILE;
+  GPS_HIP(h, hipMemcpyAsync(dVa, va.data(), va.size() * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(dUb, ub.data(), ub.size() * 8, hipMemcpyHostToDevice, h->stream));
+  double* LBbar = h->dG1.d();
+  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, GPS_TILE, dVa, GPS_TILE, dUb, GPS_TILE, LBbar, mp);
+  if (rc) return rc;
+  rc = gps_launch_diag_recip_add(h, LBbar, mp, LB, mp, m, R);
+  if (rc) return rc;
+  rc = gps_launch_tri_map(h, LBbar, mp, mp, 1);
+  if (rc) return rc;
+  double* U = h->dTmp.d();
+  rc = gps_launch_transpose(h, LB, mp, mp, mp, U, mp);
   if (rc) return rc;
   rc = gps_launch_tri_map(h, U, mp, mp, 3);
   if (rc) return rc;
-  rc = blL.trsm_rn_rec(U, mp, mp, 0, AbarT, mp, np);
+  double* B2 = h->dG2.d();                                        // 2 B_bar
+  rc = chol_adjoint2(h, blB, U, LBbar, B2, h->dTmp2.d(), mp);
   if (rc) return rc;
-  GPS_HIP(h, h->dB.ensure((size_t)mp * np * 8));
-  double* KufBar = h->dB.d();
-  rc = gps_launch_transpose(h, AbarT, mp, np, mp, KufBar, np);
+  // Ah_bar^T [np, mp] = beta vbar^T + Ah^T (2 B_bar)
+  GPS_HIP(h, h->dY.ensure((size_t)np * mp * 8));
+  double* AbarT = h->dY.d();
+  std::vector<double> zero((size_t)mp, 0.0), vmk((size_t)mp * r, 0.0);
+  for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < r; ++q) vmk[(size_t)j * r + q] = hv[(size_t)q * mp + j];
+  GPS_HIP(h, hipMemcpyAsync(dZero, zero.data(), (size_t)mp * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(dVmk, vmk.data(), vmk.size() * 8, hipMemcpyHostToDevice, h->stream));
+  rc = gps_launch_svgp_abar(h, Aht, mp, np, mp, dZero, dBetaT, np, dVmk, r, AbarT);
   if (rc) return rc;
-  // L_bar = -tril(Kuf_bar A^T) ; Kuu_bar
-  double* Lbar = h->dG1.d();
-  rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, KufBar, np, A, np, Lbar, mp);
+  rc = gps_launch_gemm_nt(h, 2, 0, np, mp, mp, Aht, mp, B2, mp, AbarT, mp);
   if (rc) return rc;
-  rc = gps_launch_tri_map(h, Lbar, mp, mp, 1);
+  // beta_bar = Ah^T vbar - beta  [n, r] ; row dots <Ah_bar^T[i], Ah^T[i]> (= w_i <Ah_bar[:, i], A[:, i]>)
+  GPS_HIP(h, h->dMean.ensure((size_t)(n * r + 2 * np) * 8));
+  double* dAv = h->dMean.d(); double* dRd = dAv + (size_t)n * r;
+  rc = gps_launch_rowdot(h, Aht, mp, n, mp, dVT, mp, r, dAv, dRd + np);
   if (rc) return rc;
-  double* K2 = h->dG2.d();                                        // 2 Kuu_bar
-  rc = chol_adjoint2(h, blL, U, Lbar, K2, h->dTmp2.d(), mp);
+  rc = gps_launch_rowdot2(h, AbarT, mp, Aht, mp, n, mp, dRd);
   if (rc) return rc;
-  for (int sI = 0; sI < ns; ++sI) grad_slots[sI] = 0.0;
-  rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 0, grad_slots);
-  if (rc) return rc;
-  {
-    std::vector<double> uu((size_t)ns, 0.0);
-    rc = gps_launch_kmat_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 0, uu.data());
-    if (rc) return rc;
-    for (int sI = 0; sI < ns; ++sI) grad_slots[sI] += 0.5 * uu[sI];
-  }
-  rc = gps_kdiag_vjp(h, prog, n_nodes, d_all, -0.5 * R * N / s, grad_slots);
-  if (rc) return rc;
-  if (grad_Z) {
-    for (i64 i = 0; i < m * d_all; ++i) grad_Z[i] = 0.0;
-    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, h->dXnew.d(), n, d_all, KufBar, np, 1.0, grad_Z);
-    if (rc) return rc;
-    rc = gps_launch_kmat_input_vjp(h, prog, n_nodes, h->dX.d(), m, nullptr, 0, d_all, K2, mp, 1.0, grad_Z);
-    if (rc) return rc;
-  }
+  std::vector<double> av((size_t)n * r), rd((size_t)n);
+  GPS_HIP(h, hipMemcpyAsync(av.data(), dAv, av.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(rd.data(), dRd, rd.size() * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
-  return GPS_OK;
+  std::vector<double> ca((size_t)np, 0.0), cb((size_t)np, 0.0), iw((size_t)np, 0.0);
+  double nubar_sum = 0.0;
+  for (i64 i = 0; i < n; ++i) {
+    const double wi = w[i], nu = 1.0 / (wi * wi);
+    double wbar = rd[i] / wi;                                     // <Ah_bar[:, i], A[:, i]>, A[:, i] = Ah[:, i] / w_i
+    for (i64 q = 0; q < r; ++q) {
+      const double beta = resid[i * r + q] * wi;
+      const double bbar = av[i * r + q] - beta;
+      wbar += bbar * resid[i * r + q];
+      if (grad_mean) grad_mean[i * r + q] = -bbar * wi;           // err = Y - mean(X)
+    }
+    const double nubar = -0.5 * wbar * wi * wi * wi - 0.5 * R / nu;
+    nubar_sum += nubar;
+    ca[i] = wi; cb[i] = -2.0 * nubar / wi;                        // A_bar^T[i] = w_i Ah_bar^T[i] - 2 nubar_i A^T[i], A^T[i] = Ah^T[i] / w_i
+    iw[i] = 1.0 / wi;
+  }
+  *grad_noise = nubar_sum;
+  GPS_HIP(h, hipMemcpyAsync(dCa, ca.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(dCb, cb.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
+  rc = gps_launch_rows_axpby(h, AbarT, mp, Aht, mp, n, mp, dCa, dCb);
+  if (rc) return rc;
+  // A = Ah diag(1 / w)  (columns of [mp, np]) for the tail
+  GPS_HIP(h, hipMemcpyAsync(dW, iw.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
+  rc = gps_launch_scale_cols(h, Ah, np, mp, n, dW, Ah, np);
+  if (rc) return rc;
+  GPS_HIP(h, hipStreamSynchronize(h->stream));                    // (host vectors above are read by the copies)
+  return sparse_grad_tail(h, prog, n_nodes, m, n, d_all, blL, AbarT, Ah, U, nubar_sum, ns, grad_slots, grad_Z);
 }
 
 extern "C" int gps_sparse_last_terms(gps_handle_t h, double* out5) {

@@ -306,6 +306,9 @@ int gps_launch_svgp_abar(gps_handle_t h, const double* Bt, i64 ld, i64 rows, i64
 int gps_launch_tri_map(gps_handle_t h, double* A, i64 ld, i64 n, int mode);
 int gps_launch_axpby_eye(gps_handle_t h, double* A, i64 ld, i64 n, i64 n_real, double alpha, double beta);
 int gps_launch_diag_recip_add(gps_handle_t h, double* A, i64 lda, const double* L, i64 ldl, i64 n, double coef);
+int gps_launch_rowdot2(gps_handle_t h, const double* A, i64 lda, const double* B, i64 ldb, i64 rows, i64 cols, double* out);
+int gps_launch_rows_axpby(gps_handle_t h, double* X, i64 ldx, const double* Y, i64 ldy, i64 rows, i64 cols, const double* a,
+                          const double* b);
 int gps_tri_dot(gps_handle_t h, const double* A, i64 lda, const double* B, i64 ldb, i64 n, double* out2);
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,

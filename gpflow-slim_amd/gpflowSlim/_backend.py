@@ -84,6 +84,9 @@ _SIGNATURES = {
     "gps_sgpr_grad": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
                       ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _c_double_p, ctypes.c_int, _c_int_p,
                       _c_double_p, _c_double_p, _c_double_p, _c_int_p],
+    "gps_fitc_grad": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
+                      ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _c_double_p, ctypes.c_int, _c_int_p,
+                      _c_double_p, _c_double_p, _c_double_p, _c_int_p],
     "gps_fitc": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, _c_double_p, _i64, _i64,
                  ctypes.c_double, ctypes.c_double, _c_double_p, _i64, _c_double_p, _i64, ctypes.c_int, _c_double_p,
                  _c_double_p, _c_double_p, _c_int_p],
@@ -511,9 +514,9 @@ class Handle(object):
             raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
         return bound.value, mean, var
 
-    def sgpr_grad(self, prog, Z, X, resid, jitter, noise_var, want_grad_Z=True):
-        """(bound, grad_slots, grad_noise, d/d mean(X) [N, R], grad_Z [M, D] or None) of the SGPR bound -- gps_sgpr_grad;
-        gradients with respect to the constrained values."""
+    def sgpr_grad(self, prog, Z, X, resid, jitter, noise_var, want_grad_Z=True, fitc=False):
+        """(bound, grad_slots, grad_noise, d/d mean(X) [N, R], grad_Z [M, D] or None) of the SGPR bound -- gps_sgpr_grad -- or,
+        with fitc=True, of the FITC log-likelihood -- gps_fitc_grad; gradients with respect to the constrained values."""
         Z, X, resid = _f64(Z), _f64(X), _f64(resid)
         m, d = Z.shape
         n, r = resid.shape
@@ -526,10 +529,11 @@ class Handle(object):
         g_Z = np.zeros((m, d))
         self.resident_token = None
         self.factor_key = None
-        self._check(self._lib.gps_sgpr_grad(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter), float(noise_var),
-                                            _ptr(resid), r, ctypes.byref(bound), _ptr(slots), cap, ctypes.byref(nslots),
-                                            ctypes.byref(gnoise), _ptr(g_mean), _ptr(g_Z) if want_grad_Z else None,
-                                            ctypes.byref(info)), "gps_sgpr_grad")
+        fn = self._lib.gps_fitc_grad if fitc else self._lib.gps_sgpr_grad
+        self._check(fn(self._h, prog, len(prog), _ptr(Z), m, _ptr(X), n, d, float(jitter), float(noise_var),
+                       _ptr(resid), r, ctypes.byref(bound), _ptr(slots), cap, ctypes.byref(nslots),
+                       ctypes.byref(gnoise), _ptr(g_mean), _ptr(g_Z) if want_grad_Z else None,
+                       ctypes.byref(info)), "gps_fitc_grad" if fitc else "gps_sgpr_grad")
         if info.value > 0:
             raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
         return bound.value, slots[:nslots.value].copy(), gnoise.value, g_mean, (g_Z if want_grad_Z else None)

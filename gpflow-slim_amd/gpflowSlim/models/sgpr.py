@@ -64,6 +64,8 @@ class SGPR(GPModel, SGPRUpperMixin):
         bound, _, _ = self._call()
         return bound
 
+    _fitc_gradient = False
+
     def compute_log_likelihood_and_gradients(self):
         """The collapsed bound and d bound / d(unconstrained parameter) for every parameter of the model (kernel, noise,
         mean function, inducing inputs -- Z is a Parameter of the feature, features.py:65): what TF autodiff through
@@ -76,7 +78,7 @@ class SGPR(GPModel, SGPRUpperMixin):
         want_z = zparam is not None and any(p is zparam for p in self.parameters)
         bound, slots, gnoise, g_mean, g_Z = be.get_handle().sgpr_grad(
             prog, self.feature.Z, self.X, err, settings.numerics.jitter_level, float(np.squeeze(self.likelihood.variance)),
-            want_grad_Z=want_z)
+            want_grad_Z=want_z, fitc=self._fitc_gradient)
         if len(layout) != len(slots):
             raise RuntimeError("gradient slot layout mismatch: %d vs %d" % (len(layout), len(slots)))
         grads = {id(p): np.zeros_like(np.atleast_1d(p.vf_val), dtype=settings.float_type) for p in self.parameters}
@@ -146,6 +148,10 @@ class GPRFITC(GPModel, SGPRUpperMixin):
         """models/sgpr.py:252-291"""
         bound, _, _ = self._call()
         return bound
+
+    # the FITC log-likelihood and its gradient (gps_fitc_grad): same assembly as SGPR's
+    _fitc_gradient = True
+    compute_log_likelihood_and_gradients = SGPR.compute_log_likelihood_and_gradients
 
     def _build_predict(self, Xnew, full_cov=False):
         """models/sgpr.py:293-318"""

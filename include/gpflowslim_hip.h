@@ -254,6 +254,13 @@ int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                   double* bound, double* grad_slots, int n_slots_cap, int* n_slots_out, double* grad_noise,
                   double* grad_mean, double* grad_Z, int* info);
 
+/* The same for the FITC log-likelihood (models/sgpr.py:229-290): arguments and outputs as gps_sgpr_grad.          */
+int gps_fitc_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
+                  const double* Z, int64_t m, const double* X, int64_t n, int64_t d_all,
+                  double jitter, double noise_var, const double* resid, int64_t r,
+                  double* bound, double* grad_slots, int n_slots_cap, int* n_slots_out, double* grad_noise,
+                  double* grad_mean, double* grad_Z, int* info);
+
 /* GP regression with the FITC approximation: models.GPRFITC._build_likelihood / _build_predict
  * (models/sgpr.py:229-318: Luu = chol(Kuu), V = Luu^-1 Kuf, nu = Kdiag - colsumsq(V) + sigma^2,
  * L = chol(I + (V/nu) V^T), gamma = L^-1 V (err/nu)).  Same arguments, layouts and outputs as gps_sgpr;

@@ -672,3 +672,60 @@ def test_sgpr_optimize_raises_the_bound(handle):
     assert np.abs(np.asarray(m.feature.Z) - Z0).max() > 1e-3
     exact = gpf.models.GPR(X, Y, m.kern, obs_var=float(np.squeeze(m.likelihood.variance))).compute_log_likelihood()
     assert -final <= exact + 1e-6 * abs(exact)
+
+
+@pytest.mark.parametrize("kind,n,m_,d,r", [("rbf_ard", 300, 40, 3, 1), ("m52_plus_periodic", 420, 130, 2, 2)])
+def test_fitc_likelihood_gradient(handle, kind, n, m_, d, r):
+    """Gradient of the FITC log-likelihood (gps_fitc_grad; models/sgpr.py:229-290 under TF autodiff) with respect to the kernel
+    parameters, the noise variance, a Linear mean function and the inducing inputs, against central differences of the
+    oracle's likelihood and of the product's own."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n + m_ + r + 1)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r)) + 0.3
+    Z = X[:m_].copy() + 0.05 * rng.standard_normal((m_, d))
+    kern, theta, fn, _ = _cases(gpf, d)[kind]()
+    Am = rng.standard_normal((d, r)) * 0.2; bm = rng.standard_normal(r) * 0.1
+    mf = gpf.mean_functions.Linear(Am.copy(), bm.copy())
+    m = gpf.models.GPRFITC(X, Y, kern, Z=Z, obs_var=0.25, mean_function=mf)
+    noise = c(0.25)
+    bound, grads = m.compute_log_likelihood_and_gradients()
+
+    def f(th=theta, nz=noise, ZZ=Z, AA=Am, bb=bm):
+        return orc.fitc_lml(fn(th), X, Y, ZZ, nz, mean_X=X @ AA + bb)
+
+    ref_bound = f()
+    assert abs(bound - ref_bound) <= 1e-8 * abs(ref_bound)
+    by = {id(p): g for p, g in grads}
+
+    def cd(make, x0, hrel=1e-6):
+        hh = hrel * max(1.0, abs(x0))
+        return (make(x0 + hh) - make(x0 - hh)) / (2 * hh)
+
+    got = _flat_constrained_grad(m, grads)
+    for i in range(theta.size):
+        def mk(v, i=i):
+            th = theta.copy(); th[i] = v
+            return f(th=th)
+        fd = cd(mk, theta[i])
+        assert abs(got[i] - fd) <= 2e-5 * max(1.0, abs(fd)), ("theta", i, got[i], fd)
+    gn = float(by[id(m.likelihood._variance)] / m.likelihood._variance.transform.forward_grad(m.likelihood._variance.vf_val))
+    fd = cd(lambda v: f(nz=v), noise)
+    assert abs(gn - fd) <= 2e-5 * max(1.0, abs(fd)), (gn, fd)
+    gz = by[id(m.feature._Z)]
+    for _ in range(6):
+        a, b = int(rng.integers(m_)), int(rng.integers(d))
+        def mk(v, a=a, b=b):
+            ZZ = Z.copy(); ZZ[a, b] = v
+            return f(ZZ=ZZ)
+        fd = cd(mk, Z[a, b])
+        assert abs(gz[a, b] - fd) <= 2e-5 * max(1.0, abs(fd)), ("Z", a, b, gz[a, b], fd)
+    gA = by[id(mf.A)]
+    a, b = 1, r - 1
+    def mkA(v):
+        AA = Am.copy(); AA[a, b] = v
+        return f(AA=AA)
+    fd = cd(mkA, Am[a, b])
+    assert abs(np.reshape(gA, Am.shape)[a, b] - fd) <= 2e-5 * max(1.0, abs(fd))
+    _fd_check(m, grads)
+    start = m.objective
+    assert m.optimize(max_iter=30) < start
