@@ -70,9 +70,34 @@ class Model(object):
         lml, grads = self.compute_log_likelihood_and_gradients()
         g = np.concatenate([np.atleast_1d(gi).ravel() if getattr(p, "trainable", True) else np.zeros(np.size(gi))
                             for p, gi in grads])
+        lp = 0.0
         if any(p.prior is not None for p in self.parameters):
-            raise NotImplementedError("optimize(): priors are not differentiated")
-        return -float(lml), -g
+            # log-priors (params.py:176-194: log p(constrained) + log |d constrained / d unconstrained|) are host functions of
+            # one parameter each, whatever object the caller supplied as `prior`: central differences over that parameter's own
+            # unconstrained entries
+            gp, lp = self._prior_and_grad([p for p, _ in grads])
+            g = g + gp
+        return -float(lml + lp), -g
+
+    def _prior_and_grad(self, params):
+        from ..params import Parameter
+        total, pieces = 0.0, []
+        for p in params:
+            u0 = np.array(p.vf_val, dtype=np.float64)
+            gpiece = np.zeros(u0.size)
+            if p.prior is not None:
+                def lp_at(u, p=p):
+                    return p._build_prior(u, p.transform.forward(u))
+                total += lp_at(u0)
+                if getattr(p, "trainable", True):
+                    flat = u0.ravel()
+                    for i in range(flat.size):
+                        hh = 1e-6 * max(1.0, abs(flat[i]))
+                        up, um = flat.copy(), flat.copy()
+                        up[i] += hh; um[i] -= hh
+                        gpiece[i] = (lp_at(up.reshape(u0.shape)) - lp_at(um.reshape(u0.shape))) / (2 * hh)
+            pieces.append(gpiece)
+        return np.concatenate(pieces) if pieces else np.zeros(0), total
 
     def optimize(self, max_iter=1000, method="L-BFGS-B", learning_rate=1e-2, callback=None, tol=None):
         """Minimise ``objective`` over the unconstrained parameters.  method: 'L-BFGS-B' (scipy, 20 corrections

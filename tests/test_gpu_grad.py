@@ -729,3 +729,35 @@ def test_fitc_likelihood_gradient(handle, kind, n, m_, d, r):
     _fd_check(m, grads)
     start = m.objective
     assert m.optimize(max_iter=30) < start
+
+
+def test_optimize_with_priors(handle):
+    """A prior on a parameter (params.py:176-194: log p(constrained) + log-Jacobian of the transform, any object with a
+    `logp`) takes part in `objective` and in the gradient optimize() descends on."""
+    import gpflowSlim as gpf
+
+    class LogNormal(object):
+        def __init__(self, mu, var):
+            self.mu, self.var = mu, var
+
+        def logp(self, x):
+            x = np.asarray(x, dtype=np.float64)
+            return -0.5 * np.log(2 * np.pi * self.var) - np.log(x) - 0.5 * np.square(np.log(x) - self.mu) / self.var
+
+    rng = np.random.default_rng(4)
+    n, d = 150, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, ARD=True), obs_var=0.3)
+    m.kern._ls.prior = LogNormal(0.0, 0.5)
+    m.likelihood._variance.prior = LogNormal(-2.0, 1.0)
+    x0 = m._pack()
+    f0, g0 = m._objective_and_grad(x0)
+    assert abs(f0 - m.objective) <= 1e-12 * abs(f0)
+    assert abs(m.objective + m.compute_log_likelihood() + m.compute_log_prior()) <= 1e-10 * abs(f0)
+    for i in range(x0.size):
+        hh = 1e-5
+        xp, xm = x0.copy(), x0.copy(); xp[i] += hh; xm[i] -= hh
+        fp, _ = m._objective_and_grad(xp); fm, _ = m._objective_and_grad(xm)
+        assert abs(g0[i] - (fp - fm) / (2 * hh)) <= 1e-5 * max(1.0, abs(g0[i])), i
+    m._unpack(x0)
+    assert m.optimize(max_iter=40) < f0
