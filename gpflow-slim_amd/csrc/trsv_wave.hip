@@ -216,12 +216,8 @@ template <int RC, bool TRANS>
 static int tw_launch(gps_handle_t h, const double* L, i64 ldl, int nblk, const double* W, double* y, i64 ldy, int r0,
                      u64* xch, unsigned* ctl) {
   const size_t lds = (size_t)(128 * 128 + 2 * RC * 128 + RC * 128 + 8 * RC * 128) * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_wave_kernel<RC, TRANS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  int rca = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsv_wave_kernel<RC, TRANS>), (int)lds);      // (per handle = per device)
+  if (rca) return rca;
   const i64 n = (i64)nblk * 128;
   hipLaunchKernelGGL(tw_init_kernel, dim3((unsigned)((n * RC + 255) / 256)), dim3(256), 0, h->stream, xch, n * RC, ctl);
   GPS_HIP(h, hipGetLastError());
