@@ -196,8 +196,7 @@ int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
 
 /* The same bound AND its gradient -- what TF autodiff through models/svgp.py:108-125 supplies to the optimiser of
  * examples/svgp.py:159-161 (which runs with whiten=False) -- for either parametrisation (white == 0: the whitened
- * gradient at m_w = Lm^-1 q_mu, L_w = Lm^-1 L_q pulled back through that map, including its dependence on Lm) and
- * with the inducing inputs Z held fixed:
+ * gradient at m_w = Lm^-1 q_mu, L_w = Lm^-1 L_q pulled back through that map, including its dependence on Lm):
  *   grad_slots   d/d kernel parameters, slot layout of gps_gpr_lml_grad;  grad_noise  d/d noise_var;
  *   grad_q_mu    host [m, k];  grad_q_sqrt  host, layout of q_sqrt ([m, k], or [k, m, m] with zeros above the diagonals);
  *   grad_mean    (optional) host [n, k] = d/d mean_function(X)  (chain rule for mean-function parameters);
