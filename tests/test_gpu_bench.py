@@ -23,7 +23,7 @@ def _last_json(text):
 
 def test_bench_one_gpu_line():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--npoints", "4096",
-                        "--cpu-sample-n", "1024", "--num-new-throughput", "1024"], capture_output=True, text=True, timeout=900)
+                        "--cpu-sample-n", "1024", "--num-new-throughput", "1024"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     out = _last_json(p.stdout)
     assert COMMON <= set(out), sorted(COMMON - set(out))
@@ -47,8 +47,8 @@ def test_bench_two_ranks_block_column_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
-           "--dist-timeout", "600", "--no-dist-autotune"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+           "--dist-timeout", "200", "--no-dist-autotune"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
     assert COMMON <= set(out), sorted(COMMON - set(out))
@@ -75,8 +75,8 @@ def test_bench_two_ranks_autotuned_panel_width():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
-           "--dist-timeout", "600", "--independent-steps", "0", "--no-roofline"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+           "--dist-timeout", "200", "--independent-steps", "0", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
     dd = out["distributed"]

@@ -103,7 +103,7 @@ def _run_virtual_ranks(world, X, Y, prog, noise, nb, lookahead=2, r_out=None):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=900)
+        t.join(timeout=300)
     return out, errs
 
 
