@@ -314,6 +314,9 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   }
   if (const char* m0 = getenv("GPS_LA_MASK0")) h->la_mask_word0 = (uint32_t)strtoul(m0, nullptr, 0);     // diagnostics
   if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
+  if (const char* v = getenv("GPS_TRSV_WAVE")) h->trsv_wave = atoi(v);                                   // (same switches as
+  if (const char* v = getenv("GPS_LEAF_PERSISTENT")) h->leaf_persistent = atoi(v);                       //  gps_set_option,
+  if (const char* v = getenv("GPS_KMAT_FAST")) h->kmat_fast = atoi(v);                                   //  for a whole run)
   if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   *out = h;
   return GPS_OK;
