@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--dims", dest="d", type=int, default=8)
     ap.add_argument("--num-new", dest="n_new", type=int, default=1024)
     ap.add_argument("--num-new-throughput", dest="n_new_tp", type=int, default=8192)
-    ap.add_argument("--cpu-sample-n", type=int, default=8192, help="oracle sample size for cpu_baseline")
+    ap.add_argument("--cpu-sample-n", type=int, default=16384, help="oracle sample size for cpu_baseline (10-30 s of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
