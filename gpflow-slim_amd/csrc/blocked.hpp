@@ -85,10 +85,14 @@ struct Blocked {
     double* A21 = A + n1 * lda;
     double* A22 = A21 + n1;
     int rc;
+    bool trailing_done = false;
     if (n1 > GPS_TILE && n1 <= ops.rl_max() && ops.rl_group() > 1 && ops.follower()) {
       // A11 is factored by the sweep: the solve of A21 against it follows the sweep on the side stream
-      rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, m2);
+      // ... and so does the trailing update of A22: every solved column block of A21 is applied to A22 at once, behind
+      // the sweep, instead of as one update after it (below: skipped)
+      rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, m2, 0, ops.trail_follows() ? A22 : nullptr, lda, n2);
       if (rc) return rc;
+      trailing_done = ops.trail_follows();
       rc = y_block(A, lda, n1, blk0, yf);
       if (rc) return rc;
       if (dj && dj->dn == n1) {
@@ -129,8 +133,10 @@ struct Blocked {
       const int rc2 = ops.y_close();
       if (rc || rc2) return rc ? rc : rc2;
     }
-    rc = ops.gemm(/*op sub*/ 0, /*lower (trapezoid when e > 0)*/ 1, m2, n2, n1, A21, lda, A21, lda, A22, lda);
-    if (rc) return rc;
+    if (!trailing_done) {
+      rc = ops.gemm(/*op sub*/ 0, /*lower (trapezoid when e > 0)*/ 1, m2, n2, n1, A21, lda, A21, lda, A22, lda);
+      if (rc) return rc;
+    }
     return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1, nullptr, e, yf ? &y2 : nullptr);
   }
 
@@ -173,8 +179,11 @@ struct Blocked {
   // all previous columns, K = c0, then the 128 g-column solve), where it fills the GPU the latency-bound chain leaves
   // idle.  What the side stream has not reached when the sweep ends is finished on the chain.
   // e: augmented rows directly below A (see potrf_rec): every "rows below" of the sweep simply has e rows more.
+  // TR (with FB): the parent's trailing matrix [fm, tn] (its A22, lower trapezoid); every solved column block X of FB is
+  // applied to it right away, TR -= X X^T, on the stream the block was solved on -- the parent's syrk in pieces, in the
+  // shadow of the sweep.
   int potrf_rl_groups(double* A, i64 lda, i64 n, i64 g, i64 blk0, i64 row0, double* FB = nullptr, i64 ldfb = 0, i64 fm = 0,
-                      i64 e = 0) {
+                      i64 e = 0, double* TR = nullptr, i64 ldt = 0, i64 tn = 0) {
     const i64 T = GPS_TILE;
     const bool la = (g >= 2) && ops.lookahead();
     const bool fol = la && FB != nullptr && fm > 0;
@@ -185,7 +194,9 @@ struct Blocked {
       int rc = 0;
       if (c_lo > 0) rc = ops.gemm(0, 0, fm, c_hi - c_lo, c_lo, FB, ldfb, A + c_lo * lda, lda, FB + c_lo, ldfb);
       if (rc) return rc;
-      return trsm_rec(A + c_lo * lda + c_lo, lda, c_hi - c_lo, blk0 + c_lo / T, FB + c_lo, ldfb, fm);
+      rc = trsm_rec(A + c_lo * lda + c_lo, lda, c_hi - c_lo, blk0 + c_lo / T, FB + c_lo, ldfb, fm);
+      if (rc || TR == nullptr) return rc;
+      return ops.gemm(0, 1, fm, tn, c_hi - c_lo, FB + c_lo, ldfb, FB + c_lo, ldfb, TR, ldt);
     };
     auto finish = [&]() -> int {
       int rc = pending ? ops.chain_join(pending) : 0;

@@ -136,6 +136,7 @@ struct HipOps {
   hipStream_t saved_stream_d = nullptr;
   bool follower() { return h->potrf_follower != 0 && lookahead() && aux_stream(); }
   i64 follower_cols() const { return h->potrf_follower_cols; }
+  bool trail_follows() const { return h->potrf_trail_follows != 0; }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
   // its second GEMM workgroup (measured: every big launch 4-10 % slower).  An event keeps the queue parked instead;
@@ -304,11 +305,11 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   if (device_id < 0 || device_id >= count) return GPS_ERR_ARG;
   gps_handle_t h = new gps_handle_s();
   h->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&h->prop, device_id) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&h->prop, device_id) != hipSuccess) {
     delete h;
     return GPS_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   for (int i = 0; i < 8; ++i) {
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   }
@@ -442,6 +443,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "kmat_fast") == 0) { h->kmat_fast = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_wave") == 0) { h->trsv_wave = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_trail_follows") == 0) { h->potrf_trail_follows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_persistent") == 0) { h->leaf_persistent = (int)value; return GPS_OK; }
   if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }

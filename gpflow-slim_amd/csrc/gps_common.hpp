@@ -111,6 +111,7 @@ struct gps_handle_s {
   // forward substitution of gps_gpr_lml following the factorisation on a stream of its own (blocked.hpp: YFollow).
   // Off: measured on MI355X, ~500 small kernels dribbling in beside the 128x128 GEMM rounds (which own every register of
   // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).
+  int potrf_trail_follows = 0;   // the trailing update behind a swept first half applied piece by piece behind the sweep (blocked.hpp): measured, loses
   int leaf_persistent = 1;       // refined solve leaves: resident workgroups walk the row tiles (trsm_leaf.hip)
   int trsv_follow = 0;
   int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp

@@ -103,6 +103,7 @@ struct CpuOps {
   int deferred_close() { if (!def_open) return -14; def_open = 0; def_unjoined = 1; return 0; }
   int deferred_join() { if (!def_unjoined) return -15; def_unjoined = 0; return 0; }
   i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
+  bool trail_follows() const { return g_lookahead == 2; }        // (both forms of the trailing update are emulated)
   unsigned long long fol_pub = 0;
   int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }
   int side_publish_join(unsigned long long t) { if (open_side != t || unjoined) return -8; unjoined = t; return 0; }
