@@ -7,11 +7,17 @@ triangular solve + log-det + reductions, nothing cached between steps: the hyper
 every step) on the BASELINE.json workload: RBF(ARD) GPR, N=32768, D=8, fp64, X resident in HBM.
 
 N = 1:  the fused single-GPU path (gps_gpr_lml).
-N > 1 (torch.distributed.run, one rank per GPU): ONE N x N factorisation per step, partitioned over all
-ranks by 1-D block-cyclic columns with the panel exchange over RCCL/xGMI (BASELINE.json configs[2];
-gpflowSlim/distributed.py) -> strong scaling: `value` = evaluations of the whole job per second.  The
-throughput of independent per-GPU evaluations (no collective) is reported beside it.
-Prints ONE JSON line on rank 0.
+N > 1 (one rank per GPU): ONE N x N factorisation per step, partitioned over all ranks by 1-D block-cyclic
+columns with the panel exchange over RCCL/xGMI (BASELINE.json configs[2]; gpflowSlim/distributed.py) ->
+strong scaling: `value` = evaluations of the whole job per second.  The throughput of independent per-GPU
+evaluations (no collective) is reported beside it.  Both launch forms run the same thing:
+
+    python bench.py --gpus N ...                                        (this process starts the N ranks itself)
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   (the ranks come from the launcher)
+
+In the first form the parent never imports torch and never touches a GPU: it starts N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relays rank 0's JSON line and exits non-zero
+if any rank does.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import hashlib
@@ -25,8 +31,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "gpflow-slim_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X spec: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -43,6 +47,53 @@ def kernel_source_sha():
     return hsh.hexdigest()[:16]
 
 
+def launch_ranks(n_ranks, argv, timeout_s):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this very script and relay
+    rank 0's output.  Runs before anything GPU-related is imported (the parent stays torch-free: a process that
+    has initialised the GPU must never be the one that starts or replaces GPU programs).  Returns the exit status:
+    0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    assert "torch" not in sys.modules, "the launcher must not have imported torch"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   GPS_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+        # rank 0 writes the JSON line to our stdout; the other ranks' stdout goes to stderr (nothing of theirs is the line)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + timeout_s
+    status = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (procs.index(p), rc), file=sys.stderr)
+                deadline = min(deadline, time.time() + 15.0)          # the others see the broken group and leave; else kill
+        if live and time.time() > deadline:
+            if status == 0:
+                status = 2
+                print("bench.py: ranks still running after %.0f s; killing them" % timeout_s, file=sys.stderr)
+            for p in live:
+                p.kill()                                              # exactly the processes started above
+            for p in live:
+                p.wait()
+            live = []
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,7 +103,10 @@ def main():
     ap.add_argument("--dims", dest="d", type=int, default=8)
     ap.add_argument("--num-new", dest="n_new", type=int, default=1024)
     ap.add_argument("--num-new-throughput", dest="n_new_tp", type=int, default=8192)
-    ap.add_argument("--cpu-sample-n", type=int, default=16384, help="oracle sample size for cpu_baseline (10-30 s of host time)")
+    ap.add_argument("--cpu-sample-n", type=int, default=32768,
+                    help="size the CPU stand-in (oracle) is timed at for cpu_baseline; default = the full workload, one repetition "
+                         "(SURVEY 8d: ~75 s on the GPU box's host); smaller values are extrapolated stage by stage and flagged")
+    ap.add_argument("--small-n", default="512,2048", help="sizes of the small-N latency table (the reference's own example is N ~ 455); '' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
@@ -64,13 +118,20 @@ def main():
     ap.add_argument("--independent-steps", type=int, default=2, help="N > 1: steps of the independent-evaluations side measurement (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before torch / the library / any GPU call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.dist_timeout + 600.0))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and (args.gpus > 1 or os.environ.get("GPS_BENCH_SELF_LAUNCHED")):
+        print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if args.force_device >= 0:
         local_rank = args.force_device
     os.environ["GPFLOWSLIM_DEVICE"] = str(local_rank)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -142,9 +203,12 @@ def main():
                                   "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": workload},
                                   "error": "watchdog: the block-column run did not finish within %.0f s" % args.dist_timeout}), flush=True)
             os._exit(2)
-        timer = threading.Timer(args.dist_timeout, on_timeout)
-        timer.daemon = True
-        timer.start()
+        def arm():
+            t = threading.Timer(args.dist_timeout, on_timeout)
+            t.daemon = True
+            t.start()
+            return t
+        timer = arm()
         comm = TorchComm()
         tune = None
         set_step(-1, False)
@@ -178,8 +242,10 @@ def main():
             lml = gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)
         sync()
         elapsed = time.perf_counter() - t0
-        state["done"] = True
+        # the collectives below (gathers, the parity evaluation, the independent evaluations, the final barrier) stay
+        # under a watchdog of their own: it is only disarmed after the last barrier
         timer.cancel()
+        timer = arm()
         scaling = "strong"
         parallelism = "1-D block-cyclic column Cholesky over %d GPUs (nb=%d, look-ahead %d, panel exchange: %s over %s)" % (
             world, args.dist_nb, args.dist_lookahead, comm.mode, args.backend)
@@ -256,6 +322,34 @@ def main():
         torch.cuda.synchronize(); t1 = time.perf_counter()
         model.compute_log_likelihood_and_gradients()
         torch.cuda.synchronize(); grad_ms = 1e3 * (time.perf_counter() - t1)
+
+        # per-step latency at the size of the reference's only exhibited workload (examples/gpr.py:36,60: N ~ 455, D = 13,
+        # 20 000 optimiser steps, each one LML + gradient): microseconds per step and launches per step, same kernel family
+        small = None
+        if args.small_n:
+            small = {}
+            for ns_ in [int(v) for v in args.small_n.split(",") if v]:
+                if ns_ > n:
+                    continue
+                ks = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls0, ARD=True)
+                msml = gpf.models.GPR(X[:ns_], Y[:ns_], ks, obs_var=0.1)
+                row = {}
+                for what, fn in (("lml", msml.compute_log_likelihood), ("lml_plus_gradient", msml.compute_log_likelihood_and_gradients)):
+                    reps = 200 if ns_ <= 1024 else 100
+                    for i in range(5):
+                        ks._ls.assign(ls0 * (1.0 + 0.01 * i)); fn()
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for i in range(reps):
+                        ks._ls.assign(ls0 * (1.0 + 0.01 * (i % 17))); fn()
+                    torch.cuda.synchronize(); us = 1e6 * (time.perf_counter() - t1) / reps
+                    h.profile_reset(); h.profile_enable(True)
+                    fn()
+                    h.profile_enable(False)
+                    launches = sum(h.profile_get(k)["launches"] for k in ("gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"))
+                    row[what] = {"us_per_step": round(us, 1), "launches_per_step": int(launches), "steps_timed": reps}
+                small["n=%d" % ns_] = row
+            small["note"] = ("wall time per call through the Python API incl. the host round trip of the result; hyper-parameters "
+                             "change every step; D=%d RBF(ARD)" % d)
 
         roofline = None
         hbm_bound = None
@@ -339,27 +433,31 @@ def main():
                 blas = ";".join(sorted({"%s %s" % (i.get("internal_api"), i.get("version")) for i in info}))
             except Exception:
                 threads, blas = os.cpu_count(), "unknown"
-            # stage-wise extrapolation to the full size: K build and the triangular solve are O(N^2), dpotrf O(N^3)
+            # the full workload, one repetition -- or, for a smaller --cpu-sample-n, a stage-wise extrapolation
+            # (K build and the triangular solve are O(N^2), dpotrf O(N^3)) that the line flags as such
             q = float(n) / ns
             full_s = tm["kmat_s"] * q ** 2 + tm["potrf_s"] * q ** 3 + tm["trsv_s"] * q ** 2
+            how = ("the full workload, timed once, nothing extrapolated" if ns == n else
+                   "extrapolated stage by stage to N=%d: K build and solve x%.0f, dpotrf x%.0f -> %.1f s per evaluation" % (
+                       n, q ** 2, q ** 3, full_s))
             cpu = {"value": round(1.0 / full_s, 6), "unit": "evals/s", "cores": threads,
-                   "kind": "port",
+                   "kind": "port", "extrapolated": ns != n,
                    "sample": "oracle (numpy/scipy %s, %d BLAS threads of %d logical cores) LML at N=%d D=%d: %.2f s = K build "
                              "unfused like the reference's TF graph %.2f (in place: %.2f) + dpotrf %.2f + dtrtrs / reductions %.2f; "
-                             "extrapolated stage by stage to N=%d: K build and solve x%.0f, dpotrf x%.0f -> %.1f s per evaluation; "
-                             "stand-in for the reference TF-CPU path, which cannot run (no TensorFlow)" % (
-                                 blas, threads, os.cpu_count(), ns, d, tm["total_s"], tm["kmat_s"], kin, tm["potrf_s"], tm["trsv_s"],
-                                 n, q ** 2, q ** 3, full_s),
+                             "%s; stand-in for the reference TF-CPU path, which cannot run (no TensorFlow)" % (
+                                 blas, threads, os.cpu_count(), ns, d, tm["total_s"], tm["kmat_s"], kin, tm["potrf_s"], tm["trsv_s"], how),
                    "sample_seconds": round(tm["total_s"], 3), "kmat_inplace_seconds": round(kin, 3),
                    "sample_parity_rel_err": abs(got - ref_lml) / abs(ref_lml)}
 
-        out = {"metric": metric, "value": round(value, 4), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+        out = {"metric": metric, "value": round(value, 4), "unit": "evals/s",
+               "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": workload, "n": n, "d": d, "n_new": args.n_new, "parallelism": parallelism},
                "predict_f_latency_ms": {"cold_refactor": round(cold_ms, 2), "warm_resident_factor": round(warm_ms, 2), "n_new": args.n_new},
                "predict_f_throughput": predict_tp,
                "lml_plus_gradient_ms": round(grad_ms, 2),
+               "small_n_latency": small,
                "stage_ms_one_gpu_eval": {k: round(v, 3) for k, v in stages.items()},
                "lml_last_step": lml,
                "roofline": roofline, "hbm_bound_kernels": hbm_bound, "cpu_baseline": cpu}
@@ -367,6 +465,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        state["done"] = True
+        timer.cancel()
         dist.destroy_process_group()
 
 

@@ -408,6 +408,11 @@ extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launc
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
     return GPS_OK;
   }
+  if (strcmp(klass, "factor_refined") == 0) {         // 1: the resident GPR factor was built (and is solved) with refined leaves
+    if (launches) *launches = h->factor_refine ? 1 : 0;
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   if (strcmp(klass, "trsv_wave_fallbacks") == 0) {    // wavefront substitutions that gave up (handle fell back to the recursive one)
     if (launches) *launches = (int64_t)h->wave_fallbacks;
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
@@ -447,10 +452,11 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "leaf_persistent") == 0) { h->leaf_persistent = (int)value; return GPS_OK; }
   if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
-  if (strcmp(key, "leaf_refine_ratio") == 0) { h->leaf_refine_ratio = value; return GPS_OK; }
+  if (strcmp(key, "leaf_refine_cond") == 0) { h->leaf_refine_cond = value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "la_fault_inject") == 0) { h->la_fault_inject = (int)value; return GPS_OK; }
+  if (strcmp(key, "wave_fault_inject") == 0) { h->wave_fault_inject = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
@@ -744,11 +750,11 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   const i64 n = h->n, np = h->npad;
   h->have_factor = false;
   {
-    // leaves refined or not: K + noise I is well conditioned unless the noise is tiny against the prior variance
+    // leaves refined or not: from the bound cond(K + noise I) <= (N Kdiag + noise) / noise (gps_gpr_needs_refine)
     double kd = 0.0;
     int rck = gps_launch_kdiag(h, prog, n_nodes, &kd);
     if (rck) return rck;
-    h->refine_now = h->leaf_refine > 0 || (h->leaf_refine < 0 && !(noise_var >= h->leaf_refine_ratio * kd));
+    h->refine_now = gps_gpr_needs_refine(h, noise_var, kd, h->n);
     h->factor_refine = h->refine_now;
   }
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
@@ -852,6 +858,9 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
                                 int* info) {
   if (!h || !lml || !grad_slots || !grad_noise || r <= 0)
     return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml_grad: bad argument");
+  // (a hand-over of the look-ahead or of the backward wavefront substitution that gives up invalidates this call, not the
+  // next one: the body runs again, once, through the recursive forms -- with_la_retry)
+  return with_la_retry(h, [&]() -> int {
   GPS_HIP(h, hipSetDevice(h->device));
   int ns = 0;
   int rc = gps_grad_slots(h, prog, n_nodes, &ns);
@@ -889,9 +898,13 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
     GPS_HIP(h, hipMemcpyAsync(kinv_resid, h->dTmp2.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
   }
   GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
-  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  // synchronises, and surfaces a backward wavefront substitution that gave up (its result would poison dA and every
+  // gradient slot) as GPS_ERR_STATE for the retry above instead of leaving the counter for the next entry point
+  rc = read_info(h, (int*)h->dInfo.p, nullptr);
+  if (rc) return rc;
   stage_time(h, 5, 6, &h->stage_ms[3]);
   return GPS_OK;
+  });
 }
 
 extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
@@ -1461,7 +1474,22 @@ static int svgp_whiten(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   return GPS_OK;
 }
 
+static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                                  int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
+                                  const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
+                                  double noise_var, double scale, double* elbo, double* grad_slots, int n_slots_cap,
+                                  int* n_slots_out, double* grad_noise, double* grad_q_mu, double* grad_q_sqrt,
+                                  double* grad_mean, double* grad_Z, int* info);
+// (wrapped like every factorising entry point: a missed look-ahead hand-over re-runs the body once, with_la_retry)
 extern "C" int gps_svgp_elbo_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                                  int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
+                                  const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
+                                  double noise_var, double scale, double* elbo, double* grad_slots, int n_slots_cap,
+                                  int* n_slots_out, double* grad_noise, double* grad_q_mu, double* grad_q_sqrt,
+                                  double* grad_mean, double* grad_Z, int* info) {
+  return with_la_retry(h, [&]() -> int { return svgp_elbo_grad_body(h, prog, n_nodes, Z, m, d_all, jitter, X, n, yres, q_mu, k, q_sqrt, q_sqrt_ndim, white, noise_var, scale, elbo, grad_slots, n_slots_cap, n_slots_out, grad_noise, grad_q_mu, grad_q_sqrt, grad_mean, grad_Z, info); });
+}
+static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                                   int64_t d_all, double jitter, const double* X, int64_t n, const double* yres,
                                   const double* q_mu, int64_t k, const double* q_sqrt, int q_sqrt_ndim, int white,
                                   double noise_var, double scale, double* elbo, double* grad_slots, int n_slots_cap,
@@ -1924,7 +1952,7 @@ extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n
     double kd = 0.0;
     int rck = gps_launch_kdiag(h, prog, n_nodes, &kd);
     if (rck) return rck;
-    h->factor_refine = h->leaf_refine > 0 || (h->leaf_refine < 0 && !(noise_var >= h->leaf_refine_ratio * kd));
+    h->factor_refine = gps_gpr_needs_refine(h, noise_var, kd, h->n);
   }
   GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
@@ -2364,7 +2392,18 @@ static int sparse_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int n_n
 //   d/d s = -|u|^2 / s^3 - <B_bar, G> / s^2 - R tr(G) / (2 s^2) - N R / (2 s) + |err|^2 / (2 s^2) + R N Kdiag / (2 s^2),
 //           <B_bar, G> = s (<LB_bar, LB> / 2 - tr B_bar)     (B = LB LB^T scales like LB^2; no second copy of G is kept)
 //   d/d mean(X) = err / s - A^T vbar ; d/d Z through k(Z, X) and k(Z, Z) (gps_launch_kmat_input_vjp).
+static int sgpr_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info);
+// (wrapped like every factorising entry point: a missed look-ahead hand-over re-runs the body once, with_la_retry)
 extern "C" int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  return with_la_retry(h, [&]() -> int { return sgpr_grad_body(h, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, bound, grad_slots, n_slots_cap, n_slots_out, grad_noise, grad_mean, grad_Z, info); });
+}
+static int sgpr_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                              const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                              const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
                              int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
@@ -2481,7 +2520,18 @@ extern "C" int gps_sgpr_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_
 //   Ah_bar = 2 B_bar Ah + vbar beta^T ; beta_bar = Ah^T vbar - beta
 //   wbar_i = <Ah_bar[:, i], A[:, i]> + <beta_bar_i, err_i> ; nubar_i = -wbar_i nu_i^-3/2 / 2 - R / (2 nu_i)
 //   sbar = sum nubar ; Kdiag_bar = sum nubar ; A_bar[:, i] = w_i Ah_bar[:, i] - 2 nubar_i A[:, i] ; then the common tail.
+static int fitc_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info);
+// (wrapped like every factorising entry point: a missed look-ahead hand-over re-runs the body once, with_la_retry)
 extern "C" int gps_fitc_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
+                             const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
+                             const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
+                             int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  return with_la_retry(h, [&]() -> int { return fitc_grad_body(h, prog, n_nodes, Z, m, X, n, d_all, jitter, noise_var, resid, r, bound, grad_slots, n_slots_cap, n_slots_out, grad_noise, grad_mean, grad_Z, info); });
+}
+static int fitc_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Z, int64_t m,
                              const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                              const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
                              int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {

@@ -128,6 +128,7 @@ struct gps_handle_s {
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
   int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
+  int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"
   bool la_timed_out = false;                   // set by read_info when a hand-over wait gave up: the entry point re-runs without look-ahead
   long long la_retries = 0;                    // evaluations re-run that way (gps_profile_get "lookahead_retries")
   PinnedRing ring;
@@ -137,11 +138,12 @@ struct gps_handle_s {
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned
-  // (every jittered path: conditional / base_conditional / SGPR / FITC / host-matrix potrf + trsm; GPR when the noise
-  // variance is below leaf_refine_ratio x Kdiag), 0 = plain product with the block inverse, 1 = always refine
+  // (every jittered path: conditional / base_conditional / SGPR / FITC / host-matrix potrf + trsm; GPR when the bound
+  // cond_2(K + s I) <= (N Kdiag + s) / s -- lambda_max <= trace -- exceeds leaf_refine_cond, see gps_gpr_needs_refine),
+  // 0 = plain product with the block inverse, 1 = always refine
   int gpr_aug_rows = -1;         // gps_gpr_lml / predict: (Y - m)^T as augmented rows of the factorisation instead of a trsv pass (-1: below 6200 points)
   int leaf_refine = -1;
-  double leaf_refine_ratio = 1e-3;
+  double leaf_refine_cond = 2e6;
   bool refine_now = false;       // resolved at every API entry
   bool factor_refine = false;    // what the resident GPR factor was built with (warm predict_f keeps it)
   int kmat_fast = 1;             // one-primitive stationary programs: the stack-free kernel-matrix kernel (kmat.hip)
@@ -283,6 +285,17 @@ int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const
                                 int upper);
 int gps_launch_trsv_leaf_refine(gps_handle_t h, const double* Wt, const double* D, i64 ldd, double* y, i64 ldy, i64 r,
                                 int upper);
+// Leaves of the GPR solves refined or not (leaf_refine = -1).  A product with an explicit block inverse is within
+// ~7 u cond of the exact solve (measured against 60-digit arithmetic, tests/golden/exact: 1.5e-7 at cond 2e8), the refined
+// leaf within ~0.6 u cond like LAPACK's substitution.  The plain leaves therefore keep the 1e-8 contract while
+// 7 u cond <= 1e-8, i.e. cond <= 1.3e7; cond_2(K + s I) <= (lambda_max + s) / s <= (N Kdiag + s) / s for every positive
+// semi-definite K with constant diagonal, so the switch is a bound that knows N, with a factor 6 to spare:
+// refine when (N Kdiag + s) / s > leaf_refine_cond = 2e6.  (Headline: N = 32768, Kdiag = 1, s = 0.1: 3.3e5 -> plain.)
+static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var, double kdiag, i64 n) {
+  if (h->leaf_refine >= 0) return h->leaf_refine > 0;
+  return !((double)n * kdiag + noise_var <= h->leaf_refine_cond * noise_var);      // (NaN / zero noise: refine)
+}
+
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
                          int trans);

@@ -250,5 +250,9 @@ int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const 
                                 : tw_launch<1, false>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl);
     if (rc) return rc;
   }
+  // diagnostics ("wave_fault_inject" = k): the k-th substitution from now leaves the give-up counter set, as a workgroup
+  // whose bounded wait ran out would (tests/test_gpu_kernels.py::test_wavefront_give_up_is_retried_by_the_gradient)
+  if (h->wave_fault_inject > 0 && --h->wave_fault_inject == 0)
+    GPS_HIP(h, hipMemsetAsync((unsigned char*)(ctl + 1), 1, 1, h->stream));
   return GPS_OK;
 }

@@ -102,6 +102,18 @@ def block_column_schedule(ops, comm, n_panels, lookahead=2):
 
 
 # ---- GPU side -------------------------------------------------------------------------------------
+_UNSUPPORTED = (NotImplementedError, RuntimeError)
+
+
+def _is_unsupported(exc):
+    """An exception a collective raises synchronously, on every rank alike, because the backend lacks the operation for
+    these tensors (gloo + device tensors: "... does not support ..." / "not implemented")."""
+    if isinstance(exc, NotImplementedError):
+        return True
+    text = str(exc).lower()
+    return any(k in text for k in ("not support", "unsupported", "not implemented", "no backend type"))
+
+
 class TorchComm(object):
     """torch.distributed (backend "nccl" = RCCL on ROCm, or "gloo") behind the tiny comm interface."""
 
@@ -135,7 +147,12 @@ class TorchComm(object):
                 torch.cuda.synchronize()
             if not bool((t == torch.arange(2 * P, dtype=torch.float64, device=dev)).all()):
                 ok = 0
-        except Exception:
+        except _UNSUPPORTED as e:
+            # only "this backend has no such operation for these tensors": raised at call time, before anything is
+            # enqueued, on every rank alike.  Anything else (an RCCL error on one rank, an aborted communicator) leaves the
+            # other ranks inside the collective -- an agreement all-reduce on the same group would hang: that is fatal.
+            if not _is_unsupported(e):
+                raise
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
@@ -169,7 +186,9 @@ class TorchComm(object):
                     self.exchange(buf, i % P).wait()
                 sync()
                 dt = (time.perf_counter() - t0) / reps
-            except Exception:
+            except _UNSUPPORTED as e:
+                if not _is_unsupported(e):          # (see _probe: only a synchronous "unsupported" may be voted on)
+                    raise
                 ok = 0
             res = torch.tensor([float(ok), dt if ok else 1e30], dtype=torch.float64, device=dev)
             agree = res.clone()
@@ -304,6 +323,11 @@ class HipPanelOps(object):
     def close(self):
         if self._installed:
             self._installed = False
+            # both lanes are drained on every exit path: when the schedule, an exchange or the finish raised (a
+            # not-positive-definite panel raises on every rank), trailing updates may still be running on the BULK lane
+            # and the caller's next launch on the handle's own stream would rebuild K under them
+            if self.bulk is not self.chain:
+                self.chain.wait_stream(self.bulk)
             self.torch.cuda.current_stream().wait_stream(self.chain)
             try:
                 self.h.dist_set_bulk_stream(0)

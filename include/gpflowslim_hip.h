@@ -348,8 +348,10 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     diagonal block (X0 = B W^T; R = B - X0 L11^T; X = X0 + R W^T, W = inv(L11): the accuracy of
  *                     tf.matrix_triangular_solve's substitution, conditionals.py:87,100) wherever the matrix may be ill
  *                     conditioned: gps_conditional / gps_base_conditional / gps_svgp_elbo / gps_gauss_kl / gps_sgpr /
- *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when noise_var <
- *                     "leaf_refine_ratio" (default 1e-3) x Kdiag; 0: plain products with the block inverses; 1: always
+ *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when the bound
+ *                     cond_2(K + noise I) <= (N Kdiag + noise) / noise exceeds "leaf_refine_cond" (default 2e6: the plain
+ *                     products are ~7 u cond from exact, 1e-8 holds up to cond 1.3e7); 0: plain products with the block
+ *                     inverses; 1: always
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always

@@ -135,9 +135,18 @@ def _worker(rank, world, port, n, nb, lookahead, mode, q):
             comm._probe()
             assert comm.mode == "scatter_allgather" and comm.bytes_sent == 0
             real = comm._scatter_allgather
-            comm._scatter_allgather = lambda *a: (_ for _ in ()).throw(RuntimeError("no scatter here"))
+            # a backend that lacks the operation raises synchronously on every rank alike ...
+            comm._scatter_allgather = lambda *a: (_ for _ in ()).throw(RuntimeError("ProcessGroup: scatter is not supported for these tensors"))
             comm._probe()
             assert comm.mode == "broadcast"                     # every rank fell back together
+            # ... anything else is not voted on (the other ranks may be inside the failed collective): it propagates
+            comm.mode = "scatter_allgather"
+            comm._scatter_allgather = lambda *a: (_ for _ in ()).throw(RuntimeError("RCCL error: unhandled system error"))
+            try:
+                comm._probe()
+                raise AssertionError("a rank-local collective failure must not be swallowed")
+            except RuntimeError as e:
+                assert "unhandled system error" in str(e)
             comm._scatter_allgather, comm.mode = real, "scatter_allgather"
             times = comm.autotune(doubles=4096, reps=2)         # measured choice of the exchange: both modes work here
             assert set(times) == {"broadcast", "scatter_allgather"} and comm.mode in times and comm.bytes_sent == 0

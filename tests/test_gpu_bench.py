@@ -67,6 +67,29 @@ def test_bench_two_ranks_block_column_gloo():
     assert out["cpu_baseline"] is None                                                        # timed at N = 1 only
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form): bench.py starts the two rank
+    processes itself and relays rank 0's line -- the block-column path, not the 1-GPU path timed twice."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512", "--dist-timeout", "200",
+           "--no-dist-autotune", "--independent-steps", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                   # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert COMMON <= set(out), sorted(COMMON - set(out))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2 and out["value"] > 0
+    dd = out["distributed"]
+    assert dd["rccl_ranks"] == 2 and dd["parity_rel_err_vs_one_gpu"] <= 1e-9
+    assert "block-cyclic" in out["config"]["parallelism"]
+    # a --gpus that disagrees with the launcher's rank count is an error, not a silently different run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
+                         text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode == 2 and "--gpus 4" in bad.stderr
+
+
 def test_bench_two_ranks_autotuned_panel_width():
     """The default N > 1 run picks the panel width (and, under RCCL, the exchange) by measurement during warm-up: the
     timed steps run the chosen configuration and the line says which."""

@@ -289,6 +289,36 @@ def test_trsv_wavefront_equals_recursive_substitution(handle, n, r):
     assert handle.profile_get("trsv_wave_fallbacks")["launches"] == 0
 
 
+@pytest.mark.parametrize("which", [1, 2])
+def test_wavefront_give_up_is_retried_by_the_gradient(which):
+    """A wavefront substitution that gives up (injected: the forward one of the likelihood, or the backward one of the
+    gradient's K^-1 y) must not leave NaN gradients behind with status OK, nor a sticky counter for the next entry point:
+    the call that caused it re-runs through the recursive substitution, the event is counted, the handle falls back."""
+    import gpflowSlim as gpf
+    from gpflowSlim import _backend as be
+    import oracle.gp_oracle as orc
+    n, d = 6400, 3                                         # (above the augmented-row limit: both solves are wavefronts)
+    X, Y, _ = orc.synthetic_gpr_data(n, d, 0, seed=21)
+    prog = gpf.kernels.RBF(d, variance=1.1, lengthscales=1.4)._program(d)
+    h = be.Handle(0)
+    try:
+        h.gpr_set_data(X, ("wavefault", which))
+        ref = h.gpr_lml_grad(prog, 0.1, Y)
+        assert h.profile_get("trsv_wave_fallbacks")["launches"] == 0
+        h.set_option("wave_fault_inject", which)
+        got = h.gpr_lml_grad(prog, 0.1, Y)
+        assert h.profile_get("trsv_wave_fallbacks")["launches"] == 1
+        for a, b in zip(got[:4], ref[:4]):
+            a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+            assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+        # the next, unrelated entry point neither fails nor retries
+        before = h.profile_get("lookahead_retries")["launches"]
+        assert abs(h.gpr_lml(prog, 0.1, Y) - ref[0]) <= 1e-12 * abs(ref[0])
+        assert h.profile_get("lookahead_retries")["launches"] == before
+    finally:
+        h.close()
+
+
 def test_release_buffers_gives_memory_back_and_the_handle_stays_usable(handle):
     import torch
     import gpflowSlim as gpf

@@ -133,6 +133,65 @@ def solve_tol(K):
     return max(RTOL, 2.0 * EPS * float(np.linalg.cond(K)))
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("n", [1024, 4096])
+@pytest.mark.parametrize("ratio", [1e-5, 1e-4, 9e-4, 1.1e-3, 5e-3, 1e-2])
+def test_gpr_low_noise_sweep(handle, kind, n, ratio):
+    """The GPR rows at the noise levels a fit actually reaches (the reference trains the likelihood variance down towards
+    its 1e-6 floor, likelihoods.py:162; models/gpr.py:69-72,119-131): noise / Kdiag from 1e-5 to 1e-2 on two-dimensional
+    inputs, where K + s I is as ill conditioned as the bound N Kdiag / s allows within a factor ~10.  LML, posterior mean and
+    variance against the oracle within solve_tol(K + s I) = max(1e-8, 2 eps cond_2), whatever the library decides about its
+    solve leaves -- and the decision itself is the conditioning bound that knows N (gps_common.hpp::gps_gpr_needs_refine),
+    not a fitted noise ratio."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(int(n + 1e7 * ratio))
+    d, ns, var = 2, 50, 1.3
+    X = rng.uniform(-3.0, 3.0, (n, d))
+    Xs = rng.uniform(-3.0, 3.0, (ns, d))
+    noise = orc.constrained(ratio * var)
+    Y = np.sin(X[:, :1]) * np.cos(0.5 * X[:, 1:2]) + np.sqrt(noise) * rng.standard_normal((n, 1))
+    c = orc.constrained
+    if kind == "rbf":
+        kern = gpf.kernels.RBF(d, variance=var, lengthscales=0.8)
+        spec = {"type": "rbf", "variance": c(var), "lengthscales": c(0.8), "input_dim": d}
+    else:
+        kern = gpf.kernels.Matern52(d, variance=var, lengthscales=1.6)
+        spec = {"type": "matern52", "variance": c(var), "lengthscales": c(1.6), "input_dim": d}
+    m = gpf.models.GPR(X, Y, kern, obs_var=ratio * var)
+    assert float(np.squeeze(m.likelihood.variance)) == pytest.approx(float(noise), rel=1e-14)
+    Ky = orc.K(spec, X) + noise * np.eye(n)
+    ev = np.linalg.eigvalsh(Ky)
+    cond = ev[-1] / ev[0]
+    assert cond <= (n * c(var) + noise) / noise                  # the bound the switch uses
+    tol = max(RTOL, 2.0 * EPS * cond)
+    lml = m.compute_log_likelihood()
+    refined = handle.profile_get("factor_refined")["launches"]
+    assert refined == int((n * float(c(var)) + noise) / noise > 2e6)
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    assert abs(lml - ref) <= tol * abs(ref), (cond, refined, abs(lml - ref) / abs(ref))
+    mu, v = m.predict_f(Xs)
+    rmu, rv = orc.gpr_predict(spec, X, Y, noise, Xs)
+    assert rel(mu, rmu) <= tol and rel(v, rv) <= tol, (cond, refined, rel(mu, rmu), rel(v, rv))
+    m.reuse_factor = True                                        # warm: the resident factor keeps its leaves' mode
+    mu2, v2 = m.predict_f(Xs)
+    assert np.array_equal(mu2, mu) and np.array_equal(v2, v)
+
+
+def test_gpr_refine_switch_knows_n(handle):
+    """The same noise / Kdiag ratio 1.1e-3 (just above the round-2 switch, which ignored N): plain leaves at N = 512
+    (bound 4.7e5), refined ones at N = 8192 (7.4e6) -- and the headline workload (N = 32768, ratio 0.1: 3.3e5) stays plain,
+    which is decided here from the bound alone, without running it."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(12)
+    for n, want in ((512, 0), (8192, 1)):
+        X = rng.uniform(-3.0, 3.0, (n, 2))
+        Y = np.sin(X[:, :1])
+        m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2, variance=1.0, lengthscales=1.0), obs_var=1.1e-3)
+        m.compute_log_likelihood()
+        assert handle.profile_get("factor_refined")["launches"] == want
+    assert (32768 * 1.0 + 0.1) / 0.1 < 2e6
+
+
 def test_gpr_mean_function_and_min_var(handle):
     import gpflowSlim as gpf
     rng = np.random.default_rng(3)

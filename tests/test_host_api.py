@@ -176,3 +176,26 @@ def test_optimize_drivers_on_a_quadratic():
         assert float(m.c.vf_val) == 7.0                       # not trainable: untouched
         assert f == pytest.approx(49.0, abs=1e-4)             # what the frozen parameter leaves
         assert m.objective == pytest.approx(f, abs=1e-9)
+
+
+def test_bench_launcher_stays_off_the_gpu_and_reports_failure():
+    """`python bench.py --gpus N` without a launcher starts the N ranks as fresh child processes; the parent must not
+    import torch (nothing that could initialise a GPU) and must exit non-zero when a rank fails -- here every rank
+    fails loudly because this machine has no GPU."""
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); import bench\n"
+            "rc = bench.launch_ranks(2, ['--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0'], 120.0)\n"
+            "assert 'torch' not in sys.modules and 'gpflowSlim' not in sys.modules, sorted(sys.modules)\n"
+            "print('launcher rc', rc)\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the failure leg needs a machine without a GPU")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "launcher rc 1" in p.stdout, (p.stdout, p.stderr[-2000:])
+    assert "needs an MI355X" in p.stderr and "exited with status" in p.stderr
+    # and through the command line: same thing, non-zero status
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert q.returncode != 0 and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]
