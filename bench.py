@@ -116,6 +116,11 @@ def main():
     ap.add_argument("--dist-timeout", type=float, default=600.0, help="watchdog (s) around the distributed run")
     ap.add_argument("--no-dist-autotune", action="store_true", help="N > 1: keep --dist-nb / --dist-lookahead and the default exchange instead of choosing by measurement during warm-up")
     ap.add_argument("--independent-steps", type=int, default=2, help="N > 1: steps of the independent-evaluations side measurement (0 = skip)")
+    ap.add_argument("--workload", default="gpr", choices=["gpr", "cfg5"],
+                    help="gpr (default): the BASELINE headline; cfg5: side line for BASELINE configs[4] -- conditional() / SVGP bound with "
+                         "M inducing points over N data points, the data points sharded over the ranks (gpflowSlim/distributed_sparse.py)")
+    ap.add_argument("--cfg5-m", type=int, default=4096)
+    ap.add_argument("--cfg5-n", type=int, default=1000000)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -142,6 +147,13 @@ def main():
         dist.init_process_group(args.backend)
 
     import gpflowSlim as gpf
+
+    if args.workload == "cfg5":
+        run_cfg5(args, rank, world, torch, dist, gpf, np)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n, d = args.n, args.d
     # synthetic inputs of SURVEY 8(d)
@@ -251,7 +263,7 @@ def main():
             world, args.dist_nb, args.dist_lookahead, comm.mode, args.backend)
         stage = h.last_stage_ms()
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {k: round(v, 3) for k, v in stage.items()})
+        dist.all_gather_object(per_rank, dict({k: round(v, 3) for k, v in stage.items()}, device_bytes=h.device_bytes()))
         sent = torch.tensor([float(comm.bytes_sent - bytes0)], dtype=torch.float64, device="cuda")
         dist.all_reduce(sent, op=dist.ReduceOp.SUM)
         try:
@@ -260,6 +272,8 @@ def main():
             rccl = None
         extra["distributed"] = {"nb": args.dist_nb, "lookahead": args.dist_lookahead, "exchange": comm.mode,
                                 "backend": args.backend, "rccl_ranks": dist.get_world_size(), "rccl_version": rccl,
+                                "factor_storage": "partitioned: a rank holds its own block columns only (8 N^2 / P bytes + O(N nb)); "
+                                                  "three comm buffers, the updates read a panel from the buffer it arrived in",
                                 "stage_ms_per_rank_last_step": per_rank,
                                 "payload_bytes_per_eval_all_ranks": float(sent.item()) / args.steps,
                                 "lml_last_step": lml, "autotune": tune}
@@ -468,6 +482,65 @@ def main():
         state["done"] = True
         timer.cancel()
         dist.destroy_process_group()
+
+
+def run_cfg5(args, rank, world, torch, dist, gpf, np):
+    """Side line for BASELINE configs[4] (examples/svgp.py shape: RBF, M inducing points, N data points): one step = one
+    conditional() (Kuu potrf + Kuf build + trsm + one-pass mean / variance; conditionals.py:24-119) over all N points, the
+    points sharded over the ranks (no data-path collective: only the gather of the [N, 1] outputs) -> weak in M, strong in
+    N: `value` = points / s of the whole job.  The SVGP bound (one scalar reduction) is timed beside it."""
+    from gpflowSlim.distributed import TorchComm, SingleComm
+    from gpflowSlim.distributed_sparse import conditional_distributed, svgp_bound_distributed
+    m, n, d = args.cfg5_m, args.cfg5_n, 8
+    rng = np.random.default_rng(20240607)
+    X = rng.standard_normal((n, d))
+    Y = np.sin(X @ (rng.standard_normal((d, 1)) / np.sqrt(d))) + 0.1 * rng.standard_normal((n, 1))
+    Z = X[:m].copy()
+    f = 0.1 * rng.standard_normal((m, 1))
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=np.sqrt(d) * np.ones(d), ARD=True)
+    comm = TorchComm() if world > 1 else SingleComm()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync(); t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / steps, out
+    t_cond, (fm, fv) = timed(lambda: conditional_distributed(X, Z, kern, f, comm=comm, white=True), args.steps, args.warmup)
+    mod = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.1), Z=Z, q_diag=True, whiten=True)
+    t_svgp, elbo = timed(lambda: svgp_bound_distributed(mod, comm), max(1, args.steps // 2), 1)
+    if rank == 0:
+        mp = ((m + 127) // 128) * 128
+        flops = float(mp) * mp * n + mp ** 3 / 3.0                       # SURVEY 8(d): trsm M^2 N + Kuu potrf
+        print(json.dumps({
+            "metric": "conditional() test points/sec, RBF, M=%d inducing points, N=%d points, fp64" % (m, n),
+            "value": round(n / t_cond, 1), "unit": "points/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_cond, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: conditional (white) with M=%d inducing points over N=%d points, D=%d, "
+                                   "data points sharded over the ranks" % (m, n, d),
+                       "parallelism": "%d rank(s), contiguous shards of the data points, Kuu factored by every rank, no data-path "
+                                      "collective (outputs gathered)" % world},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (trsm_rec)", "achieved": round(flops / t_cond / 1e12, 3),
+                         "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": round(flops / t_cond / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
+                         "note": "whole-step rate incl. the 8 M N-byte Kuf build, the mean / variance pass and the host gather"},
+            "cpu_baseline": None,
+            "svgp_bound": {"ms": round(1e3 * t_svgp, 3), "elbo": elbo, "q_diag": True,
+                           "collective": "one gathered scalar per rank, added in rank order"},
+            "checksum": {"fmean_sum": float(fm.sum()), "fvar_min": float(fv.min())}}), flush=True)
 
 
 def h_npad(n):

@@ -52,6 +52,7 @@ struct GemmArgs {
   // block; tiles entirely above a block's first row are skipped (the update is lower-trapezoidal).
   int cb_tiles;
   i64 cb_stride;
+  int cb_cpack = 0;   // C holds the owned blocks side by side (column b * nb, not b * cb_stride): partitioned storage
   // Tail split (nsplit > 1, grid = nfull + (ntiles - nfull) * nsplit): see the comment at the kernel.
   int nfull, nsplit;
   double* ws;         // [(ntiles - nfull) * nsplit][BM * BN] slice partials
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
     if (tid == 0) g.cnt[tail] = 0;       // ready for the next launch on this stream
   }
   const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
-  const i64 col0 = bcol + wc * WTN + (lane & 15);
+  const i64 col0 = (g.cb_cpack ? (i64)tn * BN : bcol) + wc * WTN + (lane & 15);
   // C read-modify-write in batches: all loads of a batch are issued before the first store.  (Written as
   // `*cp = *cp - acc` per element the compiler has to assume that a store may alias the next load -- ldc is a
   // run-time value -- and emits load / wait / store one element at a time: 64 memory round trips per thread,
@@ -547,8 +548,10 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
 // b = 0 .. nblocks-1 (nb columns each, block b starts `stride` rows / columns after block b-1):
 //     C[r][b*stride + c] -= sum_k A[r][k] * A[b*stride + c][k]     for rows r >= b*stride, c < nb
 // A: [M, K] panel rows from the first owned block on; C points at the same first row / first owned column.
+// c_packed: the owned blocks of C lie side by side (block b at column b * nb of C): every rank stores only its own block
+// columns (partitioned factor); the rows of A that form the B operand still step by `stride`.
 int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
-                              double* C, i64 ldc) {
+                              double* C, i64 ldc, int c_packed) {
   if (M <= 0 || nblocks <= 0) return GPS_OK;
   if (M % 128 || nb % 128 || stride % 128 || K % BK_MIN || stride < nb || (nblocks - 1) * stride + nb > M)
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
@@ -563,6 +566,7 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
   LaunchScope ls(h, KC_GEMM, flops, t128 * 2.0 * 128.0 * 128.0 * 8.0 + 8.0 * (double)K * (double)(M + nblocks * nb));
   const double target = (double)h->gemm_min_tiles;
   g.cb_stride = stride;
+  g.cb_cpack = c_packed ? 1 : 0;
   if (t128 >= target) { g.cb_tiles = (int)(nb / 128); return launch_cfg<128, 128, 2>(h, 0, 0, g, M, nblocks * nb); }
   if (4.0 * t128 >= target) { g.cb_tiles = (int)(nb / 64); return launch_cfg<64, 64, 2>(h, 0, 0, g, M, nblocks * nb); }
   g.cb_tiles = (int)(nb / 32);

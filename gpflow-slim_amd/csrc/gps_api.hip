@@ -115,7 +115,13 @@ struct HipOps {
       }
       if (e != hipSuccess) { h->side_stream = nullptr; return false; }
       // all or nothing: a half-initialised look-ahead (stream without flags / event) must not be used by the next call
-      if (h->dLaFlags.ensure(64) != hipSuccess || hipMemset(h->dLaFlags.p, 0, 64) != hipSuccess ||
+      // The flags are cleared ON THE HANDLE'S STREAM and the clear is complete before anything uses them.  (A plain
+      // hipMemset goes to the legacy default stream and is asynchronous to the host: it runs whenever every blocking
+      // stream of the process -- other handles' CU-masked side streams -- has drained, which with several handles in
+      // one process could be after this handle's first tickets, or its time-out count, had been written: found with
+      // four handles in four host threads, tools/concurrent_handles2.py.)
+      if (h->dLaFlags.ensure(64) != hipSuccess || hipMemsetAsync(h->dLaFlags.p, 0, 64, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess ||
           (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess)) {
         (void)hipStreamDestroy(h->side_stream);
         h->side_stream = nullptr;
@@ -345,7 +351,7 @@ extern "C" int gps_release_buffers(gps_handle_t h) {
   if (h->y_stream) GPS_HIP(h, hipStreamSynchronize(h->y_stream));
   gps_profile_collect(h);
   release_work_buffers(h, false);
-  h->have_factor = false; h->n = 0; h->npad = 0; h->r = 0;
+  h->have_factor = false; h->dist_have_part_factor = false; h->n = 0; h->npad = 0; h->r = 0;
   h->dist_np = 0; h->dist_nb = 0;          // (a distributed factorisation must start over with gps_dist_begin)
   return GPS_OK;
 }
@@ -457,6 +463,8 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "la_fault_inject") == 0) { h->la_fault_inject = (int)value; return GPS_OK; }
   if (strcmp(key, "wave_fault_inject") == 0) { h->wave_fault_inject = (int)value; return GPS_OK; }
+  if (strcmp(key, "svgp_kl_weight") == 0) { h->svgp_kl_weight = value; return GPS_OK; }
+  if (strcmp(key, "dist_partitioned") == 0) { h->dist_partitioned = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
@@ -732,11 +740,12 @@ extern "C" int gps_trsm_lower(gps_handle_t h, const double* L, int64_t n, double
 extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int64_t d_all) {
   if (!h || !X || n <= 0 || d_all <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_set_data: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
-  h->have_factor = false;
+  h->have_factor = false; h->dist_have_part_factor = false;
   h->n = n; h->d_all = d_all; h->npad = gps_pad(n);
   GPS_HIP(h, h->dX.ensure((size_t)n * d_all * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dX.p, X, (size_t)n * d_all * 8, hipMemcpyHostToDevice, h->stream));
-  GPS_HIP(h, h->dK.ensure((size_t)(h->npad + GPS_TILE) * h->npad * 8));      // + the augmented rows of gpr_factor
+  // (K itself is allocated by whoever factors it: gpr_factor the whole [N, N], a rank of the block-column path only its
+  // own block columns -- 8 N^2 / P bytes)
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(h->npad / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
@@ -748,7 +757,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   if (h->n <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_gpr_set_data has not been called");
   if (r < 0 || (r > 0 && !resid)) return gps_fail(h, GPS_ERR_ARG, "resid missing");
   const i64 n = h->n, np = h->npad;
-  h->have_factor = false;
+  h->have_factor = false; h->dist_have_part_factor = false;
   {
     // leaves refined or not: from the bound cond(K + noise I) <= (N Kdiag + noise) / noise (gps_gpr_needs_refine)
     double kd = 0.0;
@@ -1253,7 +1262,7 @@ extern "C" int gps_conditional(gps_handle_t h, const gps_kern_node_t* prog, int 
   if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
     return gps_fail(h, GPS_ERR_ARG, "gps_conditional: q_sqrt_ndim must be 2 or 3");
   GPS_HIP(h, hipSetDevice(h->device));
-  h->have_factor = false;          // dK / dLinv / dAlpha are reused below
+  h->have_factor = false; h->dist_have_part_factor = false;          // dK / dLinv / dAlpha are reused below
   h->refine_now = (h->leaf_refine != 0);
   if (info) *info = 0;
   CondIn c;
@@ -1298,7 +1307,7 @@ extern "C" int gps_base_conditional(gps_handle_t h, const double* Kmn, const dou
   if (q_sqrt && q_sqrt_ndim != 2 && q_sqrt_ndim != 3)
     return gps_fail(h, GPS_ERR_ARG, "gps_base_conditional: q_sqrt_ndim must be 2 or 3");
   GPS_HIP(h, hipSetDevice(h->device));
-  h->have_factor = false;
+  h->have_factor = false; h->dist_have_part_factor = false;
   h->n = 0;
   h->refine_now = (h->leaf_refine != 0);
   if (info) *info = 0;
@@ -1352,7 +1361,7 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
     return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: bad argument");
   if (q_sqrt_ndim != 2 && q_sqrt_ndim != 3) return gps_fail(h, GPS_ERR_ARG, "gps_svgp_elbo: q_sqrt_ndim must be 2 or 3");
   GPS_HIP(h, hipSetDevice(h->device));
-  h->have_factor = false; h->n = 0;
+  h->have_factor = false; h->dist_have_part_factor = false; h->n = 0;
   h->refine_now = (h->leaf_refine != 0);
   if (info) *info = 0;
   CondIn c;
@@ -1382,7 +1391,7 @@ extern "C" int gps_svgp_elbo(gps_handle_t h, const gps_kern_node_t* prog, int n_
   const double ve = (double)n * (double)k * (-0.5 * log(2.0 * M_PI) - 0.5 * log(noise_var)) - 0.5 * sv.sq_sum / noise_var;
   if (var_exp_sum) *var_exp_sum = ve;
   if (kl_out) *kl_out = sv.kl;
-  *elbo = ve * scale - sv.kl;
+  *elbo = ve * scale - h->svgp_kl_weight * sv.kl;       // (weight 1 / P when the data points are sharded over P ranks)
   return GPS_OK;
   });
 }
@@ -1425,7 +1434,7 @@ static int svgp_whiten(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
                        double jitter, const double* q_mu, i64 k, const double* q_sqrt, int q_sqrt_ndim,
                        std::vector<double>& mw, std::vector<double>& Lw, int* info) {
   GPS_HIP(h, hipSetDevice(h->device));
-  h->have_factor = false; h->n = 0;
+  h->have_factor = false; h->dist_have_part_factor = false; h->n = 0;
   h->refine_now = (h->leaf_refine != 0);
   const i64 mp = gps_pad(m);
   const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
@@ -1564,7 +1573,8 @@ static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int 
   GPS_HIP(h, hipMemcpyAsync(hAE.data(), dAE, hAE.size() * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipMemcpyAsync(hDiag.data(), dDiag, hDiag.size() * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
-  for (i64 i = 0; i < m * k; ++i) grad_q_mu[i] = hAE[i] - q_mu[i];                          // (KL white: q_mu)
+  const double klw = h->svgp_kl_weight;          // the KL's share of this rank (its three gradient terms below)
+  for (i64 i = 0; i < m * k; ++i) grad_q_mu[i] = hAE[i] - klw * q_mu[i];                    // (KL white: q_mu)
 
   // Abar^T [nsp, mp] = coef (.) A^T + E q_mu^T  (- (w/s2) sum_q (A^T L_q) L_q^T for a full q_sqrt, below)
   std::vector<double> coef((size_t)mp, 0.0), qmp((size_t)mp * k, 0.0);
@@ -1587,7 +1597,7 @@ static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int 
     for (i64 j = 0; j < m; ++j)
       for (i64 q = 0; q < k; ++q) {
         const double sv = q_sqrt[j * k + q];
-        grad_q_sqrt[j * k + q] = -(w / s2) * hDiag[j] * sv - sv + 1.0 / sv;
+        grad_q_sqrt[j * k + q] = -(w / s2) * hDiag[j] * sv + klw * (-sv + 1.0 / sv);
       }
   } else {
     // A A^T (lower by one long-K GEMM, mirrored) ; per latent: S += (w/s2) L_q L_q^T and (A A^T) L_q (both M^3) ; then ONE
@@ -1621,7 +1631,7 @@ static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int 
       double* gq = grad_q_sqrt + (size_t)q * m * m;
       for (i64 a = 0; a < m; ++a)
         for (i64 b = 0; b < m; ++b)
-          gq[a * m + b] = (b > a) ? 0.0 : (-(w / s2) * G[(size_t)a * mp + b] - Lq[a * m + b] + (a == b ? 1.0 / Lq[a * m + a] : 0.0));
+          gq[a * m + b] = (b > a) ? 0.0 : (-(w / s2) * G[(size_t)a * mp + b] + klw * (-Lq[a * m + b] + (a == b ? 1.0 / Lq[a * m + a] : 0.0)));
     }
     rc = gps_launch_gemm_nt(h, 0, 0, nsp, mp, mp, Bt, mp, Ssum, mp, Abar, mp);                           // Abar^T -= A^T S
     if (rc) return rc;
@@ -1870,9 +1880,14 @@ extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const do
 
 
 // ---- block-column distributed factorisation ------------------------------------------------------
-// 1-D block-cyclic columns over P ranks.  Every rank holds an [np + 128, np] buffer, builds and updates
-// only the block columns it owns (c % P == rank) and receives every factored panel (kept in place, so that L ends up
-// replicated: warm predict_f needs no further exchange).
+// 1-D block-cyclic columns over P ranks.  Two storage modes (option "dist_partitioned"):
+//   1 (default) PARTITIONED: a rank stores only the block columns it owns (c % P == rank), side by side in an
+//     [np + 128, ncl * nb] buffer -- 8 N^2 / P bytes per rank (N = 32768, P = 8: 1.07 GB) -- and the trailing
+//     updates read a received panel straight from the comm buffer it arrived in (>= 3 of them, slot = panel % count:
+//     the bulk lane may still be reading panel p - 1 while panel p + 1 arrives).  The factor stays distributed:
+//     predict_f streams the panels once more (gps_dist_solve_*), or the caller asks for the replicated mode.
+//   0 REPLICATED: every rank holds an [np + 128, np] buffer and keeps every received panel in place, so that L ends
+//     up on every rank and warm predict_f needs no further exchange (8 N^2 bytes per rank).
 //
 // Augmented rows ("alpha distributed"): rows np .. np+127 of the buffer hold (Y - m)^T (r real rows).  The
 // panel solve  X L_jj^T = B  and the trailing update treat them like any other rows below the diagonal block, which
@@ -1946,31 +1961,46 @@ extern "C" int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n
   const i64 n = h->n;
   const i64 np = ((n + nb - 1) / nb) * nb;
   const i64 nblk = np / nb;
-  h->have_factor = false;
+  h->have_factor = false; h->dist_have_part_factor = false;
   h->npad = np; h->dist_np = np; h->dist_nb = nb; h->dist_P = nparts; h->dist_rank = part; h->dist_r = r;
+  h->dist_part = h->dist_partitioned != 0;
+  h->dist_ncl = part < nblk ? (nblk - 1 - part) / nparts + 1 : 0;            // owned block columns
+  const i64 ld = h->dist_part ? (h->dist_ncl > 0 ? h->dist_ncl : 1) * nb : np;
+  h->dist_ld = ld;
   {
     double kd = 0.0;
     int rck = gps_launch_kdiag(h, prog, n_nodes, &kd);
     if (rck) return rck;
     h->factor_refine = gps_gpr_needs_refine(h, noise_var, kd, h->n);
   }
-  GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
+  GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * ld * 8));
   GPS_HIP(h, h->dLinv.ensure(2 * (size_t)(np / GPS_TILE) * GPS_TILE * GPS_TILE * 8));
   GPS_HIP(h, h->dDistScal.ensure((size_t)nblk * DIST_TAIL * 8));
   GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-  // augmented rows: (Y - m)^T, zero padded to 128 rows (all columns: owned or not, the bytes are few)
-  double* aug = h->dK.d() + np * np;
-  GPS_HIP(h, hipMemsetAsync(aug, 0, (size_t)GPS_TILE * np * 8, h->stream));
+  // augmented rows: (Y - m)^T, zero padded to 128 rows (replicated mode: all columns, owned or not -- the bytes are few;
+  // partitioned mode: the owned block columns, gathered from a transposed copy of the residual)
+  double* aug = h->dK.d() + np * ld;
+  GPS_HIP(h, hipMemsetAsync(aug, 0, (size_t)GPS_TILE * ld * 8, h->stream));
   if (r > 0) {
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
     GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
-    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, aug, np);
-    if (rc0) return rc0;
+    if (!h->dist_part) {
+      int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, aug, np);
+      if (rc0) return rc0;
+    } else {
+      GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
+      GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)r * np * 8, h->stream));
+      int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, h->dAlpha.d(), np);
+      if (rc0) return rc0;
+      for (i64 lc = 0; lc < h->dist_ncl; ++lc)
+        GPS_HIP(h, hipMemcpy2DAsync(aug + lc * nb, (size_t)ld * 8, h->dAlpha.d() + (lc * nparts + part) * nb, (size_t)np * 8,
+                                    (size_t)nb * 8, (size_t)r, hipMemcpyDeviceToDevice, h->stream));
+    }
   }
   int prep = 1;
   for (i64 c = part; c < nblk; c += nparts) {
-    double* blk = h->dK.d() + c * nb * np + c * nb;
-    int rc = gps_launch_kmat_block(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, noise_var, blk, np, c * nb,
+    double* blk = h->dist_part ? h->dK.d() + c * nb * ld + (c / nparts) * nb : h->dK.d() + c * nb * np + c * nb;
+    int rc = gps_launch_kmat_block(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, noise_var, blk, ld, c * nb,
                                    np - c * nb, c * nb, nb, prep);
     if (rc) return rc;
     prep = 0;
@@ -1990,8 +2020,21 @@ extern "C" int gps_dist_msg_doubles(gps_handle_t h, int64_t j, int64_t* out) {
 }
 
 extern "C" int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1) {
-  if (!h || !dev_buf0 || !dev_buf1) return gps_fail(h, GPS_ERR_ARG, "gps_dist_set_comm: bad argument");
-  h->dist_comm[0] = (double*)dev_buf0; h->dist_comm[1] = (double*)dev_buf1;
+  void* bufs[2] = {dev_buf0, dev_buf1};
+  return gps_dist_set_comm_bufs(h, bufs, 2);
+}
+
+extern "C" int gps_dist_set_comm_bufs(gps_handle_t h, void* const* dev_bufs, int count) {
+  if (!h || !dev_bufs || count < 2 || count > 8) return gps_fail(h, GPS_ERR_ARG, "gps_dist_set_comm_bufs: 2 .. 8 buffers");
+  for (int i = 0; i < count; ++i) if (!dev_bufs[i]) return gps_fail(h, GPS_ERR_ARG, "gps_dist_set_comm_bufs: null buffer");
+  for (int i = 0; i < 8; ++i) h->dist_comm[i] = i < count ? (double*)dev_bufs[i] : nullptr;
+  h->dist_ncomm = count;
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_comm_bufs_needed(gps_handle_t h, int* count) {
+  if (!h || !count) return GPS_ERR_ARG;
+  *count = h->dist_partitioned ? 3 : 2;
   return GPS_OK;
 }
 
@@ -2009,27 +2052,30 @@ extern "C" int gps_dist_set_bulk_stream(gps_handle_t h, void* hip_stream) {
     return gps_fail(h, GPS_ERR_ARG, "gps_dist_*: bad panel index or gps_dist_begin not called");      \
   GPS_HIP(h, hipSetDevice(h->device));                                                                \
   h->refine_now = h->factor_refine;                                                                   \
-  const i64 np = h->dist_np, nb = h->dist_nb;                                                         \
+  const i64 np = h->dist_np, nb = h->dist_nb, ld = h->dist_ld;                                        \
   const i64 rows = np + GPS_TILE - j * nb;              /* panel rows incl. the augmented ones */     \
   const i64 blk0 = j * nb / GPS_TILE, nbb = nb / GPS_TILE;                                            \
-  double* const panel = h->dK.d() + j * nb * np + j * nb;                                             \
+  /* the panel in this rank's storage (partitioned: only meaningful on the owner) */                  \
+  double* const panel = h->dK.d() + j * nb * ld + (h->dist_part ? (j / h->dist_P) * nb : j * nb);      \
   double* const linv = h->dLinv.d();                                                                  \
   double* const linvT = linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE;                                 \
-  (void)rows; (void)blk0; (void)nbb; (void)panel; (void)linvT;
+  (void)rows; (void)blk0; (void)nbb; (void)panel; (void)linvT; (void)ld;
 
 // owner of panel j: factor it in place (diagonal nb x nb block + rows below, augmented rows included), reduce its
 // share of log-det / sum alpha^2, and pack the message
 extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
   DIST_CHECK(h, j)
-  if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  if (buf < 0 || buf >= h->dist_ncomm || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  if (h->dist_part && (j % h->dist_P != h->dist_rank || buf != (int)(j % h->dist_ncomm)))
+    return gps_fail(h, GPS_ERR_ARG, "gps_dist_panel_factor: partitioned storage -- not the owner, or not the panel's comm slot (panel % count)");
   HipOps ops{h, linv, linvT, (int*)h->dInfo.p};
   Blocked<HipOps> bl(ops);
-  int rc = bl.potrf_rec(panel, np, nb, blk0, j * nb);
+  int rc = bl.potrf_rec(panel, ld, nb, blk0, j * nb);
   if (rc) return rc;
-  rc = bl.trsm_rec(panel, np, nb, blk0, panel + nb * np, np, rows - nb);
+  rc = bl.trsm_rec(panel, ld, nb, blk0, panel + nb * ld, ld, rows - nb);
   if (rc) return rc;
   double* msg = h->dist_comm[buf];
-  rc = gps_launch_extract(h, panel, np, rows, nb, msg, nb, 0);
+  rc = gps_launch_extract(h, panel, ld, rows, nb, msg, nb, 0);
   if (rc) return rc;
   const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
   double* tail = msg + rows * nb + 2 * nbb * GPS_TILE * GPS_TILE;
@@ -2038,8 +2084,8 @@ extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
                             hipMemcpyDeviceToDevice, h->stream));
   // this panel's share of  sum log L_ii  and  sum alpha^2  (the augmented rows of this block column are alpha^T now),
   // folded with the info word into the message tail -- and into this rank's own per-panel table
-  const double* aug = h->dK.d() + np * np + j * nb;
-  rc = gps_launch_lml_reduce(h, panel, np, nb, aug, np, h->dist_r, h->dScal.d());
+  const double* aug = h->dK.d() + np * ld + (h->dist_part ? (j / h->dist_P) * nb : j * nb);
+  rc = gps_launch_lml_reduce(h, panel, ld, nb, aug, ld, h->dist_r, h->dScal.d());
   if (rc) return rc;
   rc = gps_launch_dist_tail(h, h->dScal.d(), (const int*)h->dInfo.p, tail, h->dDistScal.d() + j * DIST_TAIL);
   if (rc) return rc;
@@ -2049,8 +2095,15 @@ extern "C" int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf) {
 // every other rank: copy the received panel (and its block inverses, and its scalars) into place
 extern "C" int gps_dist_unpack(gps_handle_t h, int64_t j, int buf) {
   DIST_CHECK(h, j)
-  if (buf < 0 || buf > 1 || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  if (buf < 0 || buf >= h->dist_ncomm || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
   const double* msg = h->dist_comm[buf];
+  if (h->dist_part) {
+    // partitioned storage: the panel stays in its comm slot (the updates read it there); only its scalars are kept
+    if (buf != (int)(j % h->dist_ncomm)) return gps_fail(h, GPS_ERR_ARG, "gps_dist_unpack: partitioned storage -- panel j lives in comm slot j % count");
+    GPS_HIP(h, hipMemcpyAsync(h->dDistScal.d() + j * DIST_TAIL, msg + rows * nb + 2 * nbb * GPS_TILE * GPS_TILE, DIST_TAIL * 8,
+                              hipMemcpyDeviceToDevice, h->stream));
+    return GPS_OK;
+  }
   int rc = gps_launch_extract(h, msg, nb, rows, nb, panel, np, 0);
   if (rc) return rc;
   const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
@@ -2073,11 +2126,20 @@ extern "C" int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t 
   i64 first = c_lo + ((h->dist_rank - c_lo % h->dist_P) + h->dist_P) % h->dist_P;
   if (first >= c_hi) return GPS_OK;
   const i64 count = (c_hi - 1 - first) / h->dist_P + 1;
-  const double* Lc = h->dK.d() + first * nb * np + j * nb;          // rows first*nb.. of panel j
-  double* C = h->dK.d() + first * nb * np + first * nb;
   hipStream_t saved = h->stream;
   if (lane == 1 && h->dist_bulk_set) h->stream = h->dist_bulk_stream;
-  const int rc = gps_launch_gemm_nt_cyclic(h, np + GPS_TILE - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, np, C, np);
+  int rc;
+  if (h->dist_part) {
+    // panel j as it arrived (or was packed by its owner): [rows of panel j][nb] in comm slot j % count
+    if (h->dist_ncomm < 3) { h->stream = saved; return gps_fail(h, GPS_ERR_STATE, "partitioned storage needs >= 3 comm buffers (gps_dist_set_comm_bufs)"); }
+    const double* Lc = h->dist_comm[j % h->dist_ncomm] + (first - j) * nb * nb;
+    double* C = h->dK.d() + first * nb * ld + (first / h->dist_P) * nb;
+    rc = gps_launch_gemm_nt_cyclic(h, np + GPS_TILE - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, nb, C, ld, 1);
+  } else {
+    const double* Lc = h->dK.d() + first * nb * np + j * nb;          // rows first*nb.. of panel j
+    double* C = h->dK.d() + first * nb * np + first * nb;
+    rc = gps_launch_gemm_nt_cyclic(h, np + GPS_TILE - first * nb, count, nb, (i64)h->dist_P * nb, nb, Lc, np, C, np);
+  }
   h->stream = saved;
   return rc;
 }
@@ -2090,7 +2152,7 @@ extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   const i64 n = h->n, np = h->dist_np, r = h->dist_r, nblk = np / h->dist_nb;
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   // alpha [r][np] for warm predict_f: the augmented rows of the (replicated) factor
-  if (r > 0) {
+  if (r > 0 && !h->dist_part) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, hipMemcpyAsync(h->dAlpha.p, h->dK.d() + np * np, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
   }
@@ -2110,12 +2172,116 @@ extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   if (info) *info = linfo;
   *lml = -0.5 * (double)n * (double)r * log(2.0 * M_PI) - (double)r * slog - 0.5 * ssq;
   h->r = r;
-  h->have_factor = (linfo == 0);
+  h->have_factor = (linfo == 0) && !h->dist_part;          // a partitioned factor serves gps_dist_solve_* only
+  h->dist_have_part_factor = (linfo == 0) && h->dist_part;
   stage_time(h, 0, 1, &h->stage_ms[0]);
   stage_time(h, 1, 2, &h->stage_ms[1]);
   stage_time(h, 2, 3, &h->stage_ms[2]);
   h->stage_ms[3] = 0.0;
   stage_time(h, 0, 3, &h->stage_ms[4]);
+  return GPS_OK;
+}
+
+// ---- predict_f from a PARTITIONED factor: the panels are streamed once more (models/gpr.py:119-131) -------------------
+// Every rank holds a shard of the test points and solves  A^T = Kx^T L^-T  for it panel by panel as the panels come by
+// (forward substitution at panel granularity: block column j of A^T is final after panel j, the columns to its right
+// take its update); the augmented rows of each panel message are alpha_j^T, so alpha assembles itself on every rank.
+//   gps_dist_solve_begin(Xnew shard)     Kx^T = K(Xnew, X) [n*, np], alpha <- 0
+//   for j in panels:  owner: gps_dist_solve_pack(j, buf) ; exchange (same message as the factorisation's) ;
+//                     all:   gps_dist_solve_apply(j, buf)
+//   gps_dist_solve_finish(mean, var)     fmean = A^T alpha ; fvar = Kdiag - rowsum((A^T)^2)   (full_cov == 0)
+extern "C" int gps_dist_solve_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Xnew, int64_t n_new) {
+  if (!h || !Xnew || n_new <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_dist_solve_begin: bad argument");
+  if (!h->dist_have_part_factor || h->dist_nb <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_dist_solve_begin: no partitioned factor (run the distributed factorisation first)");
+  GPS_HIP(h, hipSetDevice(h->device));
+  h->refine_now = h->factor_refine;
+  const i64 n = h->n, np = h->dist_np, d = h->d_all, r = h->dist_r;
+  const i64 nsp = gps_pad(n_new);
+  h->dist_solve_n = n_new;
+  GPS_HIP(h, h->dXnew.ensure((size_t)n_new * d * 8));
+  GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, Xnew, (size_t)n_new * d * 8, hipMemcpyHostToDevice, h->stream));
+  GPS_HIP(h, h->dB.ensure((size_t)nsp * np * 8));
+  int rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n_new, h->dX.d(), n, d, 0.0, h->dB.d(), np, nsp, np, 0, 0);
+  if (rc) return rc;
+  GPS_HIP(h, h->dAlpha.ensure((size_t)(r > 0 ? r : 1) * np * 8));
+  GPS_HIP(h, hipMemsetAsync(h->dAlpha.p, 0, (size_t)(r > 0 ? r : 1) * np * 8, h->stream));
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_solve_pack(gps_handle_t h, int64_t j, int buf) {
+  DIST_CHECK(h, j)
+  if (!h->dist_have_part_factor) return gps_fail(h, GPS_ERR_STATE, "gps_dist_solve_pack: no partitioned factor");
+  if (buf < 0 || buf >= h->dist_ncomm || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  if (j % h->dist_P != h->dist_rank) return gps_fail(h, GPS_ERR_ARG, "gps_dist_solve_pack: not the owner of this panel");
+  double* msg = h->dist_comm[buf];
+  int rc = gps_launch_extract(h, panel, ld, rows, nb, msg, nb, 0);
+  if (rc) return rc;
+  const size_t ib = (size_t)nbb * GPS_TILE * GPS_TILE * 8;
+  GPS_HIP(h, hipMemcpyAsync(msg + rows * nb, linv + blk0 * GPS_TILE * GPS_TILE, ib, hipMemcpyDeviceToDevice, h->stream));
+  GPS_HIP(h, hipMemcpyAsync(msg + rows * nb + nbb * GPS_TILE * GPS_TILE, linvT + blk0 * GPS_TILE * GPS_TILE, ib,
+                            hipMemcpyDeviceToDevice, h->stream));
+  GPS_HIP(h, hipMemsetAsync(msg + rows * nb + 2 * nbb * GPS_TILE * GPS_TILE, 0, DIST_TAIL * 8, h->stream));
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_solve_apply(gps_handle_t h, int64_t j, int buf) {
+  DIST_CHECK(h, j)
+  if (!h->dist_have_part_factor || h->dist_solve_n <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_dist_solve_apply: gps_dist_solve_begin has not been called");
+  if (buf < 0 || buf >= h->dist_ncomm || !h->dist_comm[buf]) return gps_fail(h, GPS_ERR_STATE, "gps_dist_set_comm has not been called");
+  double* msg = h->dist_comm[buf];
+  const i64 nsp = gps_pad(h->dist_solve_n);
+  double* Bj = h->dB.d() + j * nb;                                   // [nsp, nb] block column j of Kx^T / A^T, ld np
+  // B_j <- B_j L_jj^-T  (the panel's own block inverses travel with it)
+  HipOps ops{h, msg + rows * nb, msg + rows * nb + nbb * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  int rc = bl.trsm_rec(msg, nb, nb, 0, Bj, np, nsp);
+  if (rc) return rc;
+  // B_{>j} -= B_j L[>j, j]^T
+  const i64 below = np - (j + 1) * nb;
+  if (below > 0) {
+    rc = gps_launch_gemm_nt(h, 0, 0, nsp, below, nb, Bj, np, msg + nb * nb, nb, Bj + nb, np);
+    if (rc) return rc;
+  }
+  // alpha_j^T: the augmented rows of the panel
+  if (h->dist_r > 0)
+    GPS_HIP(h, hipMemcpy2DAsync(h->dAlpha.d() + j * nb, (size_t)np * 8, msg + (rows - GPS_TILE) * nb, (size_t)nb * 8, (size_t)nb * 8,
+                                (size_t)h->dist_r, hipMemcpyDeviceToDevice, h->stream));
+  return GPS_OK;
+}
+
+extern "C" int gps_dist_solve_finish(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* mean_out, double* var_out) {
+  if (!h || !var_out || h->dist_solve_n <= 0 || !h->dist_have_part_factor) return gps_fail(h, GPS_ERR_STATE, "gps_dist_solve_finish: nothing to finish");
+  if (h->dist_r > 0 && !mean_out) return gps_fail(h, GPS_ERR_ARG, "gps_dist_solve_finish: mean_out missing");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 np = h->dist_np, r = h->dist_r, n_new = h->dist_solve_n;
+  GPS_HIP(h, h->dMean.ensure((size_t)(n_new * (r > 0 ? r : 1) + n_new) * 8));
+  double* dmean = h->dMean.d();
+  double* dss = dmean + n_new * (r > 0 ? r : 1);
+  int rc = gps_launch_rowdot(h, h->dB.d(), np, n_new, np, h->dAlpha.d(), np, r, dmean, dss);
+  if (rc) return rc;
+  double kd = 0.0;
+  rc = gps_launch_kdiag(h, prog, n_nodes, &kd);
+  if (rc) return rc;
+  GPS_HIP(h, h->dVar.ensure((size_t)n_new * 8));
+  rc = gps_launch_var_finish(h, h->dVar.d(), nullptr, kd, dss, n_new);
+  if (rc) return rc;
+  GPS_HIP(h, hipMemcpyAsync(var_out, h->dVar.p, (size_t)n_new * 8, hipMemcpyDeviceToHost, h->stream));
+  if (r > 0) GPS_HIP(h, hipMemcpyAsync(mean_out, dmean, (size_t)n_new * r * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  h->dist_solve_n = 0;
+  return GPS_OK;
+}
+
+// device memory the handle holds right now (every growable buffer; the caller's comm buffers are not the handle's)
+extern "C" int gps_device_bytes(gps_handle_t h, int64_t* bytes) {
+  if (!h || !bytes) return GPS_ERR_ARG;
+  DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
+                    &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags};
+  int64_t tot = 0;
+  for (DevBuf* b : bufs) tot += (int64_t)b->cap;
+  *bytes = tot;
   return GPS_OK;
 }
 
@@ -2135,7 +2301,7 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   if (n_new > 0 && (!Xnew || !mean_out || !var_out)) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr: prediction outputs missing");
   GPS_HIP(h, hipSetDevice(h->device));
   if (info) *info = 0;
-  h->have_factor = false; h->n = 0;                       // GPR resident buffers are reused below
+  h->have_factor = false; h->dist_have_part_factor = false; h->n = 0;                       // GPR resident buffers are reused below
   h->refine_now = (h->leaf_refine != 0);
   const i64 mp = gps_pad(m), np = gps_pad(n);
   const size_t blk_bytes = (size_t)(mp / GPS_TILE) * GPS_TILE * GPS_TILE * 8;
@@ -2191,16 +2357,10 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
     if (rc) return rc;
   }
   const double wgt = fitc ? 1.0 : 1.0 / sigma2;                  // what multiplies A A^T and the c terms
-  // A = At^T [mp, np] ; B = A A^T * weight + I ; LB = chol(B)              (sgpr.py:140-142, 244-245)
+  // A = At^T [mp, np] ; A A^T (lower)                                         (sgpr.py:140-141, 244)
   rc = gps_launch_transpose(h, h->dS1.d(), mp, np, mp, h->dS2.d(), np);
   if (rc) return rc;
   rc = gps_launch_gemm_nt(h, 1, 1, mp, mp, np, h->dS2.d(), np, h->dS2.d(), np, h->dS3.d(), mp);
-  if (rc) return rc;
-  rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, wgt);
-  if (rc) return rc;
-  HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, d_info};
-  Blocked<HipOps> blB(opsB);
-  rc = blB.potrf_rec(h->dS3.d(), mp, mp, 0, 0);
   if (rc) return rc;
   // Aerr*sigma = (L^-1 Kuf) err [m, r] and rowsumsq(A*sigma) = sigma^2 diag(AAT)   (sgpr.py:143, 152)
   GPS_HIP(h, h->dAlpha.ensure((size_t)r * (np > mp ? np : mp) * 8 * 2));
@@ -2219,6 +2379,42 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   double* dAerr = h->dMean.d();                                  // [m][r]
   double* dDiag = dAerr + (size_t)mp * r;                        // [m]
   rc = gps_launch_rowdot(h, h->dS2.d(), np, m, np, dErrT, np, r, dAerr, dDiag);
+  if (rc) return rc;
+  // sum err^2 (FITC: err^2 / nu) over the data points of this call
+  double serr2 = 0.0;
+  if (fitc) {
+    for (i64 i = 0; i < n; ++i) for (i64 q = 0; q < r; ++q) { const double e = resid[i * r + q] * wsq[i]; serr2 += e * e; }
+  } else {
+    for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
+  }
+  double n_total = (double)n;
+  if (h->allreduce) {
+    // X / resid were this rank's shard: everything above that sums over data points is a partial sum.  Pack
+    // [A A^T (lower; the rest of the square is never read) | A err | diag | sum err^2, sum log nu, n], one all-reduce, unpack.
+    const i64 cnt = mp * mp + mp * r + mp + 4;
+    if (cnt > h->red_cap) return gps_fail(h, GPS_ERR_ARG, "gps_set_allreduce: the device buffer is too small for this m, r");
+    double* rb = h->red_buf;
+    const double sc[4] = {serr2, sum_log_nu, (double)n, 0.0};
+    GPS_HIP(h, hipMemcpyAsync(rb, h->dS3.p, (size_t)mp * mp * 8, hipMemcpyDeviceToDevice, h->stream));
+    GPS_HIP(h, hipMemcpyAsync(rb + mp * mp, dAerr, (size_t)(mp * r + mp) * 8, hipMemcpyDeviceToDevice, h->stream));
+    GPS_HIP(h, hipMemcpyAsync(rb + mp * mp + mp * r + mp, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+    rc = gps_launch_tri_map(h, rb, mp, mp, 0);          // mirror: what the lower-triangular GEMM left untouched would be summed as stale bytes
+    if (rc) return rc;
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->allreduce(h->allreduce_ctx, rb, cnt) != 0) return gps_fail(h, GPS_ERR_STATE, "the all-reduce callback failed");
+    double sc_out[4];
+    GPS_HIP(h, hipMemcpyAsync(h->dS3.p, rb, (size_t)mp * mp * 8, hipMemcpyDeviceToDevice, h->stream));
+    GPS_HIP(h, hipMemcpyAsync(dAerr, rb + mp * mp, (size_t)(mp * r + mp) * 8, hipMemcpyDeviceToDevice, h->stream));
+    GPS_HIP(h, hipMemcpyAsync(sc_out, rb + mp * mp + mp * r + mp, sizeof(sc_out), hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    serr2 = sc_out[0]; sum_log_nu = sc_out[1]; n_total = sc_out[2];
+  }
+  // B = A A^T * weight + I ; LB = chol(B)                                     (sgpr.py:141-142, 244-245)
+  rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, wgt);
+  if (rc) return rc;
+  HipOps opsB{h, h->dS4.d(), h->dS4.d() + blk_bytes / 8, d_info};
+  Blocked<HipOps> blB(opsB);
+  rc = blB.potrf_rec(h->dS3.d(), mp, mp, 0, 0);
   if (rc) return rc;
   // c = LB^-1 Aerr / sigma : c*sigma^2 = LB^-1 (Aerr*sigma)              (sgpr.py:144)
   GPS_HIP(h, hipMemsetAsync(dC, 0, (size_t)r * mp * 8, h->stream));
@@ -2239,23 +2435,18 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   if (rc) return rc;
   if (info) *info = linfo;
   if (linfo) return GPS_OK;
-  double slogLB = 0.0, sc2 = 0.0, trAAT = 0.0, serr2 = 0.0;
+  double slogLB = 0.0, sc2 = 0.0, trAAT = 0.0;
   for (int b = 0; b < 64; ++b) { slogLB += hp[2 * b]; sc2 += hp[2 * b + 1]; }
   for (i64 i = 0; i < m; ++i) trAAT += hdiag[i];
   h->sparse_terms[0] = slogLB; h->sparse_terms[1] = trAAT; h->sparse_terms[2] = sc2 * wgt * wgt;
   h->sparse_terms[3] = kdiag; h->sparse_terms[4] = sum_log_nu;
   trAAT *= wgt;
   sc2 *= wgt * wgt;                                              // SGPR: c = (c sigma^2) / sigma^2
-  if (fitc) {
-    for (i64 i = 0; i < n; ++i) for (i64 q = 0; q < r; ++q) { const double e = resid[i * r + q] * wsq[i]; serr2 += e * e; }
-  } else {
-    for (i64 i = 0; i < n * r; ++i) serr2 += resid[i] * resid[i];
-  }
   if (bound_out && fitc) {
-    const double N = (double)n, R = (double)r;                   // sgpr.py:256-290
+    const double N = n_total, R = (double)r;                     // sgpr.py:256-290
     *bound_out = -0.5 * serr2 + 0.5 * sc2 + R * (-0.5 * N * log(2.0 * M_PI) - 0.5 * sum_log_nu - slogLB);
   } else if (bound_out) {
-    const double N = (double)n, R = (double)r;
+    const double N = n_total, R = (double)r;
     double bound = -0.5 * N * R * log(2.0 * M_PI);               // sgpr.py:147-153
     bound += -R * slogLB;
     bound -= 0.5 * N * R * log(sigma2);
@@ -2407,6 +2598,7 @@ static int sgpr_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nod
                              const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                              const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
                              int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  if (h && h->allreduce) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradients of the sparse bounds are not available with the data sharded over ranks");
   if (!h || !bound || !grad_slots || !grad_noise) return gps_fail(h, GPS_ERR_ARG, "gps_sgpr_grad: bad argument");
   if (r > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_sgpr_grad: at most 128 outputs");
   int ns = 0;
@@ -2535,6 +2727,7 @@ static int fitc_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nod
                              const double* X, int64_t n, int64_t d_all, double jitter, double noise_var,
                              const double* resid, int64_t r, double* bound, double* grad_slots, int n_slots_cap,
                              int* n_slots_out, double* grad_noise, double* grad_mean, double* grad_Z, int* info) {
+  if (h && h->allreduce) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradients of the sparse bounds are not available with the data sharded over ranks");
   if (!h || !bound || !grad_slots || !grad_noise) return gps_fail(h, GPS_ERR_ARG, "gps_fitc_grad: bad argument");
   if (r > GPS_TILE) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gps_fitc_grad: at most 128 outputs");
   int ns = 0;
@@ -2647,6 +2840,21 @@ static int fitc_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int n_nod
   if (rc) return rc;
   GPS_HIP(h, hipStreamSynchronize(h->stream));                    // (host vectors above are read by the copies)
   return sparse_grad_tail(h, prog, n_nodes, m, n, d_all, blL, AbarT, Ah, U, nubar_sum, ns, grad_slots, grad_Z);
+}
+
+extern "C" int gps_set_allreduce(gps_handle_t h, gps_allreduce_fn fn, void* ctx, void* dev_buf, int64_t capacity_doubles) {
+  if (!h) return GPS_ERR_ARG;
+  if (fn && (!dev_buf || capacity_doubles <= 0)) return gps_fail(h, GPS_ERR_ARG, "gps_set_allreduce: a device buffer is required");
+  h->allreduce = fn; h->allreduce_ctx = fn ? ctx : nullptr;
+  h->red_buf = fn ? (double*)dev_buf : nullptr; h->red_cap = fn ? capacity_doubles : 0;
+  return GPS_OK;
+}
+
+extern "C" int gps_allreduce_doubles(int64_t m, int64_t r, int64_t* out) {
+  if (!out || m <= 0 || r < 0) return GPS_ERR_ARG;
+  const i64 mp = gps_pad(m);
+  *out = mp * mp + mp * r + mp + 4;
+  return GPS_OK;
 }
 
 extern "C" int gps_sparse_last_terms(gps_handle_t h, double* out5) {

@@ -166,6 +166,12 @@ struct gps_handle_s {
   std::vector<const void*> dyn_lds_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
   bool have_factor = false;
   double sparse_terms[5] = {0, 0, 0, 0, 0};   // gps_sparse_last_terms
+  // data-sharded sparse models ("independent over RHS columns"): every rank holds a shard of the data points
+  double svgp_kl_weight = 1.0;                 // gps_svgp_elbo(_grad): elbo = scale * sum_shard var_exp - weight * KL (1 / P per rank)
+  gps_allreduce_fn allreduce = nullptr;        // gps_set_allreduce: in-place sum over ranks of a slice of red_buf (blocking)
+  void* allreduce_ctx = nullptr;
+  double* red_buf = nullptr;                   // caller-owned device buffer the collective library knows
+  i64 red_cap = 0;
   DevBuf dX;        // [n, d_all]
   DevBuf dK;        // [npad, npad]  K then L (lower, row-major)
   DevBuf dLinv;     // [npad/128][128*128] inverses of the diagonal blocks
@@ -185,7 +191,16 @@ struct gps_handle_s {
   // ---- block-column distributed factorisation (gps_dist_*) ----
   int dist_P = 0, dist_rank = 0;
   i64 dist_nb = 0, dist_np = 0, dist_r = 0;
-  double* dist_comm[2] = {nullptr, nullptr};
+  double* dist_comm[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int dist_ncomm = 0;
+  // partitioned storage (option "dist_partitioned", default 1): dK holds ONLY the owned block columns, side by side
+  // ([np + 128 rows][ncl * nb], ncl = owned block columns): 8 N^2 / P bytes per rank; a panel is read by the trailing
+  // updates straight from the comm buffer it arrived in (slot = panel % number of comm buffers, >= 3 of them)
+  int dist_partitioned = 1;
+  bool dist_part = false;          // mode of the factorisation gps_dist_begin started
+  i64 dist_ld = 0, dist_ncl = 0;
+  bool dist_have_part_factor = false;
+  i64 dist_solve_n = 0;            // test points of the running gps_dist_solve_* pass
   hipStream_t dist_bulk_stream = nullptr; bool dist_bulk_set = false;   // second lane of the distributed schedule
   DevBuf dDistScal;                 // [n_panels][4] per-panel sum log L_ii, sum alpha^2, info
 
@@ -273,7 +288,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc);
 int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
-                              double* C, i64 ldc);
+                              double* C, i64 ldc, int c_packed = 0);
 // potrf_base.hip : factor one 128x128 diagonal block in place (lower), write its
 // inverse (full 128x128, zero upper) to Linv_blk; info word gets min(index+1) of a
 // non-positive pivot (index counted from row0).

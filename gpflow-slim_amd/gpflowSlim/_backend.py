@@ -102,11 +102,20 @@ _SIGNATURES = {
                        ctypes.c_int, ctypes.c_int, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "gps_dist_msg_doubles": [ctypes.c_void_p, _i64, ctypes.POINTER(_i64)],
     "gps_dist_set_comm": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    "gps_dist_set_comm_bufs": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
+    "gps_dist_comm_bufs_needed": [ctypes.c_void_p, _c_int_p],
+    "gps_device_bytes": [ctypes.c_void_p, ctypes.POINTER(_i64)],
+    "gps_dist_solve_begin": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64],
+    "gps_dist_solve_pack": [ctypes.c_void_p, _i64, ctypes.c_int],
+    "gps_dist_solve_apply": [ctypes.c_void_p, _i64, ctypes.c_int],
+    "gps_dist_solve_finish": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _c_double_p],
     "gps_dist_panel_factor": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_unpack": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64, ctypes.c_int],
     "gps_dist_set_bulk_stream": [ctypes.c_void_p, ctypes.c_void_p],
     "gps_dist_finish": [ctypes.c_void_p, _c_double_p, _c_int_p],
+    "gps_set_allreduce": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64],
+    "gps_allreduce_doubles": [_i64, _i64, ctypes.POINTER(_i64)],
     "gps_diag_potrf_base_stamps": [ctypes.c_void_p, ctypes.c_int, _c_double_p],
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
@@ -117,6 +126,7 @@ _SIGNATURES = {
                                ctypes.POINTER(ctypes.c_longlong), _i64, ctypes.POINTER(ctypes.c_int64), _c_double_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error"])
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _i64)      # gps_allreduce_fn
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -305,6 +315,36 @@ class Handle(object):
 
     def dist_set_comm(self, ptr0, ptr1):
         self._check(self._lib.gps_dist_set_comm(self._h, ctypes.c_void_p(ptr0), ctypes.c_void_p(ptr1)), "gps_dist_set_comm")
+
+    def dist_set_comm_bufs(self, ptrs):
+        arr = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(p) for p in ptrs])
+        self._check(self._lib.gps_dist_set_comm_bufs(self._h, arr, len(ptrs)), "gps_dist_set_comm_bufs")
+
+    def dist_comm_bufs_needed(self):
+        out = ctypes.c_int(0)
+        self._check(self._lib.gps_dist_comm_bufs_needed(self._h, ctypes.byref(out)), "gps_dist_comm_bufs_needed")
+        return out.value
+
+    def device_bytes(self):
+        out = _i64(0)
+        self._check(self._lib.gps_device_bytes(self._h, ctypes.byref(out)), "gps_device_bytes")
+        return out.value
+
+    def dist_solve_begin(self, prog, Xnew):
+        Xnew = _f64(Xnew)
+        self._check(self._lib.gps_dist_solve_begin(self._h, prog, len(prog), _ptr(Xnew), Xnew.shape[0]), "gps_dist_solve_begin")
+
+    def dist_solve_pack(self, j, buf):
+        self._check(self._lib.gps_dist_solve_pack(self._h, int(j), int(buf)), "gps_dist_solve_pack")
+
+    def dist_solve_apply(self, j, buf):
+        self._check(self._lib.gps_dist_solve_apply(self._h, int(j), int(buf)), "gps_dist_solve_apply")
+
+    def dist_solve_finish(self, prog, n_new, r):
+        mean = np.empty((n_new, max(r, 1)))
+        var = np.empty(n_new)
+        self._check(self._lib.gps_dist_solve_finish(self._h, prog, len(prog), _ptr(mean), _ptr(var)), "gps_dist_solve_finish")
+        return mean[:, :r], var
 
     def dist_panel_factor(self, j, buf):
         self._check(self._lib.gps_dist_panel_factor(self._h, int(j), int(buf)), "gps_dist_panel_factor")
@@ -537,6 +577,17 @@ class Handle(object):
         if info.value > 0:
             raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
         return bound.value, slots[:nslots.value].copy(), gnoise.value, g_mean, (g_Z if want_grad_Z else None)
+
+    def set_allreduce(self, callback, dev_ptr, capacity_doubles):
+        """gps_set_allreduce: `callback` an ALLREDUCE_FN instance (kept alive by the caller) or None to remove it."""
+        cb = ctypes.cast(callback, ctypes.c_void_p) if callback is not None else None
+        self._check(self._lib.gps_set_allreduce(self._h, cb, None, ctypes.c_void_p(dev_ptr) if dev_ptr else None,
+                                                int(capacity_doubles)), "gps_set_allreduce")
+
+    def allreduce_doubles(self, m, r):
+        out = _i64(0)
+        self._check(self._lib.gps_allreduce_doubles(int(m), int(r), ctypes.byref(out)), "gps_allreduce_doubles")
+        return out.value
 
     def sparse_last_terms(self):
         """sum log diag LB, tr(A A^T), sum c^2, Kdiag constant, sum log nu of the last sgpr() call."""

@@ -49,6 +49,11 @@ def block_column_schedule(ops, comm, n_panels, lookahead=2):
     object with wait().  `lookahead`: depth D (bool accepted: True = 2, False = 0)."""
     P, rank = comm.world, comm.rank
     D = 2 if lookahead is True else (0 if lookahead is False else int(lookahead))
+    # comm buffers: panel t travels through (and, with partitioned storage, is read by the updates from) buffer t % nbufs.
+    # Two suffice when a received panel is copied into place at once; three when the BULK update of panel p - 1 may still
+    # be reading its buffer while panel p + 1 arrives (its last reader, BULK(p - 1), is joined by the CHAIN lane at step p
+    # -- before the exchange of panel p + 2 = (p - 1) + 3 starts at step p + 1).
+    nbufs = int(getattr(ops, "n_bufs", 2))
     owner = lambda t: t % P
     two_lanes = D >= 1
     bulk_lane = BULK if two_lanes else CHAIN
@@ -70,7 +75,7 @@ def block_column_schedule(ops, comm, n_panels, lookahead=2):
 
     for p in range(n_panels - 1):
         # panel p is in place (CHAIN lane)
-        nxt, buf = p + 1, (p + 1) % 2
+        nxt, buf = p + 1, (p + 1) % nbufs
         if D == 0:
             ops.update(p, nxt, n_panels, CHAIN)
             if rank == owner(nxt):
@@ -243,6 +248,18 @@ class TorchComm(object):
         w = self._dist.broadcast(tensor, src=src, group=self.group, async_op=async_op)
         return w if w is not None else _Done()
 
+    def all_reduce_sum(self, tensor):
+        """In-place sum over ranks of a device tensor; returns once the result is visible to the device (the collective of
+        gps_set_allreduce: gpflowSlim/distributed_sparse.py).  RCCL; gloo reduces device tensors through the host."""
+        if self.world == 1:
+            return tensor
+        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self.group)
+        if tensor.is_cuda:
+            import torch
+            torch.cuda.synchronize(tensor.device)
+        self.bytes_sent += 8 * tensor.numel()
+        return tensor
+
     def all_gather_rows(self, local, counts):
         """Concatenate per-rank row blocks `local` [counts[rank], c] (numpy, host) on every rank."""
         if self.world == 1:
@@ -283,6 +300,9 @@ class SingleComm(object):
     def all_gather_rows(self, local, counts):
         return local
 
+    def all_reduce_sum(self, tensor):
+        return tensor
+
 
 class HipPanelOps(object):
     """Per-step pieces on one GPU through the C ABI.  Comm buffers are torch tensors and the two lanes are torch
@@ -290,11 +310,14 @@ class HipPanelOps(object):
     kernels and the collectives are ordered -- and the BULK lane for the trailing updates.  Use as a context manager:
     leaving it always gives the handle its own stream back."""
 
-    def __init__(self, handle, prog, noise_var, resid, nparts, part, nb, two_lanes=True):
+    def __init__(self, handle, prog, noise_var, resid, nparts, part, nb, two_lanes=True, partitioned=None):
         import torch
         self.h = handle
         self.torch = torch
         self.nparts = max(int(nparts), 1)
+        if partitioned is not None:
+            handle.set_option("dist_partitioned", 1 if partitioned else 0)
+        self.n_bufs = handle.dist_comm_bufs_needed()          # 3: partitioned storage (panels are read from the buffers); 2: replicated
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         self.chain = torch.cuda.Stream(priority=hi)
         self.bulk = torch.cuda.Stream(priority=lo) if two_lanes else self.chain
@@ -307,8 +330,8 @@ class HipPanelOps(object):
             self.n_panels, mx = handle.dist_begin(prog, noise_var, resid, nparts, part, nb)
             mx = -(-mx // max(nparts, 1)) * max(nparts, 1)          # room for equal chunks
             with torch.cuda.stream(self.chain):
-                self.bufs = [torch.empty(mx, dtype=torch.float64, device="cuda") for _ in range(2)]
-            handle.dist_set_comm(self.bufs[0].data_ptr(), self.bufs[1].data_ptr())
+                self.bufs = [torch.empty(mx, dtype=torch.float64, device="cuda") for _ in range(self.n_bufs)]
+            handle.dist_set_comm_bufs([b.data_ptr() for b in self.bufs])
         except Exception:
             self.close()
             raise
@@ -370,20 +393,30 @@ def _default_comm():
         return SingleComm()
 
 
-def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2):
+def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2, partitioned=True):
     """Log-marginal likelihood of a gpflowSlim.models.GPR with the covariance factorised across the
     ranks of `comm` (default: the default torch.distributed group, or a single rank).  Every rank must
     call this with the same model state; every rank returns the same value (bit for bit), or every rank
-    raises NotPositiveDefiniteError."""
+    raises NotPositiveDefiniteError.
+
+    partitioned=True (default): a rank stores only the block columns it owns -- 8 N^2 / P bytes -- and the
+    factor stays distributed (predict_f_distributed streams the panels once more); False: every rank keeps every
+    panel (8 N^2 bytes per rank), after which the ordinary warm predict_f works on every rank."""
     comm = comm or _default_comm()
     h = model._handle()
     prog = model.kern._program(model.X.shape[1])
     model._factor_key = None
+    model._dist_state = None
     with HipPanelOps(h, prog, float(np.squeeze(model.likelihood.variance)), model._resid(), comm.world, comm.rank,
-                     nb, two_lanes=bool(lookahead)) as ops:
+                     nb, two_lanes=bool(lookahead), partitioned=partitioned) as ops:
         block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
         lml = ops.finish()
-    model._factor_key = model._state_key()      # L and alpha are resident (replicated) on every rank
+        if partitioned:
+            # what predict_f_distributed needs to stream the panels again (the comm buffers stay alive with it)
+            model._dist_state = {"key": model._state_key(), "n_panels": ops.n_panels, "bufs": ops.bufs, "nparts": ops.nparts,
+                                 "world": comm.world}
+    if not partitioned:
+        model._factor_key = model._state_key()      # L and alpha are resident (replicated) on every rank
     return lml
 
 
@@ -399,6 +432,15 @@ def predict_f_distributed(model, Xnew, comm=None):
     bounds = [(n_new * r) // comm.world for r in range(comm.world + 1)]
     counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
     lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+    st = getattr(model, "_dist_state", None)
+    if st is not None and st["key"] == model._state_key() and st["world"] == comm.world:
+        R = model.Y.shape[1]
+        Xmine = Xnew[lo:hi]
+        mu, var = predict_streamed(model._handle(), model.kern._program(model.X.shape[1]), Xmine, comm, st["n_panels"],
+                                   st["bufs"], st["nparts"], R)
+        mu = mu + model.mean_function(Xmine) if Xmine.shape[0] else mu
+        both = comm.all_gather_rows(np.concatenate([mu, np.tile(var[:, None], [1, R])], axis=1), counts)     # models/gpr.py:131
+        return both[:, :R], both[:, R:]
     saved = model.reuse_factor
     model.reuse_factor = True
     try:
@@ -412,3 +454,44 @@ def predict_f_distributed(model, Xnew, comm=None):
     both = comm.all_gather_rows(np.concatenate([mu, var], axis=1), counts)
     R = mu.shape[1]
     return both[:, :R], both[:, R:]
+
+
+def predict_streamed(h, prog, Xmine, comm, n_panels, bufs, nparts, R):
+    """predict_f for this rank's test points from a PARTITIONED factor on handle `h` (gps_dist_solve_*): the owner of panel
+    j packs it again, the panel is exchanged like during the factorisation, every rank applies it to its right-hand sides;
+    the exchange of panel j + 1 is in flight while panel j is applied.  Returns (A^T alpha [n*, R] -- the caller adds the
+    mean function --, fvar [n*]); models/gpr.py:119-131.  `bufs`: the comm buffers of the factorisation (>= 2)."""
+    import torch
+    P, rank = comm.world, comm.rank
+    mine = Xmine.shape[0] > 0
+    lane = torch.cuda.Stream()
+    lane.wait_stream(torch.cuda.current_stream())
+    h.set_stream(lane.cuda_stream, True)
+    try:
+        h.dist_set_comm_bufs([b.data_ptr() for b in bufs])
+        if mine:
+            h.dist_solve_begin(prog, Xmine)
+
+        def send(j):
+            buf = j % 2
+            if rank == j % P:
+                h.dist_solve_pack(j, buf)
+            n = h.dist_msg_doubles(j)
+            with torch.cuda.stream(lane):
+                return comm.exchange(bufs[buf][: -(-n // nparts) * nparts], j % P)
+        pending = send(0)
+        for j in range(n_panels):
+            with torch.cuda.stream(lane):
+                pending.wait()
+            if j + 1 < n_panels:
+                pending = send(j + 1)          # (stream-ordered after apply(j - 1), the last reader of that buffer) in flight ...
+            if mine:
+                h.dist_solve_apply(j, j % 2)   # ... while panel j is applied
+        if mine:
+            mu, var = h.dist_solve_finish(prog, Xmine.shape[0], R)
+        else:
+            mu, var = np.zeros((0, R)), np.zeros((0,))
+    finally:
+        torch.cuda.current_stream().wait_stream(lane)
+        h.set_stream(0, False)
+    return mu, var

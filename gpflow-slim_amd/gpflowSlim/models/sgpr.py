@@ -52,12 +52,15 @@ class SGPR(GPModel, SGPRUpperMixin):
         self.num_latent = Y.shape[1] if num_latent is None else num_latent
         self._parameters = self._parameters + [self.feature._Z]
 
-    def _call(self, Xnew=None, full_cov=False, want_bound=True):
-        err = np.ascontiguousarray(self.Y - self.mean_function(self.X))
-        prog = self.kern._program(self.X.shape[1])
-        return be.get_handle().sgpr(prog, self.feature.Z, self.X, err, settings.numerics.jitter_level,
-                                    float(np.squeeze(self.likelihood.variance)), Xnew=Xnew, full_cov=full_cov,
-                                    want_bound=want_bound)
+    def _call(self, Xnew=None, full_cov=False, want_bound=True, X=None, Y=None, handle=None):
+        # (X, Y, handle: one rank's shard of the data points on its own handle -- gpflowSlim.distributed_sparse)
+        X = self.X if X is None else X
+        Y = self.Y if Y is None else Y
+        err = np.ascontiguousarray(Y - self.mean_function(X))
+        prog = self.kern._program(X.shape[1])
+        return (handle or be.get_handle()).sgpr(prog, self.feature.Z, X, err, settings.numerics.jitter_level,
+                                                float(np.squeeze(self.likelihood.variance)), Xnew=Xnew, full_cov=full_cov,
+                                                want_bound=want_bound)
 
     def _build_likelihood(self):
         """models/sgpr.py:121-153"""
@@ -137,12 +140,14 @@ class GPRFITC(GPModel, SGPRUpperMixin):
         self.num_latent = Y.shape[1] if num_latent is None else num_latent
         self._parameters = self._parameters + [self.feature._Z]
 
-    def _call(self, Xnew=None, full_cov=False, want_bound=True):
-        err = np.ascontiguousarray(self.Y - self.mean_function(self.X))
-        prog = self.kern._program(self.X.shape[1])
-        return be.get_handle().sgpr(prog, self.feature.Z, self.X, err, settings.numerics.jitter_level,
-                                    float(np.squeeze(self.likelihood.variance)), Xnew=Xnew, full_cov=full_cov,
-                                    want_bound=want_bound, fitc=True)
+    def _call(self, Xnew=None, full_cov=False, want_bound=True, X=None, Y=None, handle=None):
+        X = self.X if X is None else X
+        Y = self.Y if Y is None else Y
+        err = np.ascontiguousarray(Y - self.mean_function(X))
+        prog = self.kern._program(X.shape[1])
+        return (handle or be.get_handle()).sgpr(prog, self.feature.Z, X, err, settings.numerics.jitter_level,
+                                                float(np.squeeze(self.likelihood.variance)), Xnew=Xnew, full_cov=full_cov,
+                                                want_bound=want_bound, fitc=True)
 
     def _build_likelihood(self):
         """models/sgpr.py:252-291"""

@@ -62,17 +62,20 @@ class SVGP(GPModel):
             K = self.feature.Kuu(self.kern, jitter=settings.numerics.jitter_level)
         return kullback_leiblers.gauss_kl(self.q_mu, self.q_sqrt, K)
 
+    def _bound_on(self, X, Y, scale, handle=None):
+        """The Gaussian-likelihood bound on the data points (X, Y) with the given mini-batch scale: one device call.
+        (The whole data set for _build_likelihood; one rank's shard for gpflowSlim.distributed_sparse.)"""
+        yres = np.ascontiguousarray(np.broadcast_to(Y - self.mean_function(X), Y.shape))
+        elbo, _, _ = (handle or be.get_handle()).svgp_elbo(
+            self.kern._program(X.shape[1]), self.feature.Z, X, yres, self.q_mu, self.q_sqrt,
+            settings.numerics.jitter_level, float(np.squeeze(self.likelihood.variance)), white=self.whiten, scale=scale)
+        return elbo
+
     def _build_likelihood(self):
         """models/svgp.py:108-125"""
         scale = float(self.num_data) / float(self.X.shape[0])
         if type(self.likelihood) is likelihoods.Gaussian:
-            yres = self.Y - self.mean_function(self.X)
-            yres = np.ascontiguousarray(np.broadcast_to(yres, self.Y.shape))
-            elbo, _, _ = be.get_handle().svgp_elbo(self.kern._program(self.X.shape[1]), self.feature.Z, self.X, yres,
-                                                   self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
-                                                   float(np.squeeze(self.likelihood.variance)), white=self.whiten,
-                                                   scale=scale)
-            return elbo
+            return self._bound_on(self.X, self.Y, scale)
         KL = self.build_prior_KL()
         fmean, fvar = self._build_predict(self.X, full_cov=False)
         var_exp = self.likelihood.variational_expectations(fmean, fvar, self.Y)
@@ -83,17 +86,21 @@ class SVGP(GPModel):
         `tf.gradients(objective, variables)` yields in the reference (examples/svgp.py:159-161) up to the sign of
         `objective`.  Gaussian likelihood, whitened or not; the inducing inputs move only with train_inducing=True.
         Returns (bound, [(Parameter, gradient array shaped like Parameter.unconstrained_tensor), ...])."""
+        return self._bound_and_gradients_on(self.X, self.Y, float(self.num_data) / float(self.X.shape[0]))
+
+    def _bound_and_gradients_on(self, X, Y, scale, handle=None):
+        """compute_log_likelihood_and_gradients on the data points (X, Y) with the given scale (see _bound_on); every
+        output is linear in the per-point terms, which is what lets ranks add their shards' results up."""
         if type(self.likelihood) is not likelihoods.Gaussian:
             raise NotImplementedError("analytic gradients of the SVGP bound need the Gaussian likelihood")
-        d_all = self.X.shape[1]
+        d_all = X.shape[1]
         prog = self.kern._program(d_all)
         layout = self.kern._grad_layout(d_all)
-        scale = float(self.num_data) / float(self.X.shape[0])
-        yres = np.ascontiguousarray(np.broadcast_to(self.Y - self.mean_function(self.X), self.Y.shape))
+        yres = np.ascontiguousarray(np.broadcast_to(Y - self.mean_function(X), Y.shape))
         zparam = getattr(self.feature, "_Z", None)
         want_z = zparam is not None and any(p is zparam for p in self.parameters)
-        res = be.get_handle().svgp_elbo_grad(
-            prog, self.feature.Z, self.X, yres, self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
+        res = (handle or be.get_handle()).svgp_elbo_grad(
+            prog, self.feature.Z, X, yres, self.q_mu, self.q_sqrt, settings.numerics.jitter_level,
             float(np.squeeze(self.likelihood.variance)), white=self.whiten, scale=scale, want_grad_Z=want_z)
         elbo, slots, gnoise, g_qmu, g_qsqrt, g_mean = res[:6]
         g_Z = res[6] if want_z else None
@@ -118,7 +125,7 @@ class SVGP(GPModel):
         if isinstance(mf, _MConst):
             grads[id(mf.c)] = grads[id(mf.c)] + _fit(np.sum(g_mean, axis=0), mf.c.vf_val)
         elif isinstance(mf, _MLin):
-            grads[id(mf.A)] = grads[id(mf.A)] + _fit(self.X.T @ g_mean, mf.A.vf_val)
+            grads[id(mf.A)] = grads[id(mf.A)] + _fit(X.T @ g_mean, mf.A.vf_val)
             grads[id(mf.b)] = grads[id(mf.b)] + _fit(np.sum(g_mean, axis=0), mf.b.vf_val)
         out = []
         for p in self.parameters:

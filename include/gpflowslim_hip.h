@@ -269,6 +269,24 @@ int gps_fitc(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
              double jitter, double noise_var, const double* resid, int64_t r,
              const double* Xnew, int64_t n_new, int full_cov,
              double* bound_out, double* mean_out, double* var_out, int* info);
+/* ---- the sparse models with the data points sharded over ranks (no reference counterpart) ------------
+ * Every term of the SGPR / FITC bounds that touches the N data points is a sum over them (models/sgpr.py:138-153,
+ * 241-290: A A^T, A err, err^T err, sum log nu, N itself).  With a collective installed, gps_sgpr / gps_fitc take X and
+ * resid as THIS RANK'S SHARD of the data, add the partial sums of all ranks up with ONE in-place all-reduce of
+ * m_pad^2 + m_pad (r + 1) + 4 doubles in `dev_buf`, and finish redundantly on every rank (Kuu is factored by every
+ * rank: M = 4096 -> 7 ms); the bound, and predictions at any Xnew, are then those of the whole data set on every rank.
+ * `fn(ctx, dev_ptr, count)` must sum `count` doubles at device address `dev_ptr` (inside `dev_buf`, which the caller
+ * allocates so that the collective library knows the memory) over all ranks in place and return 0 once the result is
+ * visible to the device (the library has synchronised its stream before the call).  fn == NULL removes it.
+ * gps_sgpr_grad / gps_fitc_grad refuse to run while a collective is installed.
+ * The SVGP bound (models/svgp.py:108-125) needs no buffer: it is scale * sum_i var_exp_i - KL, so rank p evaluates
+ * gps_svgp_elbo(_grad) on its shard with the option "svgp_kl_weight" = 1 / P and the caller adds the P results (bound and
+ * every gradient are linear in the per-rank terms).                                                              */
+typedef int (*gps_allreduce_fn)(void* ctx, void* dev_ptr, int64_t count);
+int gps_set_allreduce(gps_handle_t h, gps_allreduce_fn fn, void* ctx, void* dev_buf, int64_t capacity_doubles);
+/* doubles gps_sgpr / gps_fitc reduce for m inducing points and r outputs (size dev_buf at least this large) */
+int gps_allreduce_doubles(int64_t m, int64_t r, int64_t* out);
+
 /* terms of the last gps_sgpr / gps_fitc call, for SGPRUpperMixin.compute_upper_bound (models/sgpr.py:55-85):
  * out[0] = sum log diag(LB), out[1] = tr(A A^T) with A = L^-1 Kuf (gps_fitc: rows weighted by 1/nu),
  * out[2] = sum c^2, out[3] = Kdiag constant, out[4] = sum log nu (gps_fitc only).                      */
@@ -319,6 +337,29 @@ int gps_dist_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, dou
                    int64_t* n_panels, int64_t* msg_doubles_max);
 int gps_dist_msg_doubles(gps_handle_t h, int64_t j, int64_t* out);
 int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1);
+/* Storage of the factor (option "dist_partitioned"; no reference counterpart -- SURVEY 8e "GPU g owns block-columns
+ * j = g (mod P) ... 1.07 GB of K/L per GPU"):
+ *   1 (default)  partitioned: the handle holds only its own block columns (8 N^2 / P bytes); a panel is read by the
+ *                trailing updates from the comm buffer it arrived in, so the caller provides
+ *                gps_dist_comm_bufs_needed() (= 3) buffers with gps_dist_set_comm_bufs and moves panel j through
+ *                buffer j % count; gps_dist_unpack only keeps the panel's scalars.  Afterwards the factor is
+ *                distributed: predictions stream the panels once more (gps_dist_solve_*).
+ *   0            replicated: every received panel is copied into an [N, N] buffer on every rank (two comm buffers);
+ *                the whole factor is resident everywhere afterwards (warm gps_gpr_predict works).                */
+int gps_dist_set_comm_bufs(gps_handle_t h, void* const* dev_bufs, int count);
+int gps_dist_comm_bufs_needed(gps_handle_t h, int* count);
+/* predict_f (models/gpr.py:119-131, full_cov == 0) from a partitioned factor: every rank passes its shard of the test
+ * points; the owner of panel j packs it again (gps_dist_solve_pack: same message layout as the factorisation's, length
+ * gps_dist_msg_doubles(j)), the caller exchanges it, every rank applies it (gps_dist_solve_apply: block column j of
+ * A^T = Kx^T L^-T becomes final, the columns to its right take its update, alpha_j is picked up from the augmented rows);
+ * gps_dist_solve_finish returns mean [n_new, r] (caller adds the mean function) and var [n_new].  Any comm slot may be
+ * used (two alternate).                                                                                          */
+int gps_dist_solve_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Xnew, int64_t n_new);
+int gps_dist_solve_pack(gps_handle_t h, int64_t j, int buf);
+int gps_dist_solve_apply(gps_handle_t h, int64_t j, int buf);
+int gps_dist_solve_finish(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* mean_out, double* var_out);
+/* device bytes held by the handle's own buffers (tests of the 8 N^2 / P + O(N nb) bound) */
+int gps_device_bytes(gps_handle_t h, int64_t* bytes);
 int gps_dist_set_bulk_stream(gps_handle_t h, void* hip_stream);
 int gps_dist_panel_factor(gps_handle_t h, int64_t j, int buf);
 int gps_dist_unpack(gps_handle_t h, int64_t j, int buf);

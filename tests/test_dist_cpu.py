@@ -119,6 +119,124 @@ class NumpyPanelOps(object):
             self.log.append(("update", j, c, lane))
 
 
+class PartitionedNumpyOps(NumpyPanelOps):
+    """The PARTITIONED storage mode of gps_dist_* (option "dist_partitioned"): a rank only ever holds its own block columns;
+    a received panel stays in the comm buffer it arrived in (slot = panel % n_bufs) and the trailing updates read it
+    there -- so a buffer may only be overwritten by a later panel once every update that reads it is ordered before the
+    write.  The vector clocks check exactly that; with two buffers and a look-ahead depth >= 2 it must fire."""
+
+    def __init__(self, A, nb, nparts, part, n_bufs=3):
+        NumpyPanelOps.__init__(self, A, nb, nparts, part)
+        self.n_bufs = n_bufs
+        mx = -(-(self.np_ * nb) // nparts) * nparts
+        self.bufs = [self.torch.full((mx,), float("nan"), dtype=self.torch.float64) for _ in range(n_bufs)]
+
+    def panel_factor(self, j, buf):
+        assert buf == j % self.n_bufs, "panel j travels through buffer j % n_bufs"
+        NumpyPanelOps.panel_factor(self, j, buf)
+
+    def message(self, j, buf):
+        assert buf == j % self.n_bufs
+        if j % self.P != self.rank:
+            self._write(0, ("buf", buf))           # the collective writes the receive buffer, ordered on the CHAIN lane
+        return NumpyPanelOps.message(self, j, buf)
+
+    def unpack(self, j, buf):
+        assert j % self.P != self.rank and buf == j % self.n_bufs
+        self._read(0, ("buf", buf))                # (only the panel's scalars are kept)
+        self.log.append(("unpack", j))
+
+    def update(self, j, c_lo, c_hi, lane=0):
+        nb, buf = self.nb, j % self.n_bufs
+        rows = self.np_ - j * nb
+        for c in range(max(c_lo, j + 1), min(c_hi, self.n_panels)):
+            if c % self.P != self.rank:
+                continue
+            self._read(lane, ("buf", buf)); self._write(lane, ("col", c))
+            panel = self.bufs[buf][: rows * nb].numpy().reshape(rows, nb)
+            Lc = panel[(c - j) * nb:]
+            assert not np.isnan(Lc).any(), "panel %d read from a buffer that does not hold it" % j
+            self.M[c * nb:, c * nb:(c + 1) * nb] -= Lc @ Lc[:nb].T
+            self.log.append(("update", j, c, lane))
+
+
+def _part_worker(rank, world, port, n, nb, lookahead, n_bufs, q):
+    sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
+    import torch.distributed as dist
+    from gpflowSlim.distributed import TorchComm, block_column_schedule
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(321)
+        G = rng.standard_normal((n, n))
+        A = G @ G.T + n * np.eye(n)
+        ops = PartitionedNumpyOps(A, nb, world, rank, n_bufs)
+        comm = TorchComm(mode="broadcast")
+        raced = None
+        try:
+            block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
+        except AssertionError as e:
+            raced = str(e)
+        L = np.linalg.cholesky(A)
+        own = [c for c in range(ops.n_panels) if c % world == rank]
+        err = max(float(np.abs(np.tril(ops.M[:, c * nb:(c + 1) * nb] - L[:, c * nb:(c + 1) * nb])[c * nb:]).max()) for c in own) if raced is None else None
+        others_untouched = all(np.isnan(ops.M[c * nb:, c * nb:(c + 1) * nb]).all() for c in range(ops.n_panels) if c % world != rank)
+        q.put((rank, err, others_untouched, raced))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,nb,lookahead", [(2, 128, 16, 2), (3, 176, 16, 3), (2, 96, 16, 1), (3, 112, 16, 0), (2, 160, 16, 5)])
+def test_partitioned_storage_schedule_gloo(world, n, nb, lookahead):
+    """Partitioned storage under gloo: every rank ends with exactly its own block columns of the factor, never touches the
+    others, and three comm buffers are enough for every look-ahead depth (vector-clock race detector)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_part_worker, args=(r, world, port, n, nb, lookahead, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, untouched, raced in res:
+        assert raced is None, raced
+        assert err <= 1e-10 and untouched
+
+
+def test_partitioned_storage_needs_three_buffers():
+    """With only two comm buffers the BULK update of panel p - 1 can still be reading its buffer when panel p + 1 is
+    received into it (look-ahead depth >= 2): the race detector must say so -- this is why gps_dist_comm_bufs_needed() is 3."""
+    sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
+    from gpflowSlim.distributed import block_column_schedule
+
+    class FakeTwoRanks(object):                    # rank 0 of 2, nothing really exchanged: every panel counts as received
+        rank, world = 0, 2
+
+        def exchange(self, tensor, src):
+            class _W(object):
+                def wait(self):
+                    return True
+            return _W()
+    rng = np.random.default_rng(5)
+    n, nb = 160, 16
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+    L = np.linalg.cholesky(A)
+
+    class Fed(PartitionedNumpyOps):                # panels of the other rank appear in the buffer as if received
+        def message(self, j, buf):
+            out = PartitionedNumpyOps.message(self, j, buf)
+            if j % 2 != 0:
+                rows = self.np_ - j * nb
+                self.bufs[buf][: rows * nb] = self.torch.from_numpy(np.ascontiguousarray(L[j * nb:, j * nb:(j + 1) * nb]).ravel())
+            return out
+    ok = Fed(A, nb, 2, 0, n_bufs=3)
+    block_column_schedule(ok, FakeTwoRanks(), ok.n_panels, lookahead=2)
+    bad = Fed(A, nb, 2, 0, n_bufs=2)
+    with pytest.raises(AssertionError, match="races"):
+        block_column_schedule(bad, FakeTwoRanks(), bad.n_panels, lookahead=2)
+
+
 def _worker(rank, world, port, n, nb, lookahead, mode, q):
     sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
     import torch.distributed as dist
@@ -266,3 +384,64 @@ def test_all_gather_rows_ragged_gloo():
     expect = [[0.0, 0.0], [1.0, 1.0], [2.0, 2.0]] + [[2.0 + i, 2.0 + i] for i in range(5)]
     for r in range(world):
         assert res[r] == expect
+
+
+# ---- config 5 sharded over ranks: the reduction logic of gpflowSlim/distributed_sparse.py under gloo ----------------------
+def _sparse_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "gpflow-slim_amd"))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle.gp_oracle as orc
+    from gpflowSlim.distributed import TorchComm
+    from gpflowSlim.distributed_sparse import shard_bounds, ordered_sum
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        comm = TorchComm(mode="broadcast")
+        rng = np.random.default_rng(77)
+        n, m, d, k = 211, 17, 2, 2
+        X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) @ np.ones((1, k)) + 0.1 * rng.standard_normal((n, k))
+        Z = X[:m].copy(); q_mu = 0.3 * rng.standard_normal((m, k)); q_sqrt = 0.5 + rng.random((m, k))
+        spec = {"type": "rbf", "variance": 1.3, "lengthscales": 0.9, "input_dim": d}
+        noise, num_data = 0.2, 3 * n
+        b = shard_bounds(n, world)
+        assert b[0] == 0 and b[-1] == n and all(0 <= (b[p + 1] - b[p]) - n // world <= 1 for p in range(world))
+        lo, hi = b[rank], b[rank + 1]
+        # what rank p evaluates: scale * sum_shard var_exp - KL / P   (models/svgp.py:108-125 is linear in the per-point terms)
+        s = float(num_data) / n
+        KL = orc.gauss_kl(q_mu, q_sqrt, None)
+        part = orc.svgp_elbo(spec, X[lo:hi], Y[lo:hi], Z, q_mu, q_sqrt, noise, whiten=True, num_data=s * (hi - lo)) + KL * (1.0 - 1.0 / world)
+        tot = ordered_sum(comm, [part, float(rank + 1)])
+        ref = orc.svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, noise, whiten=True, num_data=num_data)
+        # the SGPR partial sums: A A^T, A err, err^T err over shards add up to the whole (models/sgpr.py:138-143)
+        import scipy.linalg as sl_
+        L = np.linalg.cholesky(orc.K(spec, Z) + 1e-6 * np.eye(m))
+        A = sl_.solve_triangular(L, orc.K(spec, Z, X[lo:hi]), lower=True)
+        t = torch.from_numpy(np.concatenate([(A @ A.T).reshape(-1), (A @ Y[lo:hi]).reshape(-1), [np.sum(Y[lo:hi] ** 2), hi - lo]]))
+        comm.all_reduce_sum(t)
+        Aall = sl_.solve_triangular(L, orc.K(spec, Z, X), lower=True)
+        want = np.concatenate([(Aall @ Aall.T).reshape(-1), (Aall @ Y).reshape(-1), [np.sum(Y ** 2), n]])
+        # ragged gather incl. an empty block (more ranks than rows)
+        rows = comm.all_gather_rows(np.full((1 if rank == 0 else 0, 3), 5.0), [1] + [0] * (world - 1))
+        q.put((rank, float(tot[0]), float(tot[1]), float(ref), float(np.abs(t.numpy() - want).max() / np.abs(want).max()), rows.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sparse_reductions_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert len({r[1] for r in res}) == 1                       # bit-identical on every rank
+    for rank, tot, ranks_sum, ref, err, shape in res:
+        assert abs(tot - ref) <= 1e-12 * abs(ref)
+        assert ranks_sum == world * (world + 1) / 2
+        assert err <= 1e-13 and shape == (1, 3)

@@ -109,3 +109,21 @@ def test_bench_two_ranks_autotuned_panel_width():
     assert "nb=%d," % dd["nb"] in best and tune["chosen"]["nb"] == dd["nb"] and tune["exchange_s"] == {}
     assert dd["parity_rel_err_vs_one_gpu"] <= 1e-9 and out["value"] > 0
     assert "nb=%d" % dd["nb"] in out["config"]["parallelism"]
+
+
+def test_bench_cfg5_side_line_two_ranks():
+    """`bench.py --workload cfg5 --gpus 2`: BASELINE configs[4] with the data points sharded over the ranks (started by
+    bench.py itself, gloo, both ranks on the one GPU) -- same outputs as the one-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    outs = []
+    for gpus in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg5", "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+               "--backend", "gloo", "--force-device", "0", "--cfg5-m", "512", "--cfg5-n", "60000"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+        outs.append(_last_json(p.stdout))
+    one, two = outs
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["unit"] == "points/s" and two["value"] > 0
+    assert "configs[4]" in two["config"]["workload"] and two["scaling"] == "strong"
+    assert abs(two["svgp_bound"]["elbo"] - one["svgp_bound"]["elbo"]) <= 1e-11 * abs(one["svgp_bound"]["elbo"])
+    assert abs(two["checksum"]["fmean_sum"] - one["checksum"]["fmean_sum"]) <= 1e-9 * max(1.0, abs(one["checksum"]["fmean_sum"]))

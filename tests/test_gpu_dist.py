@@ -52,32 +52,39 @@ def _data(n, d, seed=0):
 
 @pytest.mark.parametrize("n,nb", [(300, 128), (1000, 256), (2048, 512), (1500, 512)])
 @pytest.mark.parametrize("lookahead", [0, 1, 2, 3])
-def test_single_rank_distributed_equals_fused_path(handle, n, nb, lookahead):
+@pytest.mark.parametrize("partitioned", [True, False])
+def test_single_rank_distributed_equals_fused_path(handle, n, nb, lookahead, partitioned):
     import gpflowSlim as gpf
-    from gpflowSlim.distributed import SingleComm, gpr_lml_distributed
+    from gpflowSlim.distributed import SingleComm, gpr_lml_distributed, predict_f_distributed
     X, Y, ls, spec = _data(n, 4)
     m = gpf.models.GPR(X, Y, gpf.kernels.RBF(4, variance=1.1, lengthscales=ls, ARD=True), obs_var=0.1)
     ref = orc.gpr_lml(spec, X, Y, orc.constrained(0.1))
-    got = gpr_lml_distributed(m, SingleComm(), nb=nb, lookahead=lookahead)
+    got = gpr_lml_distributed(m, SingleComm(), nb=nb, lookahead=lookahead, partitioned=partitioned)
     assert abs(got - ref) <= 1e-8 * abs(ref)
-    # the replicated factor serves predict_f (warm) afterwards
-    m.reuse_factor = True
     Xs = np.random.default_rng(1).standard_normal((33, 4))
-    mu, var = m.predict_f(Xs)
     rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
-    assert np.abs(mu - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var - rvar).max() <= 1e-8 * np.abs(rvar).max()
-    from gpflowSlim.distributed import predict_f_distributed
+    # predictions from the distributed factor: streamed panels (partitioned) or the replicated factor (warm predict_f)
     mu2, var2 = predict_f_distributed(m, Xs, SingleComm())
-    assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
+    assert np.abs(mu2 - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var2 - rvar).max() <= 1e-8 * np.abs(rvar).max()
+    if not partitioned:
+        m.reuse_factor = True
+        mu, var = m.predict_f(Xs)
+        assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
+        m.reuse_factor = False
     # and the ordinary fused path still works on the same handle afterwards
     assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
+    if partitioned:
+        # ... and has overwritten the distributed factor: the streamed prediction must refuse, not read stale panels
+        with pytest.raises(RuntimeError, match="no partitioned factor"):
+            predict_f_distributed(m, Xs, SingleComm())
 
 
-def _run_virtual_ranks(world, X, Y, prog, noise, nb, lookahead=2, r_out=None):
-    """P host threads = P virtual ranks on one GPU; returns (per-rank results or exceptions)."""
+def _run_virtual_ranks(world, X, Y, prog, noise, nb, lookahead=2, r_out=None, partitioned=None, Xnew=None, extra=None):
+    """P host threads = P virtual ranks on one GPU; returns (per-rank results or exceptions).  `extra` (a dict) receives
+    per-rank device bytes and, with Xnew, each rank's share of the streamed prediction."""
     import torch
     from gpflowSlim import _backend as be
-    from gpflowSlim.distributed import HipPanelOps, block_column_schedule
+    from gpflowSlim.distributed import HipPanelOps, block_column_schedule, predict_streamed
     shared = {"barrier": threading.Barrier(world), "slot": None}
     out, errs = [None] * world, [None] * world
 
@@ -87,9 +94,17 @@ def _run_virtual_ranks(world, X, Y, prog, noise, nb, lookahead=2, r_out=None):
             torch.cuda.set_device(0)
             h = be.Handle(0)
             h.gpr_set_data(X, ("sim", rank))
-            with HipPanelOps(h, prog, noise, Y, world, rank, nb) as ops:
-                block_column_schedule(ops, ThreadComm(rank, world, shared), ops.n_panels, lookahead=lookahead)
+            comm = ThreadComm(rank, world, shared)
+            with HipPanelOps(h, prog, noise, Y, world, rank, nb, partitioned=partitioned) as ops:
+                block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
                 out[rank] = ops.finish()
+                if extra is not None:
+                    extra.setdefault("bytes", {})[rank] = h.device_bytes()
+                    extra.setdefault("n_bufs", {})[rank] = ops.n_bufs
+                if Xnew is not None:
+                    lo, hi = Xnew.shape[0] * rank // world, Xnew.shape[0] * (rank + 1) // world
+                    extra.setdefault("pred", {})[rank] = predict_streamed(h, prog, Xnew[lo:hi], comm, ops.n_panels, ops.bufs,
+                                                                          ops.nparts, Y.shape[1])
         except be.NotPositiveDefiniteError as e:
             errs[rank] = e
         except Exception as e:        # pragma: no cover
@@ -156,6 +171,33 @@ def test_not_positive_definite_is_collective():
     assert "1024" in str(errs[0])
 
 
+@pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 1400, 256), (4, 3000, 256)])
+def test_partitioned_factor_streams_predictions(world, n, nb):
+    """Partitioned storage (the default): after the factorisation no rank holds another rank's block columns, and
+    predict_f streams the panels once more (gps_dist_solve_*: test points sharded over the ranks, alpha picked up from the
+    augmented rows of each panel) -- mean and variance against the oracle (models/gpr.py:119-131)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n)
+    d, r = 4, 2
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, r))) + 0.1 * rng.standard_normal((n, r))
+    Xs = rng.standard_normal((world * 40 + 3, d))
+    ls = np.linspace(0.9, 1.8, d)
+    kern = gpf.kernels.RBF(d, variance=1.2, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.2), "lengthscales": orc.constrained(ls), "input_dim": d}
+    noise = float(orc.constrained(0.15))
+    extra = {}
+    out, errs = _run_virtual_ranks(world, X, Y, kern._program(d), noise, nb, 2, partitioned=True, Xnew=Xs, extra=extra)
+    assert not any(errs), errs
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    assert len(set(out)) == 1 and abs(out[0] - ref) <= 1e-8 * abs(ref)
+    assert set(extra["n_bufs"].values()) == {3}
+    mu = np.concatenate([extra["pred"][k][0] for k in range(world)], axis=0)
+    var = np.concatenate([extra["pred"][k][1] for k in range(world)], axis=0)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+    assert np.abs(mu - rmu).max() <= 1e-8 * np.abs(rmu).max()
+    assert np.abs(var - rvar[:, 0]).max() <= 1e-8 * np.abs(rvar).max()
+
+
 @pytest.mark.parametrize("nb", [512, 1024])
 def test_full_size_config3_virtual_ranks(nb):
     """BASELINE configs[2] shape -- N = 32768, D = 8, block-column Cholesky over 8 ranks -- with the 8 ranks as threads
@@ -169,7 +211,17 @@ def test_full_size_config3_virtual_ranks(nb):
     m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
     ref = m.compute_log_likelihood()
     noise = float(np.squeeze(m.likelihood.variance))
-    out, errs = _run_virtual_ranks(world, X, Y, kern._program(d), noise, nb, 2)
+    extra = {}
+    out, errs = _run_virtual_ranks(world, X, Y, kern._program(d), noise, nb, 2, extra=extra)
     assert not any(errs), errs
     assert len(set(out)) == 1, out
     assert abs(out[0] - ref) <= 1e-9 * abs(ref), (out[0], ref)
+    # partitioned storage (the default): a rank holds its own block columns, not the matrix -- SURVEY 8e "1.07 GB of K/L
+    # per GPU": 8 N^2 / P plus O(N nb) of block inverses, features and scalars (the comm buffers, 3 x 8 (N + 128) nb, are
+    # the caller's)
+    bound = 8 * n * n / world + 64 * n * nb
+    assert max(extra["bytes"].values()) <= bound, (extra["bytes"], bound)
+    if nb == 512:
+        # the replicated mode is still there on request, same result bit for bit
+        out_r, errs_r = _run_virtual_ranks(world, X, Y, kern._program(d), noise, nb, 2, partitioned=False)
+        assert not any(errs_r) and set(out_r) == set(out)
