@@ -107,7 +107,7 @@ def block_column_schedule(ops, comm, n_panels, lookahead=2):
 
 
 # ---- GPU side -------------------------------------------------------------------------------------
-_UNSUPPORTED = (NotImplementedError, RuntimeError)
+_SIDE_GROUPS = {}
 
 
 def _is_unsupported(exc):
@@ -134,8 +134,37 @@ class TorchComm(object):
         self.bytes_sent = 0            # payload bytes this rank put on the wire (diagnostics for bench.py)
         self.exchanges = 0
         self._scratch = None
+        # Votes about a collective that may have FAILED are not taken on the communicator that failed: a small gloo group
+        # with a time-out beside the RCCL one (a rank stuck inside a broken collective then shows up as a time-out of the
+        # vote -- fatal, with a message -- instead of a hang).  One per process group, kept for the process' lifetime.
+        self._side = None
+        if self.backend == "nccl" and self.world > 1:
+            key = id(group) if group is not None else 0
+            if key not in _SIDE_GROUPS:
+                import datetime
+                ranks = dist.get_process_group_ranks(group) if group is not None else None
+                _SIDE_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo", timeout=datetime.timedelta(seconds=120))
+            self._side = _SIDE_GROUPS[key]
         if self.mode == "scatter_allgather" and self.world > 1 and mode is None:
             self._probe()
+
+    def _agree(self, ok, value=0.0):
+        """(min over ranks of ok, max over ranks of value).  With the gloo side group any local failure may be voted on;
+        without one (gloo itself is the backend) only failures that are raised synchronously on every rank alike."""
+        import torch
+        dist = self._dist
+        grp = self._side if self._side is not None else self.group
+        a = torch.tensor([float(ok)], dtype=torch.float64)
+        b = torch.tensor([float(value)], dtype=torch.float64)
+        try:
+            dist.all_reduce(a, op=dist.ReduceOp.MIN, group=grp)
+            dist.all_reduce(b, op=dist.ReduceOp.MAX, group=grp)
+        except Exception as e:
+            raise RuntimeError("the ranks could not agree on the outcome of a collective probe (a rank is stuck or gone): %s" % e)
+        return float(a.item()), float(b.item())
+
+    def _votable(self, exc):
+        return self._side is not None or _is_unsupported(exc)
 
     def _probe(self):
         """One tiny scatter + all-gather before the first panel: a collective library that lacks one of the two
@@ -152,16 +181,15 @@ class TorchComm(object):
                 torch.cuda.synchronize()
             if not bool((t == torch.arange(2 * P, dtype=torch.float64, device=dev)).all()):
                 ok = 0
-        except _UNSUPPORTED as e:
-            # only "this backend has no such operation for these tensors": raised at call time, before anything is
-            # enqueued, on every rank alike.  Anything else (an RCCL error on one rank, an aborted communicator) leaves the
-            # other ranks inside the collective -- an agreement all-reduce on the same group would hang: that is fatal.
-            if not _is_unsupported(e):
+        except Exception as e:
+            # Without a side group only "this backend has no such operation for these tensors" may be voted on: raised at call
+            # time, before anything is enqueued, on every rank alike.  Anything else (an RCCL error on one rank, an aborted
+            # communicator) leaves the other ranks inside the collective -- an agreement all-reduce on the same group would
+            # hang.  With the gloo side group (RCCL runs) every failure is voted on there, under a time-out.
+            if not self._votable(e):
                 raise
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 0:
+        if self._agree(ok)[0] < 0.5:
             self.mode = "broadcast"
         self.bytes_sent, self.exchanges = 0, 0
 
@@ -191,16 +219,13 @@ class TorchComm(object):
                     self.exchange(buf, i % P).wait()
                 sync()
                 dt = (time.perf_counter() - t0) / reps
-            except _UNSUPPORTED as e:
-                if not _is_unsupported(e):          # (see _probe: only a synchronous "unsupported" may be voted on)
+            except Exception as e:
+                if not self._votable(e):            # (see _probe)
                     raise
                 ok = 0
-            res = torch.tensor([float(ok), dt if ok else 1e30], dtype=torch.float64, device=dev)
-            agree = res.clone()
-            dist.all_reduce(agree[:1], op=dist.ReduceOp.MIN, group=self.group)
-            dist.all_reduce(agree[1:], op=dist.ReduceOp.MAX, group=self.group)
-            if float(agree[0].item()) > 0.5:
-                times[mode] = float(agree[1].item())
+            all_ok, worst = self._agree(ok, dt if ok else 1e30)
+            if all_ok > 0.5:
+                times[mode] = worst
         self.mode = min(times, key=times.get) if times else keep
         self.bytes_sent, self.exchanges = 0, 0
         return times
