@@ -452,6 +452,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "kmat_fast") == 0) { h->kmat_fast = (int)value; return GPS_OK; }
+  if (strcmp(key, "kmat_mfma") == 0) { h->kmat_mfma = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_wave") == 0) { h->trsv_wave = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_trail_follows") == 0) { h->potrf_trail_follows = (int)value; return GPS_OK; }

@@ -147,6 +147,7 @@ struct gps_handle_s {
   bool refine_now = false;       // resolved at every API entry
   bool factor_refine = false;    // what the resident GPR factor was built with (warm predict_f keeps it)
   int kmat_fast = 1;             // one-primitive stationary programs: the stack-free kernel-matrix kernel (kmat.hip)
+  int kmat_mfma = 1;             // chains of primitives (Sum / Product): the feature dot products on the matrix pipe (kmat_mfma_kernel); 2: one-primitive programs too
   int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* leaf_stamps = nullptr;   // phase stamps of one refined leaf launch (gps_diag_trsm_leaf)

@@ -31,6 +31,7 @@ struct PrepNorm { int f0; int nf; };
 struct KNodeDev {
   int op; int f0; int nf; int norm_row;   // norm_row: row index in Ft holding |a|^2 (or -1)
   double variance; double c0;             // c0: periodic lengthscale
+  double c1;                              // periodic: -1 / (4 c0^2)
 };
 struct KProgDev {
   int n_nodes;
@@ -82,6 +83,53 @@ __global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict
     }
     Ft[(i64)(nfeat + q) * ldf + i] = s;
   }
+}
+
+// ---- exp(x) for x <= 0 (every kernel-matrix formula of kernels.py:436-439, 560-610, 813-819 has a non-positive argument up
+// to rounding): rint reduction, degree-13 polynomial, v_ldexp_f64 -- no overflow branch, <= 1 ulp-class error.  One shared
+// path for all four tile kernels.
+// The coefficients live in constant memory: the loads are uniform, so they sit in SGPRs and every Horner step is ONE
+// v_fma_f64 with a scalar operand.  (As 64-bit literals the compiler materialised each of them with two v_mov_b32 in front of
+// a v_fmac -- 330 of the ~1000 VALU instructions a thread issued for its 16 entries; the kernels are VALU-issue-bound.)
+__constant__ double gps_exp_tab[16] = {
+    1.6059043836821613e-10,   // 1/13!
+    2.08767569878681e-09,     // 1/12!
+    2.505210838544172e-08,    // 1/11!
+    2.755731922398589e-07,    // 1/10!
+    2.7557319223985893e-06,   // 1/9!
+    2.48015873015873e-05,     // 1/8!
+    1.984126984126984e-04,    // 1/7!
+    1.3888888888888889e-03,   // 1/6!
+    8.333333333333333e-03,    // 1/5!
+    4.1666666666666664e-02,   // 1/4!
+    1.6666666666666666e-01,   // 1/3!
+    0.5, 1.0,
+    1.4426950408889634,            // [13] log2(e)
+    6.93147180369123816490e-01,    // [14] ln2 high
+    1.90821492927058770002e-10};   // [15] ln2 low
+struct ExpTab { double c[16]; };
+__device__ __forceinline__ ExpTab gps_exp_load() {
+  ExpTab t;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t.c[i] = gps_exp_tab[i];
+  return t;
+}
+__device__ __forceinline__ double gps_exp_nonpos(double x, const ExpTab& t) {        // exp(x) for x <= 0, <= 1 ulp-class error
+  const double k = rint(x * t.c[13]);
+  double r = fma(-k, t.c[14], x);
+  r = fma(-k, t.c[15], r);
+  // Taylor to degree 13 on |r| <= ln2 / 2 (remainder 4e-18), Horner
+  double p = t.c[0];
+#pragma unroll
+  for (int i = 1; i <= 10; ++i) p = fma(p, r, t.c[i]);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);                          // k >= -1075: gradual underflow to 0 like exp()
+}
+__device__ __forceinline__ double gps_exp_nonpos(double x) {        // (kernels that call it a few times only)
+  const ExpTab t = gps_exp_load();
+  return gps_exp_nonpos(x, t);
 }
 
 // ---- tile pass --------------------------------------------------------------------------------
@@ -160,7 +208,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
         for (int e = 0; e < 16; ++e) {
           // sum_d sin^2(pi (x - x')/p) / l^2 = (D - sum_d cos(a_d - b_d)) / (2 l^2)
           const double rs = (half_d - 0.5 * dot[e]) / l2;
-          v[e] = node.variance * exp(-0.5 * rs);
+          v[e] = node.variance * gps_exp_nonpos(-0.5 * rs);
         }
       } else {
         const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
@@ -171,13 +219,13 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
           r2 = fmax(r2, 0.0);
           double val;
           if (node.op == GPS_K_RBF) {
-            val = node.variance * exp(-r2 / 2.0);
+            val = node.variance * gps_exp_nonpos(-r2 / 2.0);
           } else {
             const double r = sqrt(r2 + 1e-12);
-            if (node.op == GPS_K_MATERN12) val = node.variance * exp(-r);
-            else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * exp(-0.5 * r);
-            else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * exp(-sq3 * r);
-            else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * exp(-sq5 * r);
+            if (node.op == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
+            else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
+            else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
+            else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r);
           }
           v[e] = val;
         }
@@ -220,28 +268,6 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
 // 5.2 TB/s, tools/store_bw.hip).  Same tile, same 4x4 patch, same epilogue -- no stack, no node loop, and the
 // exponential in line (arguments are <= 0: no overflow branch; rint reduction, degree-13 polynomial, v_ldexp_f64),
 // which brings the kernel under 128 VGPRs (four waves per SIMD).
-__device__ __forceinline__ double gps_exp_nonpos(double x) {        // exp(x) for x <= 0, <= 1 ulp-class error
-  const double k = rint(x * 1.4426950408889634);
-  double r = fma(-k, 6.93147180369123816490e-01, x);
-  r = fma(-k, 1.90821492927058770002e-10, r);
-  // Taylor to degree 13 on |r| <= ln2 / 2 (remainder 4e-18), Horner in pairs
-  double p = 1.6059043836821613e-10;                // 1/13!
-  p = fma(p, r, 2.08767569878681e-09);              // 1/12!
-  p = fma(p, r, 2.505210838544172e-08);             // 1/11!
-  p = fma(p, r, 2.755731922398589e-07);             // 1/10!
-  p = fma(p, r, 2.7557319223985893e-06);            // 1/9!
-  p = fma(p, r, 2.48015873015873e-05);              // 1/8!
-  p = fma(p, r, 1.984126984126984e-04);             // 1/7!
-  p = fma(p, r, 1.3888888888888889e-03);            // 1/6!
-  p = fma(p, r, 8.333333333333333e-03);             // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);            // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);            // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);                          // k >= -1075: gradual underflow to 0 like exp()
-}
-
 template <int OP>
 __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDev node) {
   const int ti = blockIdx.y, tj = blockIdx.x;
@@ -423,6 +449,179 @@ __global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev
   }
 }
 
+
+// ---- the dot products on the matrix pipe ------------------------------------------------------------------------------
+// kernels.py:408-421 is r2 = |a|^2 + |b|^2 - 2 a.b with a.b a [64 x F] x [F x 64] product per tile -- a dense contraction, and
+// for Sum / Product programs (config 4: Matern-5/2 + Periodic, 16 + 32 features) the 48 multiply-adds per entry were what
+// the fp64 VALU spent most of its time on beside the exponentials (kmat_chain_kernel: 0.95 TB/s of stores).  Here the
+// features stay feature-major in LDS ([F][KLM]: exactly the K-major operand layout of v_mfma_f64_16x16x4), wave w of the four
+// owns rows 16w .. 16w+15 of the tile and all 64 columns (four 16 x 16 accumulators), and the VALU is left with the
+// per-entry epilogue (norms, clamp, sqrt, the in-line exponential) while another wave's products run on the matrix pipe.
+// Row stride KLM = 80 doubles: lanes 16-31 of a fragment read (feature k0 + 1) land on the other half of the banks.
+// The exact diagonal of a symmetric build is r2 = 0 by construction (x_i == x_j; the VALU kernels got that from using the
+// same FMA chain for norms and products, the matrix pipe sums in another order) -- kernels.py:409-421 leaves "whatever
+// rounding leaves, clamped at 0" there.
+#define KLM 80
+typedef double v4d_k __attribute__((ext_vector_type(4)));
+
+template <int OP>
+__device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int op, double dot, double ni, double nj, bool on_diag,
+                                                     const ExpTab& et) {
+  const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+  const int o = (OP >= 0) ? OP : op;      // (always a compile-time constant at the call sites)
+  if (o == GPS_K_PERIODIC) {
+    // kernels.py:813-819 in cos / sin feature form: sum_d sin^2(pi (x - x') / p) / l^2 = (D - sum_d cos(a_d - b_d)) / (2 l^2);
+    // node.c1 = -1 / (4 l^2), folded on the host (a division per entry is ~12 VALU instructions)
+    const double arg = on_diag ? 0.0 : ((double)(node.nf / 2) - dot) * node.c1;
+    return node.variance * gps_exp_nonpos(arg, et);                             // (no clamp: kernels.py:817-819)
+  }
+  double r2 = -2.0 * dot + (ni + nj);                                                    // kernels.py:409-421
+  r2 = on_diag ? 0.0 : fmax(r2, 0.0);
+  if (o == GPS_K_RBF) return node.variance * gps_exp_nonpos(-0.5 * r2, et);
+  const double r = sqrt(r2 + 1e-12);
+  if (o == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r, et);
+  if (o == GPS_K_EXPONENTIAL) return node.variance * gps_exp_nonpos(-0.5 * r, et);
+  if (o == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r, et);
+  return node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r, et);
+}
+
+// OP >= 0: the program is that one stationary primitive (compile-time formulas); OP < 0: a left-deep chain p0 (p_i op_i)*
+//
+// Operand roles are swapped and the column operand is permuted so that the accumulator layout suits the STORES: the
+// instruction computes D = A B^T with D[(lane >> 4) + 4 r][lane & 15] in acc[r].  With A = the tile's COLUMN features, read
+// through pi(q) = 4 (q & 3) + (q >> 2), and B = the ROW features, lane (l15, kq) ends up with acc[j][r] = entry (row 16 w + l15,
+// column 16 j + 4 kq + r): four consecutive doubles of one row per 16-column block -- two 16-byte stores, and the four kq
+// lanes of a row cover 128 contiguous bytes (the VALU kernels' store shape; the natural layout -- four ROWS per lane --
+// needs 8-byte stores and measured 8 % slower than the VALU kernel on the store-bound RBF build).
+template <int OP>
+__global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev P) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
+  double* nc_s = nr_s + KT;                                // [KT]
+  double* Fr_s = nc_s + KT;                                // [maxnf4][KLM]
+  double* Fc_s = Fr_s + a.maxnf * KLM;                     // [maxnf4][KLM]   (a.maxnf: already a multiple of 4 here)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int pi = 4 * (l15 & 3) + (l15 >> 2);
+  const int row = 16 * w + l15;                            // this lane's tile row; its columns: 16 j + 4 kq + r
+  const i64 gi0 = (i64)ti * KT, gj0 = (i64)tj * KT;
+  const bool diag_tile = a.sym && (a.row_off + gi0 == a.col_off + gj0);
+  const ExpTab et = gps_exp_load();
+  double run[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) run[e] = 0.0;
+  const int n_nodes = (OP >= 0) ? 1 : P.n_nodes;
+  for (int nd = 0; nd < n_nodes; nd += (nd == 0 ? 1 : 2)) {
+    const KNodeDev node = P.nodes[nd];
+    const int op = (nd == 0) ? -1 : P.nodes[nd + 1].op;
+    double v[16];
+    if (OP < 0 && node.op == GPS_K_CONSTANT) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = node.variance;
+    } else if (OP < 0 && node.op == GPS_K_WHITE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = (diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3)) ? node.variance : 0.0;
+    } else {
+      const int nf4 = (node.nf + 3) & ~3;
+      if (nd > 0) __syncthreads();
+      for (int idx = tid; idx < nf4 * KT; idx += 256) {
+        const int f = idx >> 6, p = idx & 63;
+        const bool real = f < node.nf;
+        Fr_s[f * KLM + p] = real ? a.Fr[(i64)(node.f0 + f) * a.ldfr + gi0 + p] : 0.0;
+        Fc_s[f * KLM + p] = real ? a.Fc[(i64)(node.f0 + f) * a.ldfc + gj0 + p] : 0.0;
+      }
+      if (node.norm_row >= 0 && tid < KT) {
+        nr_s[tid] = a.Fr[(i64)node.norm_row * a.ldfr + gi0 + tid];
+        nc_s[tid] = a.Fc[(i64)node.norm_row * a.ldfc + gj0 + tid];
+      }
+      __syncthreads();
+      v4d_k acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = (v4d_k){0.0, 0.0, 0.0, 0.0};
+      const double* rp = Fr_s + kq * KLM + row;            // B operand: the wave's 16 rows
+      const double* cp = Fc_s + kq * KLM + pi;             // A operand: 16 columns of block j, permuted
+      for (int k0 = 0; k0 < nf4; k0 += 4) {
+        const double bv = rp[k0 * KLM];
+        const double a0 = cp[k0 * KLM], a1 = cp[k0 * KLM + 16], a2 = cp[k0 * KLM + 32], a3 = cp[k0 * KLM + 48];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, bv, acc[3], 0, 0, 0);
+      }
+      const double ni = (node.norm_row >= 0) ? nr_s[row] : 0.0;
+      double nj[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        nj[4 * j] = nj[4 * j + 1] = nj[4 * j + 2] = nj[4 * j + 3] = 0.0;
+        if (node.norm_row >= 0) {
+          const double2 n01 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq), n23 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq + 2);
+          nj[4 * j] = n01.x; nj[4 * j + 1] = n01.y; nj[4 * j + 2] = n23.x; nj[4 * j + 3] = n23.y;
+        }
+      }
+      // the primitive's formula is chosen ONCE per node, outside the 16 entries: every inner loop is branch-free
+#define KMAT_EVAL(OPC)                                                                                           \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                            \
+        v[e] = kmat_prim_from_dot<OPC>(node, OPC, acc[e >> 2][e & 3], ni, nj[e],                                \
+                                       diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3), et);
+      if (OP >= 0) { KMAT_EVAL(OP) }
+      else switch (node.op) {
+        case GPS_K_RBF: KMAT_EVAL(GPS_K_RBF) break;
+        case GPS_K_MATERN12: KMAT_EVAL(GPS_K_MATERN12) break;
+        case GPS_K_MATERN32: KMAT_EVAL(GPS_K_MATERN32) break;
+        case GPS_K_MATERN52: KMAT_EVAL(GPS_K_MATERN52) break;
+        case GPS_K_EXPONENTIAL: KMAT_EVAL(GPS_K_EXPONENTIAL) break;
+        default: KMAT_EVAL(GPS_K_PERIODIC) break;
+      }
+#undef KMAT_EVAL
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) run[e] = (op < 0) ? v[e] : ((op == GPS_K_ADD) ? (run[e] + v[e]) : (run[e] * v[e]));
+  }
+  // ---- store: 4 consecutive doubles per (lane, j)
+  const i64 li = gi0 + row;
+  double* dst = a.K + li * a.ldk + gj0 + 4 * kq;
+  if (!diag_tile && a.row_off + gi0 + KT <= a.n && a.col_off + gj0 + KT <= a.m) {
+    // interior tile (almost all of them): no padding, no diagonal -- no per-entry tests
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<double2*>(dst + 16 * j) = make_double2(run[j * 4], run[j * 4 + 1]);
+      *reinterpret_cast<double2*>(dst + 16 * j + 2) = make_double2(run[j * 4 + 2], run[j * 4 + 3]);
+    }
+    return;
+  }
+  const i64 gi = a.row_off + li;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const i64 gj = a.col_off + gj0 + 16 * j + 4 * kq + r;
+      double val = run[j * 4 + r];
+      if (gi >= a.n || gj >= a.m) val = (a.identity_pad && gi == gj) ? 1.0 : 0.0;
+      else if (a.sym && gi == gj) val += a.diag_add;
+      o[r] = val;
+    }
+    *reinterpret_cast<double2*>(dst + 16 * j) = make_double2(o[0], o[1]);
+    *reinterpret_cast<double2*>(dst + 16 * j + 2) = make_double2(o[2], o[3]);
+  }
+}
+
+template <int OP>
+static int launch_mfma(gps_handle_t h, KmatArgs a, const KProgDev& P, i64 prow, i64 pcol, double tiles, int nfeat_total) {
+  int maxnf = 4;
+  for (int i = 0; i < P.n_nodes; ++i) if (((P.nodes[i].nf + 3) & ~3) > maxnf) maxnf = (P.nodes[i].nf + 3) & ~3;
+  a.maxnf = maxnf;
+  const size_t lds = (size_t)(2 * KT + 2 * maxnf * KLM) * sizeof(double);
+  int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_mfma_kernel<OP>), (int)((2 * KT + 2 * KMAXF * KLM) * sizeof(double)));
+  if (rcl) return rcl;
+  LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * nfeat_total + 30.0 * ((P.n_nodes + 1) / 2)), tiles * KT * KT * 8.0);
+  hipLaunchKernelGGL(kmat_mfma_kernel<OP>, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream, a, P);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
 // p0 (p_i op_i)* with op in {ADD, MUL}
 static bool is_left_deep_chain(const KProgDev& P) {
   if (P.n_nodes < 3 || (P.n_nodes & 1) == 0) return false;
@@ -452,17 +651,17 @@ __device__ __forceinline__ double prim_value(const KNodeDev& node, double dot, d
   if (node.op == GPS_K_PERIODIC) {
     const double l2 = node.c0 * node.c0;
     const double rs = (0.5 * (double)(node.nf / 2) - 0.5 * dot) / l2;
-    return node.variance * exp(-0.5 * rs);
+    return node.variance * gps_exp_nonpos(-0.5 * rs);
   }
   const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
   double r2 = -2.0 * dot + (ni + nj);
   r2 = fmax(r2, 0.0);
-  if (node.op == GPS_K_RBF) return node.variance * exp(-r2 / 2.0);
+  if (node.op == GPS_K_RBF) return node.variance * gps_exp_nonpos(-r2 / 2.0);
   const double r = sqrt(r2 + 1e-12);
-  if (node.op == GPS_K_MATERN12) return node.variance * exp(-r);
-  if (node.op == GPS_K_EXPONENTIAL) return node.variance * exp(-0.5 * r);
-  if (node.op == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * exp(-sq3 * r);
-  return node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * exp(-sq5 * r);
+  if (node.op == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r);
+  if (node.op == GPS_K_EXPONENTIAL) return node.variance * gps_exp_nonpos(-0.5 * r);
+  if (node.op == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
+  return node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r);
 }
 
 __global__ __launch_bounds__(256) void nkn_tile_kernel(KmatArgs a, KProgDev P, NknNet net,
@@ -578,7 +777,7 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
   for (int i = 0; i < n_prim_nodes; ++i) {
     const gps_kern_node_t& nd = prog[i];
     KNodeDev& kd = out.prog.nodes[i];
-    kd.op = nd.op; kd.f0 = 0; kd.nf = 0; kd.norm_row = -1; kd.variance = nd.variance; kd.c0 = 0.0;
+    kd.op = nd.op; kd.f0 = 0; kd.nf = 0; kd.norm_row = -1; kd.variance = nd.variance; kd.c0 = 0.0; kd.c1 = 0.0;
     switch (nd.op) {
       case GPS_K_ADD: case GPS_K_MUL:
         if (depth < 2) return gps_fail(h, GPS_ERR_ARG, "kernel program: stack underflow");
@@ -605,6 +804,7 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
           }
           kd.nf = 2 * nd.n_dims;
           kd.c0 = nd.lengthscales[0];
+          kd.c1 = -1.0 / (4.0 * kd.c0 * kd.c0);
         } else {
           for (int d = 0; d < nd.n_dims; ++d) {
             if (!(nd.lengthscales[d] > 0.0))
@@ -684,6 +884,20 @@ static int launch_tiles(gps_handle_t h, const KCompiled& kc, KmatArgs& a, i64 pr
     GPS_HIP(h, hipGetLastError());
     return GPS_OK;
   }
+  // One stationary primitive: the VALU kernel is store-bound already (RBF, N = 32768: 0.99 ms = 4.3 TB/s either way; the
+  // matrix-pipe version measured 0-4 % slower), so the matrix-pipe kernel is used for it only on request ("kmat_mfma" = 2).
+  if (kc.prog.n_nodes == 1 && kc.prog.nodes[0].norm_row >= 0 && h->kmat_fast && h->kmat_mfma >= 2) {
+    switch (kc.prog.nodes[0].op) {
+      case GPS_K_RBF: return launch_mfma<GPS_K_RBF>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
+      case GPS_K_MATERN12: return launch_mfma<GPS_K_MATERN12>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
+      case GPS_K_MATERN32: return launch_mfma<GPS_K_MATERN32>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
+      case GPS_K_MATERN52: return launch_mfma<GPS_K_MATERN52>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
+      case GPS_K_EXPONENTIAL: return launch_mfma<GPS_K_EXPONENTIAL>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
+      default: break;
+    }
+  }
+  if (h->kmat_fast && h->kmat_mfma && is_left_deep_chain(kc.prog))                     // Sum / Product of primitives, same
+    return launch_mfma<-1>(h, a, kc.prog, prow, pcol, tiles, nfeat_total);
   if (kc.prog.n_nodes == 1 && kc.prog.nodes[0].norm_row >= 0 && h->kmat_fast) {      // one stationary primitive
     const KNodeDev& nd = kc.prog.nodes[0];
     switch (nd.op) {
