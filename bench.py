@@ -384,12 +384,15 @@ def main():
             alg = n ** 3 / 3.0
             achieved = alg / (g["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_gemm_f64_hbm_bytes_per_launch.json")
-            if os.path.exists(pmc) and n == 32768 and d == 8:
+            import glob
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_f64_hbm_bytes_per_launch.json")), reverse=True):
+                if not (n == 32768 and d == 8):
+                    break
                 with open(pmc) as f:
                     rec = json.load(f)
                 if rec.get("kernel_source_sha") == kernel_source_sha():      # measured on exactly these device sources
-                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "profiles/r02_gemm_f64_hbm_bytes_per_launch.json"
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
+                    break
             peak_meas, _ = h.diag_mfma_f64(2)
             roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel", "achieved": round(achieved, 3),
                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),

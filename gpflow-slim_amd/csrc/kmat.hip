@@ -494,7 +494,7 @@ __device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int o
 // lanes of a row cover 128 contiguous bytes (the VALU kernels' store shape; the natural layout -- four ROWS per lane --
 // needs 8-byte stores and measured 8 % slower than the VALU kernel on the store-bound RBF build).
 template <int OP>
-__global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev P) {
+__global__ __launch_bounds__(256, 4) void kmat_mfma_kernel(KmatArgs a, KProgDev P) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -516,13 +516,15 @@ __global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev 
   for (int nd = 0; nd < n_nodes; nd += (nd == 0 ? 1 : 2)) {
     const KNodeDev node = P.nodes[nd];
     const int op = (nd == 0) ? -1 : P.nodes[nd + 1].op;
-    double v[16];
+    // every value is folded into the running result at once (no 16-entry temporary: the kernel sits at three waves per
+    // SIMD because of its registers)
+#define KMAT_FOLD(e, val) run[e] = (op < 0) ? (val) : ((op == GPS_K_ADD) ? (run[e] + (val)) : (run[e] * (val)))
     if (OP < 0 && node.op == GPS_K_CONSTANT) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = node.variance;
+      for (int e = 0; e < 16; ++e) KMAT_FOLD(e, node.variance);
     } else if (OP < 0 && node.op == GPS_K_WHITE) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = (diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3)) ? node.variance : 0.0;
+      for (int e = 0; e < 16; ++e) KMAT_FOLD(e, (diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3)) ? node.variance : 0.0);
     } else {
       const int nf4 = (node.nf + 3) & ~3;
       if (nd > 0) __syncthreads();
@@ -550,21 +552,23 @@ __global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev 
         acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv, acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, bv, acc[3], 0, 0, 0);
       }
-      const double ni = (node.norm_row >= 0) ? nr_s[row] : 0.0;
-      double nj[16];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        nj[4 * j] = nj[4 * j + 1] = nj[4 * j + 2] = nj[4 * j + 3] = 0.0;
-        if (node.norm_row >= 0) {
-          const double2 n01 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq), n23 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq + 2);
-          nj[4 * j] = n01.x; nj[4 * j + 1] = n01.y; nj[4 * j + 2] = n23.x; nj[4 * j + 3] = n23.y;
-        }
-      }
+      const bool has_norm = node.norm_row >= 0;
+      const double ni = has_norm ? nr_s[row] : 0.0;
       // the primitive's formula is chosen ONCE per node, outside the 16 entries: every inner loop is branch-free
 #define KMAT_EVAL(OPC)                                                                                           \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                            \
-        v[e] = kmat_prim_from_dot<OPC>(node, OPC, acc[e >> 2][e & 3], ni, nj[e],                                \
-                                       diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3), et);
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+        double nj[4] = {0.0, 0.0, 0.0, 0.0};                                                                    \
+        if (has_norm) {                                                                                         \
+          const double2 n01 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq);                        \
+          const double2 n23 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq + 2);                    \
+          nj[0] = n01.x; nj[1] = n01.y; nj[2] = n23.x; nj[3] = n23.y;                                           \
+        }                                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                         \
+          const double val = kmat_prim_from_dot<OPC>(node, OPC, acc[j][r], ni, nj[r],                           \
+                                                     diag_tile && row == 16 * j + 4 * kq + r, et);              \
+          KMAT_FOLD(j * 4 + r, val);                                                                            \
+        }                                                                                                       \
+      }
       if (OP >= 0) { KMAT_EVAL(OP) }
       else switch (node.op) {
         case GPS_K_RBF: KMAT_EVAL(GPS_K_RBF) break;
@@ -576,8 +580,7 @@ __global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev 
       }
 #undef KMAT_EVAL
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) run[e] = (op < 0) ? v[e] : ((op == GPS_K_ADD) ? (run[e] + v[e]) : (run[e] * v[e]));
+#undef KMAT_FOLD
   }
   // ---- store: 4 consecutive doubles per (lane, j)
   const i64 li = gi0 + row;

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence judged under profiles/ (run on the GPU box through gpurun from the repo root):
 #   kernel-trace statistics of bench.py and of BASELINE configs 2, 4, 5; PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy)
-#   of one N = 32768 evaluation.  Outputs under gpurun_out/prof_*; tools/summarise_profiles.py turns them into profiles/r02_*.
+#   of one N = 32768 evaluation.  Outputs under gpurun_out/prof_*; tools/summarise_profiles.py turns them into profiles/${TAG}_* (TAG: round tag, default r03).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 what=${1:-all}
+TAG=${TAG:-r03}
 if [ "$what" = all ] || [ "$what" = pmc ]; then
   # counter collection serialises the dispatches: a look-ahead hand-over could only time out (and the evaluation would
   # be re-run without it) -- switch it off up front
@@ -19,12 +20,15 @@ if [ "$what" = all ] || [ "$what" = pmc ]; then
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_pmc_mfma -- python3 $R/tools/one_eval.py 32768 1 > $OUT/prof_pmc_mfma.log 2>&1 || exit 1
   echo "pmc mfma done"
   # the bench below reports roofline.traffic only from a PMC summary of the same kernel sources: write it now (on this box)
-  (cd $R && python3 tools/summarise_profiles.py r02 > $OUT/summarise_on_box.log 2>&1) || true
+  (cd $R && python3 tools/summarise_profiles.py $TAG > $OUT/summarise_on_box.log 2>&1) || true
   unset GPS_LOOKAHEAD
 fi
 if [ "$what" = all ] || [ "$what" = stats ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/prof_bench.log 2>&1 || exit 1
   echo "bench stats done"
+  # the reference's own workload size (examples/gpr.py: N ~ 455): per-step latency table, kernel statistics
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_small -- python3 $R/tools/small_n.py 512 2048 > $OUT/prof_small.log 2>&1 || exit 1
+  echo "small-N stats done"
   for c in 2 4 5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg$c -- python3 $R/tools/configs.py $c > $OUT/prof_cfg$c.log 2>&1 || exit 1
     echo "cfg$c stats done"

@@ -1,10 +1,10 @@
-"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/r02_*."""
+"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/<tag>_* (tag = argv[1], default r03)."""
 import csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out"); PROF = os.path.join(ROOT, "profiles")
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -23,11 +23,18 @@ def last_json(path):
 
 
 # kernel statistics
-for d, name in (("prof_bench", "bench"), ("prof_cfg2", "cfg2"), ("prof_cfg4", "cfg4"), ("prof_cfg5", "cfg5")):
+for d, name in (("prof_bench", "bench"), ("prof_cfg2", "cfg2"), ("prof_cfg4", "cfg4"), ("prof_cfg5", "cfg5"), ("prof_small", "small_n")):
     f = find(d, "*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(PROF, "%s_%s_kernel_stats.csv" % (tag, name)))
     log = os.path.join(OUT, d + ".log")
+    if os.path.exists(log) and name == "small_n":
+        lines = [ln for ln in open(log).read().splitlines() if ln.startswith("N=")]
+        json.dump({"lines": lines, "kernel_source_sha": sha, "commit": commit,
+                   "note": "tools/small_n.py under rocprofv3 --kernel-trace --stats (tracing adds a few microseconds per launch): wall time per call of the "
+                           "Python API / of the C entry point, GPU stage times, at the size of the reference's own example (examples/gpr.py: N ~ 455)"},
+                  open(os.path.join(PROF, "%s_%s.json" % (tag, name)), "w"), indent=1)
+        continue
     if os.path.exists(log):
         j = last_json(log)
         if j:
