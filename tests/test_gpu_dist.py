@@ -171,6 +171,43 @@ def test_not_positive_definite_is_collective():
     assert "1024" in str(errs[0])
 
 
+@pytest.mark.parametrize("partitioned", [True, False])
+def test_failure_in_the_middle_of_the_schedule_leaves_the_handle_usable(partitioned):
+    """An exchange that raises half-way through the schedule (look-ahead 2: trailing updates are in flight on the BULK lane):
+    leaving HipPanelOps drains BOTH lanes before the handle gets its own stream back, so that the next evaluation on the
+    handle -- which rebuilds K in the same buffer -- cannot race with them: it returns the ordinary result, repeatedly."""
+    import torch
+    import gpflowSlim as gpf
+    from gpflowSlim import _backend as be
+    from gpflowSlim.distributed import HipPanelOps, SingleComm, block_column_schedule
+    n, d, nb = 6144, 4, 256
+    X, Y, ls, spec = _data(n, d, seed=9)
+    prog = gpf.kernels.RBF(d, variance=1.1, lengthscales=ls, ARD=True)._program(d)
+    noise = float(orc.constrained(0.1))
+
+    class Breaks(SingleComm):
+        calls = 0
+
+        def exchange(self, tensor, src):
+            Breaks.calls += 1
+            if Breaks.calls == 9:
+                raise RuntimeError("link down (injected)")
+            return SingleComm.exchange(self, tensor, src)
+    h = be.Handle(0)
+    try:
+        h.gpr_set_data(X, ("midfail", partitioned))
+        ref = h.gpr_lml(prog, noise, Y)
+        for attempt in range(3):
+            Breaks.calls = 0
+            with pytest.raises(RuntimeError, match="injected"):
+                with HipPanelOps(h, prog, noise, Y, 1, 0, nb, partitioned=partitioned) as ops:
+                    block_column_schedule(ops, Breaks(), ops.n_panels, lookahead=2)
+            assert h.gpr_lml(prog, noise, Y) == ref            # bit for bit: nothing of the aborted run was still writing
+        torch.cuda.synchronize()
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 1400, 256), (4, 3000, 256)])
 def test_partitioned_factor_streams_predictions(world, n, nb):
     """Partitioned storage (the default): after the factorisation no rank holds another rank's block columns, and

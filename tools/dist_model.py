@@ -1,5 +1,6 @@
 """Per-panel time model of the block-column factorisation.  Measured on ONE MI355X: what rank 0 of P
-ranks computes per panel at N = 32768 -- the panel factorisation (chain) and its share of the trailing update (bulk) --
+ranks computes per panel at N = argv[1] (default 32768; partitioned storage: rank 0 holds 8 N^2 / P bytes, so N = 131072 fits
+for every P) -- the panel factorisation (chain) and its share of the trailing update (bulk) --
 with the exchange left out (other ranks' panels are garbage: kernel times do not depend on the data).  The exchange is
 modelled: scatter + all-gather moves 2 S / P bytes per rank and phase over P - 1 links; assumed per-link rate below."""
 import json, os, sys, time
@@ -11,7 +12,7 @@ import gpflowSlim as gpf
 from gpflowSlim.distributed import HipPanelOps
 import oracle.gp_oracle as orc
 
-N, d = 32768, 8
+N, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 8
 LINK_GBS = float(os.environ.get("LINK_GBS", "50"))        # assumed effective rate of one xGMI link, one direction
 COLL_LAT_US = float(os.environ.get("COLL_LAT_US", "25"))   # assumed latency of one collective call
 X, Y, _ = orc.synthetic_gpr_data(N, d, 0)
@@ -29,7 +30,7 @@ def timed(f, reps=3):
     return 1e3 * best
 
 
-for nb in (512, 1024):
+for nb in ((512, 1024) if N <= 32768 else (1024,)):
     for P in (1, 2, 4, 8):
         with HipPanelOps(h, prog, 0.1, Y, P, 0, nb, two_lanes=False) as ops:
             npan = ops.n_panels
@@ -37,7 +38,7 @@ for nb in (512, 1024):
             probe = sorted(set([own[0], own[len(own) // 4], own[len(own) // 2], own[(3 * len(own)) // 4], own[-1]]))
             fac, upd = {}, {}
             for j in probe:
-                fac[j] = timed(lambda: ops.panel_factor(j, 0))
+                fac[j] = timed(lambda: ops.panel_factor(j, j % ops.n_bufs))
             for j in sorted(set([0, npan // 4, npan // 2, (3 * npan) // 4])):
                 upd[j] = timed(lambda: ops.update(j, j + 1, npan, 0))
         # linear fits in the panel's row count
@@ -58,4 +59,10 @@ for nb in (512, 1024):
                 "bulk_ms_per_rank": round(bulk, 1), "model_ms_no_overlap": round(total1, 1), "model_ms_two_lanes": round(total2, 1)}
         out["cases"].append(case)
         print(json.dumps(case), flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dist_model.json"), "w"), indent=1)
+# the fused single-GPU evaluation of the same problem, for the "vs one GPU" column
+if N <= 131072:
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    m.compute_log_likelihood()
+    out["fused_one_gpu_ms"] = round(timed(m.compute_log_likelihood, 2), 1)
+    print(json.dumps({"fused_one_gpu_ms": out["fused_one_gpu_ms"]}), flush=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dist_model_n%d.json" % N), "w"), indent=1)
