@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--dist-timeout", type=float, default=600.0, help="watchdog (s) around the distributed run")
     ap.add_argument("--no-dist-autotune", action="store_true", help="N > 1: keep --dist-nb / --dist-lookahead and the default exchange instead of choosing by measurement during warm-up")
     ap.add_argument("--independent-steps", type=int, default=2, help="N > 1: steps of the independent-evaluations side measurement (0 = skip)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="N > 1: who issues the collectives -- torch.distributed (default: RCCL through PyTorch, the path the test suite "
+                         "exercises with two real processes over gloo) or the library's own RCCL binding (csrc/comm_rccl.hip; "
+                         "torch.distributed then only carries the 128-byte unique id at start-up; verified at world size 1 only)")
     ap.add_argument("--workload", default="gpr", choices=["gpr", "cfg5"],
                     help="gpr (default): the BASELINE headline; cfg5: side line for BASELINE configs[4] -- conditional() / SVGP bound with "
                          "M inducing points over N data points, the data points sharded over the ranks (gpflowSlim/distributed_sparse.py)")
@@ -221,14 +225,23 @@ def main():
             t.start()
             return t
         timer = arm()
-        comm = TorchComm()
+        if args.comm == "rccl":
+            from gpflowSlim.distributed import RcclComm
+
+            def carry(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = RcclComm(h, rank, world, bootstrap=carry)
+        else:
+            comm = TorchComm()
         tune = None
         set_step(-1, False)
         gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)      # (also sets the communicator up)
         if not args.no_dist_autotune:
             # untimed: pick the panel exchange and the panel width by measurement on this node (all ranks agree through
             # max-over-ranks times); the timed steps below then run one fixed configuration
-            tune = {"exchange_s": comm.autotune() if args.backend == "nccl" else {}, "candidates_ms": {}}
+            tune = {"exchange_s": comm.autotune() if (args.backend == "nccl" and args.comm == "torch") else {}, "candidates_ms": {}}
             best = None
             for nb_c, la_c in ((args.dist_nb, args.dist_lookahead), (2 * args.dist_nb, args.dist_lookahead), (args.dist_nb // 2, args.dist_lookahead)):
                 if nb_c < 128 or nb_c % 128 or n // nb_c < 2 * world:
@@ -260,7 +273,7 @@ def main():
         timer = arm()
         scaling = "strong"
         parallelism = "1-D block-cyclic column Cholesky over %d GPUs (nb=%d, look-ahead %d, panel exchange: %s over %s)" % (
-            world, args.dist_nb, args.dist_lookahead, comm.mode, args.backend)
+            world, args.dist_nb, args.dist_lookahead, comm.mode, args.backend if args.comm == "torch" else "the library's own RCCL binding")
         stage = h.last_stage_ms()
         per_rank = [None] * world
         dist.all_gather_object(per_rank, dict({k: round(v, 3) for k, v in stage.items()}, device_bytes=h.device_bytes()))

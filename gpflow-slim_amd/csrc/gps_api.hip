@@ -359,6 +359,7 @@ extern "C" int gps_release_buffers(gps_handle_t h) {
 extern "C" int gps_destroy(gps_handle_t h) {
   if (!h) return GPS_OK;
   (void)hipSetDevice(h->device);
+  (void)gps_comm_destroy(h);
   (void)hipStreamSynchronize(h->stream);
   gps_profile_collect(h);
   for (auto e : h->evt_pool) (void)hipEventDestroy(e);

@@ -202,6 +202,10 @@ struct gps_handle_s {
   i64 dist_ld = 0, dist_ncl = 0;
   bool dist_have_part_factor = false;
   i64 dist_solve_n = 0;            // test points of the running gps_dist_solve_* pass
+  // native collectives (comm_rccl.hip): an RCCL communicator of this handle's own, its stream and events
+  void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ready = nullptr, comm_done[8] = {};
   hipStream_t dist_bulk_stream = nullptr; bool dist_bulk_set = false;   // second lane of the distributed schedule
   DevBuf dDistScal;                 // [n_panels][4] per-panel sum log L_ii, sum alpha^2, info
 

@@ -114,6 +114,15 @@ _SIGNATURES = {
     "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64, ctypes.c_int],
     "gps_dist_set_bulk_stream": [ctypes.c_void_p, ctypes.c_void_p],
     "gps_dist_finish": [ctypes.c_void_p, _c_double_p, _c_int_p],
+    "gps_comm_load": [ctypes.c_char_p],
+    "gps_comm_version": [_c_int_p],
+    "gps_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
+    "gps_comm_init": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int],
+    "gps_comm_destroy": [ctypes.c_void_p],
+    "gps_comm_exchange": [ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int],
+    "gps_comm_wait": [ctypes.c_void_p, ctypes.c_int],
+    "gps_comm_allreduce": [ctypes.c_void_p, ctypes.c_void_p, _i64],
+    "gps_comm_install_allreduce": [ctypes.c_void_p, ctypes.c_void_p, _i64],
     "gps_set_allreduce": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64],
     "gps_allreduce_doubles": [_i64, _i64, ctypes.POINTER(_i64)],
     "gps_diag_potrf_base_stamps": [ctypes.c_void_p, ctypes.c_int, _c_double_p],
@@ -125,7 +134,7 @@ _SIGNATURES = {
     "gps_diag_gemm_timeline": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, ctypes.c_int,
                                ctypes.POINTER(ctypes.c_longlong), _i64, ctypes.POINTER(ctypes.c_int64), _c_double_p],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["gps_last_error", "gps_comm_load_error"])
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _i64)      # gps_allreduce_fn
 
 _lib = None
@@ -171,8 +180,50 @@ def load_library():
             fn.restype = ctypes.c_int
         lib.gps_last_error.argtypes = [ctypes.c_void_p]
         lib.gps_last_error.restype = ctypes.c_char_p
+        lib.gps_comm_load_error.argtypes = []
+        lib.gps_comm_load_error.restype = ctypes.c_char_p
         _lib = lib
         return lib
+
+
+def comm_load(path=None):
+    """Open librccl for the native collectives.  Default: the copy a PyTorch wheel bundles, if there is one (a process that also
+    imports torch then holds ONE RCCL), else the system's."""
+    lib = load_library()
+    if path is None:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec is not None and spec.submodule_search_locations:
+                cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+                if os.path.exists(cand):
+                    path = cand
+        except Exception:
+            path = None
+    rc = lib.gps_comm_load(path.encode() if path else None)
+    if rc != 0:
+        msg = lib.gps_comm_load_error()
+        raise RuntimeError("librccl could not be loaded (%d): %s" % (rc, msg.decode() if msg else ""))
+
+
+def comm_unique_id():
+    """128 opaque bytes from ncclGetUniqueId: rank 0 draws them, every rank passes them to Handle.comm_init."""
+    lib = load_library()
+    comm_load()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.gps_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise RuntimeError("gps_comm_unique_id failed (%d)" % rc)
+    return buf.raw
+
+
+def comm_version():
+    lib = load_library()
+    comm_load()
+    v = ctypes.c_int(0)
+    if lib.gps_comm_version(ctypes.byref(v)) != 0:
+        raise RuntimeError("gps_comm_version failed")
+    return v.value
 
 
 class NotPositiveDefiniteError(ValueError):
@@ -577,6 +628,28 @@ class Handle(object):
         if info.value > 0:
             raise NotPositiveDefiniteError("Cholesky decomposition was not successful (order %d)" % info.value)
         return bound.value, slots[:nslots.value].copy(), gnoise.value, g_mean, (g_Z if want_grad_Z else None)
+
+    # ---- native collectives (csrc/comm_rccl.hip; driven by gpflowSlim.distributed.RcclComm)
+    def comm_init(self, rank, world, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), len(unique_id))
+        self._check(self._lib.gps_comm_init(self._h, int(rank), int(world), buf, len(unique_id)), "gps_comm_init")
+
+    def comm_destroy(self):
+        self._check(self._lib.gps_comm_destroy(self._h), "gps_comm_destroy")
+
+    def comm_exchange(self, dev_ptr, count, root, mode, slot):
+        self._check(self._lib.gps_comm_exchange(self._h, ctypes.c_void_p(dev_ptr), int(count), int(root), int(mode), int(slot)),
+                    "gps_comm_exchange")
+
+    def comm_wait(self, slot):
+        self._check(self._lib.gps_comm_wait(self._h, int(slot)), "gps_comm_wait")
+
+    def comm_allreduce(self, dev_ptr, count):
+        self._check(self._lib.gps_comm_allreduce(self._h, ctypes.c_void_p(dev_ptr), int(count)), "gps_comm_allreduce")
+
+    def comm_install_allreduce(self, dev_ptr, capacity_doubles):
+        self._check(self._lib.gps_comm_install_allreduce(self._h, ctypes.c_void_p(dev_ptr), int(capacity_doubles)),
+                    "gps_comm_install_allreduce")
 
     def set_allreduce(self, callback, dev_ptr, capacity_doubles):
         """gps_set_allreduce: `callback` an ALLREDUCE_FN instance (kept alive by the caller) or None to remove it."""

@@ -301,6 +301,77 @@ class TorchComm(object):
         return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, counts)], axis=0)
 
 
+class _NativeWork(object):
+    def __init__(self, handle, slot):
+        self.h, self.slot = handle, slot
+
+    def wait(self):
+        self.h.comm_wait(self.slot)          # the handle's stream waits; the host does not
+        return True
+
+
+class RcclComm(object):
+    """RCCL called by the library itself (csrc/comm_rccl.hip: gps_comm_*) behind the same small comm interface -- no
+    PyTorch in the data path; torch (or anything else) is only the side channel that carries the 128-byte unique id from
+    rank 0 to the others at start-up.  One communicator per library handle.
+
+    `bootstrap(payload_or_None) -> payload`: called once with rank 0's unique id (None on the other ranks); must return
+    rank 0's bytes on every rank (e.g. torch.distributed.broadcast_object_list over gloo, an MPI bcast, a shared file).
+    Verified on hardware at world size 1 only -- the build loop has one GPU; TorchComm stays the default of bench.py."""
+
+    def __init__(self, handle, rank, world, bootstrap=None, mode="scatter_allgather"):
+        from . import _backend as be
+        self.h, self.rank, self.world, self.mode = handle, int(rank), int(world), mode
+        self.backend = "rccl-native"
+        self.bytes_sent = 0
+        self.exchanges = 0
+        self._slot = 0
+        uid = be.comm_unique_id() if self.rank == 0 else None
+        if self.world > 1:
+            if bootstrap is None:
+                raise ValueError("RcclComm: world > 1 needs a bootstrap callable that carries rank 0's unique id to every rank")
+            uid = bootstrap(uid)
+        handle.comm_init(self.rank, self.world, uid)
+
+    def close(self):
+        self.h.comm_destroy()
+
+    def exchange(self, tensor, src):
+        """`tensor`: anything with data_ptr() / numel() holding doubles on the handle's device (a torch tensor)."""
+        n = tensor.numel()
+        P = self.world
+        mode = 1 if (self.mode == "scatter_allgather" and n >= 2 * P) else 0
+        slot = self._slot
+        self._slot = (self._slot + 1) % 8
+        self.h.comm_exchange(tensor.data_ptr(), n, src, mode, slot)
+        self.exchanges += 1
+        if P > 1:
+            chunk = n // P
+            self.bytes_sent += (8 * chunk * (P - 1) * (2 if self.rank == src else 1)) if mode == 1 else (8 * n * (P - 1) if self.rank == src else 0)
+        return _NativeWork(self.h, slot)
+
+    def all_reduce_sum(self, tensor):
+        self.h.comm_allreduce(tensor.data_ptr(), tensor.numel())
+        self.bytes_sent += 8 * tensor.numel()
+        return tensor
+
+    def all_gather_rows(self, local, counts):
+        """Ragged row blocks of host arrays: every rank writes its rows into a zeroed [sum(counts), c] device buffer, one
+        all-reduce adds the ranks' contributions up (x + 0 = x: exact)."""
+        if self.world == 1:
+            return local
+        import torch
+        c = local.shape[1]
+        tot = int(sum(counts))
+        off = int(sum(counts[: self.rank]))
+        buf = torch.zeros((max(tot, 1), c), dtype=torch.float64, device=torch.device("cuda", self.h.device))
+        if local.shape[0]:
+            buf[off:off + local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(buf.device)
+        torch.cuda.synchronize(buf.device)
+        self.h.comm_allreduce(buf.data_ptr(), buf.numel())
+        return buf[:tot].cpu().numpy()
+
+
 class _Works(object):
     def __init__(self, works):
         self.works = [w for w in works if w is not None]

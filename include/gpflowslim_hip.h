@@ -287,6 +287,29 @@ int gps_set_allreduce(gps_handle_t h, gps_allreduce_fn fn, void* ctx, void* dev_
 /* doubles gps_sgpr / gps_fitc reduce for m inducing points and r outputs (size dev_buf at least this large) */
 int gps_allreduce_doubles(int64_t m, int64_t r, int64_t* out);
 
+/* ---- native collectives: RCCL called from the library itself (csrc/comm_rccl.hip; no reference counterpart) -----------
+ * "ncclBroadcast (RCCL) per panel, root = owner, on a dedicated stream".  librccl is opened with dlopen on
+ * first use (gps_comm_load(path): a specific librccl -- e.g. the one a PyTorch wheel bundles, so that a process holds one
+ * copy --, NULL: the system's).  One communicator per handle: rank 0 draws a unique id (128 bytes), the caller carries it to
+ * the other ranks by whatever side channel it has (a file, MPI, torch.distributed's store), every rank calls gps_comm_init.
+ *   gps_comm_exchange(h, dev_buf, count, root, mode, slot)  `count` doubles at dev_buf, complete on `root`, become complete on
+ *        every rank; enqueued on the communicator's own stream after everything the handle's stream has done so far, returns
+ *        at once.  mode 0: one broadcast; mode 1: scatter of P equal chunks over all of the root's links + in-place all-gather.
+ *   gps_comm_wait(h, slot)          the handle's stream waits for the exchange that used `slot` (0..7)
+ *   gps_comm_allreduce(h, p, n)     in-place sum of n doubles over the ranks, blocking
+ *   gps_comm_install_allreduce      makes that the collective of gps_sgpr / gps_fitc on data shards (see gps_set_allreduce)
+ * Verified on hardware at world size 1 only (the build box has one GPU); gpflowSlim.distributed.RcclComm drives it.     */
+int gps_comm_load(const char* path);
+const char* gps_comm_load_error(void);
+int gps_comm_version(int* version);
+int gps_comm_unique_id(void* out, int capacity);
+int gps_comm_init(gps_handle_t h, int rank, int world, const void* unique_id, int id_len);
+int gps_comm_destroy(gps_handle_t h);
+int gps_comm_exchange(gps_handle_t h, void* dev_buf, int64_t count, int root, int mode, int slot);
+int gps_comm_wait(gps_handle_t h, int slot);
+int gps_comm_allreduce(gps_handle_t h, void* dev_ptr, int64_t count);
+int gps_comm_install_allreduce(gps_handle_t h, void* dev_buf, int64_t capacity_doubles);
+
 /* terms of the last gps_sgpr / gps_fitc call, for SGPRUpperMixin.compute_upper_bound (models/sgpr.py:55-85):
  * out[0] = sum log diag(LB), out[1] = tr(A A^T) with A = L^-1 Kuf (gps_fitc: rows weighted by 1/nu),
  * out[2] = sum c^2, out[3] = Kdiag constant, out[4] = sum log nu (gps_fitc only).                      */

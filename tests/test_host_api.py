@@ -199,3 +199,16 @@ def test_bench_launcher_stays_off_the_gpu_and_reports_failure():
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], capture_output=True,
                        text=True, timeout=300, env=env)
     assert q.returncode != 0 and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_native_rccl_binding_loads_without_a_gpu(gpf):
+    """csrc/comm_rccl.hip binds librccl with dlopen on first use: the library itself still links libamdhip64 only, RCCL
+    resolves (version, a unique id) on a machine without a GPU, and a communicator cannot be had without one."""
+    from gpflowSlim import _backend as be
+    lib = os.path.join(ROOT, "gpflow-slim_amd", "lib", "libgpflowslim_hip.so")
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower() and "libamdhip64" in needed
+    be.comm_load()
+    assert be.comm_version() >= 20000
+    uid = be.comm_unique_id()
+    assert isinstance(uid, bytes) and len(uid) == 128 and uid != be.comm_unique_id()
