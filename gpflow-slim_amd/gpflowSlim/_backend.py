@@ -187,9 +187,11 @@ def load_library():
 
 
 def comm_load(path=None):
-    """Open librccl for the native collectives.  Default: the copy a PyTorch wheel bundles, if there is one (a process that also
-    imports torch then holds ONE RCCL), else the system's."""
+    """Open librccl for the native collectives.  Default: $GPFLOWSLIM_RCCL_LIB if set, else the copy a PyTorch wheel bundles, if
+    there is one (a process that also imports torch then holds ONE RCCL), else the system's."""
     lib = load_library()
+    if path is None:
+        path = os.environ.get("GPFLOWSLIM_RCCL_LIB") or None
     if path is None:
         try:
             import importlib.util

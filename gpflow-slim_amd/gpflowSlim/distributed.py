@@ -317,7 +317,8 @@ class RcclComm(object):
 
     `bootstrap(payload_or_None) -> payload`: called once with rank 0's unique id (None on the other ranks); must return
     rank 0's bytes on every rank (e.g. torch.distributed.broadcast_object_list over gloo, an MPI bcast, a shared file).
-    Verified on hardware at world size 1 only -- the build loop has one GPU; TorchComm stays the default of bench.py."""
+    Verified on hardware with the real RCCL at world size 1 and, through the shared-memory stand-in transport of tests/fake_rccl,
+    with two processes on one GPU -- the build loop has one GPU; TorchComm stays the default of bench.py."""
 
     def __init__(self, handle, rank, world, bootstrap=None, mode="scatter_allgather"):
         from . import _backend as be
@@ -326,6 +327,7 @@ class RcclComm(object):
         self.bytes_sent = 0
         self.exchanges = 0
         self._slot = 0
+        be.comm_load()                        # every rank binds the same librccl ($GPFLOWSLIM_RCCL_LIB / PyTorch's / the system's)
         uid = be.comm_unique_id() if self.rank == 0 else None
         if self.world > 1:
             if bootstrap is None:

@@ -298,7 +298,8 @@ int gps_allreduce_doubles(int64_t m, int64_t r, int64_t* out);
  *   gps_comm_wait(h, slot)          the handle's stream waits for the exchange that used `slot` (0..7)
  *   gps_comm_allreduce(h, p, n)     in-place sum of n doubles over the ranks, blocking
  *   gps_comm_install_allreduce      makes that the collective of gps_sgpr / gps_fitc on data shards (see gps_set_allreduce)
- * Verified on hardware at world size 1 only (the build box has one GPU); gpflowSlim.distributed.RcclComm drives it.     */
+ * Verified on hardware with the real RCCL at world size 1, and at world size 2 through a stand-in transport behind the same
+ * API (tests/fake_rccl; the build box has one GPU); gpflowSlim.distributed.RcclComm drives it.                       */
 int gps_comm_load(const char* path);
 const char* gps_comm_load_error(void);
 int gps_comm_version(int* version);

@@ -127,3 +127,29 @@ def test_bench_cfg5_side_line_two_ranks():
     assert "configs[4]" in two["config"]["workload"] and two["scaling"] == "strong"
     assert abs(two["svgp_bound"]["elbo"] - one["svgp_bound"]["elbo"]) <= 1e-11 * abs(one["svgp_bound"]["elbo"])
     assert abs(two["checksum"]["fmean_sum"] - one["checksum"]["fmean_sum"]) <= 1e-9 * max(1.0, abs(one["checksum"]["fmean_sum"]))
+
+
+def test_bench_two_ranks_native_communicator_stand_in_transport():
+    """`bench.py --gpus 2 --comm rccl`: the block-column run with the collectives issued by the library's own RCCL binding
+    (csrc/comm_rccl.hip) instead of torch.distributed -- two real processes on the one GPU, the RCCL *transport* replaced by
+    the shared-memory stand-in of tests/fake_rccl ($GPFLOWSLIM_RCCL_LIB); torch.distributed (gloo) only carries the unique id."""
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, src, "-lrt", "-Wl,-Bsymbolic"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPFLOWSLIM_RCCL_LIB"] = lib
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "rccl", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512", "--dist-timeout", "200",
+           "--no-dist-autotune", "--independent-steps", "0", "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    dd = out["distributed"]
+    assert dd["parity_rel_err_vs_one_gpu"] <= 1e-9 and dd["exchange"] == "scatter_allgather"
+    assert "own RCCL binding" in out["config"]["parallelism"]
+    n_panels = 4096 // 256
+    rows = lambda j: 4096 + 128 - j * 256
+    payload = sum(-(-(rows(j) * 256 + 2 * 2 * 128 * 128 + 4) // 2) * 2 for j in range(n_panels)) * 8
+    assert abs(dd["payload_bytes_per_eval_all_ranks"] - 1.5 * payload) <= 1e-6 * payload      # scatter + all-gather: (P + 1) / P of a broadcast's bytes

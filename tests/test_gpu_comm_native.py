@@ -94,3 +94,54 @@ def test_sparse_bound_reduces_through_the_native_allreduce(comm_handle):
             h.set_allreduce(None, 0, 0)
         assert abs(hooked - plain) <= 1e-12 * abs(plain)
         assert float(buf[-4 + 2]) == n                 # the reduced data-point count travelled through the buffer
+
+
+def test_two_ranks_through_a_stand_in_transport(tmp_path):
+    """World size 2 for the native communicator on the one GPU of the box: two real processes, each with its own handle and
+    communicator, and tests/fake_rccl -- a shared-memory stand-in for the RCCL *transport* behind the same API -- loaded through
+    gps_comm_load(path).  Everything on our side of that API is the production code: gps_comm_exchange's chunking (scatter
+    of P chunks + in-place all-gather, ragged end, plain broadcast), roots, slots, the communicator's stream and events,
+    gps_comm_allreduce as the sparse models' collective, RcclComm.  Checked against the oracle and the one-GPU results."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import gpflowSlim as gpf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, src, "-lrt", "-Wl,-Bsymbolic"])
+    uid = str(tmp_path / "uid.bin")
+    outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_native_comm_worker.py"), str(r), "2", uid, lib, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    res = [json.load(open(o)) for o in outs]
+    # references
+    n, d = 3000, 3
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 45, seed=13)
+    ls = np.linspace(0.9, 1.6, d)
+    spec = {"type": "rbf", "variance": orc.constrained(1.2), "lengthscales": orc.constrained(ls), "input_dim": d}
+    noise = orc.constrained(0.1)
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+    for r in res:
+        assert abs(r["lml_part_sag"] - ref) <= 1e-8 * abs(ref) and abs(r["lml_repl_bcast"] - ref) <= 1e-8 * abs(ref)
+        assert np.abs(np.array(r["mu"]) - rmu).max() <= 1e-8 * np.abs(rmu).max()
+        assert np.abs(np.array(r["var"]) - rvar).max() <= 1e-8 * np.abs(rvar).max()
+        assert r["exchanges"] > 20 and r["bytes_sent"] > 0
+    assert res[0]["lml_part_sag"] == res[1]["lml_part_sag"] and res[0]["lml_repl_bcast"] == res[1]["lml_repl_bcast"]
+    assert res[0]["mu"] == res[1]["mu"] and res[0]["cond_mean"] == res[1]["cond_mean"]
+    Z = X[:150].copy()
+    k2 = gpf.kernels.RBF(d, variance=1.3, lengthscales=1.1)
+    sg = gpf.models.SGPR(X, Y, k2, Z=Z, obs_var=0.15)
+    want = sg.compute_log_likelihood()
+    assert all(abs(r["sgpr"] - want) <= 1e-12 * abs(want) for r in res) and res[0]["sgpr"] == res[1]["sgpr"]
+    fm, _ = gpf.conditionals.conditional(Xs, Z, k2, np.sin(Z[:, :2]))
+    assert np.abs(np.array(res[0]["cond_mean"]) - fm).max() <= 1e-9 * max(1.0, np.abs(fm).max())
+    sv = gpf.models.SVGP(X, Y, k2, gpf.likelihoods.Gaussian(0.2), Z=Z, q_diag=True)
+    wsv = sv.compute_log_likelihood()
+    assert all(abs(r["svgp"] - wsv) <= 1e-12 * abs(wsv) for r in res) and res[0]["svgp"] == res[1]["svgp"]
