@@ -334,7 +334,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave};
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
 }
@@ -2184,6 +2184,108 @@ extern "C" int gps_dist_finish(gps_handle_t h, double* lml, int* info) {
   return GPS_OK;
 }
 
+// ---- the whole block-column factorisation driven from here (no host language in the panel loop) ------------------------
+// gpflowSlim/distributed.py::block_column_schedule, statement for statement (that Python function stays the specification:
+// it is what the vector-clock race detector of tests/test_dist_cpu.py validates), with the per-step pieces above, the
+// handle's native communicator (comm_rccl.hip) for the exchange and HIP streams / events for the two lanes:
+//   CHAIN lane: urgent updates, panel factorisations, exchanges (a high-priority stream installed as the handle's stream)
+//   BULK  lane: the rest of every trailing update (a low-priority stream)
+// lookahead = D: panel p's update of columns p+1 .. p+D runs on the CHAIN lane, the rest on the BULK lane; D = 0: one lane.
+extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var, const double* resid,
+                            int64_t r, int64_t nb, int lookahead, int exchange_mode, double* lml, int* info) {
+  if (!h || !lml) return gps_fail(h, GPS_ERR_ARG, "gps_dist_lml: bad argument");
+  if (!h->comm) return gps_fail(h, GPS_ERR_STATE, "gps_dist_lml: the handle has no communicator (gps_comm_init)");
+  if (h->ext_stream) return gps_fail(h, GPS_ERR_STATE, "gps_dist_lml: an external stream is installed (gps_set_stream)");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const int P = h->comm_world, rank = h->comm_rank, D = lookahead < 0 ? 0 : lookahead;
+  int lo = 0, hi = 0;
+  GPS_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  hipStream_t chain = nullptr, bulk = nullptr;
+  GPS_HIP(h, hipStreamCreateWithPriority(&chain, hipStreamNonBlocking, hi));
+  if (D >= 1) GPS_HIP(h, hipStreamCreateWithPriority(&bulk, hipStreamNonBlocking, lo));
+  std::vector<hipEvent_t> events;
+  auto new_event = [&]() -> hipEvent_t { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; };
+  int rc = gps_set_stream(h, chain, 1);
+  auto cleanup = [&](int code) -> int {
+    // both lanes drained on every exit path, the handle's own stream back
+    (void)hipStreamSynchronize(chain);
+    if (bulk) (void)hipStreamSynchronize(bulk);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    (void)gps_dist_set_bulk_stream(h, nullptr);
+    (void)gps_set_stream(h, nullptr, 0);
+    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(chain);
+    if (bulk) (void)hipStreamDestroy(bulk);
+    return code;
+  };
+  if (rc) return cleanup(rc);
+  rc = gps_dist_set_bulk_stream(h, bulk);
+  if (rc) return cleanup(rc);
+  int64_t n_panels = 0, mx = 0;
+  rc = gps_dist_begin(h, prog, n_nodes, noise_var, resid, r, P, rank, nb, &n_panels, &mx);
+  if (rc) return cleanup(rc);
+  const int nbufs = h->dist_partitioned ? 3 : 2;
+  const i64 cap = ((mx + P - 1) / P) * P;                       // whole chunks for the scatter + all-gather
+  void* bufs[3] = {nullptr, nullptr, nullptr};
+  for (int b = 0; b < nbufs; ++b) {
+    hipError_t e = h->dDistComm[b].ensure((size_t)cap * 8);
+    if (e != hipSuccess) return cleanup(gps_fail(h, GPS_ERR_HIP, "gps_dist_lml: comm buffer allocation failed"));
+    bufs[b] = h->dDistComm[b].p;
+  }
+  rc = gps_dist_set_comm_bufs(h, bufs, nbufs);
+  if (rc) return cleanup(rc);
+  auto owner = [&](i64 t) { return (int)(t % P); };
+  auto exchange = [&](i64 t, int buf) -> int {                  // returns rc; the slot is t % 8
+    const i64 n = dist_msg_doubles(h, t);
+    return gps_comm_exchange(h, bufs[buf], ((n + P - 1) / P) * P, owner(t), exchange_mode, (int)(t % 8));
+  };
+  auto receive = [&](i64 t, int buf) -> int {
+    int rcc = gps_comm_wait(h, (int)(t % 8));
+    if (rcc) return rcc;
+    return rank != owner(t) ? gps_dist_unpack(h, t, buf) : GPS_OK;
+  };
+#define GPS_TRY(call) do { rc = (call); if (rc) return cleanup(rc); } while (0)
+  if (rank == owner(0)) GPS_TRY(gps_dist_panel_factor(h, 0, 0));
+  GPS_TRY(exchange(0, 0));
+  GPS_TRY(receive(0, 0));
+  std::vector<hipEvent_t> bulk_done((size_t)n_panels, nullptr);
+  for (i64 p = 0; p + 1 < n_panels; ++p) {
+    const i64 nxt = p + 1; const int buf = (int)(nxt % nbufs);
+    if (D == 0) {
+      GPS_TRY(gps_dist_update(h, p, nxt, n_panels, 0));
+      if (rank == owner(nxt)) GPS_TRY(gps_dist_panel_factor(h, nxt, buf));
+      GPS_TRY(exchange(nxt, buf));
+      GPS_TRY(receive(nxt, buf));
+      continue;
+    }
+    hipEvent_t in_place = new_event();
+    GPS_HIP(h, hipEventRecord(in_place, chain));
+    const i64 last_urgent = (p + D < n_panels - 1) ? p + D : n_panels - 1;
+    auto urgent = [&](i64 c) -> int {
+      // first CHAIN update of column c = p + D: the BULK updates of panels <= p - 1 may still be running on it
+      if (c == p + D && p >= 1 && bulk_done[p - 1]) { GPS_HIP(h, hipStreamWaitEvent(chain, bulk_done[p - 1], 0)); bulk_done[p - 1] = nullptr; }
+      return gps_dist_update(h, p, c, c + 1, 0);
+    };
+    GPS_TRY(urgent(nxt));
+    if (rank == owner(nxt)) GPS_TRY(gps_dist_panel_factor(h, nxt, buf));
+    GPS_TRY(exchange(nxt, buf));                                  // in flight while ...
+    for (i64 c = nxt + 1; c <= last_urgent; ++c) GPS_TRY(urgent(c));   // ... the other urgent columns
+    if (last_urgent + 1 < n_panels) {                            // ... and the bulk of the update run
+      GPS_HIP(h, hipStreamWaitEvent(bulk, in_place, 0));
+      GPS_TRY(gps_dist_update(h, p, last_urgent + 1, n_panels, 1));
+      bulk_done[p] = new_event();
+      GPS_HIP(h, hipEventRecord(bulk_done[p], bulk));
+    }
+    GPS_TRY(receive(nxt, buf));
+  }
+  for (hipEvent_t e : bulk_done) if (e) GPS_HIP(h, hipStreamWaitEvent(chain, e, 0));
+  int linfo = 0;
+  rc = gps_dist_finish(h, lml, &linfo);
+  if (info) *info = linfo;
+#undef GPS_TRY
+  return cleanup(rc);
+}
+
 // ---- predict_f from a PARTITIONED factor: the panels are streamed once more (models/gpr.py:119-131) -------------------
 // Every rank holds a shard of the test points and solves  A^T = Kx^T L^-T  for it panel by panel as the panels come by
 // (forward substitution at panel granularity: block column j of A^T is final after panel j, the columns to its right
@@ -2271,6 +2373,41 @@ extern "C" int gps_dist_solve_finish(gps_handle_t h, const gps_kern_node_t* prog
   if (r > 0) GPS_HIP(h, hipMemcpyAsync(mean_out, dmean, (size_t)n_new * r * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   h->dist_solve_n = 0;
+  return GPS_OK;
+}
+
+// predict_f for this rank's shard of the test points from the partitioned factor gps_dist_lml left behind: gps_dist_solve_*
+// with the native communicator, the exchange of panel j + 1 in flight while panel j is applied (gpflowSlim/distributed.py::
+// predict_streamed, statement for statement).  n_new may be 0 (the rank still takes part in the exchanges).
+extern "C" int gps_dist_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Xnew, int64_t n_new,
+                                int exchange_mode, double* mean_out, double* var_out) {
+  if (!h || n_new < 0 || (n_new > 0 && (!Xnew || !var_out))) return gps_fail(h, GPS_ERR_ARG, "gps_dist_predict: bad argument");
+  if (!h->comm) return gps_fail(h, GPS_ERR_STATE, "gps_dist_predict: the handle has no communicator (gps_comm_init)");
+  if (!h->dist_have_part_factor || h->dist_nb <= 0) return gps_fail(h, GPS_ERR_STATE, "gps_dist_predict: no partitioned factor (gps_dist_lml first)");
+  GPS_HIP(h, hipSetDevice(h->device));
+  const int P = h->comm_world, rank = h->comm_rank;
+  const i64 n_panels = h->dist_np / h->dist_nb;
+  const i64 cap = ((dist_msg_doubles(h, 0) + P - 1) / P) * P;
+  void* bufs[2];
+  for (int b = 0; b < 2; ++b) { GPS_HIP(h, h->dDistComm[b].ensure((size_t)cap * 8)); bufs[b] = h->dDistComm[b].p; }
+  int rc = gps_dist_set_comm_bufs(h, bufs, 2);
+  if (rc) return rc;
+  if (n_new > 0) { rc = gps_dist_solve_begin(h, prog, n_nodes, Xnew, n_new); if (rc) return rc; }
+  auto send = [&](i64 j) -> int {
+    const int buf = (int)(j % 2);
+    if (rank == (int)(j % P)) { int rcc = gps_dist_solve_pack(h, j, buf); if (rcc) return rcc; }
+    const i64 n = dist_msg_doubles(h, j);
+    return gps_comm_exchange(h, bufs[buf], ((n + P - 1) / P) * P, (int)(j % P), exchange_mode, (int)(j % 8));
+  };
+  rc = send(0);
+  for (i64 j = 0; j < n_panels && !rc; ++j) {
+    rc = gps_comm_wait(h, (int)(j % 8));
+    if (!rc && j + 1 < n_panels) rc = send(j + 1);            // (stream-ordered after apply(j - 1), the last reader of that buffer)
+    if (!rc && n_new > 0) rc = gps_dist_solve_apply(h, j, (int)(j % 2));
+  }
+  if (rc) { (void)hipStreamSynchronize(h->stream); if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream); return rc; }
+  if (n_new > 0) return gps_dist_solve_finish(h, prog, n_nodes, mean_out, var_out);
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
 }
 

@@ -208,6 +208,7 @@ struct gps_handle_s {
   hipEvent_t comm_ready = nullptr, comm_done[8] = {};
   hipStream_t dist_bulk_stream = nullptr; bool dist_bulk_set = false;   // second lane of the distributed schedule
   DevBuf dDistScal;                 // [n_panels][4] per-panel sum log L_ii, sum alpha^2, info
+  DevBuf dDistComm[3];              // comm buffers of gps_dist_lml (the all-native driver; other callers bring their own)
 
   DevBuf dA;        // [r][npad]  K_y^-1 (Y - m)                         (gradient path)
   DevBuf dY;        // [npad, npad]  L^-T                                 (gradient path)

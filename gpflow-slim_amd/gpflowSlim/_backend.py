@@ -109,6 +109,9 @@ _SIGNATURES = {
     "gps_dist_solve_pack": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_solve_apply": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_solve_finish": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _c_double_p],
+    "gps_dist_lml": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, ctypes.c_double, _c_double_p, _i64, _i64, ctypes.c_int,
+                     ctypes.c_int, _c_double_p, _c_int_p],
+    "gps_dist_predict": [ctypes.c_void_p, ctypes.POINTER(KernNode), ctypes.c_int, _c_double_p, _i64, ctypes.c_int, _c_double_p, _c_double_p],
     "gps_dist_panel_factor": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_unpack": [ctypes.c_void_p, _i64, ctypes.c_int],
     "gps_dist_update": [ctypes.c_void_p, _i64, _i64, _i64, ctypes.c_int],
@@ -397,6 +400,28 @@ class Handle(object):
         mean = np.empty((n_new, max(r, 1)))
         var = np.empty(n_new)
         self._check(self._lib.gps_dist_solve_finish(self._h, prog, len(prog), _ptr(mean), _ptr(var)), "gps_dist_solve_finish")
+        return mean[:, :r], var
+
+    def dist_lml(self, prog, noise_var, resid, nb, lookahead, exchange_mode):
+        """gps_dist_lml: the whole block-column factorisation driven inside the library (native communicator required)."""
+        resid = _f64(resid)
+        lml = ctypes.c_double(0)
+        info = ctypes.c_int(0)
+        self.resident_token_factor = None
+        self._check(self._lib.gps_dist_lml(self._h, prog, len(prog), float(noise_var), _ptr(resid), resid.shape[1], int(nb), int(lookahead),
+                                           int(exchange_mode), ctypes.byref(lml), ctypes.byref(info)), "gps_dist_lml")
+        if info.value > 0:
+            raise NotPositiveDefiniteError(
+                "Cholesky decomposition was not successful: leading minor of order %d is not positive definite" % info.value)
+        return lml.value
+
+    def dist_predict(self, prog, Xnew, r, exchange_mode):
+        Xnew = _f64(Xnew)
+        n_new = Xnew.shape[0]
+        mean = np.empty((n_new, max(r, 1)))
+        var = np.empty(n_new)
+        self._check(self._lib.gps_dist_predict(self._h, prog, len(prog), _ptr(Xnew) if n_new else None, n_new, int(exchange_mode),
+                                               _ptr(mean) if n_new else None, _ptr(var) if n_new else None), "gps_dist_predict")
         return mean[:, :r], var
 
     def dist_panel_factor(self, j, buf):

@@ -324,6 +324,7 @@ class RcclComm(object):
         from . import _backend as be
         self.h, self.rank, self.world, self.mode = handle, int(rank), int(world), mode
         self.backend = "rccl-native"
+        self.native_schedule = True        # gpr_lml_distributed / predict_f_distributed run gps_dist_lml / gps_dist_predict (False: the Python schedule)
         self.bytes_sent = 0
         self.exchanges = 0
         self._slot = 0
@@ -505,6 +506,23 @@ def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2, partitioned=True)
     prog = model.kern._program(model.X.shape[1])
     model._factor_key = None
     model._dist_state = None
+    if isinstance(comm, RcclComm) and comm.native_schedule and comm.h is h:
+        # the library's own communicator: the whole schedule runs inside the library too (gps_dist_lml) -- no Python per panel
+        h.set_option("dist_partitioned", 1 if partitioned else 0)
+        mode = 1 if comm.mode == "scatter_allgather" else 0
+        lml = h.dist_lml(prog, float(np.squeeze(model.likelihood.variance)), model._resid(), nb, 2 if lookahead is True else int(lookahead), mode)
+        n_panels = -(-model.X.shape[0] // nb)
+        comm.exchanges += n_panels
+        for j in range(n_panels):              # the payload the library put on the wire (what RcclComm.exchange would have counted)
+            cnt = -(-h.dist_msg_doubles(j) // comm.world) * comm.world
+            root = (j % comm.world) == comm.rank
+            if comm.world > 1:
+                comm.bytes_sent += (8 * (cnt // comm.world) * (comm.world - 1) * (2 if root else 1)) if mode == 1 else (8 * cnt * (comm.world - 1) if root else 0)
+        if partitioned:
+            model._dist_state = {"key": model._state_key(), "native": True, "world": comm.world}
+        else:
+            model._factor_key = model._state_key()
+        return lml
     with HipPanelOps(h, prog, float(np.squeeze(model.likelihood.variance)), model._resid(), comm.world, comm.rank,
                      nb, two_lanes=bool(lookahead), partitioned=partitioned) as ops:
         block_column_schedule(ops, comm, ops.n_panels, lookahead=lookahead)
@@ -531,6 +549,13 @@ def predict_f_distributed(model, Xnew, comm=None):
     counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
     lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
     st = getattr(model, "_dist_state", None)
+    if st is not None and st.get("native") and st["key"] == model._state_key() and st["world"] == comm.world:
+        R = model.Y.shape[1]
+        Xmine = Xnew[lo:hi]
+        mu, var = model._handle().dist_predict(model.kern._program(model.X.shape[1]), Xmine, R, 1 if comm.mode == "scatter_allgather" else 0)
+        mu = mu + model.mean_function(Xmine) if Xmine.shape[0] else mu
+        both = comm.all_gather_rows(np.concatenate([mu, np.tile(var[:, None], [1, R])], axis=1), counts)
+        return both[:, :R], both[:, R:]
     if st is not None and st["key"] == model._state_key() and st["world"] == comm.world:
         R = model.Y.shape[1]
         Xmine = Xnew[lo:hi]

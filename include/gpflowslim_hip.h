@@ -372,6 +372,13 @@ int gps_dist_set_comm(gps_handle_t h, void* dev_buf0, void* dev_buf1);
  *                the whole factor is resident everywhere afterwards (warm gps_gpr_predict works).                */
 int gps_dist_set_comm_bufs(gps_handle_t h, void* const* dev_bufs, int count);
 int gps_dist_comm_bufs_needed(gps_handle_t h, int* count);
+/* The whole factorisation from inside the library: gps_dist_begin ... gps_dist_finish with the two-lane look-ahead schedule
+ * (gpflowSlim/distributed.py::block_column_schedule ported statement for statement), the handle's native communicator
+ * (gps_comm_init) for the panel exchange and HIP streams / events for the lanes -- no host-language call per panel.
+ * Collective: every rank calls it with the same arguments; same result bits on every rank; info as gps_dist_finish.
+ * exchange_mode: 0 broadcast, 1 scatter + all-gather.                                                            */
+int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var, const double* resid,
+                 int64_t r, int64_t nb, int lookahead, int exchange_mode, double* lml, int* info);
 /* predict_f (models/gpr.py:119-131, full_cov == 0) from a partitioned factor: every rank passes its shard of the test
  * points; the owner of panel j packs it again (gps_dist_solve_pack: same message layout as the factorisation's, length
  * gps_dist_msg_doubles(j)), the caller exchanges it, every rank applies it (gps_dist_solve_apply: block column j of
@@ -382,6 +389,10 @@ int gps_dist_solve_begin(gps_handle_t h, const gps_kern_node_t* prog, int n_node
 int gps_dist_solve_pack(gps_handle_t h, int64_t j, int buf);
 int gps_dist_solve_apply(gps_handle_t h, int64_t j, int buf);
 int gps_dist_solve_finish(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double* mean_out, double* var_out);
+/* ... and the whole streamed prediction from inside the library (native communicator; after gps_dist_lml): this rank's
+ * shard of the test points (n_new may be 0), mean [n_new, r] without the mean function, var [n_new].               */
+int gps_dist_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* Xnew, int64_t n_new,
+                     int exchange_mode, double* mean_out, double* var_out);
 /* device bytes held by the handle's own buffers (tests of the 8 N^2 / P + O(N nb) bound) */
 int gps_device_bytes(gps_handle_t h, int64_t* bytes);
 int gps_dist_set_bulk_stream(gps_handle_t h, void* hip_stream);

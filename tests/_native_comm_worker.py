@@ -44,6 +44,12 @@ res["mu"], res["var"] = mu.tolist(), var.tolist()
 comm.mode = "broadcast"
 res["lml_repl_bcast"] = gpr_lml_distributed(m, comm, nb=512, lookahead=1, partitioned=False)
 comm.mode = "scatter_allgather"
+# the same through the Python schedule (RcclComm.exchange per panel) instead of gps_dist_lml / gps_dist_predict
+comm.native_schedule = False
+res["lml_part_py"] = gpr_lml_distributed(m, comm, nb=256, lookahead=2, partitioned=True)
+mu2, var2 = predict_f_distributed(m, Xs, comm)
+res["mu_py"] = mu2.tolist()
+comm.native_schedule = True
 res["exchanges"], res["bytes_sent"] = comm.exchanges, comm.bytes_sent
 # config 5 pieces through the same communicator
 rng = np.random.default_rng(5)

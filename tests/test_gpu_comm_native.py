@@ -45,14 +45,16 @@ def test_collectives_world_one(comm_handle):
         h.comm_init(0, 1, be.comm_unique_id())
 
 
+@pytest.mark.parametrize("native_schedule", [True, False])
 @pytest.mark.parametrize("partitioned", [True, False])
-def test_block_column_factorisation_through_the_native_communicator(comm_handle, partitioned):
+def test_block_column_factorisation_through_the_native_communicator(comm_handle, partitioned, native_schedule):
     """gpr_lml_distributed + predict_f_distributed with RcclComm as the communicator (exchange = gps_comm_exchange on the
     communicator's stream, wait = an event wait of the chain lane): LML and predictions against the oracle."""
     import gpflowSlim as gpf
     from gpflowSlim import _backend as be
     from gpflowSlim.distributed import gpr_lml_distributed, predict_f_distributed
     h, comm = comm_handle
+    comm.native_schedule = native_schedule        # True: gps_dist_lml / gps_dist_predict (the schedule inside the library); False: the Python schedule
     n, d = 2500, 4
     X, Y, Xs = orc.synthetic_gpr_data(n, d, 40, seed=3)
     ls = np.linspace(0.9, 1.7, d)
@@ -134,6 +136,8 @@ def test_two_ranks_through_a_stand_in_transport(tmp_path):
         assert np.abs(np.array(r["var"]) - rvar).max() <= 1e-8 * np.abs(rvar).max()
         assert r["exchanges"] > 20 and r["bytes_sent"] > 0
     assert res[0]["lml_part_sag"] == res[1]["lml_part_sag"] and res[0]["lml_repl_bcast"] == res[1]["lml_repl_bcast"]
+    # the schedule inside the library (gps_dist_lml) and the Python schedule issue the same launches in the same order
+    assert all(r["lml_part_py"] == r["lml_part_sag"] and r["mu_py"] == r["mu"] for r in res)
     assert res[0]["mu"] == res[1]["mu"] and res[0]["cond_mean"] == res[1]["cond_mean"]
     Z = X[:150].copy()
     k2 = gpf.kernels.RBF(d, variance=1.3, lengthscales=1.1)
