@@ -153,3 +153,23 @@ def test_bench_two_ranks_native_communicator_stand_in_transport():
     rows = lambda j: 4096 + 128 - j * 256
     payload = sum(-(-(rows(j) * 256 + 2 * 2 * 128 * 128 + 4) // 2) * 2 for j in range(n_panels)) * 8
     assert abs(dd["payload_bytes_per_eval_all_ranks"] - 1.5 * payload) <= 1e-6 * payload      # scatter + all-gather: (P + 1) / P of a broadcast's bytes
+
+
+def test_example_gpr_distributed_two_ranks():
+    """examples/gpr_distributed.py under torch.distributed.run with two ranks (gloo, both on the one GPU): partitioned
+    factorisation + streamed predictions, the printed numbers equal to the one-rank run's."""
+    import re
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    vals = []
+    for nproc in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "examples", "gpr_distributed.py"), "--npoints", "3000", "--dims", "4", "--num-test", "101",
+               "--block", "256", "--backend", "gloo", "--force-device", "0"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+        m = re.search(r"log marginal likelihood (-?[\d.]+) .* rmse vs noise-free truth ([\d.]+)", p.stdout)
+        assert m, p.stdout[-2000:]
+        vals.append((float(m.group(1)), float(m.group(2))))
+    assert abs(vals[0][0] - vals[1][0]) <= 1e-6 * abs(vals[0][0]) and abs(vals[0][1] - vals[1][1]) <= 1e-4
+    assert vals[0][1] < 0.1                     # the GP has learnt the function
