@@ -563,5 +563,29 @@ def h_npad(n):
     return ((n + 127) // 128) * 128
 
 
+def _main_reporting_failures():
+    """A rank of a multi-rank run that fails says so in the contract's own format before it dies: rank 0 prints one JSON line
+    with `value` 0 and an `error` field (the driver's record then carries the reason, not an empty stdout), every rank exits
+    non-zero at once -- without running the interpreter's clean-up, which could wait on a broken process group -- so that the
+    launcher (torch.distributed.run, or launch_ranks above) stops the other ranks instead of leaving them in a collective."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or "RANK" not in os.environ:
+        return main()
+    try:
+        return main()
+    except SystemExit:
+        raise
+    except BaseException as e:       # noqa: BLE001 -- reported, then the process ends
+        import traceback
+        traceback.print_exc()
+        if os.environ.get("RANK", "0") == "0":
+            print(json.dumps({"metric": "GPR log-marginal-likelihood evals/sec + predict_f latency, fp64, N=32768 D=8", "value": 0.0,
+                              "unit": "evals/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "failed run"},
+                              "error": "%s: %s" % (type(e).__name__, str(e)[:500])}), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
+
+
 if __name__ == "__main__":
-    main()
+    _main_reporting_failures()

@@ -2,6 +2,7 @@
 compiler, and the C-ABI library surface (loads, exports every declared symbol, refuses to run
 without a GPU instead of falling back)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -193,12 +194,13 @@ def test_bench_launcher_stays_off_the_gpu_and_reports_failure():
         pytest.skip("the failure leg needs a machine without a GPU")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert "launcher rc 1" in p.stdout, (p.stdout, p.stderr[-2000:])
+    assert "launcher rc 3" in p.stdout, (p.stdout, p.stderr[-2000:])
     assert "needs an MI355X" in p.stderr and "exited with status" in p.stderr
-    # and through the command line: same thing, non-zero status
+    # and through the command line: same thing, non-zero status -- and the one JSON line rank 0 leaves says why (value 0)
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], capture_output=True,
                        text=True, timeout=300, env=env)
-    assert q.returncode != 0 and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]
+    lines = [json.loads(ln) for ln in q.stdout.splitlines() if ln.startswith("{")]
+    assert q.returncode != 0 and len(lines) == 1 and lines[0]["value"] == 0.0 and "needs an MI355X" in lines[0]["error"]
 
 
 def test_native_rccl_binding_loads_without_a_gpu(gpf):
