@@ -68,6 +68,16 @@ def launch_ranks(n_ranks, argv, timeout_s):
         # rank 0 writes the JSON line to our stdout; the other ranks' stdout goes to stderr (nothing of theirs is the line)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
+    # the ranks must not outlive this process: whoever stops the launcher (a driver's time-out sends SIGTERM) stops them too
+    import signal
+
+    def stop_ranks(signum, frame):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                              # exactly the processes started above
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop_ranks)
     deadline = time.time() + timeout_s
     status = 0
     live = list(procs)

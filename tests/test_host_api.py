@@ -214,3 +214,31 @@ def test_native_rccl_binding_loads_without_a_gpu(gpf):
     assert be.comm_version() >= 20000
     uid = be.comm_unique_id()
     assert isinstance(uid, bytes) and len(uid) == 128 and uid != be.comm_unique_id()
+
+
+def test_bench_launcher_takes_its_ranks_with_it():
+    """Whoever stops `python bench.py --gpus N` (a driver's time-out: SIGTERM) stops the rank processes it started too --
+    no orphaned GPU processes."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=env)
+    kids = []
+    for _ in range(50):
+        time.sleep(0.1)
+        kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+        if len(kids) == 2:
+            break
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    time.sleep(0.5)
+
+    def alive(pid):
+        try:
+            return "zombie" not in open("/proc/%s/status" % pid).read().lower()
+        except OSError:
+            return False
+    assert p.returncode == 128 + signal.SIGTERM
+    assert not [k for k in kids if alive(k)]
