@@ -516,7 +516,7 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
     points sharded over the ranks (no data-path collective: only the gather of the [N, 1] outputs) -> weak in M, strong in
     N: `value` = points / s of the whole job.  The SVGP bound (one scalar reduction) is timed beside it."""
     from gpflowSlim.distributed import TorchComm, SingleComm
-    from gpflowSlim.distributed_sparse import conditional_distributed, svgp_bound_distributed
+    from gpflowSlim.distributed_sparse import conditional_distributed, svgp_bound_distributed, sparse_bound_distributed
     m, n, d = args.cfg5_m, args.cfg5_n, 8
     rng = np.random.default_rng(20240607)
     X = rng.standard_normal((n, d))
@@ -547,6 +547,8 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
     t_cond, (fm, fv) = timed(lambda: conditional_distributed(X, Z, kern, f, comm=comm, white=True), args.steps, args.warmup)
     mod = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.1), Z=Z, q_diag=True, whiten=True)
     t_svgp, elbo = timed(lambda: svgp_bound_distributed(mod, comm), max(1, args.steps // 2), 1)
+    sg = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.1)
+    t_sgpr, sbound = timed(lambda: sparse_bound_distributed(sg, comm), max(1, args.steps // 2), 1)
     if rank == 0:
         mp = ((m + 127) // 128) * 128
         flops = float(mp) * mp * n + mp ** 3 / 3.0                       # trsm M^2 N + Kuu potrf
@@ -566,6 +568,9 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
             "cpu_baseline": None,
             "svgp_bound": {"ms": round(1e3 * t_svgp, 3), "elbo": elbo, "q_diag": True,
                            "collective": "one gathered scalar per rank, added in rank order"},
+            "sgpr_bound": {"ms": round(1e3 * t_sgpr, 3), "bound": sbound,
+                           "collective": "one in-place device all-reduce of [A A^T | A err | diag | scalars] (%d doubles) inside gps_sgpr" % (
+                               mp * mp + mp * 1 + mp + 4)},
             "checksum": {"fmean_sum": float(fm.sum()), "fvar_min": float(fv.min())}}), flush=True)
 
 
