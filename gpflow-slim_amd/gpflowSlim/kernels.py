@@ -74,6 +74,37 @@ class Kernel(object):
     def Kdiag(self, X, presliced=False):
         raise NotImplementedError
 
+    # eager helpers of the reference (kernels.py:68-75): there they build the tensor and evaluate it; here K / Kdiag are eager
+    def compute_K(self, X, Z):
+        return self.K(X, Z)
+
+    def compute_K_symm(self, X):
+        return self.K(X)
+
+    def compute_Kdiag(self, X):
+        return self.Kdiag(X)
+
+    def _slice(self, X, X2):
+        """kernels.py:217-253: the columns this kernel reads (host-side view; the device kernels gather the active dims
+        themselves from the un-sliced X)."""
+        X = np.asarray(X, dtype=settings.float_type)
+        dims = self._dims(False, X.shape[1])
+        Xs = X[:, dims]
+        X2s = None if X2 is None else np.asarray(X2, dtype=settings.float_type)[:, dims]
+        if Xs.shape[1] != self.input_dim:
+            raise ValueError("Input 1st dimension does not match kernel dimension.")
+        return Xs, X2s
+
+    def Kdim(self, dim, X, X2=None):
+        """kernels.py:287-306: the covariance along one input dimension -- X [n, 1] is placed in column `dim` of an otherwise
+        zero [n, input_dim] input."""
+        def pad(a):
+            a = np.asarray(a, dtype=settings.float_type)
+            out = np.zeros((a.shape[0], self.input_dim), dtype=settings.float_type)
+            out[:, dim] = a[:, 0]
+            return out
+        return self.K(pad(X), None if X2 is None else pad(X2), presliced=True)
+
     def __add__(self, other):
         return Sum([self, other])
 
@@ -165,6 +196,12 @@ class Stationary(Kernel):
         nd = len(self._dims(False, d_all))
         ard = np.atleast_1d(self.lengthscales).size > 1
         return [(self._variance, None)] + [(self._ls, d if ard else None) for d in range(nd)]
+
+    def dimwise(self, dim):
+        """kernels.py:441-444, 579-582, ...: the one-dimensional factor of this kernel along `dim` (variance^(1 / input_dim))."""
+        ls = np.atleast_1d(self.lengthscales)
+        return type(self)(input_dim=1, variance=float(np.squeeze(self.variance)) ** (1.0 / self.input_dim),
+                          lengthscales=float(ls[dim] if self.ARD else ls[0]), name='%s_dimwise_%d' % (type(self).__name__, dim))
 
 
 class RBF(Stationary):

@@ -901,3 +901,31 @@ def test_ill_conditioned_conditional_against_exact_arithmetic(handle):
     gm = lambda v: float(np.exp(np.mean(np.log(v))))
     assert gm(errs) <= 2.0 * gm(lap) and max(errs) <= 2.0 * max(lap), (gm(errs), gm(lap), max(errs), max(lap))
     assert gm(plain) >= 3.0 * gm(errs), (gm(plain), gm(errs))               # the refinement is what buys the digit
+
+
+def test_kernel_helper_methods(handle):
+    """The reference's eager helpers on the kernel objects (kernels.py:68-75 compute_K / compute_K_symm / compute_Kdiag,
+    :217-253 _slice, :287-306 Kdim, :441-444 dimwise): thin, but part of the surface a user of the reference calls."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(0)
+    d = 3
+    X = rng.standard_normal((40, 5)); Z = rng.standard_normal((17, 5))
+    dims = [4, 0, 2]
+    ls = np.array([0.7, 1.1, 1.9])
+    k = gpf.kernels.RBF(d, variance=1.7, lengthscales=ls, ARD=True, active_dims=dims)
+    spec = {"type": "rbf", "variance": orc.constrained(1.7), "lengthscales": orc.constrained(ls), "active_dims": dims, "input_dim": d}
+    assert rel(k.compute_K(X, Z), orc.K(spec, X, Z)) <= 1e-12 and rel(k.compute_K_symm(X), orc.K(spec, X)) <= 1e-12
+    assert np.array_equal(k.compute_Kdiag(X), k.Kdiag(X))
+    Xs, Zs = k._slice(X, Z)
+    assert np.array_equal(Xs, X[:, dims]) and np.array_equal(Zs, Z[:, dims]) and k._slice(X, None)[1] is None
+    # Kdim / dimwise: for RBF the product over dimensions of the dimwise kernels is the kernel (variance^(1/D) each)
+    x1 = rng.standard_normal((25, 1))
+    prod = np.ones((25, 25))
+    for j in range(d):
+        kj = k.dimwise(j)
+        assert kj.input_dim == 1 and abs(float(np.squeeze(kj.lengthscales)) - float(k.lengthscales[j])) <= 1e-12
+        prod *= kj.K(rng.standard_normal((25, 1)) * 0 + X[:25, [dims[j]]])
+        one = k.Kdim(j, x1)                                      # the other dimensions at zero distance
+        s1 = {"type": "rbf", "variance": orc.constrained(1.7), "lengthscales": orc.constrained(ls[j]), "input_dim": 1}
+        assert rel(one, orc.K(s1, x1)) <= 1e-12
+    assert rel(prod, k.K(X[:25])) <= 1e-12
