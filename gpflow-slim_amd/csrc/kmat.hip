@@ -220,9 +220,12 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
           double val;
           if (node.op == GPS_K_RBF) {
             val = node.variance * gps_exp_nonpos(-r2 / 2.0);
+          } else if (node.op == GPS_K_SQDIST) {
+            val = node.variance * r2;                                    // kernels.py:408-421 as a callable
           } else {
             const double r = sqrt(r2 + 1e-12);
             if (node.op == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
+            else if (node.op == GPS_K_EUCLID) val = node.variance * r;    // kernels.py:424-426
             else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
             else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
             else val = node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r);
@@ -628,7 +631,8 @@ static int launch_mfma(gps_handle_t h, KmatArgs a, const KProgDev& P, i64 prow, 
 // p0 (p_i op_i)* with op in {ADD, MUL}
 static bool is_left_deep_chain(const KProgDev& P) {
   if (P.n_nodes < 3 || (P.n_nodes & 1) == 0) return false;
-  auto prim = [](int op) { return op != GPS_K_ADD && op != GPS_K_MUL && op < GPS_K_NKN_LINROW; };
+  // (the distance ops are evaluated by the interpreter only: they are helpers, not kernels of a model)
+  auto prim = [](int op) { return op != GPS_K_ADD && op != GPS_K_MUL && op != GPS_K_SQDIST && op != GPS_K_EUCLID && op < GPS_K_NKN_LINROW; };
   if (!prim(P.nodes[0].op)) return false;
   for (int i = 1; i < P.n_nodes; i += 2) {
     if (!prim(P.nodes[i].op)) return false;
@@ -773,6 +777,9 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
     while (n_prim_nodes < n_nodes && prog[n_prim_nodes].op < GPS_K_ADD) ++n_prim_nodes;
     if (n_prim_nodes == 0 || n_prim_nodes > NKN_MAXP)
       return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: 1..8 primitive kernels first");
+    for (int i = 0; i < n_prim_nodes; ++i)
+      if (prog[i].op == GPS_K_SQDIST || prog[i].op == GPS_K_EUCLID)
+        return gps_fail(h, GPS_ERR_UNSUPPORTED, "NKN program: the distance ops are not kernels");
     for (int i = n_prim_nodes; i < n_nodes; ++i)
       if (prog[i].op < GPS_K_NKN_LINROW) return gps_fail(h, GPS_ERR_ARG, "NKN program: layers must follow the primitives");
     out.prog.n_nodes = n_prim_nodes;
@@ -790,7 +797,7 @@ static int compile_prog(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes
         depth += 1;
         break;
       case GPS_K_RBF: case GPS_K_MATERN12: case GPS_K_MATERN32: case GPS_K_MATERN52:
-      case GPS_K_EXPONENTIAL: case GPS_K_PERIODIC: {
+      case GPS_K_EXPONENTIAL: case GPS_K_PERIODIC: case GPS_K_SQDIST: case GPS_K_EUCLID: {
         if (nd.n_dims <= 0 || nd.n_dims > GPS_MAX_DIMS)
           return gps_fail(h, GPS_ERR_ARG, "kernel program: n_dims out of range");
         kd.f0 = (int)out.feats.size();

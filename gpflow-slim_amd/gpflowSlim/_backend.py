@@ -16,6 +16,7 @@ GPS_MAX_STACK = 4
 
 # enum gps_kern_op
 K_RBF, K_MATERN12, K_MATERN32, K_MATERN52, K_PERIODIC, K_WHITE, K_CONSTANT, K_EXPONENTIAL = 1, 2, 3, 4, 5, 6, 7, 8
+K_SQDIST, K_EUCLID = 9, 10
 K_ADD, K_MUL = 16, 17
 K_NKN_LINROW, K_NKN_PRODUCT, K_NKN_ACT = 32, 33, 34
 

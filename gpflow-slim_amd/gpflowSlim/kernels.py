@@ -197,6 +197,22 @@ class Stationary(Kernel):
         ard = np.atleast_1d(self.lengthscales).size > 1
         return [(self._variance, None)] + [(self._ls, d if ard else None) for d in range(nd)]
 
+    def _dist(self, op, X, X2):
+        # the reference calls these on already-sliced inputs (K slices first, kernels.py:436-438): columns 0 .. input_dim - 1
+        X = np.asarray(X, dtype=settings.float_type)
+        ls = np.atleast_1d(self.lengthscales)
+        node = be.primitive_node(op, 1.0, list(range(X.shape[1])), ls)
+        return be.get_handle().kmat(be.make_program([node]), X, None if X2 is None else np.asarray(X2, dtype=settings.float_type))
+
+    def square_dist(self, X, X2):
+        """kernels.py:408-421: max(0, |a|^2 + |b|^2 - 2 a.b) with a = X / lengthscales -- evaluated by the same device tile pass
+        (program op GPS_K_SQDIST) every stationary K is built on."""
+        return self._dist(be.K_SQDIST, X, X2)
+
+    def euclid_dist(self, X, X2):
+        """kernels.py:424-426: sqrt(square_dist + 1e-12)"""
+        return self._dist(be.K_EUCLID, X, X2)
+
     def dimwise(self, dim):
         """kernels.py:441-444, 579-582, ...: the one-dimensional factor of this kernel along `dim` (variance^(1 / input_dim))."""
         ls = np.atleast_1d(self.lengthscales)

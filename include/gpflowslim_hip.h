@@ -53,6 +53,9 @@ enum gps_kern_op {
   GPS_K_CONSTANT = 7,  /* Constant.K       kernels.py:345-350; also the
                           scalars of Combination.const_list :1026-1027      */
   GPS_K_EXPONENTIAL = 8, /* Exponential.K  kernels.py:560-565 */
+  GPS_K_SQDIST   = 9,  /* Stationary.square_dist  kernels.py:408-421: variance * max(0, |a|^2 + |b|^2 - 2 a.b), a = x / l (the
+                          callable form of the distance every stationary primitive is built on; not differentiable here) */
+  GPS_K_EUCLID   = 10, /* Stationary.euclid_dist  kernels.py:424-426: variance * sqrt(square_dist + 1e-12)               */
   GPS_K_ADD      = 16, /* Sum.K     reduce(tf.add, ...)      :1073          */
   GPS_K_MUL      = 17, /* Product.K reduce(tf.multiply, ...) :1081          */
   /* Neural Kernel Network (neural_kernel_network/neural_kernel_network.py:41-47): a program that

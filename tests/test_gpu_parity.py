@@ -929,3 +929,19 @@ def test_kernel_helper_methods(handle):
         s1 = {"type": "rbf", "variance": orc.constrained(1.7), "lengthscales": orc.constrained(ls[j]), "input_dim": 1}
         assert rel(one, orc.K(s1, x1)) <= 1e-12
     assert rel(prod, k.K(X[:25])) <= 1e-12
+    # Stationary.square_dist / euclid_dist (kernels.py:408-426) as callables, on pre-sliced inputs like in the reference
+    for a, b in ((Xs, Zs), (Xs, None)):
+        r2 = k.square_dist(a, b)
+        want = orc.square_dist(a, a if b is None else b, orc.constrained(ls))
+        assert r2.shape == want.shape and np.abs(r2 - want).max() <= 1e-12 * max(1.0, np.abs(want).max()) and r2.min() >= 0.0
+        r = k.euclid_dist(a, b)
+        off = ~np.eye(*want.shape, dtype=bool) if b is None else np.ones(want.shape, dtype=bool)
+        assert np.abs(r - np.sqrt(want + 1e-12))[off].max() <= 1e-11 * max(1.0, np.sqrt(want).max())
+    assert np.all(np.diag(k.square_dist(Xs, None)) == 0.0)           # exactly zero on the diagonal of the symmetric form
+    iso = gpf.kernels.Matern32(2, lengthscales=1.3)
+    assert rel(iso.square_dist(X[:, :2], Z[:, :2]), orc.square_dist(X[:, :2], Z[:, :2], orc.constrained(1.3))) <= 1e-12
+    # the distance ops are helpers, not model kernels: the gradient entry points refuse them
+    with pytest.raises(RuntimeError):
+        from gpflowSlim import _backend as be
+        handle.gpr_set_data(X, ("dist-op",))
+        handle.gpr_lml_grad(be.make_program([be.primitive_node(be.K_SQDIST, 1.0, [0, 1], [1.0, 1.0])]), 0.1, X[:, :1])
