@@ -2205,7 +2205,10 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
   if (D >= 1) GPS_HIP(h, hipStreamCreateWithPriority(&bulk, hipStreamNonBlocking, lo));
   std::vector<hipEvent_t> events;
   auto new_event = [&]() -> hipEvent_t { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; };
+  // (inside this function every failure leaves through cleanup(): the handle must get its own stream back)
+#define DL_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return dl_fail(std::string(#call) + ": " + hipGetErrorString(e__)); } while (0)
   int rc = gps_set_stream(h, chain, 1);
+  auto dl_fail = [&](const std::string& msg) -> int { return gps_fail(h, GPS_ERR_HIP, msg); };
   auto cleanup = [&](int code) -> int {
     // both lanes drained on every exit path, the handle's own stream back
     (void)hipStreamSynchronize(chain);
@@ -2259,11 +2262,11 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
       continue;
     }
     hipEvent_t in_place = new_event();
-    GPS_HIP(h, hipEventRecord(in_place, chain));
+    GPS_TRY([&]() -> int { DL_HIP(hipEventRecord(in_place, chain)); return GPS_OK; }());
     const i64 last_urgent = (p + D < n_panels - 1) ? p + D : n_panels - 1;
     auto urgent = [&](i64 c) -> int {
       // first CHAIN update of column c = p + D: the BULK updates of panels <= p - 1 may still be running on it
-      if (c == p + D && p >= 1 && bulk_done[p - 1]) { GPS_HIP(h, hipStreamWaitEvent(chain, bulk_done[p - 1], 0)); bulk_done[p - 1] = nullptr; }
+      if (c == p + D && p >= 1 && bulk_done[p - 1]) { DL_HIP(hipStreamWaitEvent(chain, bulk_done[p - 1], 0)); bulk_done[p - 1] = nullptr; }
       return gps_dist_update(h, p, c, c + 1, 0);
     };
     GPS_TRY(urgent(nxt));
@@ -2271,18 +2274,19 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
     GPS_TRY(exchange(nxt, buf));                                  // in flight while ...
     for (i64 c = nxt + 1; c <= last_urgent; ++c) GPS_TRY(urgent(c));   // ... the other urgent columns
     if (last_urgent + 1 < n_panels) {                            // ... and the bulk of the update run
-      GPS_HIP(h, hipStreamWaitEvent(bulk, in_place, 0));
+      GPS_TRY([&]() -> int { DL_HIP(hipStreamWaitEvent(bulk, in_place, 0)); return GPS_OK; }());
       GPS_TRY(gps_dist_update(h, p, last_urgent + 1, n_panels, 1));
       bulk_done[p] = new_event();
-      GPS_HIP(h, hipEventRecord(bulk_done[p], bulk));
+      GPS_TRY([&]() -> int { DL_HIP(hipEventRecord(bulk_done[p], bulk)); return GPS_OK; }());
     }
     GPS_TRY(receive(nxt, buf));
   }
-  for (hipEvent_t e : bulk_done) if (e) GPS_HIP(h, hipStreamWaitEvent(chain, e, 0));
+  for (hipEvent_t e : bulk_done) if (e) GPS_TRY([&]() -> int { DL_HIP(hipStreamWaitEvent(chain, e, 0)); return GPS_OK; }());
   int linfo = 0;
   rc = gps_dist_finish(h, lml, &linfo);
   if (info) *info = linfo;
 #undef GPS_TRY
+#undef DL_HIP
   return cleanup(rc);
 }
 
