@@ -119,7 +119,10 @@ class DeviceAllReduce(object):
         import torch
         self.h, self.comm = handle, comm
         self.cap = handle.allreduce_doubles(m, r)
-        self.buf = torch.zeros(self.cap, dtype=torch.float64, device=torch.device("cuda", handle.device))
+        # (empty, not zeros: the library writes every double it reduces, and a fill kernel on torch's stream would not be
+        # ordered against the library's own non-blocking stream)
+        self.buf = torch.empty(self.cap, dtype=torch.float64, device=torch.device("cuda", handle.device))
+        torch.cuda.synchronize(self.buf.device)
         self.error = None
         base = self.buf.data_ptr()
 

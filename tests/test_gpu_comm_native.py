@@ -89,6 +89,7 @@ def test_sparse_bound_reduces_through_the_native_allreduce(comm_handle):
     for fitc in (False, True):
         plain = h.sgpr(prog, Z, X, Y, 1e-6, 0.15, fitc=fitc)[0]
         buf = torch.zeros(h.allreduce_doubles(m, r), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()                       # (the fill runs on torch's stream, the library on its own)
         h.comm_install_allreduce(buf.data_ptr(), buf.numel())
         try:
             hooked = h.sgpr(prog, Z, X, Y, 1e-6, 0.15, fitc=fitc)[0]
