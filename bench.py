@@ -47,61 +47,198 @@ def kernel_source_sha():
     return hsh.hexdigest()[:16]
 
 
-def launch_ranks(n_ranks, argv, timeout_s):
-    """`python bench.py --gpus N` without a launcher: start N rank processes of this very script and relay
-    rank 0's output.  Runs before anything GPU-related is imported (the parent stays torch-free: a process that
-    has initialised the GPU must never be the one that starts or replaces GPU programs).  Returns the exit status:
-    0 only if every rank exited 0."""
+ATTEMPTS = {
+    # name -> (what the rank processes do differently, what it is)
+    "rccl": "the library's own RCCL binding (csrc/comm_rccl.hip) and the in-library two-lane schedule (gps_dist_lml)",
+    "torch": "torch.distributed issues the collectives (RCCL through PyTorch); exchange and panel width chosen by measurement",
+    "torch-broadcast": "torch.distributed, one plain broadcast per panel, fixed panel width (the most conservative form)",
+}
+
+
+def plan_attempts(args):
+    """Which configurations a multi-rank run tries, in order.  An explicit --comm means exactly that one."""
+    if args.attempts:
+        names = [a for a in args.attempts.split(",") if a]
+    elif args.comm == "auto":
+        names = ["rccl", "torch", "torch-broadcast"] if (args.backend == "nccl" and args.workload == "gpr") else ["torch"]
+    else:
+        names = [args.comm]
+    for a in names:
+        if a not in ATTEMPTS:
+            raise SystemExit("bench.py: unknown attempt %r (known: %s)" % (a, ", ".join(ATTEMPTS)))
+    return names
+
+
+def _atomic_write(path, text):
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def supervise(local_ranks, world, argv, attempts, rdv_dir, first_stall_s, stall_s, clean_dir):
+    """The GPU-free parent of the rank processes (it never imports torch and never touches a GPU: a process that has
+    initialised the GPU must never be the one that starts or replaces GPU programs).
+
+    `local_ranks`: the ranks this process is responsible for -- all of them when `python bench.py --gpus N` is its own
+    launcher, one when a launcher (torch.distributed.run) started one bench.py per rank; the supervisors of one run then meet
+    in `rdv_dir` (same node: files).  For every attempt, in order: FRESH rank processes (new rendezvous port), each watched
+    through a progress file it appends to; an attempt ends for everybody as soon as one rank fails or stalls (the others are
+    killed: they would sit in a collective), and only if every rank exited 0 is rank 0's JSON line relayed -- with a `launch`
+    object that says which attempt produced it and why the earlier ones did not.  Returns the exit status."""
+    import signal
     import socket
     import subprocess
-    assert "torch" not in sys.modules, "the launcher must not have imported torch"
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   GPS_BENCH_SELF_LAUNCHED="1")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
-        # rank 0 writes the JSON line to our stdout; the other ranks' stdout goes to stderr (nothing of theirs is the line)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    # the ranks must not outlive this process: whoever stops the launcher (a driver's time-out sends SIGTERM) stops them too
-    import signal
+    assert "torch" not in sys.modules, "the supervisor must not have imported torch"
+    leader = 0 in local_ranks
+    os.makedirs(rdv_dir, exist_ok=True)
+    procs = {}
 
     def stop_ranks(signum, frame):
-        for p in procs:
+        for p in procs.values():
             if p.poll() is None:
-                p.kill()                                              # exactly the processes started above
+                p.kill()                                              # exactly the processes started here
         os._exit(128 + signum)
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, stop_ranks)
-    deadline = time.time() + timeout_s
-    status = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            rc = p.poll()
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0 and status == 0:
-                status = rc if rc > 0 else 1
-                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (procs.index(p), rc), file=sys.stderr)
-                deadline = min(deadline, time.time() + 15.0)          # the others see the broken group and leave; else kill
-        if live and time.time() > deadline:
-            if status == 0:
-                status = 2
-                print("bench.py: ranks still running after %.0f s; killing them" % timeout_s, file=sys.stderr)
-            for p in live:
-                p.kill()                                              # exactly the processes started above
-            for p in live:
-                p.wait()
-            live = []
+
+    def wait_for(path, seconds):
+        t_end = time.time() + seconds
+        while time.time() < t_end:
+            v = _read(path)
+            if v is not None:
+                return v
+            time.sleep(0.05)
+        return None
+
+    failed = []
+    status = 3
+    last_error_line = None
+    for k, name in enumerate(attempts):
+        tag = os.path.join(rdv_dir, "a%d" % k)
+        if leader:
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            _atomic_write(tag + ".port", str(port))
+        port = wait_for(tag + ".port", 180.0)
+        if port is None:
+            failed.append({"attempt": name, "reason": "no rendezvous port from rank 0's supervisor"})
+            break
+        procs.clear()
+        t_start = time.time()
+        for r in local_ranks:
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       GPS_BENCH_CHILD="1", GPS_BENCH_PROGRESS="%s.r%d.progress" % (tag, r))
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)             # the ranks bring their own store up on the fresh port
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
+            _atomic_write(env["GPS_BENCH_PROGRESS"], "")
+            # rank 0's stdout (the JSON line) goes to a file that is relayed only if the whole attempt succeeds
+            out = open("%s.r0.out" % tag, "w") if r == 0 else sys.stderr
+            procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + ["--attempt-name", name],
+                                        env=env, stdout=out)
+        live = dict(procs)
+        peer_failed_at = None
+        why = {}
+        while live:
+            time.sleep(0.2)
+            now = time.time()
+            for r, p in list(live.items()):
+                rc = p.poll()
+                if rc is None:
+                    # stalled?  (no line appended to its progress file for too long)
+                    prog = env_prog = "%s.r%d.progress" % (tag, r)
+                    try:
+                        last = os.path.getmtime(prog)
+                    except OSError:
+                        last = t_start
+                    text = _read(env_prog) or ""
+                    limit = stall_s if text.strip() else first_stall_s
+                    if now - max(last, t_start) > limit:
+                        p.kill(); p.wait()
+                        rc = 98
+                        why[r] = "rank %d made no progress for %.0f s after '%s'" % (r, limit, (text.strip().splitlines() or ["start"])[-1])
+                    elif peer_failed_at is not None and now - peer_failed_at > 10.0:
+                        p.kill(); p.wait()
+                        rc = 97
+                    else:
+                        continue
+                elif rc != 0:
+                    why.setdefault(r, "rank %d exited with status %d" % (r, rc))
+                del live[r]
+                _atomic_write("%s.r%d.rc" % (tag, r), "%d\n%s" % (rc, why.get(r, "")))
+            if peer_failed_at is None:
+                for r in range(world):
+                    v = _read("%s.r%d.rc" % (tag, r))
+                    if v is not None and v.split("\n")[0].strip() not in ("0", ""):
+                        peer_failed_at = now
+                        break
+        # every rank's verdict (the other supervisors write theirs)
+        rcs, reasons = [], []
+        for r in range(world):
+            v = wait_for("%s.r%d.rc" % (tag, r), stall_s + 60.0)
+            code = int(v.split("\n")[0]) if v and v.split("\n")[0].strip().lstrip("-").isdigit() else 96
+            rcs.append(code)
+            if code not in (0, 97):
+                reasons.append((v.split("\n", 1)[1].strip() if v and "\n" in v else "") or "rank %d: no verdict" % r)
+        if all(c == 0 for c in rcs):
+            status = 0
+            if leader:
+                lines = [ln for ln in (_read("%s.r0.out" % tag) or "").splitlines() if ln.startswith("{")]
+                try:
+                    rec = json.loads(lines[-1])
+                    rec["launch"] = {"attempt": name, "what": ATTEMPTS[name], "index": k, "tried": attempts, "failed_attempts": failed,
+                                     "supervisor": "bench.py (GPU-free parent; fresh rank processes per attempt)"}
+                    print(json.dumps(rec), flush=True)
+                except (IndexError, ValueError):
+                    print("bench.py: rank 0 exited 0 without a JSON line", file=sys.stderr)
+                    status = 3
+            break
+        reason = "; ".join(reasons) or "a rank failed"
+        failed.append({"attempt": name, "reason": reason[:400]})
+        print("bench.py: attempt '%s' failed (%s)%s" % (name, reason, "; trying the next one" if k + 1 < len(attempts) else ""),
+              file=sys.stderr, flush=True)
+        if leader:
+            err = [ln for ln in (_read("%s.r0.out" % tag) or "").splitlines() if ln.startswith("{")]
+            if err:
+                last_error_line = err[-1]
+                print("bench.py: rank 0 of the failed attempt said: %s" % err[-1][:600], file=sys.stderr, flush=True)
+    if status != 0 and leader:
+        # one JSON line even then: what rank 0 of the last attempt left (its `error` says why), or a generic one
+        rec = None
+        try:
+            rec = json.loads(last_error_line) if last_error_line else None
+        except ValueError:
+            rec = None
+        if not isinstance(rec, dict) or "error" not in rec:
+            rec = {"metric": "GPR log-marginal-likelihood evals/sec + predict_f latency, fp64, N=32768 D=8", "value": 0.0,
+                   "unit": "evals/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "failed run"},
+                   "error": "every attempt failed"}
+        rec["value"] = 0.0
+        rec["launch"] = {"tried": attempts, "failed_attempts": failed}
+        print(json.dumps(rec), flush=True)
+    if clean_dir:
+        import shutil
+        shutil.rmtree(rdv_dir, ignore_errors=True)
     return status
+
+
+_PROGRESS = os.environ.get("GPS_BENCH_PROGRESS")
+
+
+def progress(tag):
+    """A rank process tells its supervisor that it is alive and where it is (one appended line)."""
+    if _PROGRESS:
+        with open(_PROGRESS, "a") as f:
+            f.write("%s %.3f\n" % (tag, time.time()))
 
 
 def main():
@@ -126,10 +263,17 @@ def main():
     ap.add_argument("--dist-timeout", type=float, default=600.0, help="watchdog (s) around the distributed run")
     ap.add_argument("--no-dist-autotune", action="store_true", help="N > 1: keep --dist-nb / --dist-lookahead and the default exchange instead of choosing by measurement during warm-up")
     ap.add_argument("--independent-steps", type=int, default=2, help="N > 1: steps of the independent-evaluations side measurement (0 = skip)")
-    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
-                    help="N > 1: who issues the collectives -- torch.distributed (default: RCCL through PyTorch, the path the test suite "
-                         "exercises with two real processes over gloo) or the library's own RCCL binding (csrc/comm_rccl.hip; "
-                         "torch.distributed then only carries the 128-byte unique id at start-up; verified at world size 1 only)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "torch", "rccl"],
+                    help="N > 1: who issues the collectives -- the library's own RCCL binding (csrc/comm_rccl.hip; torch.distributed "
+                         "then only carries the 128-byte unique id at start-up) or torch.distributed (RCCL through PyTorch).  auto "
+                         "(default, backend nccl): try rccl first and fall back -- by FRESH rank processes started from the GPU-free "
+                         "supervisor -- to torch, then to torch with plain broadcasts; the line's `launch` object says which ran")
+    ap.add_argument("--attempts", default="", help="N > 1: explicit comma-separated list of attempts (%s)" % ", ".join(ATTEMPTS))
+    ap.add_argument("--attempt-name", default="", help=argparse.SUPPRESS)      # set by the supervisor for a rank process
+    ap.add_argument("--exchange", default="auto", choices=["auto", "broadcast", "scatter_allgather"],
+                    help="N > 1, torch.distributed: the panel exchange (auto: probed / chosen by measurement)")
+    ap.add_argument("--first-stall", type=float, default=360.0, help="supervisor: seconds a rank process may take to its first progress mark (the first `import torch` of a fresh box takes minutes)")
+    ap.add_argument("--stall", type=float, default=240.0, help="supervisor: seconds without a new progress mark after which a rank process counts as hung")
     ap.add_argument("--workload", default="gpr", choices=["gpr", "cfg5"],
                     help="gpr (default): the BASELINE headline; cfg5: side line for BASELINE configs[4] -- conditional() / SVGP bound with "
                          "M inducing points over N data points, the data points sharded over the ranks (gpflowSlim/distributed_sparse.py)")
@@ -137,13 +281,36 @@ def main():
     ap.add_argument("--cfg5-n", type=int, default=1000000)
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher around us: be the launcher (before torch / the library / any GPU call)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.dist_timeout + 600.0))
+    if args.gpus > 1 and not os.environ.get("GPS_BENCH_CHILD"):
+        # Not a rank process yet: be the GPU-free supervisor of the rank processes (before torch / the library / any GPU call).
+        attempts = plan_attempts(args)
+        if "WORLD_SIZE" not in os.environ:
+            # no launcher around us: start all N ranks
+            import tempfile
+            sys.exit(supervise(list(range(args.gpus)), args.gpus, sys.argv[1:], attempts, tempfile.mkdtemp(prefix="gps_bench_"),
+                               args.first_stall, args.stall, True))
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            print("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE)" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+            sys.exit(2)
+        if len(attempts) > 1:
+            # a launcher started one bench.py per rank: each becomes the supervisor of its own rank process; the supervisors of
+            # the run meet in a directory named after what they share (the launcher's pid and rendezvous port; same node)
+            rdv = os.environ.get("GPS_BENCH_RDV_DIR") or os.path.join(
+                "/tmp", "gps_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+            r = int(os.environ.get("RANK", "0"))
+            sys.exit(supervise([r], args.gpus, sys.argv[1:], attempts, rdv, args.first_stall, args.stall, False))
+        args.attempt_name = attempts[0]          # one configuration only: the launcher's rank process runs it itself
+    if args.attempt_name:
+        args.comm = "rccl" if args.attempt_name == "rccl" else "torch"
+        if args.attempt_name == "torch-broadcast":
+            args.exchange, args.no_dist_autotune = "broadcast", True
+    elif args.comm == "auto":
+        args.comm = "torch"
+    progress("start")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and (args.gpus > 1 or os.environ.get("GPS_BENCH_SELF_LAUNCHED")):
+    if args.gpus != world and (args.gpus > 1 or os.environ.get("GPS_BENCH_CHILD")):
         print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if args.force_device >= 0:
@@ -153,12 +320,14 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    progress("torch_imported")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend)
+        progress("process_group_up")
 
     import gpflowSlim as gpf
 
@@ -214,6 +383,7 @@ def main():
             lml = model.compute_log_likelihood()
         sync()
         elapsed = time.perf_counter() - t0
+        progress("timed_steps_done")
         scaling, parallelism = "weak", "1 GPU (fused single-GPU path)"
     else:
         # ---- one factorisation over all ranks per step; a hang in the collective path must end the process, not the round
@@ -244,14 +414,19 @@ def main():
                 return box[0]
             comm = RcclComm(h, rank, world, bootstrap=carry)
         else:
-            comm = TorchComm()
+            comm = TorchComm(mode=None if args.exchange == "auto" else args.exchange)
+        progress("communicator_up")
         tune = None
         set_step(-1, False)
         gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)      # (also sets the communicator up)
+        sync()
+        progress("first_distributed_evaluation_done")
         if not args.no_dist_autotune:
             # untimed: pick the panel exchange and the panel width by measurement on this node (all ranks agree through
             # max-over-ranks times); the timed steps below then run one fixed configuration
-            tune = {"exchange_s": comm.autotune() if (args.backend == "nccl" and args.comm == "torch") else {}, "candidates_ms": {}}
+            tune = {"exchange_s": comm.autotune() if (args.backend == "nccl" and args.comm == "torch" and args.exchange == "auto") else {},
+                    "candidates_ms": {}}
+            progress("exchange_chosen")
             best = None
             for nb_c, la_c in ((args.dist_nb, args.dist_lookahead), (2 * args.dist_nb, args.dist_lookahead), (args.dist_nb // 2, args.dist_lookahead)):
                 if nb_c < 128 or nb_c % 128 or n // nb_c < 2 * world:
@@ -261,6 +436,7 @@ def main():
                 sync()
                 dt = max_over_ranks(time.perf_counter() - tc)
                 tune["candidates_ms"]["nb=%d,lookahead=%d" % (nb_c, la_c)] = round(1e3 * dt, 3)
+                progress("candidate_nb_%d" % nb_c)
                 if best is None or dt < best[0]:
                     best = (dt, nb_c, la_c)
             if best is not None:
@@ -270,6 +446,7 @@ def main():
             set_step(-1 - i, False)
             gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)
         sync()
+        progress("warmup_done")
         bytes0 = comm.bytes_sent
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -277,6 +454,7 @@ def main():
             lml = gpr_lml_distributed(model, comm, nb=args.dist_nb, lookahead=args.dist_lookahead)
         sync()
         elapsed = time.perf_counter() - t0
+        progress("timed_steps_done")
         # the collectives below (gathers, the parity evaluation, the independent evaluations, the final barrier) stay
         # under a watchdog of their own: it is only disarmed after the last barrier
         timer.cancel()
@@ -318,6 +496,7 @@ def main():
                 model.compute_log_likelihood()
             sync()
             ti = max_over_ranks(time.perf_counter() - t1)
+            progress("independent_evaluations_done")
             extra["independent_evals"] = {"evals_per_s_all_gpus": round(world * args.independent_steps / ti, 4),
                                           "ms_per_eval_per_gpu": round(1e3 * ti / args.independent_steps, 3),
                                           "steps": args.independent_steps, "scaling": "weak", "collective": None}
@@ -329,14 +508,24 @@ def main():
         if world > 1:
             set_step(args.steps, False); model.compute_log_likelihood(); stages = h.last_stage_ms()
         # predict_f latency (reference semantics = cold: re-factorises, models/gpr.py:119-121)
+        # five calls each, median reported with min / max beside it: one slow call (a clock ramp, a page fault of a fresh
+        # box) then shows up as an outlier instead of as the number
+        def latency(reps=5):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                model.predict_f(Xnew)
+                torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t1))
+            ts.sort()
+            return {"median": round(ts[len(ts) // 2], 2), "min": round(ts[0], 2), "max": round(ts[-1], 2), "calls": reps}
         model.reuse_factor = False
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        model.predict_f(Xnew)
-        torch.cuda.synchronize(); cold_ms = 1e3 * (time.perf_counter() - t1)
+        model.predict_f(Xnew)                       # (allocates the [n_new, N] work space)
+        cold = latency()
         model.reuse_factor = True
-        torch.cuda.synchronize(); t1 = time.perf_counter()
         model.predict_f(Xnew)
-        torch.cuda.synchronize(); warm_ms = 1e3 * (time.perf_counter() - t1)
+        warm = latency()
+        cold_ms, warm_ms = cold["median"], warm["median"]
+        progress("predict_latency_done")
         # predict_f throughput at N* = 8192 on the resident factor: trsm N^2 N* flop on the MFMA, then one
         # HBM pass over A^T for the mean and the variance
         Xtp = rng.standard_normal((args.n_new_tp, d))
@@ -353,6 +542,7 @@ def main():
                       "rowdot_gbs": round(8.0 * args.n_new_tp * h_npad(n) / (pr["ms"] * 1e-3) / 1e9, 1),
                       "rowdot_frac_of_hbm_peak": round(8.0 * args.n_new_tp * h_npad(n) / (pr["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+        progress("predict_throughput_done")
         # LML + analytic gradient (the quantity an optimiser step consumes)
         model.reuse_factor = False
         model.compute_log_likelihood_and_gradients()          # first call allocates the K^-1 work space
@@ -388,6 +578,7 @@ def main():
             small["note"] = ("wall time per call through the Python API incl. the host round trip of the result; hyper-parameters "
                              "change every step; D=%d RBF(ARD)" % d)
 
+        progress("gradient_and_small_n_done")
         roofline = None
         hbm_bound = None
         if not args.no_roofline:
@@ -453,8 +644,23 @@ def main():
                          "rowdot_predict_f": {"gbs": predict_tp["rowdot_gbs"], "frac_of_hbm_peak": predict_tp["rowdot_frac_of_hbm_peak"]},
                          "peak_gbs": HBM_PEAK_GBS}
 
+        progress("roofline_done")
+        if world > 1 and roofline is not None:
+            # the line of a multi-GPU run is about the whole job: algorithmic flop of one evaluation over the time of the
+            # block-column step on P GPUs against P times the peak (= the per-GPU fraction); the per-kernel evidence of the
+            # single-GPU instrumented pass stays beside it
+            one = roofline
+            ach = flops_eval / (ms_per_step * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (panel solves + trailing updates of the block-column schedule, all ranks)",
+                        "achieved": round(ach, 3), "peak": round(FP64_MFMA_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
+                        "frac": round(ach / (FP64_MFMA_PEAK_TFLOPS * world), 4), "per_gpu_frac": round(ach / (FP64_MFMA_PEAK_TFLOPS * world), 4),
+                        "per_gpu_tflops": round(ach / world, 3), "traffic": None,
+                        "algorithmic_flops_per_step": flops_eval, "ms_per_step": round(ms_per_step, 3),
+                        "note": "whole job: SURVEY 8(d) flop of ONE evaluation / (the measured step time x P GPUs x 78.6 TFLOP/s); "
+                                "`one_gpu_kernel` = the instrumented fused evaluation on rank 0's GPU",
+                        "one_gpu_kernel": one}
         cpu = None
-        if not args.no_cpu_baseline and world == 1:       # the CPU stand-in is timed at N = 1 only
+        if not args.no_cpu_baseline:       # rank 0's host cores, whatever the number of GPUs (the other ranks wait at the last barrier)
             import oracle.gp_oracle as orc       # the checker: cpu_baseline leg + its parity gate only
             ns = min(args.cpu_sample_n, n)
             Xc, Yc = X[:ns], Y[:ns]
@@ -494,7 +700,12 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": workload, "n": n, "d": d, "n_new": args.n_new, "parallelism": parallelism},
-               "predict_f_latency_ms": {"cold_refactor": round(cold_ms, 2), "warm_resident_factor": round(warm_ms, 2), "n_new": args.n_new},
+               "predict_f_latency_ms": {"cold_refactor": round(cold_ms, 2), "warm_resident_factor": round(warm_ms, 2), "n_new": args.n_new,
+                                        "statistic": "median of 5 calls", "cold_calls": cold, "warm_calls": warm},
+               "fallback_counters": {"lookahead_retries": int(h.profile_get("lookahead_retries")["launches"]),
+                                     "trsv_wave_fallbacks": int(h.profile_get("trsv_wave_fallbacks")["launches"]),
+                                     "note": "evaluations re-run without look-ahead after a missed hand-over / wavefront substitutions "
+                                             "that gave up, over the whole life of this process' handle (0 = the fast paths ran)"},
                "predict_f_throughput": predict_tp,
                "lml_plus_gradient_ms": round(grad_ms, 2),
                "small_n_latency": small,
@@ -502,6 +713,7 @@ def main():
                "lml_last_step": lml,
                "roofline": roofline, "hbm_bound_kernels": hbm_bound, "cpu_baseline": cpu}
         out.update(extra)
+        progress("cpu_baseline_done")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -525,6 +737,24 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
     f = 0.1 * rng.standard_normal((m, 1))
     kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=np.sqrt(d) * np.ones(d), ARD=True)
     comm = TorchComm() if world > 1 else SingleComm()
+    # a rank that leaves a sharded evaluation early (an error on its shard) would leave the others in the collective: the
+    # run is under a watchdog like the block-column one
+    done = {"v": False}
+
+    def on_timeout():
+        if done["v"]:
+            return
+        if rank == 0:
+            print(json.dumps({"metric": "conditional() test points/sec, RBF, M=%d inducing points, N=%d points, fp64" % (m, n), "value": 0.0,
+                              "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "BASELINE configs[4]"},
+                              "error": "watchdog: the sharded run did not finish within %.0f s" % args.dist_timeout}), flush=True)
+        os._exit(2)
+    watchdog = threading.Timer(args.dist_timeout, on_timeout)
+    watchdog.daemon = True
+    if world > 1:
+        watchdog.start()
 
     def sync():
         if world > 1:
@@ -545,6 +775,7 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
             dt = float(t.item())
         return dt / steps, out
     t_cond, (fm, fv) = timed(lambda: conditional_distributed(X, Z, kern, f, comm=comm, white=True), args.steps, args.warmup)
+    progress("conditional_done")
     mod = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(0.1), Z=Z, q_diag=True, whiten=True)
     t_svgp, elbo = timed(lambda: svgp_bound_distributed(mod, comm), max(1, args.steps // 2), 1)
     sg = gpf.models.SGPR(X, Y, kern, Z=Z, obs_var=0.1)
@@ -572,6 +803,10 @@ def run_cfg5(args, rank, world, torch, dist, gpf, np):
                            "collective": "one in-place device all-reduce of [A A^T | A err | diag | scalars] (%d doubles) inside gps_sgpr" % (
                                mp * mp + mp * 1 + mp + 4)},
             "checksum": {"fmean_sum": float(fm.sum()), "fvar_min": float(fv.min())}}), flush=True)
+    if world > 1:
+        dist.barrier()
+    done["v"] = True
+    watchdog.cancel()
 
 
 def h_npad(n):
@@ -593,6 +828,11 @@ def _main_reporting_failures():
     except BaseException as e:       # noqa: BLE001 -- reported, then the process ends
         import traceback
         traceback.print_exc()
+        try:                             # a native communicator is given up at once: the peers' collectives then fail instead of waiting
+            import gpflowSlim
+            gpflowSlim.get_handle().comm_abort()
+        except BaseException:            # noqa: BLE001
+            pass
         if os.environ.get("RANK", "0") == "0":
             print(json.dumps({"metric": "GPR log-marginal-likelihood evals/sec + predict_f latency, fp64, N=32768 D=8", "value": 0.0,
                               "unit": "evals/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,

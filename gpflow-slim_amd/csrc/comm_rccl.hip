@@ -23,6 +23,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;          // optional: absent from a transport stand-in
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -53,7 +54,8 @@ int load_api(const char* path) {
     if (!n || !*n) continue;
     lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (lib) break;
-    g_api_error = std::string("dlopen: ") + (dlerror() ? dlerror() : "?");
+    const char* e = dlerror();                      // (a second dlerror() would return NULL: the first call clears it)
+    g_api_error = std::string("dlopen: ") + (e ? e : "?");
   }
   if (!lib) return GPS_ERR_UNSUPPORTED;
   RcclApi a;
@@ -65,6 +67,7 @@ int load_api(const char* path) {
                   bind(lib, "ncclGroupStart", a.GroupStart) && bind(lib, "ncclGroupEnd", a.GroupEnd) &&
                   bind(lib, "ncclGetVersion", a.GetVersion);
   if (!ok) { dlclose(lib); return GPS_ERR_UNSUPPORTED; }
+  a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(lib, "ncclCommAbort"));
   g_api = a;
   return GPS_OK;
 }
@@ -75,6 +78,20 @@ int load_api(const char* path) {
     if (r__ != ncclSuccess)                                                                        \
       return gps_fail(h, GPS_ERR_HIP, std::string(#call) + ": " + g_api.GetErrorString(r__));      \
   } while (0)
+
+// A collective that failed on this rank leaves the peers inside theirs: abort the communicator so that they come back with an
+// error instead of waiting for this rank's part for ever (ncclCommAbort tears the transport down; the handle then has no
+// communicator and every later gps_comm_* call says so).  Returns `code` for `return comm_failed(...)`.
+int comm_failed(gps_handle_t h, int code, const std::string& what, ncclResult_t r) {
+  std::string msg = what + ": " + (g_api.GetErrorString ? g_api.GetErrorString(r) : "?");
+  if (h->comm) {
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(h->comm);
+    h->comm = nullptr;
+    if (g_api.CommAbort) (void)g_api.CommAbort(comm); else (void)g_api.CommDestroy(comm);
+    msg += " (communicator aborted)";
+  }
+  return gps_fail(h, code, msg);
+}
 
 int allreduce_cb(void* ctx, void* dev_ptr, int64_t count) {
   return gps_comm_allreduce(reinterpret_cast<gps_handle_t>(ctx), dev_ptr, count);
@@ -119,15 +136,26 @@ extern "C" int gps_comm_init(gps_handle_t h, int rank, int world, const void* un
 
 extern "C" int gps_comm_destroy(gps_handle_t h) {
   if (!h) return GPS_ERR_ARG;
-  if (!h->comm) return GPS_OK;
+  if (!h->comm && !h->comm_stream) return GPS_OK;
   (void)hipSetDevice(h->device);
-  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->comm && h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);      // (an aborted communicator's stream is not waited for)
   if (h->allreduce == allreduce_cb) { h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->red_buf = nullptr; h->red_cap = 0; }
-  (void)g_api.CommDestroy(reinterpret_cast<ncclComm_t>(h->comm));
+  if (h->comm) (void)g_api.CommDestroy(reinterpret_cast<ncclComm_t>(h->comm));
   h->comm = nullptr;
   if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
   if (h->comm_ready) { (void)hipEventDestroy(h->comm_ready); h->comm_ready = nullptr; }
   for (int i = 0; i < 8; ++i) if (h->comm_done[i]) { (void)hipEventDestroy(h->comm_done[i]); h->comm_done[i] = nullptr; }
+  return GPS_OK;
+}
+
+// Give up the communicator without waiting for the peers (a rank that has failed outside a collective calls this so that the
+// others' pending collectives return with an error; bench.py's watchdog).  Safe without a communicator.
+extern "C" int gps_comm_abort(gps_handle_t h) {
+  if (!h) return GPS_ERR_ARG;
+  if (!h->comm) return GPS_OK;
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(h->comm);
+  h->comm = nullptr;
+  if (g_api.CommAbort) (void)g_api.CommAbort(comm); else (void)g_api.CommDestroy(comm);
   return GPS_OK;
 }
 
@@ -144,21 +172,31 @@ extern "C" int gps_comm_exchange(gps_handle_t h, void* dev_buf, int64_t count, i
   GPS_HIP(h, hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
   if (P > 1) {
     const i64 chunk = count / P;
+    ncclResult_t r = ncclSuccess;
+    const char* at = "";
     if (mode == 1 && chunk > 0) {
-      GPS_NCCL(h, g_api.GroupStart());
-      if (me == root) {
-        for (int p = 0; p < P; ++p)
-          if (p != root) GPS_NCCL(h, g_api.Send(buf + (i64)p * chunk, (size_t)chunk, ncclDouble, p, comm, h->comm_stream));
-      } else {
-        GPS_NCCL(h, g_api.Recv(buf + (i64)me * chunk, (size_t)chunk, ncclDouble, root, comm, h->comm_stream));
+      r = g_api.GroupStart(); at = "ncclGroupStart";
+      if (r == ncclSuccess) {
+        // whatever a send / receive returns, the group is closed again: an open group would swallow every later call
+        ncclResult_t rg = ncclSuccess;
+        if (me == root) {
+          for (int p = 0; p < P && rg == ncclSuccess; ++p)
+            if (p != root) { rg = g_api.Send(buf + (i64)p * chunk, (size_t)chunk, ncclDouble, p, comm, h->comm_stream); at = "ncclSend"; }
+        } else {
+          rg = g_api.Recv(buf + (i64)me * chunk, (size_t)chunk, ncclDouble, root, comm, h->comm_stream); at = "ncclRecv";
+        }
+        const ncclResult_t re = g_api.GroupEnd();
+        if (rg != ncclSuccess) r = rg; else if (re != ncclSuccess) { r = re; at = "ncclGroupEnd"; }
       }
-      GPS_NCCL(h, g_api.GroupEnd());
-      GPS_NCCL(h, g_api.AllGather(buf + (i64)me * chunk, buf, (size_t)chunk, ncclDouble, comm, h->comm_stream));
-      if (chunk * P < count)        // ragged end of the message
-        GPS_NCCL(h, g_api.Broadcast(buf + chunk * P, buf + chunk * P, (size_t)(count - chunk * P), ncclDouble, root, comm, h->comm_stream));
+      if (r == ncclSuccess) { r = g_api.AllGather(buf + (i64)me * chunk, buf, (size_t)chunk, ncclDouble, comm, h->comm_stream); at = "ncclAllGather"; }
+      if (r == ncclSuccess && chunk * P < count) {       // ragged end of the message
+        r = g_api.Broadcast(buf + chunk * P, buf + chunk * P, (size_t)(count - chunk * P), ncclDouble, root, comm, h->comm_stream);
+        at = "ncclBroadcast";
+      }
     } else {
-      GPS_NCCL(h, g_api.Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm, h->comm_stream));
+      r = g_api.Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm, h->comm_stream); at = "ncclBroadcast";
     }
+    if (r != ncclSuccess) return comm_failed(h, GPS_ERR_HIP, std::string("gps_comm_exchange: ") + at, r);
   }
   GPS_HIP(h, hipEventRecord(h->comm_done[slot], h->comm_stream));
   return GPS_OK;
@@ -176,7 +214,8 @@ extern "C" int gps_comm_allreduce(gps_handle_t h, void* dev_ptr, int64_t count) 
   if (!dev_ptr || count <= 0) return gps_fail(h, GPS_ERR_ARG, "gps_comm_allreduce: bad argument");
   GPS_HIP(h, hipSetDevice(h->device));
   ncclComm_t comm = reinterpret_cast<ncclComm_t>(h->comm);
-  GPS_NCCL(h, g_api.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, comm, h->stream));
+  const ncclResult_t r = g_api.AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, comm, h->stream);
+  if (r != ncclSuccess) return comm_failed(h, GPS_ERR_HIP, "gps_comm_allreduce: ncclAllReduce", r);
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
 }

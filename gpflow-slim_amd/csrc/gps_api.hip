@@ -369,6 +369,9 @@ extern "C" int gps_destroy(gps_handle_t h) {
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }
   if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); }
+  if (h->dist_chain) { (void)hipStreamSynchronize(h->dist_chain); (void)hipStreamDestroy(h->dist_chain); }
+  if (h->dist_bulk_own) { (void)hipStreamSynchronize(h->dist_bulk_own); (void)hipStreamDestroy(h->dist_bulk_own); }
+  for (auto e : h->dist_events) (void)hipEventDestroy(e);
   for (auto e : h->y_events) (void)hipEventDestroy(e);
   if (h->ev_y_join) (void)hipEventDestroy(h->ev_y_join);
   if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
@@ -2198,13 +2201,26 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
   if (h->ext_stream) return gps_fail(h, GPS_ERR_STATE, "gps_dist_lml: an external stream is installed (gps_set_stream)");
   GPS_HIP(h, hipSetDevice(h->device));
   const int P = h->comm_world, rank = h->comm_rank, D = lookahead < 0 ? 0 : lookahead;
-  int lo = 0, hi = 0;
-  GPS_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-  hipStream_t chain = nullptr, bulk = nullptr;
-  GPS_HIP(h, hipStreamCreateWithPriority(&chain, hipStreamNonBlocking, hi));
-  if (D >= 1) GPS_HIP(h, hipStreamCreateWithPriority(&bulk, hipStreamNonBlocking, lo));
-  std::vector<hipEvent_t> events;
-  auto new_event = [&]() -> hipEvent_t { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; };
+  // the two lanes and the events of the schedule belong to the HANDLE: created on the first call, reused by every later one
+  // (an evaluation of a fit creates no stream and no event), destroyed by gps_destroy
+  if (!h->dist_chain) {
+    int lo = 0, hi = 0;
+    GPS_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t c = nullptr, b = nullptr;
+    GPS_HIP(h, hipStreamCreateWithPriority(&c, hipStreamNonBlocking, hi));
+    hipError_t e = hipStreamCreateWithPriority(&b, hipStreamNonBlocking, lo);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c); return gps_fail(h, GPS_ERR_HIP, std::string("gps_dist_lml: bulk lane: ") + hipGetErrorString(e)); }
+    h->dist_chain = c; h->dist_bulk_own = b;
+  }
+  hipStream_t chain = h->dist_chain, bulk = D >= 1 ? h->dist_bulk_own : nullptr;
+  h->dist_event_next = 0;
+  auto new_event = [&]() -> hipEvent_t {
+    if (h->dist_event_next < h->dist_events.size()) return h->dist_events[h->dist_event_next++];
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    h->dist_events.push_back(e); h->dist_event_next++;
+    return e;
+  };
   // (inside this function every failure leaves through cleanup(): the handle must get its own stream back)
 #define DL_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return dl_fail(std::string(#call) + ": " + hipGetErrorString(e__)); } while (0)
   int rc = gps_set_stream(h, chain, 1);
@@ -2213,12 +2229,9 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
     // both lanes drained on every exit path, the handle's own stream back
     (void)hipStreamSynchronize(chain);
     if (bulk) (void)hipStreamSynchronize(bulk);
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->comm && h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     (void)gps_dist_set_bulk_stream(h, nullptr);
     (void)gps_set_stream(h, nullptr, 0);
-    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(chain);
-    if (bulk) (void)hipStreamDestroy(bulk);
     return code;
   };
   if (rc) return cleanup(rc);
@@ -2262,6 +2275,7 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
       continue;
     }
     hipEvent_t in_place = new_event();
+    if (!in_place) return cleanup(gps_fail(h, GPS_ERR_HIP, "gps_dist_lml: hipEventCreate failed"));
     GPS_TRY([&]() -> int { DL_HIP(hipEventRecord(in_place, chain)); return GPS_OK; }());
     const i64 last_urgent = (p + D < n_panels - 1) ? p + D : n_panels - 1;
     auto urgent = [&](i64 c) -> int {
@@ -2277,6 +2291,7 @@ extern "C" int gps_dist_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_n
       GPS_TRY([&]() -> int { DL_HIP(hipStreamWaitEvent(bulk, in_place, 0)); return GPS_OK; }());
       GPS_TRY(gps_dist_update(h, p, last_urgent + 1, n_panels, 1));
       bulk_done[p] = new_event();
+      if (!bulk_done[p]) return cleanup(gps_fail(h, GPS_ERR_HIP, "gps_dist_lml: hipEventCreate failed"));
       GPS_TRY([&]() -> int { DL_HIP(hipEventRecord(bulk_done[p], bulk)); return GPS_OK; }());
     }
     GPS_TRY(receive(nxt, buf));
@@ -2409,19 +2424,21 @@ extern "C" int gps_dist_predict(gps_handle_t h, const gps_kern_node_t* prog, int
     if (!rc && j + 1 < n_panels) rc = send(j + 1);            // (stream-ordered after apply(j - 1), the last reader of that buffer)
     if (!rc && n_new > 0) rc = gps_dist_solve_apply(h, j, (int)(j % 2));
   }
-  if (rc) { (void)hipStreamSynchronize(h->stream); if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream); return rc; }
+  if (rc) { (void)hipStreamSynchronize(h->stream); if (h->comm && h->comm_stream) (void)hipStreamSynchronize(h->comm_stream); return rc; }
   if (n_new > 0) return gps_dist_solve_finish(h, prog, n_nodes, mean_out, var_out);
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   return GPS_OK;
 }
 
-// device memory the handle holds right now (every growable buffer; the caller's comm buffers are not the handle's)
+// device memory the handle holds right now: every growable buffer, the comm buffers of the all-native driver (gps_dist_lml /
+// gps_dist_predict allocate them on the handle) included; comm buffers a caller brings (gps_dist_set_comm_bufs) are its own
 extern "C" int gps_device_bytes(gps_handle_t h, int64_t* bytes) {
   if (!h || !bytes) return GPS_ERR_ARG;
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags};
+                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
+                    &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   int64_t tot = 0;
   for (DevBuf* b : bufs) tot += (int64_t)b->cap;
   *bytes = tot;
@@ -2480,7 +2497,7 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   rc = gps_launch_kdiag(h, prog, n_nodes, &kdiag);
   if (rc) return rc;
   std::vector<double> wsq;                                       // FITC: 1/sqrt(nu_i)
-  double sum_log_nu = 0.0;
+  double sum_log_nu = 0.0, shard_err = 0.0;
   if (fitc) {
     // diag Qff = rowsumsq((L^-1 Kuf)^T) ; nu = Kdiag - diag Qff + sigma^2          (sgpr.py:241-242)
     GPS_HIP(h, h->dTmp3.ensure((size_t)np * 8));
@@ -2490,11 +2507,14 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
     GPS_HIP(h, hipMemcpyAsync(wsq.data(), h->dTmp3.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
     for (i64 i = 0; i < n; ++i) {
-      const double nu = kdiag - wsq[i] + sigma2;
-      if (!(nu > 0.0)) return gps_fail(h, GPS_ERR_ARG, "gps_fitc: non-positive FITC variance nu");
+      double nu = kdiag - wsq[i] + sigma2;
+      // a failure that depends on this rank's data must not leave before the collective below (the peers would wait in it
+      // for ever): carry on with a harmless value, send the flag along, fail on EVERY rank after the reduction
+      if (!(nu > 0.0)) { shard_err = 1.0; nu = 1.0; }
       sum_log_nu += log(nu);
       wsq[i] = 1.0 / sqrt(nu);
     }
+    if (shard_err != 0.0 && !h->allreduce) return gps_fail(h, GPS_ERR_ARG, "gps_fitc: non-positive FITC variance nu");
     GPS_HIP(h, hipMemcpyAsync(h->dTmp3.p, wsq.data(), (size_t)np * 8, hipMemcpyHostToDevice, h->stream));
     rc = gps_launch_scale_rows(h, h->dS1.d(), mp, n, mp, h->dTmp3.d());
     if (rc) return rc;
@@ -2537,7 +2557,7 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
     const i64 cnt = mp * mp + mp * r + mp + 4;
     if (cnt > h->red_cap) return gps_fail(h, GPS_ERR_ARG, "gps_set_allreduce: the device buffer is too small for this m, r");
     double* rb = h->red_buf;
-    const double sc[4] = {serr2, sum_log_nu, (double)n, 0.0};
+    const double sc[4] = {serr2, sum_log_nu, (double)n, shard_err};        // [3]: data-dependent failures of the shards, summed
     GPS_HIP(h, hipMemcpyAsync(rb, h->dS3.p, (size_t)mp * mp * 8, hipMemcpyDeviceToDevice, h->stream));
     GPS_HIP(h, hipMemcpyAsync(rb + mp * mp, dAerr, (size_t)(mp * r + mp) * 8, hipMemcpyDeviceToDevice, h->stream));
     GPS_HIP(h, hipMemcpyAsync(rb + mp * mp + mp * r + mp, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
@@ -2551,6 +2571,7 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
     GPS_HIP(h, hipMemcpyAsync(sc_out, rb + mp * mp + mp * r + mp, sizeof(sc_out), hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
     serr2 = sc_out[0]; sum_log_nu = sc_out[1]; n_total = sc_out[2];
+    if (sc_out[3] != 0.0) return gps_fail(h, GPS_ERR_ARG, "gps_fitc: non-positive FITC variance nu (on at least one shard)");
   }
   // B = A A^T * weight + I ; LB = chol(B)                                     (sgpr.py:141-142, 244-245)
   rc = gps_launch_scale_add_eye(h, h->dS3.d(), mp, mp, m, wgt);

@@ -207,6 +207,9 @@ struct gps_handle_s {
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ready = nullptr, comm_done[8] = {};
   hipStream_t dist_bulk_stream = nullptr; bool dist_bulk_set = false;   // second lane of the distributed schedule
+  // gps_dist_lml's own two lanes (high / low priority) and its event pool: created once per handle, not per evaluation
+  hipStream_t dist_chain = nullptr, dist_bulk_own = nullptr;
+  std::vector<hipEvent_t> dist_events; size_t dist_event_next = 0;
   DevBuf dDistScal;                 // [n_panels][4] per-panel sum log L_ii, sum alpha^2, info
   DevBuf dDistComm[3];              // comm buffers of gps_dist_lml (the all-native driver; other callers bring their own)
 

@@ -9,15 +9,17 @@
 // One workgroup of 8 waves, LDS image [128][129], 8 steps of 16 columns.  The kernel is one long dependent chain
 // (128 pivots), so the waves are specialised and everything that is not on the chain runs in its shadow:
 //
-//   phase A(g)  PANEL waves: each holds the 16 rows of the diagonal block g in lanes 0..15 (every panel wave factors
-//               it, redundantly, in registers: v_readlane broadcasts, hardware rsqrt + one third-order correction, no barrier)
-//               and rows below it in its other lanes -- those lanes execute the very same instruction stream, which
-//               for them IS the forward substitution x L_gg^T = b against the block, so the whole 16-column panel is
-//               finished when the diagonal block is.  Lanes 16..31 of wave 0 start from the rows of the identity
-//               instead: what they end with is e_c^T L_gg^-T, i.e. column c of inv(L_gg) -- the 16x16 triangular
-//               inverse costs no instruction of its own.  (Wave 0: 32 rows below the block, the others 48 each.)
+//   phase A(g)  PANEL waves (wave 0, and wave 1 while more than 48 rows lie below the block): every ROW of 16 lanes holds a
+//               copy of the 16 rows of diagonal block g and factors it in registers (hardware rsqrt + one third-order
+//               correction, no barrier; broadcasts by DPP row_newbcast -- panel_step_dpp below); every lane carries a second
+//               vector, a row below the block, that takes the very same updates -- which for it IS the forward substitution
+//               x L_gg^T = b -- so the whole 16-column panel is finished when the diagonal block is.  Lanes 0..15 of
+//               wave 0 carry the rows of the identity instead: what they end with is e_c^T L_gg^-T, i.e. column c of
+//               inv(L_gg) -- the 16x16 triangular inverse costs no instruction of its own.
 //               UPDATE waves (all others), meanwhile: the rest of the trailing update of step g-1 (16x16 tiles
-//               C_IJ -= P_I P_J^T on the fp64 MFMA, J >= g+1) and block row g-1 of the inverse (below).
+//               C_IJ -= P_I P_J^T on the fp64 MFMA, J >= g+1; operands fetched one tile ahead), block row g-1 of the
+//               inverse (below), and the stores of what is final: rows of block g-1 of L, rows of block g-2 of inv(L)
+//               and the matching strip of its transpose leave for HBM here instead of in one burst at the end.
 //   phase B(g)  waves 1..7: the tiles of block column g+1 of the trailing update of step g (the only ones the next
 //               panel needs), one per wave; wave 0 puts the factored block and its inverse back into the image.
 //
@@ -34,14 +36,6 @@
 #define NT 512
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-
-// wave-uniform broadcast of lane `lane`'s fp64 value (lane is a compile-time constant at every call)
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
 
 // whole 128x128 block -> LDS image; 16-byte loads, all 16 of a thread in flight at once (one memory round trip:
 // a lone workgroup draws ~40 GB/s, so the tile load is latency, not bandwidth); the upper triangle is loaded too:
@@ -74,110 +68,108 @@ __device__ __forceinline__ double x_elem(const double* a, const double* dinv, in
   return (r > c) ? off : ((r == c) ? dia : 0.0);
 }
 
-// ---- phase A, panel wave: 16 columns o..o+15.  Lanes 0..15: rows of the diagonal block.  Owner (wave 0): lanes
-// 16..31 rows of the identity (-> columns of the block's inverse), lanes 32..63 rows o+16 .. o+47; other panel waves:
-// lanes 16..63 rows xrow0 .. xrow0+47 (rows >= 128 are idle lanes).  Branch-free body (one basic block): the scheduler
-// can overlap column j's trailing updates with the rsqrt chain of column j+1.
-// The rows below go back to the image here; the diagonal block's rows and the inverse's columns stay in r[] (lanes
-// 0..31 of the owner) and are written by the caller AFTER the barrier that ends the phase: the other panel waves read
-// the same block.
-__device__ __forceinline__ void panel_step(double* a, double* scr, int* info, int row0, int o, int lane, int xrow0,
-                                           bool owner, double (&r)[16]) {
-  const bool is_diag = lane < 16;
-  const bool is_inv = owner && lane >= 16 && lane < 32;
-  const int row = is_diag ? o + lane : (owner ? o + lane - 16 : xrow0 + lane - 16);
-  const bool valid = row < PB;
-  const int rr = valid ? row : PB - 1;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const double v = a[rr * PS + o + c];
-    r[c] = is_inv ? ((c == lane - 16) ? 1.0 : 0.0) : v;
-  }
-  // Column j: pivot p_j = L_jj^2, y_j = 1/sqrt(p_j), scale the column, then r[k] -= r[j] * L_kj for k > j (L_kj
-  // broadcast from diagonal lane k).  The 16 pivots are one dependent chain; everything else is kept off it:
-  //  * The next pivot does not wait for the vector update of column j+1.  With s = r[j] and d = r[j+1] of diagonal
-  //    lane j+1 read (v_readlane) BEFORE column j is scaled -- both are complete one column earlier --
-  //    p_{j+1} = d - (s y_j)^2 is two uniform operations after y_j (the same mul / fma the lanes execute, so it is
-  //    the value lane j+1 ends up with).
-  //  * 1/sqrt: hardware estimate y0 (2^-24) and ONE third-order step, e = 1 - p y0^2, y = y0 + y0 e (1/2 + 3/8 e)
-  //    (error 5/16 e^3 ~ 2^-70): four dependent operations instead of the six of two Newton steps.
-  //  * Only the updates of columns j+1 and j+2 take the v_readlane path.  For k >= j+3 the diagonal lanes publish the
-  //    scaled column in an LDS scratch of this wave and every lane reads it back as broadcast ds_read_b128 (two values
-  //    per read, no SGPR traffic); those updates are applied one column later.  (Updates of one register commute;
-  //    r[k] is complete before it is read for pivot k: its LDS-path updates come from columns <= k-3.)
-  //  The vector work is placed in the latency gaps of the pivot chain and the order pinned with sched_barrier: left
-  //  alone, the compiler finishes every update of column j before it starts the next pivot.
-#define PB_UPD(kk) do { if ((kk) < 16) { const double l_ = readlane_f64(r[j], (kk)); r[(kk)] -= r[j] * l_; } } while (0)
-#define PB_LUPD(kk) do { if (j >= 1 && (kk) < 16) r[(kk)] -= r[j - 1] * lq[(kk)]; } while (0)
+// ---- phase A, panel wave: 16 columns o..o+15, broadcasts by DPP (round 4; rounds 1-3 used v_readlane + an LDS scratch).
+// gfx950 has two fp64 DPP forms, v_fmac_f64_dpp and v_mov_b64_dpp, and for the DP ALU only the control row_newbcast:k
+// (lane k of each ROW of 16 lanes to every lane of that row).  Measured (tools/dpp_probe.hip, one wave alone on its SIMD):
+// a broadcast update by two v_readlane + v_fma_f64 issues every 23 cycles, v_fmac_f64_dpp every 6.4 -- the price of a
+// plain v_fma_f64.  A row broadcast cannot reach another row of 16 lanes, so every row of the wave keeps its OWN copy of
+// the 16 rows of the diagonal block (r[], factored four times over by the same instructions) and every lane carries a
+// second vector x[] -- a row below the block, or (owner, lanes 0..15) a row of the identity, which ends as a column of
+// inv(L_gg) -- that takes the same updates with the multiplier broadcast from the lane's own copy of the block:
+//     r[k] -= r[j] * bcast(r[j], lane k)        x[k] -= x[j] * bcast(r[j], lane k)
+// 480 instructions per 16 columns instead of ~620, none of them a v_readlane, no LDS scratch, 64 rows below per wave
+// (owner: 48) so two panel waves cover what took three.  Same arithmetic per element as the v_readlane form (one fma
+// per update, in the same column order): the factor is bit-identical.
+// Hazards (the compiler pads nothing inside or around an asm statement): a VGPR written by a VALU instruction must not
+// be read through DPP for two wait states -- the scaling of column j ends with s_nop 1, and every other DPP source was
+// written at least two instructions earlier (order of the volatile statements below).
+#define PB_FMAC_DPP(d, a, b, k) asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(k))
+#define PB_MOV_DPP(d, a, k) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a), "n"(k))
+#define PB_SCALE2(a, b, y) asm volatile("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2\n\ts_nop 1" : "+v"(a), "+v"(b) : "v"(y))
+// updates of column K by column J (K > J): the diagonal copy and the lane's own row
+#define PB_UPD2(J, K) do { PB_FMAC_DPP(r[K], r[J], r[J], K); PB_FMAC_DPP(x[K], r[J], x[J], K); } while (0)
+
+template <int J>
+__device__ __forceinline__ void pb_pivot(double (&r)[16], double (&x)[16], double& p, double& y, double& sd, double& dd, int& bad) {
+  // ---- chain: l = s y_j, p_{j+1} = d - l^2 (the value lane j+1 of the copy ends up with), its reciprocal square root.
+  // One chain operation per group of updates, the order pinned with sched_barrier: left alone the compiler issues the
+  // five dependent operations of the rsqrt refinement back to back (10 cycles each instead of an issue slot of 6.4).
 #define PB_FENCE() __builtin_amdgcn_sched_barrier(0)
+  const double lj = sd * y;
+  PB_SCALE2(r[J], x[J], y);                      // column j: L_kj (rows of the block) / x_j (rows below)
+  PB_FENCE();
+  const double pn = __builtin_fma(-lj, lj, dd);
+  // the two columns the next pivot reads first, then its s and d (two other instructions between a write and its DPP read)
+  if constexpr (J + 1 < 16) PB_UPD2(J, J + 1);
+  PB_FENCE();
+  double yn = __builtin_amdgcn_rsq(pn);
+  bad = (!(pn > 0.0) && bad == 0x7fffffff) ? J + 1 : bad;
+  if constexpr (J + 2 < 16) PB_UPD2(J, J + 2);
+  if constexpr (J + 3 < 16) PB_UPD2(J, J + 3);
+  PB_FENCE();
+  const double t = pn * yn;
+  if constexpr (J + 2 < 16) { PB_MOV_DPP(sd, r[J + 1], J + 2); PB_MOV_DPP(dd, r[J + 2], J + 2); }
+  if constexpr (J + 4 < 16) PB_UPD2(J, J + 4);
+  PB_FENCE();
+  const double e = __builtin_fma(-t, yn, 1.0);
+  if constexpr (J + 5 < 16) PB_UPD2(J, J + 5);
+  if constexpr (J + 6 < 16) PB_UPD2(J, J + 6);
+  if constexpr (J + 7 < 16) PB_UPD2(J, J + 7);
+  PB_FENCE();
+  const double q = __builtin_fma(0.375, e, 0.5);
+  const double ye = yn * e;
+  if constexpr (J + 8 < 16) PB_UPD2(J, J + 8);
+  if constexpr (J + 9 < 16) PB_UPD2(J, J + 9);
+  if constexpr (J + 10 < 16) PB_UPD2(J, J + 10);
+  if constexpr (J + 11 < 16) PB_UPD2(J, J + 11);
+  PB_FENCE();
+  yn = __builtin_fma(ye, q, yn);
+  if constexpr (J + 12 < 16) PB_UPD2(J, J + 12);
+  if constexpr (J + 13 < 16) PB_UPD2(J, J + 13);
+  if constexpr (J + 14 < 16) PB_UPD2(J, J + 14);
+  if constexpr (J + 15 < 16) PB_UPD2(J, J + 15);
+  PB_FENCE();
+#undef PB_FENCE
+  y = yn; p = pn;
+}
+
+// owner (wave 0): lanes 0..15 carry the rows of the identity, lanes 16..63 rows o+16 .. o+63; the other panel wave:
+// rows xrow0 .. xrow0+63.  On return r[] (any row of lanes) holds the factored diagonal block, x[] of the owner's lanes
+// 0..15 the columns of its inverse; rows below have gone back to the image.
+__device__ __forceinline__ void panel_step_dpp(double* a, int* info, int row0, int o, int lane, int xrow0, bool owner,
+                                               double (&r)[16], double (&x)[16]) {
+  const int c = lane & 15;
+  const bool is_inv = owner && lane < 16;
+  const int row = owner ? o + lane : xrow0 + lane;       // (owner: lanes 16.. are rows o+16..)
+  const bool valid = !is_inv && row < PB;
+  const int rr = (row < PB) ? row : PB - 1;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    r[k] = a[(o + c) * PS + o + k];
+    const double v = a[rr * PS + o + k];
+    x[k] = is_inv ? ((k == c) ? 1.0 : 0.0) : v;
+  }
   int bad = 0x7fffffff;
-  double p = readlane_f64(r[0], 0);            // pivot of the current column (uniform)
+  double p, y, sd, dd;
+  PB_MOV_DPP(p, r[0], 0);                        // pivot of the current column (the same in every lane)
   bad = !(p > 0.0) ? 0 : bad;
-  double y;                                    // its reciprocal square root
   {
     const double y0 = __builtin_amdgcn_rsq(p);
     const double t = p * y0;
     const double e = __builtin_fma(-t, y0, 1.0);
     y = __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
   }
-  double sd = readlane_f64(r[0], 1), dd = readlane_f64(r[1], 1);     // s, d of the next pivot
-  double lq[16];                                  // L_k,j-1 (k >= j+2) of the column whose LDS-path updates are pending
-#pragma unroll
-  for (int k = 0; k < 16; ++k) lq[k] = 0.0;
-#pragma unroll
-  for (int j = 0; j < 15; ++j) {
-    double ln[16];
-    // ---- chain: l = s y_j
-    const double lj = sd * y;
-    r[j] = (lane == j) ? p * y : r[j] * y;       // rows below: x_j = (a_ij - sum_k<j x_k l_jk) / l_jj
-    PB_FENCE();
-    // ---- chain: p_{j+1}
-    const double pn = __builtin_fma(-lj, lj, dd);
-    if (j + 3 < 16) {
-      scr[lane] = r[j];          // slots 16..63 are never read: an unconditional store keeps the column loop one basic block
-#pragma unroll
-      for (int m = (j + 3) / 2; m < 8; ++m) {
-        const double2 v = *reinterpret_cast<const double2*>(scr + 2 * m);
-        ln[2 * m] = v.x; ln[2 * m + 1] = v.y;
-      }
-    }
-    PB_FENCE();
-    // ---- chain: estimate
-    double yn = __builtin_amdgcn_rsq(pn);
-    PB_LUPD(j + 2);
-    PB_UPD(j + 1);
-    PB_FENCE();
-    // ---- chain: t = p y0
-    const double t = pn * yn;
-    bad = (!(pn > 0.0) && bad == 0x7fffffff) ? j + 1 : bad;
-    PB_UPD(j + 2);
-    PB_FENCE();
-    // ---- chain: e = 1 - t y0
-    const double e = __builtin_fma(-t, yn, 1.0);
-    if (j + 2 < 16) { sd = readlane_f64(r[j + 1], j + 2); dd = readlane_f64(r[j + 2], j + 2); }
-    PB_LUPD(j + 3); PB_LUPD(j + 4); PB_LUPD(j + 5);
-    PB_FENCE();
-    // ---- chain: q, y0 e
-    const double q = __builtin_fma(0.375, e, 0.5);
-    const double ye = yn * e;
-    PB_LUPD(j + 6); PB_LUPD(j + 7); PB_LUPD(j + 8); PB_LUPD(j + 9); PB_LUPD(j + 10);
-    PB_FENCE();
-    // ---- chain: y_{j+1}
-    yn = __builtin_fma(ye, q, yn);
-    PB_LUPD(j + 11); PB_LUPD(j + 12); PB_LUPD(j + 13); PB_LUPD(j + 14); PB_LUPD(j + 15);
-    PB_FENCE();
-    y = yn; p = pn;
-#pragma unroll
-    for (int k = j + 3; k < 16; ++k) lq[k] = ln[k];
-  }
-  r[15] = (lane == 15) ? p * y : r[15] * y;
-#undef PB_UPD
-#undef PB_LUPD
-#undef PB_FENCE
+  PB_MOV_DPP(sd, r[0], 1); PB_MOV_DPP(dd, r[1], 1);
+  pb_pivot<0>(r, x, p, y, sd, dd, bad);  pb_pivot<1>(r, x, p, y, sd, dd, bad);  pb_pivot<2>(r, x, p, y, sd, dd, bad);
+  pb_pivot<3>(r, x, p, y, sd, dd, bad);  pb_pivot<4>(r, x, p, y, sd, dd, bad);  pb_pivot<5>(r, x, p, y, sd, dd, bad);
+  pb_pivot<6>(r, x, p, y, sd, dd, bad);  pb_pivot<7>(r, x, p, y, sd, dd, bad);  pb_pivot<8>(r, x, p, y, sd, dd, bad);
+  pb_pivot<9>(r, x, p, y, sd, dd, bad);  pb_pivot<10>(r, x, p, y, sd, dd, bad); pb_pivot<11>(r, x, p, y, sd, dd, bad);
+  pb_pivot<12>(r, x, p, y, sd, dd, bad); pb_pivot<13>(r, x, p, y, sd, dd, bad); pb_pivot<14>(r, x, p, y, sd, dd, bad);
+  PB_SCALE2(r[15], x[15], y);
   if (owner && lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
-  if (!is_diag && !is_inv && valid) {
+  if (valid) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[row * PS + o + c] = r[c];
+    for (int k = 0; k < 16; ++k) a[row * PS + o + k] = x[k];
   }
 }
 
@@ -203,6 +195,86 @@ __device__ __forceinline__ void tri_index(int t, int j0, int& I, int& J) {
   int Ip = 0, rem = t;
   while (rem >= Ip + 1) { rem -= Ip + 1; ++Ip; }
   I = j0 + Ip; J = j0 + rem;
+}
+
+// The same tile in three pieces, so that a wave with several tiles to do fetches the operands of the next one before the
+// four dependent MFMAs (64 cycles each) of the current one: a tile costs its MFMAs instead of MFMAs + an LDS round trip.
+struct UTile { double av[4], bv[4]; v4d acc; int I, J; };
+__device__ __forceinline__ void ut_load(UTile& t, const double* a, int I, int J, int o, int fr, int fk) {
+  t.I = I; t.J = J;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    t.av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
+    t.bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) t.acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
+}
+__device__ __forceinline__ void ut_run_store(UTile& t, double* a, int fr, int fk) {
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) t.acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t.av[s4], t.bv[s4], t.acc, 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) a[(16 * t.I + fk + 4 * rg) * PS + 16 * t.J + fr] = t.acc[rg];
+}
+// tiles first, first + stride, ... < ntile of the trailing update (blocks j0..7, panel columns o..o+15); returns the first
+// item index >= ntile of this wave's round-robin sequence
+__device__ __forceinline__ int update_tiles_pipelined(double* a, int first, int stride, int ntile, int j0, int o, int fr, int fk) {
+  int item = first;
+  if (item >= ntile) return item;
+  UTile ta, tb;
+  int I, J;
+  tri_index(item, j0, I, J);
+  ut_load(ta, a, I, J, o, fr, fk);
+  for (;;) {
+    bool more = item + stride < ntile;
+    if (more) { tri_index(item + stride, j0, I, J); ut_load(tb, a, I, J, o, fr, fk); }
+    __builtin_amdgcn_sched_barrier(0);
+    ut_run_store(ta, a, fr, fk);
+    item += stride;
+    if (!more) break;
+    more = item + stride < ntile;
+    if (more) { tri_index(item + stride, j0, I, J); ut_load(ta, a, I, J, o, fr, fk); }
+    __builtin_amdgcn_sched_barrier(0);
+    ut_run_store(tb, a, fr, fk);
+    item += stride;
+    if (!more) break;
+  }
+  return item;
+}
+
+// ---- finished pieces go to HBM in the shadow of later panels (one wave each; 16-byte stores)
+// rows i0 .. i0+7 of L (upper triangle zero-filled, like tf.cholesky)
+__device__ __forceinline__ void store_L_rows8(const double* a, double* __restrict__ A, i64 lda, int i0, int lane) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + u, j = 2 * lane;
+    double2 v;
+    v.x = (j <= i) ? a[i * PS + j] : 0.0;
+    v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
+    *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
+  }
+}
+// rows i0 .. i0+7 of inv(L)
+__device__ __forceinline__ void store_inv_rows8(const double* a, const double* dinv, double* __restrict__ Linv, int i0, int lane) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + u, c = 2 * lane;
+    double2 v;
+    v.x = x_elem(a, dinv, i, c);
+    v.y = x_elem(a, dinv, i, c + 1);
+    *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
+  }
+}
+// columns 16 gp .. 16 gp + 15 of inv(L)^T for rows c0 .. c0+63:  LinvT[c][i] = X[i][c]
+__device__ __forceinline__ void store_invT_strip64(const double* a, const double* dinv, double* __restrict__ LinvT, int gp, int c0, int lane) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = c0 + 8 * u + (lane >> 3), i = 16 * gp + 2 * (lane & 7);
+    double2 v;
+    v.x = x_elem(a, dinv, i, c);
+    v.y = x_elem(a, dinv, i + 1, c);
+    *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
+  }
 }
 
 // 16x16 triangular inverse of diagonal block gb, one column per lane (lanes 0..15 of one wave).
@@ -292,37 +364,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int g = 0; g < 8; ++g) {
       const int o = 16 * g;
       const int nrows = PB - o - 16;                       // rows below the diagonal block
-      const int npanel = nrows > 32 ? 1 + (nrows - 32 + 47) / 48 : 1;   // wave 0 takes 32 of them, every further panel wave 48
+      const int npanel = nrows > 48 ? 2 : 1;               // wave 0 takes 48 of them, wave 1 the other (up to) 64
       if (stamps && (tid == 0 || (lane == 0 && stamps[31]))) t0 = (long long)wall_clock64();
       // ---- phase A
-      double r[16];
+      double r[16], x[16];
       if (wave < npanel) {
-        panel_step(a, dinv + PB + 64 * wave, info, row0, o, lane, o + 48 * wave, wave == 0, r);
+        panel_step_dpp(a, info, row0, o, lane, o + 64 * wave, wave == 0, r, x);
       } else if (g >= 1) {
+        // update waves, one round-robin list of items:
+        //   the rest of the trailing update of step g-1 (tiles (I, J), g+1 <= J <= I <= 7), operands fetched one tile ahead
+        //   block row g-1 of the inverse
+        //   what is final goes back to HBM: rows of block g-1 of L, rows of block g-2 of inv(L) (completed in phase A(g-1)) and
+        //   the matching column strip of inv(L)^T -- spread over the panels instead of one burst behind the last one
         const int nuw = 8 - npanel;
-        int item = wave - npanel;
-        // rest of the trailing update of step g-1: tiles (I, J), g+1 <= J <= I <= 7
         const int nt = 7 - g, ntile = nt * (nt + 1) / 2;
-        for (; item < ntile; item += nuw) {
-          int I, J;
-          tri_index(item, g + 1, I, J);
-          update_tile(a, I, J, o - 16, fr, fk);
-        }
-        item -= ntile;
-        // block row g-1 of the inverse
+        int item = update_tiles_pipelined(a, wave - npanel, nuw, ntile, g + 1, o - 16, fr, fk) - ntile;
         for (; item < g - 1; item += nuw) inv_row_tile(a, dinv, g - 1, item, fr, fk);
-        // last step: rows 0..111 of L are final and go back to HBM in the last panel's shadow (upper triangle
-        // zero-filled, like tf.cholesky), 16 rows per update wave
-        if (g == 7) {
-          const int r0 = 16 * (wave - 1), r1 = r0 + 16;
-#pragma unroll 4
-          for (int i = r0; i < r1; ++i) {
-            const int j = 2 * lane;
-            double2 v;
-            v.x = (j <= i) ? a[i * PS + j] : 0.0;
-            v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
-            *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
-          }
+        item -= g - 1;
+        for (; item < 2; item += nuw) store_L_rows8(a, A, lda, 16 * (g - 1) + 8 * item, lane);
+        item -= 2;
+        if (g >= 2) {
+          for (; item < 2; item += nuw) store_inv_rows8(a, dinv, Linv, 16 * (g - 2) + 8 * item, lane);
+          item -= 2;
+          if (LinvT) for (; item < 2; item += nuw) store_invT_strip64(a, dinv, LinvT, g - 2, 64 * item, lane);
         }
       }
       if (stamps && lane == 0 && stamps[31]) stamps[32 + 8 * g + wave] = (long long)wall_clock64() - t0;   // diagnostics (stamps[31] != 0): per-wave end of phase A
@@ -331,18 +395,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // ---- phase B: the factored diagonal block and its inverse go back to the image (wave 0), block column g+1
       // of the trailing update of step g (neither reads the other's data)
       if (wave == 0) {
-        // row o+c of the image = [ L[c][0..c] (lane c) | X[c+1..15][c] (lane 16+c: column c of inv(L_gg), transposed) ];
-        // masked-out elements go to a per-lane dummy slot instead of a divergent branch per element
+        // row o+c of the image = [ L[c][0..c] (lane 16+c: its copy of the block) | X[c+1..15][c] (lane c: column c of
+        // inv(L_gg), transposed) ]; masked-out elements go to a per-lane dummy slot instead of a divergent branch per element
         const int c = lane & 15;
-        const bool lo = lane < 16, act = lane < 32;
-        double dc = r[0];                      // X[c][c] = 1 / L_cc (the pivot's refined reciprocal square root)
+        const bool inv_l = lane < 16, act = lane < 32;
+        double dc = x[0];                      // X[c][c] = 1 / L_cc (the pivot's refined reciprocal square root)
 #pragma unroll
-        for (int k = 1; k < 16; ++k) dc = (k == c) ? r[k] : dc;
-        if (act && !lo) dinv[o + c] = dc;
+        for (int k = 1; k < 16; ++k) dc = (k == c) ? x[k] : dc;
+        if (inv_l) dinv[o + c] = dc;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          const bool w = act && (lo ? (k <= c) : (k > c));
-          a[w ? (o + c) * PS + o + k : PB * PS + PB + lane] = r[k];
+          const bool w = act && (inv_l ? (k > c) : (k <= c));
+          a[w ? (o + c) * PS + o + k : PB * PS + PB + lane] = inv_l ? x[k] : r[k];
         }
       }
       else {
@@ -381,21 +445,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 
   STAMP(5);
-  // inverse (and its transpose) to HBM, full blocks with explicit zeros, 16-byte stores
-  for (int idx = tid; idx < PB * PB / 2; idx += NT) {
-    const int i = idx >> 6, c = (idx & 63) * 2;
-    double2 v;
-    v.x = x_elem(a, dinv, i, c);
-    v.y = x_elem(a, dinv, i, c + 1);
-    *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
-  }
-  if (LinvT) {
-    for (int idx = tid; idx < PB * PB / 2; idx += NT) {
-      const int c = idx >> 6, i = (idx & 63) * 2;        // LinvT[c][i] = X[i][c]
+  // inverse (and its transpose) to HBM, explicit zeros above the diagonal, 16-byte stores.  With factor != 0 the block rows
+  // 0..5 (and the matching column strips of the transpose) left in the panels' shadow: only block rows 6 and 7 remain
+  {
+    const int b0 = factor ? 6 : 0, i0 = 16 * b0, w2 = (PB - i0) / 2;      // w2: double2 per row of the transposed strip
+    for (int idx = i0 * 64 + tid; idx < PB * PB / 2; idx += NT) {
+      const int i = idx >> 6, c = (idx & 63) * 2;
       double2 v;
       v.x = x_elem(a, dinv, i, c);
-      v.y = x_elem(a, dinv, i + 1, c);
-      *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
+      v.y = x_elem(a, dinv, i, c + 1);
+      *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
+    }
+    if (LinvT) {
+      for (int idx = tid; idx < PB * w2; idx += NT) {
+        const int c = idx / w2, i = i0 + 2 * (idx - c * w2);        // LinvT[c][i] = X[i][c]
+        double2 v;
+        v.x = x_elem(a, dinv, i, c);
+        v.y = x_elem(a, dinv, i + 1, c);
+        *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
+      }
     }
   }
   __syncthreads();

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "gps_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
     "gps_comm_init": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int],
     "gps_comm_destroy": [ctypes.c_void_p],
+    "gps_comm_abort": [ctypes.c_void_p],
     "gps_comm_exchange": [ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int],
     "gps_comm_wait": [ctypes.c_void_p, ctypes.c_int],
     "gps_comm_allreduce": [ctypes.c_void_p, ctypes.c_void_p, _i64],
@@ -294,7 +295,21 @@ class Handle(object):
         self._h = h
         self.device = int(device)
         self.resident_token = None     # identity of the data set held by gps_gpr_set_data
+        self.dist_state = None         # what a PARTITIONED factor on this handle was computed from (gpflowSlim.distributed)
         self.factor_key = None         # what the resident Cholesky factor / alpha were computed from (models/gpr.py)
+
+    @property
+    def factor_key(self):
+        return self._factor_key
+
+    @factor_key.setter
+    def factor_key(self, key):
+        # The claims "a factor is resident" live on the HANDLE, next to the factor: every evaluation that touches the
+        # factor buffers passes through this setter (models/gpr.py, every sparse / conditional entry below), and whatever
+        # partitioned factor a distributed evaluation left behind is gone with it -- gpr_lml_distributed records its claim
+        # (dist_state) AFTER resetting the key.
+        self._factor_key = key
+        self.dist_state = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -664,6 +679,10 @@ class Handle(object):
 
     def comm_destroy(self):
         self._check(self._lib.gps_comm_destroy(self._h), "gps_comm_destroy")
+
+    def comm_abort(self):
+        """ncclCommAbort: leave the communicator without waiting for the peers (a failing rank's way out)."""
+        self._check(self._lib.gps_comm_abort(self._h), "gps_comm_abort")
 
     def comm_exchange(self, dev_ptr, count, root, mode, slot):
         self._check(self._lib.gps_comm_exchange(self._h, ctypes.c_void_p(dev_ptr), int(count), int(root), int(mode), int(slot)),

@@ -504,8 +504,7 @@ def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2, partitioned=True)
     comm = comm or _default_comm()
     h = model._handle()
     prog = model.kern._program(model.X.shape[1])
-    model._factor_key = None
-    model._dist_state = None
+    model._factor_key = None               # (the handle's setter also drops any partitioned-factor claim)
     if isinstance(comm, RcclComm) and comm.native_schedule and comm.h is h:
         # the library's own communicator: the whole schedule runs inside the library too (gps_dist_lml) -- no Python per panel
         h.set_option("dist_partitioned", 1 if partitioned else 0)
@@ -519,7 +518,7 @@ def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2, partitioned=True)
             if comm.world > 1:
                 comm.bytes_sent += (8 * (cnt // comm.world) * (comm.world - 1) * (2 if root else 1)) if mode == 1 else (8 * cnt * (comm.world - 1) if root else 0)
         if partitioned:
-            model._dist_state = {"key": model._state_key(), "native": True, "world": comm.world}
+            h.dist_state = {"key": model._state_key(), "native": True, "world": comm.world}
         else:
             model._factor_key = model._state_key()
         return lml
@@ -529,8 +528,8 @@ def gpr_lml_distributed(model, comm=None, nb=512, lookahead=2, partitioned=True)
         lml = ops.finish()
         if partitioned:
             # what predict_f_distributed needs to stream the panels again (the comm buffers stay alive with it)
-            model._dist_state = {"key": model._state_key(), "n_panels": ops.n_panels, "bufs": ops.bufs, "nparts": ops.nparts,
-                                 "world": comm.world}
+            h.dist_state = {"key": model._state_key(), "n_panels": ops.n_panels, "bufs": ops.bufs, "nparts": ops.nparts,
+                            "world": comm.world}
     if not partitioned:
         model._factor_key = model._state_key()      # L and alpha are resident (replicated) on every rank
     return lml
@@ -548,7 +547,9 @@ def predict_f_distributed(model, Xnew, comm=None):
     bounds = [(n_new * r) // comm.world for r in range(comm.world + 1)]
     counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
     lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
-    st = getattr(model, "_dist_state", None)
+    # the claim "a partitioned factor of THIS model state is resident" is the handle's (several models may share a handle and
+    # even an X array; any other evaluation on the handle clears it): no match -> the ordinary path below re-factorises
+    st = model._handle().dist_state
     if st is not None and st.get("native") and st["key"] == model._state_key() and st["world"] == comm.world:
         R = model.Y.shape[1]
         Xmine = Xnew[lo:hi]

@@ -301,6 +301,10 @@ int gps_allreduce_doubles(int64_t m, int64_t r, int64_t* out);
  *   gps_comm_wait(h, slot)          the handle's stream waits for the exchange that used `slot` (0..7)
  *   gps_comm_allreduce(h, p, n)     in-place sum of n doubles over the ranks, blocking
  *   gps_comm_install_allreduce      makes that the collective of gps_sgpr / gps_fitc on data shards (see gps_set_allreduce)
+ *   gps_comm_abort(h)               gives the communicator up without waiting for the peers (ncclCommAbort): what a rank that
+ *        has failed calls so that the others' pending collectives return an error instead of waiting for its part; a collective
+ *        that fails inside gps_comm_exchange / gps_comm_allreduce does the same by itself (an open send / receive group is always
+ *        closed first).  The handle has no communicator afterwards (gps_comm_init again for a new one).
  * Verified on hardware with the real RCCL at world size 1, and at world size 2 through a stand-in transport behind the same
  * API (tests/fake_rccl; the build box has one GPU); gpflowSlim.distributed.RcclComm drives it.                       */
 int gps_comm_load(const char* path);
@@ -309,6 +313,7 @@ int gps_comm_version(int* version);
 int gps_comm_unique_id(void* out, int capacity);
 int gps_comm_init(gps_handle_t h, int rank, int world, const void* unique_id, int id_len);
 int gps_comm_destroy(gps_handle_t h);
+int gps_comm_abort(gps_handle_t h);
 int gps_comm_exchange(gps_handle_t h, void* dev_buf, int64_t count, int root, int mode, int slot);
 int gps_comm_wait(gps_handle_t h, int slot);
 int gps_comm_allreduce(gps_handle_t h, void* dev_ptr, int64_t count);

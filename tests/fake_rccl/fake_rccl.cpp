@@ -5,7 +5,10 @@
 // product (gps_comm_load(path) is handed this library by tests/test_gpu_comm_native.py only).
 // Build with -Wl,-Bsymbolic: the internal calls (ncclBroadcast -> ncclSend ...) must bind to THIS library even when a real
 // librccl (PyTorch's) is already in the process' global scope.
-// Implements exactly the entry points comm_rccl.hip binds (rccl.h:187,220,260,339,591,611,678,700,722).
+// Implements exactly the entry points comm_rccl.hip binds (rccl.h:187,220,260,339,591,611,678,700,722) plus ncclCommAbort.
+// Fault injection (tests of the failure paths): FAKE_RCCL_FAIL_RANK=r makes rank r's ncclSend call number
+// FAKE_RCCL_FAIL_AFTER + 1 (default 1) fail -- FAKE_RCCL_FAIL_MODE=error (default): it returns ncclSystemError, as a send
+// that fails inside an open group does; =stall: it never returns (a rank stuck in the transport).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <atomic>
@@ -104,9 +107,20 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   delete c;
   return ncclSuccess;
 }
+ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }
 ncclResult_t ncclGroupStart() { ++group_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { if (--group_depth == 0) return flush(); return ncclSuccess; }
+static bool inject_fault(Comm* c) {
+  static const int fail_rank = getenv("FAKE_RCCL_FAIL_RANK") ? atoi(getenv("FAKE_RCCL_FAIL_RANK")) : -1;
+  static const long fail_after = getenv("FAKE_RCCL_FAIL_AFTER") ? atol(getenv("FAKE_RCCL_FAIL_AFTER")) : 0;
+  static const bool stall = getenv("FAKE_RCCL_FAIL_MODE") && !strcmp(getenv("FAKE_RCCL_FAIL_MODE"), "stall");
+  static std::atomic<long> calls{0};
+  if (c->rank != fail_rank || ++calls <= fail_after) return false;
+  if (stall) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+  return true;
+}
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s) {
+  if (inject_fault(reinterpret_cast<Comm*>(comm))) return ncclSystemError;
   queue.push_back({0, const_cast<void*>(buf), count * dsize(t), peer, reinterpret_cast<Comm*>(comm), s});
   return group_depth ? ncclSuccess : flush();
 }

@@ -74,9 +74,32 @@ def test_single_rank_distributed_equals_fused_path(handle, n, nb, lookahead, par
     # and the ordinary fused path still works on the same handle afterwards
     assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
     if partitioned:
-        # ... and has overwritten the distributed factor: the streamed prediction must refuse, not read stale panels
-        with pytest.raises(RuntimeError, match="no partitioned factor"):
-            predict_f_distributed(m, Xs, SingleComm())
+        # ... and has overwritten the distributed factor.  The claim "a partitioned factor is resident" lives on the handle
+        # and went with it: the prediction neither reads stale panels nor refuses, it factorises again
+        assert handle.dist_state is None
+        mu3, var3 = predict_f_distributed(m, Xs, SingleComm())
+        assert np.abs(mu3 - rmu).max() <= 1e-8 * np.abs(rmu).max() and np.abs(var3 - rvar).max() <= 1e-8 * np.abs(rvar).max()
+
+
+def test_partitioned_factor_belongs_to_the_handle_not_the_model(handle):
+    """Two models that share X and the handle: B's distributed evaluation leaves B's partitioned factor behind; a streamed
+    prediction for A must not use it (it factorises again), and B's own prediction still streams."""
+    import gpflowSlim as gpf
+    from gpflowSlim.distributed import SingleComm, gpr_lml_distributed, predict_f_distributed
+    X, Y, ls, spec = _data(700, 4)
+    YB = 2.0 * Y + 0.3
+    a = gpf.models.GPR(X, Y, gpf.kernels.RBF(4, variance=1.1, lengthscales=ls, ARD=True), obs_var=0.1)
+    b = gpf.models.GPR(X, YB, gpf.kernels.RBF(4, variance=1.1, lengthscales=ls, ARD=True), obs_var=0.1)
+    Xs = np.random.default_rng(2).standard_normal((21, 4))
+    gpr_lml_distributed(a, SingleComm(), nb=256)
+    gpr_lml_distributed(b, SingleComm(), nb=256)
+    assert handle.dist_state is not None and handle.dist_state["key"] == b._state_key()
+    ra, rva = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
+    rb, rvb = orc.gpr_predict(spec, X, YB, orc.constrained(0.1), Xs)
+    mb, vb = predict_f_distributed(b, Xs, SingleComm())
+    assert np.abs(mb - rb).max() <= 1e-8 * np.abs(rb).max() and np.abs(vb - rvb).max() <= 1e-8 * np.abs(rvb).max()
+    ma, va = predict_f_distributed(a, Xs, SingleComm())
+    assert np.abs(ma - ra).max() <= 1e-8 * np.abs(ra).max() and np.abs(va - rva).max() <= 1e-8 * np.abs(rva).max()
 
 
 def _run_virtual_ranks(world, X, Y, prog, noise, nb, lookahead=2, r_out=None, partitioned=None, Xnew=None, extra=None):

@@ -184,8 +184,8 @@ def test_bench_launcher_stays_off_the_gpu_and_reports_failure():
     import torch (nothing that could initialise a GPU) and must exit non-zero when a rank fails -- here every rank
     fails loudly because this machine has no GPU."""
     import subprocess
-    code = ("import sys, os; sys.path.insert(0, %r); import bench\n"
-            "rc = bench.launch_ranks(2, ['--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0'], 120.0)\n"
+    code = ("import sys, os, tempfile; sys.path.insert(0, %r); import bench\n"
+            "rc = bench.supervise([0, 1], 2, ['--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0'], ['torch'], tempfile.mkdtemp(), 120.0, 120.0, True)\n"
             "assert 'torch' not in sys.modules and 'gpflowSlim' not in sys.modules, sorted(sys.modules)\n"
             "print('launcher rc', rc)\n" % ROOT)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -201,6 +201,38 @@ def test_bench_launcher_stays_off_the_gpu_and_reports_failure():
                        text=True, timeout=300, env=env)
     lines = [json.loads(ln) for ln in q.stdout.splitlines() if ln.startswith("{")]
     assert q.returncode != 0 and len(lines) == 1 and lines[0]["value"] == 0.0 and "needs an MI355X" in lines[0]["error"]
+    assert lines[0]["launch"]["tried"] == ["torch"] and len(lines[0]["launch"]["failed_attempts"]) == 1
+
+
+def test_bench_supervisor_walks_through_its_attempts():
+    """Every attempt of a multi-rank run is a set of FRESH rank processes started by the GPU-free supervisor; a failed attempt
+    is followed by the next one, and the one JSON line says what was tried and why it failed.  Here (no GPU) every attempt
+    fails: both forms -- bench.py as its own launcher, and one bench.py per rank under a launcher, whose per-rank supervisors
+    meet in a rendezvous directory -- must walk through the whole list and end with ONE line from rank 0."""
+    import tempfile
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the failure legs need a machine without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", "2", "--backend", "gloo", "--attempts", "rccl,torch,torch-broadcast", "--steps", "1", "--warmup", "0"]
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env)
+    lines = [json.loads(ln) for ln in q.stdout.splitlines() if ln.startswith("{")]
+    assert q.returncode != 0 and len(lines) == 1, (q.stdout, q.stderr[-2000:])
+    la = lines[0]["launch"]
+    assert la["tried"] == ["rccl", "torch", "torch-broadcast"] and [f["attempt"] for f in la["failed_attempts"]] == la["tried"]
+    assert all("exited with status" in f["reason"] for f in la["failed_attempts"])
+    # one supervisor per rank (what a launcher such as torch.distributed.run starts)
+    rdv = tempfile.mkdtemp(prefix="gps_bench_test_")
+    procs = []
+    for r in (0, 1):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", GPS_BENCH_RDV_DIR=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=e))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode != 0 for p in procs)
+    lines0 = [json.loads(ln) for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    assert [f["attempt"] for f in lines0[0]["launch"]["failed_attempts"]] == ["rccl", "torch", "torch-broadcast"]
 
 
 def test_native_rccl_binding_loads_without_a_gpu(gpf):
