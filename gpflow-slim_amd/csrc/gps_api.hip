@@ -323,6 +323,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
   if (const char* v = getenv("GPS_TRSV_WAVE")) h->trsv_wave = atoi(v);                                   // (same switches as
   if (const char* v = getenv("GPS_LEAF_PERSISTENT")) h->leaf_persistent = atoi(v);                       //  gps_set_option,
+  if (const char* v = getenv("GPS_SMALL_N")) h->small_n = atoi(v);
   if (const char* v = getenv("GPS_KMAT_FAST")) h->kmat_fast = atoi(v);                                   //  for a whole run)
   if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   *out = h;
@@ -336,6 +337,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
                     &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
+  if (all) h->dSmallSync.release();
   if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
 }
 
@@ -423,6 +425,11 @@ extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launc
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
     return GPS_OK;
   }
+  if (strcmp(klass, "small_n_fallbacks") == 0) {      // one-launch factorisations of small problems that gave up and were redone launch by launch
+    if (launches) *launches = (int64_t)h->small_fallbacks;
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   if (strcmp(klass, "trsv_wave_fallbacks") == 0) {    // wavefront substitutions that gave up (handle fell back to the recursive one)
     if (launches) *launches = (int64_t)h->wave_fallbacks;
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
@@ -483,6 +490,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
+  if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
 
@@ -535,7 +543,9 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
     GPS_HIP(h, hipMemcpyAsync(dA, A.data(), bb, hipMemcpyHostToDevice, h->stream));
     int rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
     if (rc) return rc;
-    rc = gps_launch_potrf_base(h, dA, GPS_TILE, dA + GPS_TILE * GPS_TILE, dA + 2 * GPS_TILE * GPS_TILE, (int*)h->dInfo.p, 0, factor, dS);
+    // (GPS_PB_NO_T: without the transposed inverse, as the GPR path runs it -- the transposes come from one batched launch)
+    rc = gps_launch_potrf_base(h, dA, GPS_TILE, dA + GPS_TILE * GPS_TILE, getenv("GPS_PB_NO_T") ? nullptr : dA + 2 * GPS_TILE * GPS_TILE,
+                               (int*)h->dInfo.p, 0, factor, dS);
     if (rc) return rc;
     GPS_HIP(h, hipMemcpyAsync(hs, dS, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
@@ -785,21 +795,65 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   const bool aug = r > 0 && r <= GPS_TILE && (h->gpr_aug_rows > 0 || (h->gpr_aug_rows < 0 && np < 6200));
   GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
   double* const dAug = h->dK.d() + np * np;
+  // Small problems (the reference's own size: examples/gpr.py, N ~ 455): the whole factorisation, alpha and the two
+  // reductions of the likelihood as ONE cooperative launch (small_n.hip) -- three launches per evaluation with the two of the
+  // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
+  h->small_valid = false;
+  const bool small = h->small_n > 0 && aug && np <= 768 && r <= 32 && !h->refine_now && h->prop.multiProcessorCount >= 160;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
     GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
-    double* dst = aug ? dAug : h->dAlpha.d();
-    GPS_HIP(h, hipMemsetAsync(dst, 0, (size_t)(aug ? GPS_TILE : r) * np * 8, h->stream));
-    int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dst, np);
-    if (rc0) return rc0;
+    if (!small) {
+      double* dst = aug ? dAug : h->dAlpha.d();
+      GPS_HIP(h, hipMemsetAsync(dst, 0, (size_t)(aug ? GPS_TILE : r) * np * 8, h->stream));
+      int rc0 = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dst, np);
+      if (rc0) return rc0;
+    }
   }
   int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np,
                            np, np, /*lower_only*/ 1, /*identity_pad*/ 1);
   if (rc) return rc;
   GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   int* d_info = (int*)h->dInfo.p;
+  if (small) {
+    double* d_res = h->dScal.d() + 256;
+    double* linv = h->dLinv.d();
+    rc = gps_launch_small_factor(h, h->dK.d(), np, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, h->dTmp2.d(), n, r, d_info, d_res,
+                                 h->dAlpha.d(), np, r);
+    if (rc == GPS_OK) {
+      GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+      double res[4] = {0.0, 0.0, 0.0, 1.0};
+      GPS_HIP(h, hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      if (res[3] == 0.0) {
+        const int v = (int)res[2];
+        if (info) *info = (v == INT_MAX) ? 0 : v;
+        h->r = r;
+        h->small_valid = true; h->small_slog = res[0]; h->small_ssq = res[1];
+        h->have_factor = (info == nullptr) || (*info == 0);
+        return GPS_OK;
+      }
+      // a bounded wait of the launch ran out (never seen; e.g. several such launches of one process interleaved on the GPU
+      // so that none was fully resident): counters back to zero, this evaluation again launch by launch
+      h->small_fallbacks++;
+      rc = gps_small_factor_reset(h);
+      if (rc) return rc;
+      const int saved = h->small_n;
+      h->small_n = 0;
+      rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, info);
+      h->small_n = saved;
+      return rc;
+    }
+    if (rc != GPS_ERR_UNSUPPORTED) return rc;
+    // (not a shape for that path after all: the residual still has to go where the launch-by-launch path expects it)
+    if (r > 0) {
+      GPS_HIP(h, hipMemsetAsync(dAug, 0, (size_t)GPS_TILE * np * 8, h->stream));
+      rc = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dAug, np);
+      if (rc) return rc;
+    }
+  }
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
@@ -845,22 +899,29 @@ extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   if (info) *info = linfo;
   if (rc) return rc;
   const i64 n = h->n, np = h->npad;
-  double* part = h->dScal.d();
-  rc = gps_launch_lml_reduce(h, h->dK.d(), np, n, h->dAlpha.d(), np, r, part);
-  if (rc) return rc;
-  GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
-  double hp[2 * 64];
-  GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
-  GPS_HIP(h, hipStreamSynchronize(h->stream));
   double slog = 0.0, ssq = 0.0;
-  for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; ssq += hp[2 * b + 1]; }
+  if (h->small_valid) {
+    // (the one-launch factorisation of a small problem has reduced both sums itself and they are on the host already)
+    slog = h->small_slog; ssq = h->small_ssq;
+    h->ev3_is_ev2 = true;
+  } else {
+    h->ev3_is_ev2 = false;
+    double* part = h->dScal.d();
+    rc = gps_launch_lml_reduce(h, h->dK.d(), np, n, h->dAlpha.d(), np, r, part);
+    if (rc) return rc;
+    GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+    double hp[2 * 64];
+    GPS_HIP(h, hipMemcpyAsync(hp, part, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < 64; ++b) { slog += hp[2 * b]; ssq += hp[2 * b + 1]; }
+  }
   // densities.py:92-94
   *lml = -0.5 * (double)n * (double)r * log(2.0 * M_PI) - (double)r * slog - 0.5 * ssq;
   stage_time(h, 0, 1, &h->stage_ms[0]);
   stage_time(h, 1, 2, &h->stage_ms[1]);
-  stage_time(h, 2, 3, &h->stage_ms[2]);
+  if (h->ev3_is_ev2) h->stage_ms[2] = 0.0; else stage_time(h, 2, 3, &h->stage_ms[2]);
   h->stage_ms[3] = 0.0;
-  stage_time(h, 0, 3, &h->stage_ms[4]);
+  stage_time(h, 0, h->ev3_is_ev2 ? 2 : 3, &h->stage_ms[4]);
   return GPS_OK;
   });
 }

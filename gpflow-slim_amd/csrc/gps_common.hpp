@@ -221,6 +221,11 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
+  DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
+  int small_n = 1;            // option "small_n": GPR problems of up to 768 padded rows are factored by one cooperative launch
+  long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
+  bool small_valid = false; double small_slog = 0.0, small_ssq = 0.0;   // reductions the last small launch produced
+  bool ev3_is_ev2 = false;
   DevBuf dGemmWs, dGemmCnt;   // slice partials + arrival counters of the GEMM tail split
   DevBuf dGemvWs, dGemvCnt;   // slice partials + arrival counters of the split transposed gemv (blas1.hip)
 };
@@ -320,6 +325,10 @@ static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var,
   return !((double)n * kdiag + noise_var <= h->leaf_refine_cond * noise_var);      // (NaN / zero noise: refine)
 }
 
+// small_n.hip : the whole factorisation of a small problem as one cooperative launch
+int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
+                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows);
+int gps_small_factor_reset(gps_handle_t h);
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
                          int trans);

@@ -9,19 +9,20 @@
 // One workgroup of 8 waves, LDS image [128][129], 8 steps of 16 columns.  The kernel is one long dependent chain
 // (128 pivots), so the waves are specialised and everything that is not on the chain runs in its shadow:
 //
-//   phase A(g)  PANEL waves (wave 0, and wave 1 while more than 48 rows lie below the block): every ROW of 16 lanes holds a
-//               copy of the 16 rows of diagonal block g and factors it in registers (hardware rsqrt + one third-order
-//               correction, no barrier; broadcasts by DPP row_newbcast -- panel_step_dpp below); every lane carries a second
-//               vector, a row below the block, that takes the very same updates -- which for it IS the forward substitution
-//               x L_gg^T = b -- so the whole 16-column panel is finished when the diagonal block is.  Lanes 0..15 of
-//               wave 0 carry the rows of the identity instead: what they end with is e_c^T L_gg^-T, i.e. column c of
-//               inv(L_gg) -- the 16x16 triangular inverse costs no instruction of its own.
-//               UPDATE waves (all others), meanwhile: the rest of the trailing update of step g-1 (16x16 tiles
-//               C_IJ -= P_I P_J^T on the fp64 MFMA, J >= g+1; operands fetched one tile ahead), block row g-1 of the
-//               inverse (below), and the stores of what is final: rows of block g-1 of L, rows of block g-2 of inv(L)
-//               and the matching strip of its transpose leave for HBM here instead of in one burst at the end.
-//   phase B(g)  waves 1..7: the tiles of block column g+1 of the trailing update of step g (the only ones the next
-//               panel needs), one per wave; wave 0 puts the factored block and its inverse back into the image.
+//   phase A(g)  PANEL waves (wave 0; wave 1 while more than 32 rows lie below the block; wave 2 at step 0): every ROW of 16
+//               lanes holds a copy of the 16 rows of diagonal block g and factors it in registers (hardware rsqrt + one
+//               third-order correction, no barrier; broadcasts by DPP row_newbcast -- panel_step_dpp below); every lane
+//               carries a second vector, a row below the block, that takes the very same updates -- which for it IS the forward
+//               substitution x L_gg^T = b -- so the whole 16-column panel is finished when the diagonal block is.  Lanes
+//               0..15 of wave 0 carry the rows of the identity instead (they end as the columns of inv(L_gg): the 16x16
+//               triangular inverse costs no instruction of its own), lanes 16..31 the rows of the block itself (they end as
+//               the rows of L_gg); one loop of 16 LDS stores per lane puts all of it back into the image.
+//               The OTHER waves, meanwhile, pull items from two work queues (LDS counters, longest items first): MFMA items --
+//               block row g-1 of the inverse (below) and the LEFT-LOOKING update of block column g+1 with the panels 0..g-1
+//               (one accumulator chain of 4 g MFMAs per 16x16 tile, operands fetched one panel ahead) --, then store items:
+//               the rows of block g-1 of L leave for HBM here instead of in one burst at the end.
+//   phase B(g)  block column g+1 takes panel g (the only update the next panel waits for): one 4-MFMA tile per wave.
+//   tail        block row 7 of the inverse; beside it (queue) the rows of inv(L) that are final and the last rows of L.
 //
 // Inverse X = inv(L), built by block rows in the shadow of the factorisation: the lower triangle of the image holds
 // L, the strictly upper triangle receives X^T (X is lower triangular, so its transpose fits exactly there), 1/L_ii
@@ -34,8 +35,16 @@
 #define PB 128
 #define PS 129
 #define NT 512
-
+// Measured and not kept (tools/pb_stamps.py, tools/dpp_probe.hip; round 4):
+//  * no fp64 MFMA on a panel wave's SIMD.  The fp64 vector FMAs of a wave drop from one per 6.4 cycles to one per 22 while
+//    ANOTHER wave of the same SIMD issues fp64 MFMAs (the two share the DP pipe and the MFMA wins), so with the partners of
+//    the panel waves idle the pivot chain runs at 1.55 instead of 1.9 us per 16 columns -- but the other waves' work then sits
+//    on two SIMDs: 29.9 us per call against 29.3 with every non-panel wave pulling from both queues.
+//  * s_setprio for the panel waves: no effect either way.
+//  * rows of inv(L) stored in the panels' shadow as well: +2 us (the waves that would have the issue slots for it do not
+//    have the time); they leave beside block row 7 of the inverse instead.
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) int lds_int;
 
 // whole 128x128 block -> LDS image; 16-byte loads, all 16 of a thread in flight at once (one memory round trip:
 // a lone workgroup draws ~40 GB/s, so the tile load is latency, not bandwidth); the upper triangle is loaded too:
@@ -136,19 +145,36 @@ __device__ __forceinline__ void pb_pivot(double (&r)[16], double (&x)[16], doubl
 // owner (wave 0): lanes 0..15 carry the rows of the identity, lanes 16..63 rows o+16 .. o+63; the other panel wave:
 // rows xrow0 .. xrow0+63.  On return r[] (any row of lanes) holds the factored diagonal block, x[] of the owner's lanes
 // 0..15 the columns of its inverse; rows below have gone back to the image.
-__device__ __forceinline__ void panel_step_dpp(double* a, int* info, int row0, int o, int lane, int xrow0, bool owner,
-                                               double (&r)[16], double (&x)[16]) {
+__device__ __forceinline__ void panel_step_dpp(double* a, int* info, int row0, int o, int lane, int pw, int n_pw,
+                                               lds_int* pflag, int flag_target) {
+  // What the lane's own vector x is (pw: index of this panel wave; the r copy of the block is in every lane):
+  //   owner (pw 0)  lanes  0..15  row c of the identity      -> column c of inv(L_gg): X[k][c], k > c, into the strict upper
+  //                               triangle of the image (transposed), X[c][c] into dinv; zeros (exactly) for k < c
+  //                 lanes 16..31  row c of the block itself   -> row c of L_gg (A_gg L_gg^-T = L_gg: the same recurrence in the
+  //                               same order as the copy r, the same bits), k <= c into the lower triangle
+  //                 lanes 32..63  rows o+16 .. o+47 below the block
+  //   pw 1: rows o+48 .. o+111;  pw 2 (only at o = 0, where every other wave is idle anyway): rows o+112 ..
+  // so that ONE loop of 16 LDS stores with a per-lane address (column range [klo, khi] of the row at `base`, anything else to a
+  // dummy slot, the diagonal of the inverse to dinv) puts everything back -- the factored block included, at the end of this
+  // phase rather than in a phase of its own.
   const int c = lane & 15;
-  const bool is_inv = owner && lane < 16;
-  const int row = owner ? o + lane : xrow0 + lane;       // (owner: lanes 16.. are rows o+16..)
-  const bool valid = !is_inv && row < PB;
-  const int rr = (row < PB) ? row : PB - 1;
+  const bool owner = pw == 0;
+  const bool is_inv = owner && lane < 16, is_diag = owner && lane >= 16 && lane < 32;
+  const int row = owner ? (lane < 32 ? o + c : o + lane - 16) : o + 48 + 64 * (pw - 1) + lane;
+  const bool valid = row < PB;
+  const int rr = valid ? row : PB - 1;
+  double r[16], x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     r[k] = a[(o + c) * PS + o + k];
     const double v = a[rr * PS + o + k];
     x[k] = is_inv ? ((k == c) ? 1.0 : 0.0) : v;
   }
+  // The other panel waves have their copies of the block in registers: from then on the owner may overwrite it (below).  (The
+  // LDS executes a wave's instructions in issue order: once the counter add has executed, so have the loads above.  The counter is
+  // accessed through an explicit LDS pointer with relaxed atomics: an ordered access through a GENERIC pointer may touch
+  // private memory as far as the compiler knows, and r[] / x[] would live in scratch instead of registers.)
+  if (!owner && lane == 0) __hip_atomic_fetch_add(pflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   int bad = 0x7fffffff;
   double p, y, sd, dd;
   PB_MOV_DPP(p, r[0], 0);                        // pivot of the current column (the same in every lane)
@@ -167,27 +193,36 @@ __device__ __forceinline__ void panel_step_dpp(double* a, int* info, int row0, i
   pb_pivot<12>(r, x, p, y, sd, dd, bad); pb_pivot<13>(r, x, p, y, sd, dd, bad); pb_pivot<14>(r, x, p, y, sd, dd, bad);
   PB_SCALE2(r[15], x[15], y);
   if (owner && lane == 0 && bad != 0x7fffffff) atomicMin(info, row0 + o + bad + 1);
-  if (valid) {
+  if (owner && n_pw > 1) { while (__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_target) __builtin_amdgcn_s_sleep(1); }
+  const int base = rr * PS + o;
+  const int klo = is_inv ? c + 1 : (valid ? 0 : 16);
+  const int khi = is_diag ? c : 15;
+  const int kd = is_inv ? c : -1;                 // the column whose value is the inverse's diagonal entry
+  const int dummy = PB * PS + PB + lane, dslot = PB * PS + o + c;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[row * PS + o + k] = x[k];
+  for (int k = 0; k < 16; ++k) {
+    int addr = (k >= klo && k <= khi) ? base + k : dummy;
+    addr = (k == kd) ? dslot : addr;
+    a[addr] = x[k];
   }
 }
 
-// trailing-update tile: C_IJ -= P_I P_J^T, P = columns o..o+15 (one wave, fp64 MFMA 16x16x4)
+// trailing-update tile: C_IJ -= P_I P_J^T, P = columns o..o+15 (one wave, fp64 MFMA 16x16x4).  I, J, o are wave-uniform:
+// every address is a scalar base + the lane's constant fr * PS + fk (operands) / fk * PS + fr (accumulator) + an immediate.
 __device__ __forceinline__ void update_tile(double* a, int I, int J, int o, int fr, int fk) {
   v4d acc;
   double av[4], bv[4];
+  const double* pa = a + (16 * I * PS + o) + (fr * PS + fk);
+  const double* pb = a + (16 * J * PS + o) + (fr * PS + fk);
+  double* pc = a + (16 * I * PS + 16 * J) + (fk * PS + fr);
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
-    bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
-  }
+  for (int s4 = 0; s4 < 4; ++s4) { av[s4] = -pa[4 * s4]; bv[s4] = pb[4 * s4]; }
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = pc[4 * rg * PS];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr] = acc[rg];
+  for (int rg = 0; rg < 4; ++rg) pc[4 * rg * PS] = acc[rg];
 }
 
 // tile t (row-major over the lower triangle I >= J) of the blocks j0..7
@@ -197,86 +232,79 @@ __device__ __forceinline__ void tri_index(int t, int j0, int& I, int& J) {
   I = j0 + Ip; J = j0 + rem;
 }
 
-// The same tile in three pieces, so that a wave with several tiles to do fetches the operands of the next one before the
-// four dependent MFMAs (64 cycles each) of the current one: a tile costs its MFMAs instead of MFMAs + an LDS round trip.
-struct UTile { double av[4], bv[4]; v4d acc; int I, J; };
-__device__ __forceinline__ void ut_load(UTile& t, const double* a, int I, int J, int o, int fr, int fk) {
-  t.I = I; t.J = J;
+// Left-looking tile: C_IJ -= sum over the panels p = 0 .. np-1 (columns 0 .. 16 np - 1) of P_I P_J^T -- what the right-looking
+// form applied panel by panel (one LDS round trip of the accumulator and one 4-MFMA tile per panel) as ONE accumulator chain,
+// the operands of panel p+1 fetched while the MFMAs of panel p run.  Same operands in the same order: the same bits.
+// (The fetch is unconditional -- the last panel is fetched twice -- so that no control-flow merge sits between the loads and
+// the MFMAs: at a merge the compiler's wait is lgkmcnt(0), i.e. no overlap.)
+__device__ __forceinline__ void lookleft_tile(double* a, int I, int J, int np, int fr, int fk) {
+  const double* pa = a + 16 * I * PS + (fr * PS + fk);
+  const double* pb = a + 16 * J * PS + (fr * PS + fk);
+  double* pc = a + (16 * I * PS + 16 * J) + (fk * PS + fr);
+  v4d acc;
+  double av[4], bv[4];
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    t.av[s4] = -a[(16 * I + fr) * PS + o + 4 * s4 + fk];
-    t.bv[s4] = a[(16 * J + fr) * PS + o + 4 * s4 + fk];
+  for (int s4 = 0; s4 < 4; ++s4) { av[s4] = pa[4 * s4]; bv[s4] = pb[4 * s4]; }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) acc[rg] = pc[4 * rg * PS];
+  for (int p = 0; p < np; ++p) {
+    const int q = (p + 1 < np) ? p + 1 : p;
+    double an[4], bn[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { an[s4] = pa[16 * q + 4 * s4]; bn[s4] = pb[16 * q + 4 * s4]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { av[s4] = an[s4]; bv[s4] = bn[s4]; }
   }
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) t.acc[rg] = a[(16 * I + fk + 4 * rg) * PS + 16 * J + fr];
-}
-__device__ __forceinline__ void ut_run_store(UTile& t, double* a, int fr, int fk) {
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) t.acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t.av[s4], t.bv[s4], t.acc, 0, 0, 0);
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) a[(16 * t.I + fk + 4 * rg) * PS + 16 * t.J + fr] = t.acc[rg];
-}
-// tiles first, first + stride, ... < ntile of the trailing update (blocks j0..7, panel columns o..o+15); returns the first
-// item index >= ntile of this wave's round-robin sequence
-__device__ __forceinline__ int update_tiles_pipelined(double* a, int first, int stride, int ntile, int j0, int o, int fr, int fk) {
-  int item = first;
-  if (item >= ntile) return item;
-  UTile ta, tb;
-  int I, J;
-  tri_index(item, j0, I, J);
-  ut_load(ta, a, I, J, o, fr, fk);
-  for (;;) {
-    bool more = item + stride < ntile;
-    if (more) { tri_index(item + stride, j0, I, J); ut_load(tb, a, I, J, o, fr, fk); }
-    __builtin_amdgcn_sched_barrier(0);
-    ut_run_store(ta, a, fr, fk);
-    item += stride;
-    if (!more) break;
-    more = item + stride < ntile;
-    if (more) { tri_index(item + stride, j0, I, J); ut_load(ta, a, I, J, o, fr, fk); }
-    __builtin_amdgcn_sched_barrier(0);
-    ut_run_store(tb, a, fr, fk);
-    item += stride;
-    if (!more) break;
-  }
-  return item;
+  for (int rg = 0; rg < 4; ++rg) pc[4 * rg * PS] = acc[rg];
 }
 
-// ---- finished pieces go to HBM in the shadow of later panels (one wave each; 16-byte stores)
-// rows i0 .. i0+7 of L (upper triangle zero-filled, like tf.cholesky)
-__device__ __forceinline__ void store_L_rows8(const double* a, double* __restrict__ A, i64 lda, int i0, int lane) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = i0 + u, j = 2 * lane;
-    double2 v;
-    v.x = (j <= i) ? a[i * PS + j] : 0.0;
-    v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
-    *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
-  }
-}
-// rows i0 .. i0+7 of inv(L)
-__device__ __forceinline__ void store_inv_rows8(const double* a, const double* dinv, double* __restrict__ Linv, int i0, int lane) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = i0 + u, c = 2 * lane;
-    double2 v;
-    v.x = x_elem(a, dinv, i, c);
-    v.y = x_elem(a, dinv, i, c + 1);
-    *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
-  }
-}
-// columns 16 gp .. 16 gp + 15 of inv(L)^T for rows c0 .. c0+63:  LinvT[c][i] = X[i][c]
-__device__ __forceinline__ void store_invT_strip64(const double* a, const double* dinv, double* __restrict__ LinvT, int gp, int c0, int lane) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int c = c0 + 8 * u + (lane >> 3), i = 16 * gp + 2 * (lane & 7);
-    double2 v;
-    v.x = x_elem(a, dinv, i, c);
-    v.y = x_elem(a, dinv, i + 1, c);
-    *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
-  }
+// next item of a work queue in LDS (one counter per queue and step, zeroed at kernel start): wave-uniform
+__device__ __forceinline__ int q_pull(int* counter, int lane) {
+  int t = 0;
+  if (lane == 0) t = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(t);
 }
 
+// ---- finished pieces go to HBM in the shadow of later panels (one wave per item; branch-free: unconditional LDS reads +
+// selects, 16-byte stores at 32-bit offsets from a wave-uniform base)
+// rows i0 .. i0+NR-1 of L (upper triangle zero-filled, like tf.cholesky)
+template <int NR>
+__device__ __forceinline__ void store_L_rows(const double* a, double* __restrict__ A, i64 lda, int i0, int lane) {
+  const int j = 2 * lane;
+  char* base = reinterpret_cast<char*>(A + (i64)i0 * lda) + 16 * lane;
+  const unsigned step = (unsigned)lda * 8u;
+  double2 v[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) { v[u].x = a[(i0 + u) * PS + j]; v[u].y = a[(i0 + u) * PS + j + 1]; }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int i = i0 + u;
+    v[u].x = (j <= i) ? v[u].x : 0.0;
+    v[u].y = (j + 1 <= i) ? v[u].y : 0.0;
+    *reinterpret_cast<double2*>(base + (size_t)(u * step)) = v[u];
+  }
+}
+// X[r][c] for r > c sits at a[c][r]; the diagonal in dinv; zeros above
+// rows i0 .. i0+NR-1 of inv(L)
+template <int NR>
+__device__ __forceinline__ void store_inv_rows(const double* a, const double* dinv, double* __restrict__ Linv, int i0, int lane) {
+  const int c = 2 * lane;
+  double2 v[NR];
+  double d[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) { v[u].x = a[c * PS + i0 + u]; v[u].y = a[(c + 1) * PS + i0 + u]; d[u] = dinv[i0 + u]; }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int i = i0 + u;
+    v[u].x = (i > c) ? v[u].x : ((i == c) ? d[u] : 0.0);
+    v[u].y = (i > c + 1) ? v[u].y : ((i == c + 1) ? d[u] : 0.0);
+    *reinterpret_cast<double2*>(Linv + i * PB + c) = v[u];
+  }
+}
 // 16x16 triangular inverse of diagonal block gb, one column per lane (lanes 0..15 of one wave).
 // X[i][c] is stored at a[c][i] (i > c); X[c][c] = dinv[c].  The column stays in registers: reading back the X
 // entries this lane has just written would make every step wait for an LDS store -> load round trip.
@@ -340,75 +368,63 @@ __device__ __forceinline__ void inv_row_tile(double* a, const double* dinv, int 
 
 // factor != 0: A holds the SPD block, L is written back.  factor == 0: A already holds L
 // (caller-supplied factor); only the inverse is produced.  LinvT (optional) receives inv(L)^T.
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void potrf_base_kernel(double* __restrict__ A, i64 lda,
-                                                        double* __restrict__ Linv,
-                                                        double* __restrict__ LinvT,
-                                                        int* __restrict__ info, int row0,
-                                                        int factor, long long* __restrict__ stamps) {
+// One 128x128 block, by the calling workgroup (NT threads, `smem_raw`: PB_LDS_BYTES of LDS); every thread returns after the
+// block's last global store has been ISSUED (callers that hand the results to other workgroups fence / drain themselves).
+__device__ __forceinline__ void potrf_base_body(char* smem_raw, double* __restrict__ A, i64 lda, double* __restrict__ Linv,
+                                                double* __restrict__ LinvT, int* __restrict__ info, int row0, int factor,
+                                                long long* __restrict__ stamps) {
 #define STAMP(q) do { if (stamps && threadIdx.x == 0) { stamps[q] = (long long)wall_clock64(); stamps[8 + q] = (long long)clock64(); } } while (0)
   STAMP(0);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);   // [PB][PS]
-  double* dinv = a + PB * PS;                        // [PB], then 3 x 64 slots: panel-wave scratch (phase A) / dummy store targets (phase B)
+  double* dinv = a + PB * PS;                        // [PB], then 3 x 64 dummy store targets
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // (readfirstlane: the compiler cannot prove tid >> 6 wave-uniform and would otherwise run every role branch, item loop and
+  // tile index below as divergent control flow with per-lane copies of the scalars)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
 
+  int* q_mfma = reinterpret_cast<int*>(dinv + PB + 192);           // [9] next item of the MFMA queue of step g; [8]: the queue of the tail
+  int* q_store = q_mfma + 9;                                        // [8] ... of the store queue
+  lds_int* pflag = (lds_int*)(q_store + 8);                         // panel waves (other than the owner) whose copy of the diagonal block is in registers, all steps so far
+  __syncthreads();                                                  // (a caller's previous use of the LDS is over)
+  if (tid < 18) q_mfma[tid] = 0;
   load_image(a, A, lda, tid);
   __syncthreads();
   STAMP(1);
 
+  int tail_row0 = 0;         // first row of inv(L) that the common tail still has to store
+  int flag_sum = 0;          // panel waves other than the owner that have announced their copy of the block, all steps so far
   if (factor) {
     long long t_a = 0, t_b = 0, t0 = 0;
     for (int g = 0; g < 8; ++g) {
       const int o = 16 * g;
       const int nrows = PB - o - 16;                       // rows below the diagonal block
-      const int npanel = nrows > 48 ? 2 : 1;               // wave 0 takes 48 of them, wave 1 the other (up to) 64
+      // panel waves: the owner takes 32 of the rows below, wave 1 up to 64 more, wave 2 the last 16 of step 0
+      const int npanel = nrows > 96 ? 3 : (nrows > 32 ? 2 : 1);
       if (stamps && (tid == 0 || (lane == 0 && stamps[31]))) t0 = (long long)wall_clock64();
       // ---- phase A
-      double r[16], x[16];
       if (wave < npanel) {
-        panel_step_dpp(a, info, row0, o, lane, o + 64 * wave, wave == 0, r, x);
+        flag_sum += npanel - 1;
+        panel_step_dpp(a, info, row0, o, lane, wave, npanel, pflag, flag_sum);
       } else if (g >= 1) {
-        // update waves, one round-robin list of items:
-        //   the rest of the trailing update of step g-1 (tiles (I, J), g+1 <= J <= I <= 7), operands fetched one tile ahead
-        //   block row g-1 of the inverse
-        //   what is final goes back to HBM: rows of block g-1 of L, rows of block g-2 of inv(L) (completed in phase A(g-1)) and
-        //   the matching column strip of inv(L)^T -- spread over the panels instead of one burst behind the last one
-        const int nuw = 8 - npanel;
-        const int nt = 7 - g, ntile = nt * (nt + 1) / 2;
-        int item = update_tiles_pipelined(a, wave - npanel, nuw, ntile, g + 1, o - 16, fr, fk) - ntile;
-        for (; item < g - 1; item += nuw) inv_row_tile(a, dinv, g - 1, item, fr, fk);
-        item -= g - 1;
-        for (; item < 2; item += nuw) store_L_rows8(a, A, lda, 16 * (g - 1) + 8 * item, lane);
-        item -= 2;
-        if (g >= 2) {
-          for (; item < 2; item += nuw) store_inv_rows8(a, dinv, Linv, 16 * (g - 2) + 8 * item, lane);
-          item -= 2;
-          if (LinvT) for (; item < 2; item += nuw) store_invT_strip64(a, dinv, LinvT, g - 2, 64 * item, lane);
+        {
+          const int n_inv = g - 1, n_ll = (g <= 6) ? 7 - g : 0, n_items = n_inv + n_ll;
+          for (int it = q_pull(q_mfma + g, lane); it < n_items; it = q_pull(q_mfma + g, lane)) {
+            // order: inverse tile 0 | left-looking tiles | inverse tiles 1 ..
+            if (n_inv > 0 && it == 0) inv_row_tile(a, dinv, g - 1, 0, fr, fk);
+            else if (it - (n_inv > 0 ? 1 : 0) < n_ll) lookleft_tile(a, g + 1 + it - (n_inv > 0 ? 1 : 0), g + 1, g, fr, fk);
+            else inv_row_tile(a, dinv, g - 1, it - n_ll, fr, fk);
+          }
         }
+        for (int it = q_pull(q_store + g, lane); it < 4; it = q_pull(q_store + g, lane))
+          store_L_rows<4>(a, A, lda, 16 * (g - 1) + 4 * it, lane);
       }
       if (stamps && lane == 0 && stamps[31]) stamps[32 + 8 * g + wave] = (long long)wall_clock64() - t0;   // diagnostics (stamps[31] != 0): per-wave end of phase A
       __syncthreads();
       if (stamps && tid == 0) { const long long t1 = (long long)wall_clock64(); t_a += t1 - t0; t0 = t1; }
-      // ---- phase B: the factored diagonal block and its inverse go back to the image (wave 0), block column g+1
-      // of the trailing update of step g (neither reads the other's data)
-      if (wave == 0) {
-        // row o+c of the image = [ L[c][0..c] (lane 16+c: its copy of the block) | X[c+1..15][c] (lane c: column c of
-        // inv(L_gg), transposed) ]; masked-out elements go to a per-lane dummy slot instead of a divergent branch per element
-        const int c = lane & 15;
-        const bool inv_l = lane < 16, act = lane < 32;
-        double dc = x[0];                      // X[c][c] = 1 / L_cc (the pivot's refined reciprocal square root)
-#pragma unroll
-        for (int k = 1; k < 16; ++k) dc = (k == c) ? x[k] : dc;
-        if (inv_l) dinv[o + c] = dc;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const bool w = act && (inv_l ? (k > c) : (k <= c));
-          a[w ? (o + c) * PS + o + k : PB * PS + PB + lane] = inv_l ? x[k] : r[k];
-        }
-      }
+      // ---- phase B: block column g+1 takes panel g (the only update the next panel waits for), one tile per wave
+      if (wave == 0) { }
       else {
         const int I = g + wave;                                  // waves 1..7: tiles (g+1 .. 7, g+1)
         if (I < 8) update_tile(a, I, g + 1, o, fr, fk);
@@ -418,18 +434,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     if (stamps && tid == 0) { stamps[16] = t_a; stamps[17] = t_b; stamps[18] = 0; }
     STAMP(2);
-    // rows 112..127 of L
-    for (int idx = 112 * 64 + tid; idx < PB * PB / 2; idx += NT) {
-      const int i = idx >> 6, j = (idx & 63) * 2;
-      double2 v;
-      v.x = (j <= i) ? a[i * PS + j] : 0.0;
-      v.y = (j + 1 <= i) ? a[i * PS + j + 1] : 0.0;
-      *reinterpret_cast<double2*>(A + (i64)i * lda + j) = v;
-    }
+    // ---- what is left: block row 7 of the inverse (tile c = 0 is the longest chain: wave 0 takes it, wave 6 the shortest), and
+    // beside it the stores that are possible already -- rows 112..127 of L, and the rows of inv(L) of the block rows that are
+    // final (0..6): pulled in 4-row pieces from a queue by wave 7 at once and by every other wave as soon as its tile is done
     STAMP(3);
-    // ---- what is left of the inverse: block row 7
     STAMP(4);
     if (wave < 7) inv_row_tile(a, dinv, 7, wave, fr, fk);
+    {
+      for (int it = q_pull(q_mfma + 8, lane); it < 4 + 28; it = q_pull(q_mfma + 8, lane)) {
+        if (it < 4) store_L_rows<4>(a, A, lda, 112 + 4 * it, lane);
+        else store_inv_rows<4>(a, dinv, Linv, 4 * (it - 4), lane);
+      }
+    }
+    tail_row0 = 112;
     __syncthreads();
   } else {
     if (tid < PB) dinv[tid] = 1.0 / a[tid * PS + tid];
@@ -445,11 +462,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 
   STAMP(5);
-  // inverse (and its transpose) to HBM, explicit zeros above the diagonal, 16-byte stores.  With factor != 0 the block rows
-  // 0..5 (and the matching column strips of the transpose) left in the panels' shadow: only block rows 6 and 7 remain
+  // inverse (and its transpose) to HBM, explicit zeros above the diagonal, 16-byte stores.  With factor != 0 the rows 0..111
+  // of the inverse left beside the computation of its block row 7: only that block row remains
   {
-    const int b0 = factor ? 6 : 0, i0 = 16 * b0, w2 = (PB - i0) / 2;      // w2: double2 per row of the transposed strip
-    for (int idx = i0 * 64 + tid; idx < PB * PB / 2; idx += NT) {
+    const int i0 = 0, w2 = PB / 2;                     // (the whole transposed inverse: nothing of it left early)
+    for (int idx = tail_row0 * 64 + tid; idx < PB * PB / 2; idx += NT) {
       const int i = idx >> 6, c = (idx & 63) * 2;
       double2 v;
       v.x = x_elem(a, dinv, i, c);
@@ -471,9 +488,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef STAMP
 }
 
+
+#define PB_LDS_BYTES ((PB * PS + PB + 192 + 10) * 8)      // image, dinv, 3 x 64 dummy slots, queue counters + flag (18 ints)
+
+#ifndef GPS_PB_DEVICE_ONLY
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void potrf_base_kernel(double* __restrict__ A, i64 lda,
+                                                        double* __restrict__ Linv,
+                                                        double* __restrict__ LinvT,
+                                                        int* __restrict__ info, int row0,
+                                                        int factor, long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  potrf_base_body(smem_raw, A, lda, Linv, LinvT, info, row0, factor, stamps);
+}
+
 int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
                           double* LinvT_blk, int* d_info, i64 row0, int factor, long long* d_stamps) {
-  const size_t lds = (size_t)(PB * PS + PB + 192) * sizeof(double);   // image, dinv, 3 x 64 scratch / dummy slots
+  const size_t lds = (size_t)PB_LDS_BYTES;
   int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&potrf_base_kernel), (int)lds);
   if (rc0) return rc0;
   // potrf n^3/3 + trtri n^3/3
@@ -483,3 +513,4 @@ int gps_launch_potrf_base(gps_handle_t h, double* A, i64 lda, double* Linv_blk,
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
+#endif   // GPS_PB_DEVICE_ONLY

@@ -1,0 +1,257 @@
+// Exact-GP factorisation of a SMALL covariance (up to 768 padded rows) as ONE launch.
+//
+// The reference's own workload is this size (examples/gpr.py:36,48-61: N ~ 455, 20 000 optimiser steps; each step
+// tf.cholesky + tf.matrix_triangular_solve, models/gpr.py:70, densities.py:82).  Launch by launch (blocked.hpp) such a
+// factorisation is a chain of potrf_base / panel solve / update launches, each at the launch-latency floor: 14 launches at
+// N = 512.  Here the whole of
+//     L = chol(K),  inv of the diagonal blocks,  alpha^T = (Y - m)^T L^-T  (augmented rows),  sum log L_ii,  sum alpha^2
+// runs in one persistent launch of 1 + P workgroups (all resident: one per CU), synchronised by monotone counters in HBM:
+//
+//   workgroup 0, the CHAIN: for every 128-column block j: wait until the updates of the panels before it have reached the
+//     diagonal block, factor + invert it (potrf_base_body: the kernel of potrf_base.hip as a device function), publish F[j].
+//   workgroup 1 + p, a PAIR (row slab s of SH rows, block column k): owns the SH x 128 piece of the matrix at (s, k) for the
+//     whole launch -- applies panel j = 0 .. k-1 to it as soon as the slabs it needs are solved (U: C -= X_s,j X_k,j^T),
+//     then, once F[k] is there, solves it against the block's inverse (S: X <- X W_k^T) and publishes that.  The pieces
+//     of a diagonal block only take the updates (and count them for the chain); the augmented rows (Y - m)^T are one more
+//     block row of slabs that is never factored.  Every product is a [SH x 128] x [128 x 128]^T MFMA product with both
+//     operands straight from L2 into registers.
+//
+// Hand-overs (cdna_hip_programming.md, Guideline 16): producer -- every storing wave drains its stores, workgroup barrier, one
+// lane's agent-scope release fence, relaxed agent-scope add on the counter; consumer -- one lane polls (relaxed, s_sleep,
+// bounded by the wall clock), agent-scope acquire, barrier, plain loads.  A wait that runs out sets the abort word: every
+// workgroup leaves, the host falls back to the launch-by-launch path (and counts it).  The counters are zeroed by the chain
+// at the very end (nobody reads them any more), so an evaluation costs no memset.
+#define GPS_PB_DEVICE_ONLY
+#include "potrf_base.hip"
+
+typedef unsigned int u32;
+
+// sync words (u32), each counter on a 64-byte line of its own
+#define SN_LINE 16
+#define SN_F(j) ((j) * SN_LINE)                              // [8]   block j factored and inverted
+#define SN_D(j) ((8 + (j)) * SN_LINE)                        // [8]   update pieces applied to diagonal block j
+#define SN_XB(i, j) ((16 + (i) * 8 + (j)) * SN_LINE)         // [9][8] slabs of block row i (8 = the augmented rows) solved against panel j
+#define SN_ADONE ((16 + 72) * SN_LINE)                       // solves of the augmented rows
+#define SN_ABORT ((16 + 72 + 1) * SN_LINE)
+#define SN_WORDS ((16 + 72 + 2) * SN_LINE)
+
+struct SmallArgs {
+  double* K; i64 ld;             // [np + aug rows][ld]: K + noise (lower, identity padded), then the augmented rows
+  double* Linv; double* LinvT;   // [nblk][128 * 128] each (LinvT may be null)
+  const double* resid;           // [n][r] on the device
+  int n, r, nblk;
+  int* info;
+  u32* sync;                     // SN_WORDS words, zero on entry
+  double* res;                   // [0] sum log L_ii  [1] sum alpha^2  [2] info  [3] abort
+  double* alpha; i64 ld_alpha; int alpha_rows;   // optional second home of alpha^T: [alpha_rows][ld_alpha]
+};
+
+__device__ __forceinline__ u32 sn_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// every thread's stores are done, then one lane releases and adds
+__device__ __forceinline__ void sn_publish(u32* counter, u32* counter2) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (counter2) __hip_atomic_fetch_add(counter2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// wait until *c1 >= t1 and (c2 ? *c2 >= t2 : true); false: aborted (this wait ran out, or another one did)
+__device__ __forceinline__ bool sn_wait(u32* sync, const u32* c1, u32 t1, const u32* c2, u32 t2, int* s_flag) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      if (sn_load(c1) >= t1 && (!c2 || sn_load(c2) >= t2)) break;
+      if (sn_load(sync + SN_ABORT) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > 200000000ull) {                    // 2 s at 100 MHz: a scheduling surprise is an error, not a hang
+        __hip_atomic_store(sync + SN_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0; break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const int ok = *s_flag;
+  __syncthreads();
+  return ok != 0;
+}
+
+// [SH x 128] x [128 x 128]^T product of one pair, wave w = column tile w (columns 16 w .. 16 w + 15):
+//   UPDATE: C[SH][128 @ ldc] -= A[SH][K = 128 @ lda] * Bm[128][K @ ldb]^T
+//   SOLVE : C <- A * Bm^T in place (A == C), Bm lower triangular: k-steps beyond the tile's last column are skipped
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void sn_product(const double* A, i64 lda, const double* __restrict__ Bm, i64 ldb,
+                                           double* C, i64 ldc, double* C2, i64 ldc2, int c2_rows, int wave, int fr, int fk) {
+  constexpr int RT = SH / 16;
+  const int ks = SOLVE ? 4 * (wave + 1) : 32;                    // k-steps of 4
+  double bv[32], av[RT][32];
+  const double* pb = Bm + (i64)(16 * wave + fr) * ldb + fk;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) bv[s] = (s < ks) ? pb[4 * s] : 0.0;
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const double* pa = A + (i64)(16 * t + fr) * lda + fk;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) av[t][s] = (s < ks) ? pa[4 * s] : 0.0;
+  }
+  v4d acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[t][rg] = SOLVE ? 0.0 : C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr];
+  if (SOLVE) {                                                   // every wave has its copy of the rows that are about to be overwritten
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    if (s < ks) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? av[t][s] : -av[t][s], bv[s], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr] = acc[t][rg];
+      if (C2 && 16 * t + fk + 4 * rg < c2_rows) C2[(i64)(16 * t + fk + 4 * rg) * ldc2 + 16 * wave + fr] = acc[t][rg];   // (alpha^T also where the other entry points expect it)
+    }
+}
+
+template <int SH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
+  // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + PB_LDS_BYTES);
+  double* const s_red = reinterpret_cast<double*>(smem_raw + PB_LDS_BYTES + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
+  const i64 ld = g.ld, np = (i64)nblk * 128;
+  u32* sync = g.sync;
+
+  if (blockIdx.x == 0) {
+    // ---------------------------------------------------------------- the chain
+    if (tid == 0) *g.info = 0x7fffffff;
+    double slog = 0.0;
+    bool ok = true;
+    for (int j = 0; j < nblk && ok; ++j) {
+      if (j > 0) ok = sn_wait(sync, sync + SN_D(j), (u32)(spb * j), nullptr, 0u, s_flag_p);
+      if (!ok) break;
+      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
+                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+      sn_publish(sync + SN_F(j), nullptr);
+      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
+      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
+    }
+    // sum alpha^2 once every slab of the augmented rows has been solved against every block
+    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+    double ssq = 0.0;
+    if (ok) {
+      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
+        const i64 q = idx / np, i = idx - q * np;
+        const double v = g.K[(np + q) * ld + i];
+        ssq = fma(v, v, ssq);
+      }
+    }
+    // fixed-order reductions: lanes by shuffle, waves through LDS
+    for (int which = 0; which < 2; ++which) {
+      double v = which ? ssq : slog;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) s_red[wave] = v;
+      __syncthreads();
+      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      g.res[2] = (double)*g.info;
+      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
+    }
+    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
+    __syncthreads();
+    if (ok) for (int i = tid; i < SN_WORDS; i += NT) sync[i] = 0u;
+    return;
+  }
+
+  // ------------------------------------------------------------------ a pair (row slab, block column)
+  int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
+  for (int i = 1; i <= nblk && bi < 0; ++i) {
+    const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
+    if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
+  }
+  if (bi < 0) return;
+  const bool aug = bi == nblk;
+  const i64 r0 = aug ? np + (i64)sl * SH : (i64)bi * 128 + (i64)sl * SH;
+  double* C = g.K + r0 * ld + (i64)k * 128;
+  if (aug) {
+    // this pair's piece of the augmented rows: (Y - m)^T, zero beyond the r outputs / n points
+    for (int idx = tid; idx < SH * 128; idx += NT) {
+      const int q = idx >> 7, c = idx & 127;
+      const i64 pt = (i64)k * 128 + c, out = (i64)sl * SH + q;
+      C[(i64)q * ld + c] = (out < g.r && pt < g.n) ? g.resid[pt * g.r + out] : 0.0;
+    }
+    __syncthreads();
+  }
+  const u32 my_slabs = (u32)(aug ? aug_slabs : spb);
+  for (int j = 0; j < k; ++j) {
+    if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
+    sn_product<SH, false>(g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0, wave, fr, fk);
+    if (bi == k) sn_publish(sync + SN_D(k), nullptr);
+  }
+  if (bi != k) {
+    if (!sn_wait(sync, sync + SN_F(k), 1u, nullptr, 0u, s_flag_p)) return;
+    double* mirror = (aug && g.alpha) ? g.alpha + (i64)sl * SH * g.ld_alpha + (i64)k * 128 : nullptr;      // (that buffer has r rows only)
+    sn_product<SH, true>(C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH, wave, fr, fk);
+    sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
+  }
+}
+
+// K (lower, + noise, identity padded) is in dK [np + 128][np]; resid [n][r] on the device.  On success dK holds L and the
+// augmented rows alpha^T, linv / linvT the block inverses, res4 (host) = {sum log L_ii, sum alpha^2, info, abort}.
+// GPS_ERR_UNSUPPORTED: not a shape for this path (the caller takes the launch-by-launch one).
+int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
+                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows) {
+  // (up to 768 padded rows: 87 workgroups at most, so that two such launches of one process still fit the GPU side by side)
+  if (np % 128 || np < 128 || np > 768 || r < 1 || r > 32) return GPS_ERR_UNSUPPORTED;
+  if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
+  const int nblk = (int)(np / 128);
+  const int SH = (np <= 512 && r <= 16) ? 16 : 32;
+  const int spb = 128 / SH, aug_slabs = (int)((r + SH - 1) / SH);
+  int pairs = 0;
+  for (int i = 1; i < nblk; ++i) pairs += spb * (i + 1);
+  pairs += aug_slabs * nblk;
+  if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
+  if (!h->dSmallSync.p) {
+    GPS_HIP(h, h->dSmallSync.ensure((size_t)SN_WORDS * 4));
+    GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4, h->stream));
+  }
+  SmallArgs a;
+  a.K = dK; a.ld = np; a.Linv = linv; a.LinvT = linvT; a.resid = d_resid; a.n = (int)n; a.r = (int)r; a.nblk = nblk;
+  a.info = d_info; a.sync = (u32*)h->dSmallSync.p; a.res = d_res4;
+  a.alpha = d_alpha; a.ld_alpha = ld_alpha; a.alpha_rows = (int)alpha_rows;
+  const size_t lds = (size_t)PB_LDS_BYTES + 128;
+  const void* fn = SH == 16 ? reinterpret_cast<const void*>(&small_factor_kernel<16>) : reinterpret_cast<const void*>(&small_factor_kernel<32>);
+  int rc0 = gps_dyn_lds(h, fn, (int)lds);
+  if (rc0) return rc0;
+  LaunchScope ls(h, KC_POTRF_BASE, (double)np * np * np / 3.0, 8.0 * np * np);
+  if (SH == 16) hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
+  else hipLaunchKernelGGL(small_factor_kernel<32>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+// after an aborted launch the counters are in an unknown state
+int gps_small_factor_reset(gps_handle_t h) {
+  if (h->dSmallSync.p) GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4, h->stream));
+  return GPS_OK;
+}

@@ -34,6 +34,31 @@ h = be.Handle(0)
 be.set_handle(h)
 comm = RcclComm(h, rank, world, bootstrap=carry)
 res = {"rank": rank}
+if os.environ.get("GPS_WORKER_MODE") == "fault":
+    # tests/test_gpu_comm_native.py::test_a_failing_send_aborts_the_communicator_and_leaves_the_handle_usable: rank 1's transport
+    # fails inside an open send / receive group (FAKE_RCCL_FAIL_*): every rank must come back with an error, without a
+    # communicator, and with a handle that still evaluates
+    n, d = 1500, 3
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 10, seed=4)
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, variance=1.2, lengthscales=1.3), obs_var=0.1)
+    try:
+        gpr_lml_distributed(m, comm, nb=256, lookahead=2, partitioned=True)
+        res["error"] = None
+    except RuntimeError as e:
+        res["error"] = str(e)
+    try:
+        h.comm_exchange(0, 16, 0, 0, 0)
+        res["after"] = "exchange accepted"
+    except RuntimeError as e:
+        res["after"] = str(e)
+    res["lml_after"] = m.compute_log_likelihood()
+    spec = {"type": "rbf", "variance": orc.constrained(1.2), "lengthscales": orc.constrained(1.3), "input_dim": d}
+    res["lml_ref"] = orc.gpr_lml(spec, X, Y, orc.constrained(0.1))
+    comm.close()
+    h.close()
+    with open(out_file, "w") as f:
+        json.dump(res, f)
+    sys.exit(0)
 n, d = 3000, 3
 X, Y, Xs = orc.synthetic_gpr_data(n, d, 45, seed=13)
 ls = np.linspace(0.9, 1.6, d)

@@ -38,7 +38,8 @@ char* slot_data(Comm* c, int from, int to) { return c->data + ((size_t)from * MA
 template <class F> bool spin(F f) {
   const auto t0 = std::chrono::steady_clock::now();
   while (!f()) {
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return false;
+    static const int limit_s = getenv("FAKE_RCCL_TIMEOUT_S") ? atoi(getenv("FAKE_RCCL_TIMEOUT_S")) : 60;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit_s)) return false;
     std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
   return true;

@@ -47,7 +47,7 @@ def test_bench_two_ranks_block_column_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
-           "--dist-timeout", "200", "--no-dist-autotune"]
+           "--dist-timeout", "200", "--no-dist-autotune", "--cpu-sample-n", "1024"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
@@ -64,7 +64,12 @@ def test_bench_two_ranks_block_column_gloo():
     assert abs(dd["payload_bytes_per_eval_all_ranks"] - payload) <= 1e-6 * payload
     assert "block-cyclic" in out["config"]["parallelism"]
     assert out["independent_evals"]["scaling"] == "weak" and out["independent_evals"]["evals_per_s_all_gpus"] > 0
-    assert out["cpu_baseline"] is None                                                        # timed at N = 1 only
+    # N > 1 lines carry the whole-job roofline (per-GPU fraction) and the CPU stand-in timed on rank 0's host cores
+    rf = out["roofline"]
+    assert rf["peak"] == pytest.approx(2 * 78.6) and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["one_gpu_kernel"]["kernel"] == "gemm_nt_f64_kernel"
+    assert abs(rf["achieved"] - rf["algorithmic_flops_per_step"] / (out["ms_per_step"] * 1e-3) / 1e12) <= 1e-2 * rf["achieved"]
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["predict_f_latency_ms"]["warm_calls"]["calls"] == 5 and out["fallback_counters"]["lookahead_retries"] == 0
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
@@ -73,7 +78,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
            "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512", "--dist-timeout", "200",
-           "--no-dist-autotune", "--independent-steps", "1"]
+           "--no-dist-autotune", "--independent-steps", "1", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -84,6 +89,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     dd = out["distributed"]
     assert dd["rccl_ranks"] == 2 and dd["parity_rel_err_vs_one_gpu"] <= 1e-9
     assert "block-cyclic" in out["config"]["parallelism"]
+    assert out["launch"]["attempt"] == "torch" and out["launch"]["failed_attempts"] == []          # (backend gloo: the one attempt)
     # a --gpus that disagrees with the launcher's rank count is an error, not a silently different run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
                          text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
@@ -98,7 +104,7 @@ def test_bench_two_ranks_autotuned_panel_width():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512",
-           "--dist-timeout", "200", "--independent-steps", "0", "--no-roofline"]
+           "--dist-timeout", "200", "--independent-steps", "0", "--no-roofline", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
@@ -142,11 +148,12 @@ def test_bench_two_ranks_native_communicator_stand_in_transport():
     env["GPFLOWSLIM_RCCL_LIB"] = lib
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "rccl", "--steps", "2", "--warmup", "1", "--backend", "gloo",
            "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "512", "--dist-timeout", "200",
-           "--no-dist-autotune", "--independent-steps", "0", "--no-roofline"]
+           "--no-dist-autotune", "--independent-steps", "0", "--no-roofline", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["launch"]["attempt"] == "rccl" and out["launch"]["tried"] == ["rccl"]
     dd = out["distributed"]
     assert dd["parity_rel_err_vs_one_gpu"] <= 1e-9 and dd["exchange"] == "scatter_allgather"
     assert "own RCCL binding" in out["config"]["parallelism"]
@@ -154,6 +161,57 @@ def test_bench_two_ranks_native_communicator_stand_in_transport():
     rows = lambda j: 4096 + 128 - j * 256
     payload = sum(-(-(rows(j) * 256 + 2 * 2 * 128 * 128 + 4) // 2) * 2 for j in range(n_panels)) * 8
     assert abs(dd["payload_bytes_per_eval_all_ranks"] - 1.5 * payload) <= 1e-6 * payload      # scatter + all-gather: (P + 1) / P of a broadcast's bytes
+
+
+def _fake_rccl_env():
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, src, "-lrt", "-Wl,-Bsymbolic"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPFLOWSLIM_RCCL_LIB"] = lib
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--backend", "gloo", "--force-device", "0", "--npoints", "4096", "--dist-nb", "256",
+         "--num-new-throughput", "512", "--dist-timeout", "200", "--no-dist-autotune", "--independent-steps", "0", "--no-roofline",
+         "--no-cpu-baseline", "--small-n", ""]
+
+
+@pytest.mark.parametrize("mode", ["error", "stall"])
+def test_bench_falls_back_to_fresh_ranks_when_the_native_communicator_fails(mode):
+    """The first attempt of a multi-GPU run is the library's own RCCL binding.  Here its transport (the stand-in) fails on
+    rank 1 in the middle of the schedule -- an ncclSend that returns an error inside an open group, or one that never
+    returns --: the GPU-free supervisor ends that attempt (rank processes killed), starts FRESH rank processes with
+    torch.distributed as the carrier, and rank 0's one JSON line says so."""
+    env = dict(_fake_rccl_env(), FAKE_RCCL_FAIL_RANK="1", FAKE_RCCL_FAIL_AFTER="5", FAKE_RCCL_FAIL_MODE=mode, FAKE_RCCL_TIMEOUT_S="8")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--attempts", "rccl,torch", "--stall", "25"] + SMALL
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    la = out["launch"]
+    assert la["attempt"] == "torch" and la["index"] == 1 and [f["attempt"] for f in la["failed_attempts"]] == ["rccl"], la
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["distributed"]["parity_rel_err_vs_one_gpu"] <= 1e-9
+    assert "attempt 'rccl' failed" in p.stderr
+
+
+def test_bench_fallback_under_a_launcher():
+    """The same with the ranks started by torch.distributed.run (the driver's command form): every rank's bench.py becomes
+    the supervisor of its own rank process, the supervisors agree through the rendezvous directory, the second attempt runs."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(_fake_rccl_env(), FAKE_RCCL_FAIL_RANK="1", FAKE_RCCL_FAIL_AFTER="5", FAKE_RCCL_TIMEOUT_S="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--attempts", "rccl,torch", "--stall", "25"] + SMALL
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["launch"]["attempt"] == "torch" and [f["attempt"] for f in out["launch"]["failed_attempts"]] == ["rccl"]
+    assert out["n_gpus"] == 2 and out["value"] > 0
 
 
 def test_example_gpr_distributed_two_ranks():

@@ -150,3 +150,40 @@ def test_two_ranks_through_a_stand_in_transport(tmp_path):
     sv = gpf.models.SVGP(X, Y, k2, gpf.likelihoods.Gaussian(0.2), Z=Z, q_diag=True)
     wsv = sv.compute_log_likelihood()
     assert all(abs(r["svgp"] - wsv) <= 1e-12 * abs(wsv) for r in res) and res[0]["svgp"] == res[1]["svgp"]
+
+
+def _fake_lib():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp")
+    lib = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, src, "-lrt", "-Wl,-Bsymbolic"])
+    return root, lib
+
+
+def test_a_failing_send_aborts_the_communicator_and_leaves_the_handle_usable(tmp_path):
+    """Rank 1's ncclSend fails in the middle of the schedule, between ncclGroupStart and ncclGroupEnd (stand-in transport with
+    fault injection).  The group is closed all the same, the communicator aborted, gps_dist_lml leaves through its clean-up
+    (the handle gets its own stream back): every rank reports an error instead of hanging, has no communicator afterwards,
+    and its handle evaluates the ordinary single-GPU path correctly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root, lib = _fake_lib()
+    uid = str(tmp_path / "uid.bin")
+    outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPS_WORKER_MODE="fault", FAKE_RCCL_FAIL_RANK="1", FAKE_RCCL_FAIL_AFTER="2",
+               FAKE_RCCL_TIMEOUT_S="5")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_native_comm_worker.py"), str(r), "2", uid, lib, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        assert r["error"] and "communicator aborted" in r["error"], r
+        assert "no communicator" in r["after"], r
+        assert abs(r["lml_after"] - r["lml_ref"]) <= 1e-8 * abs(r["lml_ref"])
+    assert "gps_comm_exchange: nccl" in res[1]["error"]          # (the failing call itself, or the group end that reports it)

@@ -248,6 +248,19 @@ def test_native_rccl_binding_loads_without_a_gpu(gpf):
     assert isinstance(uid, bytes) and len(uid) == 128 and uid != be.comm_unique_id()
 
 
+def test_load_of_a_missing_library_fails_cleanly():
+    """gps_comm_load of a path that does not exist must come back with an error (and fall through to the system's librccl),
+    not crash on a NULL dlerror() string."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r]; from gpflowSlim import _backend as be\n"
+            "be.comm_load('/nonexistent/librccl_nowhere.so'); print('version', be.comm_version())\n" % os.path.join(root, "gpflow-slim_amd"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "version" in p.stdout, (p.stdout, p.stderr[-2000:])
+
+
 def test_bench_launcher_takes_its_ranks_with_it():
     """Whoever stops `python bench.py --gpus N` (a driver's time-out: SIGTERM) stops the rank processes it started too --
     no orphaned GPU processes."""
