@@ -766,6 +766,15 @@ extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int6
   return GPS_OK;
 }
 
+// the transposed block inverses of the resident GPR factor, if the factorisation left them out (the one-launch small path)
+static int gpr_ensure_linvT(gps_handle_t h) {
+  if (!h->gpr_linvT_stale) return GPS_OK;
+  const i64 nb = h->npad / GPS_TILE;
+  int rc = gps_launch_transpose_blocks(h, h->dLinv.d(), h->dLinv.d() + nb * GPS_TILE * GPS_TILE, nb);
+  if (rc == GPS_OK) h->gpr_linvT_stale = false;
+  return rc;
+}
+
 // K + noise I -> L, alpha.  Records ev[0..3].
 static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, double noise_var,
                       const double* resid, i64 r, int* info) {
@@ -820,8 +829,10 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   if (small) {
     double* d_res = h->dScal.d() + 256;
     double* linv = h->dLinv.d();
-    rc = gps_launch_small_factor(h, h->dK.d(), np, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, h->dTmp2.d(), n, r, d_info, d_res,
-                                 h->dAlpha.d(), np, r);
+    // (the transposed block inverses are not on the path of the likelihood: whoever needs them afterwards -- the gradient,
+    // a prediction from this factor -- has them produced by one batched launch then: gpr_ensure_linvT)
+    rc = gps_launch_small_factor(h, h->dK.d(), np, linv, nullptr, h->dTmp2.d(), n, r, d_info, d_res, h->dAlpha.d(), np, r);
+    h->gpr_linvT_stale = true;
     if (rc == GPS_OK) {
       GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
       double res[4] = {0.0, 0.0, 0.0, 1.0};
@@ -854,6 +865,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
       if (rc) return rc;
     }
   }
+  h->gpr_linvT_stale = false;
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
@@ -946,6 +958,8 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   rc = gps_gpr_lml(h, prog, n_nodes, noise_var, resid, r, lml, &linfo);
   if (info) *info = linfo;
   if (rc || linfo) return rc;
+  rc = gpr_ensure_linvT(h);
+  if (rc) return rc;
   const i64 n = h->n, np = h->npad;
   GPS_HIP(h, hipEventRecord(h->ev[5], h->stream));
   double* linv = h->dLinv.d();
@@ -998,10 +1012,14 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
     if (info) *info = linfo;
     if (rc) return rc;
     if (linfo) return GPS_OK;             // not positive definite: outputs undefined
+    rc = gpr_ensure_linvT(h);
+    if (rc) return rc;
   } else {
     if (!h->have_factor) return gps_fail(h, GPS_ERR_STATE, "no resident factor: call gps_gpr_lml first or pass refactor=1");
     if (r != h->r) return gps_fail(h, GPS_ERR_STATE, "resident alpha has a different number of outputs");
     h->refine_now = h->factor_refine;
+    rc = gpr_ensure_linvT(h);
+    if (rc) return rc;
     GPS_HIP(h, hipEventRecord(h->ev[0], h->stream));
     GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
     GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));

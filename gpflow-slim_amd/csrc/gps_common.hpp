@@ -226,6 +226,7 @@ struct gps_handle_s {
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
   bool small_valid = false; double small_slog = 0.0, small_ssq = 0.0;   // reductions the last small launch produced
   bool ev3_is_ev2 = false;
+  bool gpr_linvT_stale = false;    // the resident GPR factor's transposed block inverses have not been produced yet (gpr_ensure_linvT)
   DevBuf dGemmWs, dGemmCnt;   // slice partials + arrival counters of the GEMM tail split
   DevBuf dGemvWs, dGemvCnt;   // slice partials + arrival counters of the split transposed gemv (blas1.hip)
 };

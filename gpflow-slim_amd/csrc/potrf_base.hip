@@ -44,6 +44,22 @@
 //  * rows of inv(L) stored in the panels' shadow as well: +2 us (the waves that would have the issue slots for it do not
 //    have the time); they leave beside block row 7 of the inverse instead.
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d_ __attribute__((ext_vector_type(2)));
+
+// 16-byte global store of a result another WORKGROUP may read inside the same launch (small_n.hip): write-through (sc1), so
+// that the consumer needs no release fence on this side -- only the drained stores and a flag (cdna_hip_programming.md,
+// Guideline 16 R1).  GPS_PB_WT 0 (the stand-alone kernel): a plain store.
+#ifndef GPS_PB_WT
+#define GPS_PB_WT 0
+#endif
+__device__ __forceinline__ void pb_store16(double* p, double2 v) {
+#if GPS_PB_WT
+  v2d_ w; w.x = v.x; w.y = v.y;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+#else
+  *reinterpret_cast<double2*>(p) = v;
+#endif
+}
 typedef __attribute__((address_space(3))) int lds_int;
 
 // whole 128x128 block -> LDS image; 16-byte loads, all 16 of a thread in flight at once (one memory round trip:
@@ -285,7 +301,7 @@ __device__ __forceinline__ void store_L_rows(const double* a, double* __restrict
     const int i = i0 + u;
     v[u].x = (j <= i) ? v[u].x : 0.0;
     v[u].y = (j + 1 <= i) ? v[u].y : 0.0;
-    *reinterpret_cast<double2*>(base + (size_t)(u * step)) = v[u];
+    pb_store16(reinterpret_cast<double*>(base + (size_t)(u * step)), v[u]);
   }
 }
 // X[r][c] for r > c sits at a[c][r]; the diagonal in dinv; zeros above
@@ -302,7 +318,7 @@ __device__ __forceinline__ void store_inv_rows(const double* a, const double* di
     const int i = i0 + u;
     v[u].x = (i > c) ? v[u].x : ((i == c) ? d[u] : 0.0);
     v[u].y = (i > c + 1) ? v[u].y : ((i == c + 1) ? d[u] : 0.0);
-    *reinterpret_cast<double2*>(Linv + i * PB + c) = v[u];
+    pb_store16(Linv + i * PB + c, v[u]);
   }
 }
 // 16x16 triangular inverse of diagonal block gb, one column per lane (lanes 0..15 of one wave).
@@ -471,7 +487,7 @@ __device__ __forceinline__ void potrf_base_body(char* smem_raw, double* __restri
       double2 v;
       v.x = x_elem(a, dinv, i, c);
       v.y = x_elem(a, dinv, i, c + 1);
-      *reinterpret_cast<double2*>(Linv + i * PB + c) = v;
+      pb_store16(Linv + i * PB + c, v);
     }
     if (LinvT) {
       for (int idx = tid; idx < PB * w2; idx += NT) {
@@ -479,7 +495,7 @@ __device__ __forceinline__ void potrf_base_body(char* smem_raw, double* __restri
         double2 v;
         v.x = x_elem(a, dinv, i, c);
         v.y = x_elem(a, dinv, i + 1, c);
-        *reinterpret_cast<double2*>(LinvT + c * PB + i) = v;
+        pb_store16(LinvT + c * PB + i, v);
       }
     }
   }

@@ -22,6 +22,7 @@
 // workgroup leaves, the host falls back to the launch-by-launch path (and counts it).  The counters are zeroed by the chain
 // at the very end (nobody reads them any more), so an evaluation costs no memset.
 #define GPS_PB_DEVICE_ONLY
+#define GPS_PB_WT 1            // the chain's results leave with write-through stores
 #include "potrf_base.hip"
 
 typedef unsigned int u32;
@@ -44,20 +45,24 @@ struct SmallArgs {
   u32* sync;                     // SN_WORDS words, zero on entry
   double* res;                   // [0] sum log L_ii  [1] sum alpha^2  [2] info  [3] abort
   double* alpha; i64 ld_alpha; int alpha_rows;   // optional second home of alpha^T: [alpha_rows][ld_alpha]
+  long long* stamps;             // diagnostics (GPS_SMALL_STAMPS): 100 MHz wall-clock stamps of the chain [0..63] and of the pairs of the first slab of each block row
 };
 
 __device__ __forceinline__ u32 sn_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// every thread's stores are done, then one lane releases and adds
+// The handed-off data was stored write-through (sc1) by whoever stored it: every storing wave drains its stores, the workgroup
+// meets, one lane adds to the counter -- no release fence (Guideline 16, R1).
 __device__ __forceinline__ void sn_publish(u32* counter, u32* counter2) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (counter2) __hip_atomic_fetch_add(counter2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+__device__ __forceinline__ void sn_store(double* p, double v) {          // 8-byte write-through store
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // wait until *c1 >= t1 and (c2 ? *c2 >= t2 : true); false: aborted (this wait ran out, or another one did)
@@ -123,7 +128,7 @@ __device__ __forceinline__ void sn_product(const double* A, i64 lda, const doubl
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr] = acc[t][rg];
+      sn_store(&C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr], acc[t][rg]);
       if (C2 && 16 * t + fk + 4 * rg < c2_rows) C2[(i64)(16 * t + fk + 4 * rg) * ldc2 + 16 * wave + fr] = acc[t][rg];   // (alpha^T also where the other entry points expect it)
     }
 }
@@ -145,17 +150,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (tid == 0) *g.info = 0x7fffffff;
     double slog = 0.0;
     bool ok = true;
+#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
+    SN_STAMP(0);
     for (int j = 0; j < nblk && ok; ++j) {
       if (j > 0) ok = sn_wait(sync, sync + SN_D(j), (u32)(spb * j), nullptr, 0u, s_flag_p);
       if (!ok) break;
+      SN_STAMP(1 + 3 * j);
       potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
                       g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+      SN_STAMP(2 + 3 * j);
       sn_publish(sync + SN_F(j), nullptr);
+      SN_STAMP(3 + 3 * j);
       // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
       if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
     }
     // sum alpha^2 once every slab of the augmented rows has been solved against every block
     if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+    SN_STAMP(30);
     double ssq = 0.0;
     if (ok) {
       for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
@@ -180,6 +191,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
     __syncthreads();
     if (ok) for (int i = tid; i < SN_WORDS; i += NT) sync[i] = 0u;
+    SN_STAMP(31);
     return;
   }
 
@@ -203,16 +215,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
   }
   const u32 my_slabs = (u32)(aug ? aug_slabs : spb);
+  long long* ps = (g.stamps && sl == 0) ? g.stamps + 64 + ((aug ? 8 : bi) * 8 + k) * 24 : nullptr;
+#define SN_PSTAMP(q) do { if (ps && tid == 0) ps[q] = (long long)wall_clock64(); } while (0)
+  SN_PSTAMP(0);
   for (int j = 0; j < k; ++j) {
     if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
+    SN_PSTAMP(1 + 2 * j);
     sn_product<SH, false>(g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0, wave, fr, fk);
     if (bi == k) sn_publish(sync + SN_D(k), nullptr);
+    SN_PSTAMP(2 + 2 * j);
   }
   if (bi != k) {
     if (!sn_wait(sync, sync + SN_F(k), 1u, nullptr, 0u, s_flag_p)) return;
     double* mirror = (aug && g.alpha) ? g.alpha + (i64)sl * SH * g.ld_alpha + (i64)k * 128 : nullptr;      // (that buffer has r rows only)
     sn_product<SH, true>(C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH, wave, fr, fk);
+    SN_PSTAMP(21);
     sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
+    SN_PSTAMP(22);
   }
 }
 
@@ -239,6 +258,14 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   a.K = dK; a.ld = np; a.Linv = linv; a.LinvT = linvT; a.resid = d_resid; a.n = (int)n; a.r = (int)r; a.nblk = nblk;
   a.info = d_info; a.sync = (u32*)h->dSmallSync.p; a.res = d_res4;
   a.alpha = d_alpha; a.ld_alpha = ld_alpha; a.alpha_rows = (int)alpha_rows;
+  a.stamps = nullptr;
+  static const bool want_stamps = getenv("GPS_SMALL_STAMPS") != nullptr;
+  const size_t stamp_words = 64 + 9 * 8 * 24;
+  if (want_stamps) {
+    GPS_HIP(h, h->dTmp3.ensure(stamp_words * 8));
+    GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, stamp_words * 8, h->stream));
+    a.stamps = (long long*)h->dTmp3.p;
+  }
   const size_t lds = (size_t)PB_LDS_BYTES + 128;
   const void* fn = SH == 16 ? reinterpret_cast<const void*>(&small_factor_kernel<16>) : reinterpret_cast<const void*>(&small_factor_kernel<32>);
   int rc0 = gps_dyn_lds(h, fn, (int)lds);
@@ -247,6 +274,23 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   if (SH == 16) hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
   else hipLaunchKernelGGL(small_factor_kernel<32>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
+  if (want_stamps) {
+    std::vector<long long> st(stamp_words);
+    GPS_HIP(h, hipMemcpyAsync(st.data(), h->dTmp3.p, stamp_words * 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    const long long t0 = st[0];
+    fprintf(stderr, "small_n chain (us since start):");
+    for (int j = 0; j < nblk; ++j) fprintf(stderr, "  blk%d: D ready %.1f factored %.1f published %.1f |", j, (st[1 + 3 * j] - t0) * 0.01, (st[2 + 3 * j] - t0) * 0.01, (st[3 + 3 * j] - t0) * 0.01);
+    fprintf(stderr, "  alpha done %.1f end %.1f\n", (st[30] - t0) * 0.01, (st[31] - t0) * 0.01);
+    for (int bi = 1; bi <= 8; ++bi) for (int k = 0; k < 8; ++k) {
+      const long long* ps = st.data() + 64 + (bi * 8 + k) * 24;
+      if (!ps[0]) continue;
+      fprintf(stderr, "  pair (row %d%s, col %d) start %.1f:", bi, bi == 8 ? " = aug" : "", k, (ps[0] - t0) * 0.01);
+      for (int j = 0; j < k; ++j) fprintf(stderr, " U%d wait-end %.1f done %.1f;", j, (ps[1 + 2 * j] - t0) * 0.01, (ps[2 + 2 * j] - t0) * 0.01);
+      if (ps[20]) fprintf(stderr, " S wait-end %.1f computed %.1f published %.1f", (ps[20] - t0) * 0.01, (ps[21] - t0) * 0.01, (ps[22] - t0) * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
   return GPS_OK;
 }
 

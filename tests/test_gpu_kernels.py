@@ -365,3 +365,56 @@ def test_kernel_matrix_chain_kernel_equals_interpreter(handle, n, m):
             handle.set_option("kmat_fast", 1)
         assert out[1].shape == out[0].shape
         assert np.abs(out[1] - out[0]).max() <= 4e-15 * np.abs(out[0]).max()
+
+
+@pytest.mark.parametrize("n,r", [(1, 1), (2, 1), (50, 1), (128, 2), (129, 1), (300, 3), (455, 1), (512, 1), (640, 2), (768, 1)])
+def test_one_launch_factorisation_of_small_problems(handle, n, r):
+    """Problems of up to 768 padded rows (the reference's own example is N ~ 455, examples/gpr.py:36) are factored by ONE
+    cooperative launch (csrc/small_n.hip): chain workgroup + slab workgroups, hand-overs through counters.  Same likelihood,
+    predictions and gradient as the launch-by-launch path and as the oracle; three launches per evaluation; no fall-back."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    d = 3
+    X, Y, Xs = orc.synthetic_gpr_data(n, d, 17, seed=100 + n)
+    if r > 1:
+        Y = np.concatenate([Y * (q + 1) + 0.1 * q for q in range(r)], axis=1)
+    ls = np.linspace(0.8, 1.5, d)
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, variance=1.3, lengthscales=ls, ARD=True), obs_var=0.1)
+    spec = {"type": "rbf", "variance": orc.constrained(1.3), "lengthscales": orc.constrained(ls), "input_dim": d}
+    ref = orc.gpr_lml(spec, X, Y, orc.constrained(0.1))
+    before = handle.profile_get("small_n_fallbacks")["launches"]
+    res = {}
+    for small in (1, 0):
+        handle.set_option("small_n", small)
+        handle.profile_reset()
+        lml = m.compute_log_likelihood()
+        launches = sum(handle.profile_get(k)["launches"] for k in ("gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"))
+        mu, var = m.predict_f(Xs)                            # cold: factors again, then needs the transposed inverses
+        lg, grads = m.compute_log_likelihood_and_gradients()
+        res[small] = (lml, mu, var, lg, np.concatenate([np.ravel(g) for _, g in grads]), launches)
+    handle.set_option("small_n", 1)
+    one, many = res[1], res[0]
+    assert abs(one[0] - ref) <= 1e-8 * abs(ref) and abs(one[0] - many[0]) <= 1e-11 * abs(ref)
+    assert one[5] <= 3 and (many[5] > one[5] or n <= 128), (one[5], many[5])          # kmat prep + kmat + the factorisation
+    rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
+    assert np.abs(one[1] - rmu).max() <= 1e-8 * max(1.0, np.abs(rmu).max()) and np.abs(one[2] - rvar).max() <= 1e-8 * np.abs(rvar).max()
+    assert np.abs(one[1] - many[1]).max() <= 1e-10 * max(1.0, np.abs(rmu).max())
+    assert abs(one[3] - many[3]) <= 1e-11 * abs(ref) and np.abs(one[4] - many[4]).max() <= 1e-9 * max(1.0, np.abs(many[4]).max())
+    assert handle.profile_get("small_n_fallbacks")["launches"] == before
+
+
+def test_one_launch_factorisation_reports_not_positive_definite(handle):
+    import gpflowSlim as gpf
+    X = np.zeros((300, 2)); X[:, 0] = np.arange(300) % 7; Y = np.ones((300, 1))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2), obs_var=1e-30, min_var=0.0)
+    m.likelihood._variance.transform._lower = -1.0     # a negative "variance" on the diagonal: duplicate points -> singular
+    handle.set_option("small_n", 1)
+    with pytest.raises(gpf.NotPositiveDefiniteError):
+        m.compute_log_likelihood()
+    # ... and the handle evaluates a proper problem right afterwards (counters back in order)
+    import oracle.gp_oracle as orc
+    Xg, Yg, _ = orc.synthetic_gpr_data(400, 2, 0, seed=5)
+    mg = gpf.models.GPR(Xg, Yg, gpf.kernels.RBF(2, lengthscales=1.2), obs_var=0.1)
+    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(1.2), "input_dim": 2}
+    ref = orc.gpr_lml(spec, Xg, Yg, orc.constrained(0.1))
+    assert abs(mg.compute_log_likelihood() - ref) <= 1e-8 * abs(ref)
