@@ -231,18 +231,18 @@ struct HipOps {
   }
 };
 
-// L a = y / L^T a = y for r right-hand sides (rows of y): one wavefront launch (trsv_wave.hip) unless the leaves are
-// to be refined against the diagonal blocks (jittered factors), where the recursive substitution with its refined
-// leaves stays.
+// L a = y / L^T a = y for r right-hand sides (rows of y): one wavefront launch (trsv_wave.hip) -- with one refinement step
+// per diagonal block inside the wavefront where the leaves are to be refined (jittered / low-noise factors; round 4: the
+// recursive substitution with refined leaves, 4 N / 128 launches, stays as the option "trsv_wave_refine" = 0).
 static int trsv_forward(gps_handle_t h, HipOps& ops, const double* L, i64 ldl, i64 n, double* y, i64 ldy, i64 r) {
-  if (h->trsv_wave && !h->refine_now && ops.linvT && n >= 2 * GPS_TILE)
-    return gps_launch_trsv_wave(h, L, ldl, n, ops.linvT, y, ldy, r, 0);
+  if (h->trsv_wave && (!h->refine_now || h->trsv_wave_refine) && ops.linvT && n >= 2 * GPS_TILE)
+    return gps_launch_trsv_wave(h, L, ldl, n, ops.linvT, y, ldy, r, 0, h->refine_now ? 1 : 0);
   Blocked<HipOps> bl(ops);
   return bl.trsv_rec(L, ldl, n, 0, y, ldy, r);
 }
 static int trsv_backward(gps_handle_t h, HipOps& ops, const double* L, i64 ldl, i64 n, double* y, i64 ldy, i64 r) {
-  if (h->trsv_wave && !h->refine_now && n >= 2 * GPS_TILE)
-    return gps_launch_trsv_wave(h, L, ldl, n, ops.linv, y, ldy, r, 1);
+  if (h->trsv_wave && (!h->refine_now || h->trsv_wave_refine) && n >= 2 * GPS_TILE)
+    return gps_launch_trsv_wave(h, L, ldl, n, ops.linv, y, ldy, r, 1, h->refine_now ? 1 : 0);
   Blocked<HipOps> bl(ops);
   return bl.trsv_t_rec(L, ldl, n, 0, y, ldy, r);
 }
@@ -491,6 +491,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
+  if (strcmp(key, "trsv_wave_refine") == 0) { h->trsv_wave_refine = (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
 

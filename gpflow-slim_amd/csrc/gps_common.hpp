@@ -115,6 +115,7 @@ struct gps_handle_s {
   int leaf_persistent = 1;       // refined solve leaves: resident workgroups walk the row tiles (trsm_leaf.hip)
   int trsv_follow = 0;
   int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp
+  int trsv_wave_refine = 1;      // ... also where the leaves are refined (one refinement step per block inside the wavefront); 0: the recursion with refined leaves
   unsigned long long wave_fallbacks = 0;
   hipStream_t y_stream = nullptr;
   std::vector<hipEvent_t> y_events; size_t y_event_next = 0;
@@ -332,7 +333,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
 int gps_small_factor_reset(gps_handle_t h);
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
-                         int trans);
+                         int trans, int refine = 0);
 // blas1.hip
 int gps_launch_trsv_base(gps_handle_t h, const double* Linv_blk, double* y, i64 ldy, i64 r);
 // look-ahead hand-over kernels (blas1.hip): optional publish of *sig = sval, then wait (bounded) until *flag >= val

@@ -94,7 +94,8 @@ __device__ __forceinline__ bool sn_wait(u32* sync, const u32* c1, u32 t1, const 
 //   SOLVE : C <- A * Bm^T in place (A == C), Bm lower triangular: k-steps beyond the tile's last column are skipped
 template <int SH, bool SOLVE>
 __device__ __forceinline__ void sn_product(const double* A, i64 lda, const double* __restrict__ Bm, i64 ldb,
-                                           double* C, i64 ldc, double* C2, i64 ldc2, int c2_rows, int wave, int fr, int fk) {
+                                           double* C, i64 ldc, double* C2, i64 ldc2, int c2_rows, int wave, int fr, int fk,
+                                           long long* st = nullptr) {
   constexpr int RT = SH / 16;
   const int ks = SOLVE ? 4 * (wave + 1) : 32;                    // k-steps of 4
   double bv[32], av[RT][32];
@@ -115,7 +116,8 @@ __device__ __forceinline__ void sn_product(const double* A, i64 lda, const doubl
   if (SOLVE) {                                                   // every wave has its copy of the rows that are about to be overwritten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
+  } else if (st) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (st && threadIdx.x == 0) st[0] = (long long)wall_clock64();
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
     if (s < ks) {
@@ -124,6 +126,7 @@ __device__ __forceinline__ void sn_product(const double* A, i64 lda, const doubl
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? av[t][s] : -av[t][s], bv[s], acc[t], 0, 0, 0);
     }
   }
+  if (st && threadIdx.x == 0) st[1] = (long long)wall_clock64();
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -221,14 +224,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int j = 0; j < k; ++j) {
     if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
     SN_PSTAMP(1 + 2 * j);
-    sn_product<SH, false>(g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0, wave, fr, fk);
+    sn_product<SH, false>(g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0, wave, fr, fk, (ps && j == 0) ? ps + 12 : nullptr);
+    if (ps && j == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) ps[14] = (long long)wall_clock64(); }
     if (bi == k) sn_publish(sync + SN_D(k), nullptr);
     SN_PSTAMP(2 + 2 * j);
   }
   if (bi != k) {
     if (!sn_wait(sync, sync + SN_F(k), 1u, nullptr, 0u, s_flag_p)) return;
     double* mirror = (aug && g.alpha) ? g.alpha + (i64)sl * SH * g.ld_alpha + (i64)k * 128 : nullptr;      // (that buffer has r rows only)
-    sn_product<SH, true>(C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH, wave, fr, fk);
+    sn_product<SH, true>(C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH, wave, fr, fk, ps ? ps + 16 : nullptr);
     SN_PSTAMP(21);
     sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
     SN_PSTAMP(22);
@@ -287,7 +291,8 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
       if (!ps[0]) continue;
       fprintf(stderr, "  pair (row %d%s, col %d) start %.1f:", bi, bi == 8 ? " = aug" : "", k, (ps[0] - t0) * 0.01);
       for (int j = 0; j < k; ++j) fprintf(stderr, " U%d wait-end %.1f done %.1f;", j, (ps[1 + 2 * j] - t0) * 0.01, (ps[2 + 2 * j] - t0) * 0.01);
-      if (ps[20]) fprintf(stderr, " S wait-end %.1f computed %.1f published %.1f", (ps[20] - t0) * 0.01, (ps[21] - t0) * 0.01, (ps[22] - t0) * 0.01);
+      if (k > 0) fprintf(stderr, " [U0: operands in %.1f, mfma done %.1f, stores drained %.1f]", (ps[12] - t0) * 0.01, (ps[13] - t0) * 0.01, (ps[14] - t0) * 0.01);
+      if (ps[20]) fprintf(stderr, " S wait-end %.1f [operands in %.1f, mfma done %.1f] stored %.1f published %.1f", (ps[20] - t0) * 0.01, (ps[16] - t0) * 0.01, (ps[17] - t0) * 0.01, (ps[21] - t0) * 0.01, (ps[22] - t0) * 0.01);
       fprintf(stderr, "\n");
     }
   }

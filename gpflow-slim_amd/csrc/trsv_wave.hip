@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void tw_init_kernel(u64* __restrict__ xch, i64
   if (i == 0) ctl[0] = 0u;
 }
 
-template <int RC, bool TRANS>
+// REFINE: the diagonal solve a_i = W t is followed by one step of iterative refinement against the diagonal block of the factor
+// itself,  a_i += W (t - L_ii a_i)  (L_ii^T for the transposed solve) -- what trsv_leaf_refine_kernel does for the leaves of the
+// recursive substitution (trsm_leaf.hip), here inside the wavefront: jittered / low-noise factors no longer fall back
+// to the 4 N / 128 launches of the recursion.  The 32 entries of L_ii a thread needs sit in registers from the start.
+template <int RC, bool TRANS, bool REFINE>
 __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict__ L, i64 ldl, int nblk,
                                                         const double* __restrict__ Wall, double* __restrict__ y,
                                                         i64 ldy, int r0, u64* __restrict__ xch,
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
   double* ys = Ws + 128 * 128;                // [2][RC][128] the solution block being consumed (double-buffered)
   double* tv = ys + 2 * RC * 128;             // [RC][128]    right-hand side of the diagonal solve
   double* red = tv + RC * 128;                // [8][RC][128] cross-wave partial sums (backward) / [4][RC][128] W product
+  double* a0s = red + 8 * RC * 128;           // [RC][128]    (REFINE) first solution / residual
   __shared__ int s_blk, s_bad;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) { s_blk = (int)atomicAdd(ctl, 1u); s_bad = 0; }
@@ -60,6 +65,13 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
     const double* Wp = Wall + (i64)i * 128 * 128 + (i64)(32 * part) * 128 + oc;
 #pragma unroll
     for (int k = 0; k < 32; ++k) wr[k] = Wp[k * 128];
+  }
+  // (REFINE) this thread's 32 entries of the diagonal block: row oc of L_ii (forward) / column oc (backward), k = 32 part ..
+  double lr[REFINE ? 32 : 1];
+  if (REFINE) {
+    const double* Dp = L + (i64)i * 128 * ldl + (i64)i * 128;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lr[k] = TRANS ? Dp[(i64)(32 * part + k) * ldl + oc] : Dp[(i64)oc * ldl + 32 * part + k];
   }
   // first block of the panel:  forward j = 0..i-1 (block column j of block row i);  backward j = nblk-1..i+1 (block row j
   // of block column i).  Step s of the loop is block jj(s).
@@ -200,9 +212,44 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
 #pragma unroll
   for (int q = 0; q < RC; ++q) red[(part * RC + q) * 128 + oc] = ps[q];
   __syncthreads();
+  double a = 0.0;
+  const int o = tid & 127;
+  if (poller) a = (red[(0 * RC + pq) * 128 + o] + red[(1 * RC + pq) * 128 + o]) + (red[(2 * RC + pq) * 128 + o] + red[(3 * RC + pq) * 128 + o]);
+  if (REFINE) {
+    // residual  rr = t - L_ii a  (fixed order of additions), then  a += W rr
+    if (poller) a0s[pq * 128 + o] = a;
+    __syncthreads();
+    double pr[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) pr[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+#pragma unroll
+      for (int q = 0; q < RC; ++q) pr[q] = fma(lr[k], a0s[q * 128 + 32 * part + k], pr[q]);
+    }
+    __syncthreads();                                                   // (everybody has read the first product's partial sums)
+#pragma unroll
+    for (int q = 0; q < RC; ++q) red[(part * RC + q) * 128 + oc] = pr[q];
+    __syncthreads();
+    if (poller) {
+      const double la = (red[(0 * RC + pq) * 128 + o] + red[(1 * RC + pq) * 128 + o]) + (red[(2 * RC + pq) * 128 + o] + red[(3 * RC + pq) * 128 + o]);
+      a0s[pq * 128 + o] = tv[pq * 128 + o] - la;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RC; ++q) ps[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const double wv = Ws[(32 * part + k) * 128 + oc];
+#pragma unroll
+      for (int q = 0; q < RC; ++q) ps[q] = fma(wv, a0s[q * 128 + 32 * part + k], ps[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < RC; ++q) red[(part * RC + q) * 128 + oc] = ps[q];
+    __syncthreads();
+    if (poller) a += (red[(0 * RC + pq) * 128 + o] + red[(1 * RC + pq) * 128 + o]) + (red[(2 * RC + pq) * 128 + o] + red[(3 * RC + pq) * 128 + o]);
+  }
   if (poller) {
-    const int o = tid & 127;
-    double a = (red[(0 * RC + pq) * 128 + o] + red[(1 * RC + pq) * 128 + o]) + (red[(2 * RC + pq) * 128 + o] + red[(3 * RC + pq) * 128 + o]);
     u64 bits = (u64)__double_as_longlong(a);
     if (bits == TW_EMPTY || bits == TW_POISON) bits = 0x7ff8000000000000ull;      // cannot come out of arithmetic; be safe
     if (s_bad) { bits = TW_POISON; a = __longlong_as_double((long long)0x7ff8000000000000ull); }
@@ -212,17 +259,17 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
   if (tid == 0 && s_bad) atomicAdd(ctl + 1, 1u);
 }
 
-template <int RC, bool TRANS>
+template <int RC, bool TRANS, bool REFINE>
 static int tw_launch(gps_handle_t h, const double* L, i64 ldl, int nblk, const double* W, double* y, i64 ldy, int r0,
                      u64* xch, unsigned* ctl) {
-  const size_t lds = (size_t)(128 * 128 + 2 * RC * 128 + RC * 128 + 8 * RC * 128) * 8;
-  int rca = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsv_wave_kernel<RC, TRANS>), (int)lds);      // (per handle = per device)
+  const size_t lds = (size_t)(128 * 128 + 2 * RC * 128 + RC * 128 + 8 * RC * 128 + RC * 128) * 8;
+  int rca = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsv_wave_kernel<RC, TRANS, REFINE>), (int)lds);      // (per handle = per device)
   if (rca) return rca;
   const i64 n = (i64)nblk * 128;
   hipLaunchKernelGGL(tw_init_kernel, dim3((unsigned)((n * RC + 255) / 256)), dim3(256), 0, h->stream, xch, n * RC, ctl);
   GPS_HIP(h, hipGetLastError());
   LaunchScope ls(h, KC_TRSV, 2.0 * n * n / 2 * RC, (double)n * n / 2 * 8.0);
-  hipLaunchKernelGGL((trsv_wave_kernel<RC, TRANS>), dim3((unsigned)nblk), dim3(512), lds, h->stream, L, ldl, nblk, W, y,
+  hipLaunchKernelGGL((trsv_wave_kernel<RC, TRANS, REFINE>), dim3((unsigned)nblk), dim3(512), lds, h->stream, L, ldl, nblk, W, y,
                      ldy, r0, xch, ctl);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
@@ -230,8 +277,15 @@ static int tw_launch(gps_handle_t h, const double* L, i64 ldl, int nblk, const d
 
 // L a = y (trans 0, W = transposed block inverses) or L^T a = y (trans 1, W = block inverses) in place, r right-hand
 // sides as rows y[q * ldy + .]; n = 128 nblk.  Two right-hand sides share one pass over L.
+template <bool REFINE>
+static int tw_pick(gps_handle_t h, const double* L, i64 ldl, int nblk, const double* W, double* y, i64 ldy, int r0, u64* xch,
+                   unsigned* ctl, bool two, int trans) {
+  if (two) return trans ? tw_launch<2, true, REFINE>(h, L, ldl, nblk, W, y, ldy, r0, xch, ctl) : tw_launch<2, false, REFINE>(h, L, ldl, nblk, W, y, ldy, r0, xch, ctl);
+  return trans ? tw_launch<1, true, REFINE>(h, L, ldl, nblk, W, y, ldy, r0, xch, ctl) : tw_launch<1, false, REFINE>(h, L, ldl, nblk, W, y, ldy, r0, xch, ctl);
+}
+
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
-                         int trans) {
+                         int trans, int refine) {
   if (n <= 0 || r <= 0) return GPS_OK;
   if (n % 128) return gps_fail(h, GPS_ERR_ARG, "trsv wavefront: n must be a multiple of 128");
   const int nblk = (int)(n / 128);
@@ -243,11 +297,8 @@ int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const 
   unsigned* ctl = (unsigned*)h->dWaveCtl.p;
   u64* xch = (u64*)h->dWave.p;
   for (i64 r0 = 0; r0 < r; r0 += 2) {
-    int rc;
-    if (r - r0 >= 2) rc = trans ? tw_launch<2, true>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl)
-                                : tw_launch<2, false>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl);
-    else             rc = trans ? tw_launch<1, true>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl)
-                                : tw_launch<1, false>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl);
+    const int rc = refine ? tw_pick<true>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl, r - r0 >= 2, trans)
+                          : tw_pick<false>(h, L, ldl, nblk, W, y, ldy, (int)r0, xch, ctl, r - r0 >= 2, trans);
     if (rc) return rc;
   }
   // diagnostics ("wave_fault_inject" = k): the k-th substitution from now leaves the give-up counter set, as a workgroup

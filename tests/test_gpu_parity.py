@@ -240,6 +240,48 @@ def test_gpr_not_positive_definite_raises(handle):
         m.compute_log_likelihood()
 
 
+@pytest.mark.parametrize("ratio", [1e-5, 1e-4])
+def test_gpr_low_noise_sweep_large(handle, ratio):
+    """The low-noise end of the sweep above at N = 16384 (the regime a fit ends in, at a size where the substitution is a
+    wavefront over 128 blocks): refined leaves in the factorisation AND the refined wavefront substitution (trsv_wave.hip,
+    one refinement step per diagonal block) -- LML, mean and variance against LAPACK within max(1e-8, 2 eps cond_2), the
+    condition number from the two extreme eigenvalues; and the wavefront equals the recursive substitution with refined
+    leaves to rounding."""
+    import gpflowSlim as gpf
+    n, d, ns, var = 16384, 2, 40, 1.3
+    rng = np.random.default_rng(int(1e7 * ratio) + 3)
+    X = rng.uniform(-3.0, 3.0, (n, d)); Xs = rng.uniform(-3.0, 3.0, (ns, d))
+    noise = orc.constrained(ratio * var)
+    Y = np.sin(X[:, :1]) * np.cos(0.5 * X[:, 1:2]) + np.sqrt(noise) * rng.standard_normal((n, 1))
+    c = orc.constrained
+    spec = {"type": "rbf", "variance": c(var), "lengthscales": c(0.8), "input_dim": d}
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, variance=var, lengthscales=0.8), obs_var=ratio * var)
+    # cond_2(K + s I) <= (lambda_max(K) + s) / s  (K is positive semi-definite); lambda_max by power iteration (an eigenvalue
+    # decomposition of a 16384 x 16384 matrix would cost minutes of the suite's time)
+    Kx = orc.K(spec, X)
+    v = rng.standard_normal(n); lam = 0.0
+    for _ in range(40):
+        w = Kx @ v
+        lam = float(np.linalg.norm(w)); v = w / lam
+    del Kx
+    cond_bound = (1.02 * lam + noise) / noise
+    assert cond_bound <= (n * c(var) + noise) / noise
+    tol = max(RTOL, 2.0 * EPS * cond_bound)
+    lml = m.compute_log_likelihood()
+    assert handle.profile_get("factor_refined")["launches"] == 1 and handle.profile_get("trsv_wave_fallbacks")["launches"] == 0
+    ref = orc.gpr_lml(spec, X, Y, noise)
+    assert abs(lml - ref) <= tol * abs(ref), (cond_bound, abs(lml - ref) / abs(ref))
+    mu, vv = m.predict_f(Xs)
+    rmu, rv = orc.gpr_predict(spec, X, Y, noise, Xs)
+    assert rel(mu, rmu) <= tol and rel(vv, rv) <= tol, (cond_bound, rel(mu, rmu), rel(vv, rv))
+    handle.set_option("trsv_wave_refine", 0)
+    try:
+        lml_rec = m.compute_log_likelihood()
+    finally:
+        handle.set_option("trsv_wave_refine", 1)
+    assert abs(lml_rec - lml) <= 1e-3 * tol * abs(ref) + 1e-12 * abs(ref)
+
+
 @pytest.mark.parametrize("white", [True, False])
 @pytest.mark.parametrize("full_cov", [False, True])
 @pytest.mark.parametrize("q", [None, 2, 3])

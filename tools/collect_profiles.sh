@@ -8,7 +8,7 @@ OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 what=${1:-all}
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 if [ "$what" = all ] || [ "$what" = pmc ]; then
   # counter collection serialises the dispatches: a look-ahead hand-over could only time out (and the evaluation would
   # be re-run without it) -- switch it off up front
@@ -29,8 +29,17 @@ if [ "$what" = all ] || [ "$what" = stats ]; then
   # the reference's own workload size (examples/gpr.py: N ~ 455): per-step latency table, kernel statistics
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_small -- python3 $R/tools/small_n.py 512 2048 > $OUT/prof_small.log 2>&1 || exit 1
   echo "small-N stats done"
+  # potrf_base phase stamps (with and without the transposed inverse) and the DPP / SIMD-sharing probe behind its design
+  (cd $R && python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids; GPS_PB_NO_T=1 python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids) > $OUT/potrf_base_stamps.txt || true
+  [ -x $R/tools/bin/dpp_probe ] && $R/tools/bin/dpp_probe > $OUT/dpp_probe.txt 2>&1 || true
+  (cd $R && GPS_SMALL_STAMPS=1 python3 tools/sn_once.py 2>&1 | grep -v amdgpu.ids | tail -16) > $OUT/small_n_stamps.txt || true
   for c in 2 4 5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg$c -- python3 $R/tools/configs.py $c > $OUT/prof_cfg$c.log 2>&1 || exit 1
     echo "cfg$c stats done"
   done
+fi
+if [ "$what" = all ] || [ "$what" = soak ]; then
+  # long mixed run of every entry point on the final sources (summary -> gpurun_out/soak.json, copied by summarise_profiles.py)
+  (cd $R && python3 tools/soak.py ${SOAK_STEPS:-20000} > $OUT/soak.log 2>&1) || exit 1
+  tail -1 $OUT/soak.log
 fi

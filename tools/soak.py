@@ -43,7 +43,17 @@ for it in range(steps):
     assert np.isfinite(v), (it, kind, n, d, v)
     print("%4d %-13s n=%5d d=%d  %.1f ms" % (it, kind, n, d, 1e3 * dt), flush=True)
 h = gpf.get_handle()
-print("done: %d steps in %.1f s, slowest step %.2f s, look-ahead retries %d / %d, wavefront fall-backs %d / %d" % (
-    steps, time.perf_counter() - t_start, worst, h.profile_get("lookahead_retries")["launches"], h2.profile_get("lookahead_retries")["launches"],
-    h.profile_get("trsv_wave_fallbacks")["launches"], h2.profile_get("trsv_wave_fallbacks")["launches"]), flush=True)
+summary = {"steps": steps, "seconds": round(time.perf_counter() - t_start, 1), "slowest_step_s": round(worst, 3),
+           "lookahead_retries": [h.profile_get("lookahead_retries")["launches"], h2.profile_get("lookahead_retries")["launches"]],
+           "trsv_wave_fallbacks": [h.profile_get("trsv_wave_fallbacks")["launches"], h2.profile_get("trsv_wave_fallbacks")["launches"]],
+           "small_n_fallbacks": [h.profile_get("small_n_fallbacks")["launches"], h2.profile_get("small_n_fallbacks")["launches"]],
+           "what": "tools/soak.py: mixed sequence of every entry point (GPR LML / gradient / predict_f, conditional, SVGP / SGPR / FITC gradients) on two "
+                   "handles, sizes 130 .. 16384 (the one-launch small-N path, the look-ahead sweeps, the wavefront substitution all take part)"}
+print("done: %d steps in %.1f s, slowest step %.2f s, look-ahead retries %s, wavefront fall-backs %s, small-N fall-backs %s" % (
+    steps, summary["seconds"], worst, summary["lookahead_retries"], summary["trsv_wave_fallbacks"], summary["small_n_fallbacks"]), flush=True)
+import json
+from bench import kernel_source_sha
+summary["kernel_source_sha"] = kernel_source_sha()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "soak.json"), "w"), indent=1)
 h2.close()

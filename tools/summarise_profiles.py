@@ -1,10 +1,10 @@
-"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/<tag>_* (tag = argv[1], default r03)."""
+"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/<tag>_* (tag = argv[1], default r04)."""
 import csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out"); PROF = os.path.join(ROOT, "profiles")
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -40,6 +40,17 @@ for d, name in (("prof_bench", "bench"), ("prof_cfg2", "cfg2"), ("prof_cfg4", "c
         if j:
             j["kernel_source_sha"], j["commit"] = sha, commit
             json.dump(j, open(os.path.join(PROF, "%s_%s.json" % (tag, name)), "w"), indent=1)
+
+
+for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("dpp_probe.txt", "dpp_probe.txt"),
+                 ("small_n_stamps.txt", "small_n_stamps.txt")):
+    f = os.path.join(OUT, src)
+    if os.path.exists(f):
+        if src.endswith(".json"):
+            j = json.load(open(f)); j["commit"] = commit
+            json.dump(j, open(os.path.join(PROF, "%s_%s" % (tag, dst)), "w"), indent=1)
+        else:
+            shutil.copy(f, os.path.join(PROF, "%s_%s" % (tag, dst)))
 
 
 def per_kernel(d, counters):
