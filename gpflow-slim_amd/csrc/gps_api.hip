@@ -809,7 +809,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // reductions of the likelihood as ONE cooperative launch (small_n.hip) -- three launches per evaluation with the two of the
   // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
   h->small_valid = false;
-  const bool small = h->small_n > 0 && aug && np <= 768 && r <= 32 && !h->refine_now && h->prop.multiProcessorCount >= 160;
+  const bool small = h->small_n > 0 && aug && np <= 512 && r <= 16 && !h->refine_now && h->prop.multiProcessorCount >= 160;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));

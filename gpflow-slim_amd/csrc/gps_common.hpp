@@ -223,7 +223,7 @@ struct gps_handle_s {
   DevBuf dTmp2;
   DevBuf dTmp3;
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
-  int small_n = 1;            // option "small_n": GPR problems of up to 768 padded rows are factored by one cooperative launch
+  int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
   bool small_valid = false; double small_slog = 0.0, small_ssq = 0.0;   // reductions the last small launch produced
   bool ev3_is_ev2 = false;

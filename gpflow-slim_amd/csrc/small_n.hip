@@ -1,4 +1,4 @@
-// Exact-GP factorisation of a SMALL covariance (up to 768 padded rows) as ONE launch.
+// Exact-GP factorisation of a SMALL covariance (up to 512 padded rows) as ONE launch.
 //
 // The reference's own workload is this size (examples/gpr.py:36,48-61: N ~ 455, 20 000 optimiser steps; each step
 // tf.cholesky + tf.matrix_triangular_solve, models/gpr.py:70, densities.py:82).  Launch by launch (blocked.hpp) such a
@@ -92,56 +92,91 @@ __device__ __forceinline__ bool sn_wait(u32* sync, const u32* c1, u32 t1, const 
 // [SH x 128] x [128 x 128]^T product of one pair, wave w = column tile w (columns 16 w .. 16 w + 15):
 //   UPDATE: C[SH][128 @ ldc] -= A[SH][K = 128 @ lda] * Bm[128][K @ ldb]^T
 //   SOLVE : C <- A * Bm^T in place (A == C), Bm lower triangular: k-steps beyond the tile's last column are skipped
+// Both operands go through LDS: whole rows by coalesced 16-byte loads (a wave stages the 16 rows of Bm its column tile needs
+// into a region of its own, the workgroup the SH rows of A together), then the MFMA fragments by conflict-free ds_read_b64
+// (row stride 130 doubles).  Fetching the fragments straight from L2 (8 bytes per lane, 32-byte runs) took 7.5 us per
+// product (stamps: profiles/r04_small_n_stamps.txt) -- the operands have just been written by other CUs and come from HBM.
+// What the pair OWNS is fetched before it waits for anybody: the C tile (UPDATE) or its rows of A (SOLVE) -- sn_own.
+#define SN_LS 130                                     // LDS row stride (doubles)
+#define SN_LDS_BYTES ((8 * 16 * SN_LS + 16 * SN_LS) * 8)   // 8 wave regions of Bm rows + the 16 rows of A (150 KB: slabs of 32 rows would not fit)
+
+template <int SH>
+__device__ __forceinline__ void sn_stage_rows(double* lds, const double* g, i64 ldg, int row_lo, int row_hi, int lane) {
+  // rows [row_lo, row_hi) of a [.. x 128] global block -> lds[row][SN_LS], one 1-KB row per wave instruction
+  double2 v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) if (row_lo + u < row_hi) v[u] = *reinterpret_cast<const double2*>(g + (i64)(row_lo + u) * ldg + 2 * lane);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) if (row_lo + u < row_hi) *reinterpret_cast<double2*>(lds + (row_lo + u) * SN_LS + 2 * lane) = v[u];
+}
+
 template <int SH, bool SOLVE>
-__device__ __forceinline__ void sn_product(const double* A, i64 lda, const double* __restrict__ Bm, i64 ldb,
-                                           double* C, i64 ldc, double* C2, i64 ldc2, int c2_rows, int wave, int fr, int fk,
-                                           long long* st = nullptr) {
+struct SnOwn { v4d acc[SH / 16]; };
+
+// before the wait: the accumulators (UPDATE: the C tile; SOLVE: zero) and, for SOLVE, this pair's rows of A into LDS
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void sn_own(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* C, i64 ldc,
+                                       int wave, int lane, int fr, int fk) {
   constexpr int RT = SH / 16;
-  const int ks = SOLVE ? 4 * (wave + 1) : 32;                    // k-steps of 4
-  double bv[32], av[RT][32];
-  const double* pb = Bm + (i64)(16 * wave + fr) * ldb + fk;
-#pragma unroll
-  for (int s = 0; s < 32; ++s) bv[s] = (s < ks) ? pb[4 * s] : 0.0;
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    const double* pa = A + (i64)(16 * t + fr) * lda + fk;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) av[t][s] = (s < ks) ? pa[4 * s] : 0.0;
-  }
-  v4d acc[RT];
+  double* As = reinterpret_cast<double*>(smem) + 8 * 16 * SN_LS;
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[t][rg] = SOLVE ? 0.0 : C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr];
-  if (SOLVE) {                                                   // every wave has its copy of the rows that are about to be overwritten
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  } else if (st) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int rg = 0; rg < 4; ++rg) o.acc[t][rg] = SOLVE ? 0.0 : C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr];
+  if (SOLVE) sn_stage_rows<SH>(As, A, lda, wave * (SH / 8), (wave + 1) * (SH / 8), lane);
+}
+
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void sn_product(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* __restrict__ Bm,
+                                           i64 ldb, double* C, i64 ldc, double* C2, i64 ldc2, int c2_rows, int wave, int lane,
+                                           int fr, int fk, long long* st = nullptr) {
+  constexpr int RT = SH / 16;
+  const int ks = SOLVE ? 4 * (wave + 1) : 32;                    // k-steps of 4
+  double* Bs = reinterpret_cast<double*>(smem) + wave * 16 * SN_LS;
+  double* As = reinterpret_cast<double*>(smem) + 8 * 16 * SN_LS;
+  sn_stage_rows<SH>(Bs - 16 * wave * SN_LS, Bm - 0, ldb, 16 * wave, 16 * wave + 16, lane);      // rows 16 w .. of Bm -> this wave's region (indexed by absolute row)
+  if (!SOLVE) sn_stage_rows<SH>(As, A, lda, wave * (SH / 8), (wave + 1) * (SH / 8), lane);
+  __syncthreads();                                               // A rows of every wave are in LDS (and, SOLVE: everybody has read the rows about to be overwritten)
   if (st && threadIdx.x == 0) st[0] = (long long)wall_clock64();
+  const double* pb = Bs + fr * SN_LS + fk;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
     if (s < ks) {
+      const double b = pb[4 * s];
 #pragma unroll
-      for (int t = 0; t < RT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? av[t][s] : -av[t][s], bv[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) {
+        const double a = As[(16 * t + fr) * SN_LS + 4 * s + fk];
+        o.acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? a : -a, b, o.acc[t], 0, 0, 0);
+      }
     }
   }
   if (st && threadIdx.x == 0) st[1] = (long long)wall_clock64();
+  // The tile leaves as whole 128-byte row segments: transposed through this wave's LDS region (its fragments have been read),
+  // lane l then stores columns 2 (l & 7), +1 of row l >> 3 (and of row 8 + (l >> 3)) with one 16-byte write-through store --
+  // full lines for the consumers on other CUs, instead of 8-byte stores scattered over four rows.
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < RT; ++t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      sn_store(&C[(i64)(16 * t + fk + 4 * rg) * ldc + 16 * wave + fr], acc[t][rg]);
-      if (C2 && 16 * t + fk + 4 * rg < c2_rows) C2[(i64)(16 * t + fk + 4 * rg) * ldc2 + 16 * wave + fr] = acc[t][rg];   // (alpha^T also where the other entry points expect it)
+    for (int rg = 0; rg < 4; ++rg) Bs[(fk + 4 * rg) * SN_LS + fr] = o.acc[t][rg];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int row = 8 * hlf + (lane >> 3), col = 2 * (lane & 7);
+      const double2 v = *reinterpret_cast<const double2*>(Bs + row * SN_LS + col);
+      pb_store16(&C[(i64)(16 * t + row) * ldc + 16 * wave + col], v);
+      if (C2 && 16 * t + row < c2_rows) *reinterpret_cast<double2*>(&C2[(i64)(16 * t + row) * ldc2 + 16 * wave + col]) = v;   // (alpha^T also where the other entry points expect it)
     }
+  }
+  __syncthreads();                                               // (the LDS regions are free again)
 }
 
 template <int SH>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
   // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + PB_LDS_BYTES);
-  double* const s_red = reinterpret_cast<double*>(smem_raw + PB_LDS_BYTES + 16);
+  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
+  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
@@ -222,17 +257,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define SN_PSTAMP(q) do { if (ps && tid == 0) ps[q] = (long long)wall_clock64(); } while (0)
   SN_PSTAMP(0);
   for (int j = 0; j < k; ++j) {
+    SnOwn<SH, false> own;
+    sn_own<SH, false>(own, smem_raw, nullptr, 0, C, ld, wave, lane, fr, fk);
     if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
     SN_PSTAMP(1 + 2 * j);
-    sn_product<SH, false>(g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0, wave, fr, fk, (ps && j == 0) ? ps + 12 : nullptr);
+    sn_product<SH, false>(own, smem_raw, g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0,
+                          wave, lane, fr, fk, (ps && j == 0) ? ps + 12 : nullptr);
     if (ps && j == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) ps[14] = (long long)wall_clock64(); }
     if (bi == k) sn_publish(sync + SN_D(k), nullptr);
     SN_PSTAMP(2 + 2 * j);
   }
   if (bi != k) {
+    SnOwn<SH, true> own;
+    sn_own<SH, true>(own, smem_raw, C, ld, C, ld, wave, lane, fr, fk);
     if (!sn_wait(sync, sync + SN_F(k), 1u, nullptr, 0u, s_flag_p)) return;
+    SN_PSTAMP(20);
     double* mirror = (aug && g.alpha) ? g.alpha + (i64)sl * SH * g.ld_alpha + (i64)k * 128 : nullptr;      // (that buffer has r rows only)
-    sn_product<SH, true>(C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH, wave, fr, fk, ps ? ps + 16 : nullptr);
+    sn_product<SH, true>(own, smem_raw, C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH,
+                         wave, lane, fr, fk, ps ? ps + 16 : nullptr);
     SN_PSTAMP(21);
     sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
     SN_PSTAMP(22);
@@ -244,11 +286,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // GPS_ERR_UNSUPPORTED: not a shape for this path (the caller takes the launch-by-launch one).
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows) {
-  // (up to 768 padded rows: 87 workgroups at most, so that two such launches of one process still fit the GPU side by side)
-  if (np % 128 || np < 128 || np > 768 || r < 1 || r > 32) return GPS_ERR_UNSUPPORTED;
+  // (up to 512 padded rows in slabs of 16: 85 workgroups at most, so that two such launches of one process still fit the GPU side by side)
+  if (np % 128 || np < 128 || np > 512 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
   if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
   const int nblk = (int)(np / 128);
-  const int SH = (np <= 512 && r <= 16) ? 16 : 32;
+  const int SH = 16;
   const int spb = 128 / SH, aug_slabs = (int)((r + SH - 1) / SH);
   int pairs = 0;
   for (int i = 1; i < nblk; ++i) pairs += spb * (i + 1);
@@ -270,13 +312,12 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
     GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, stamp_words * 8, h->stream));
     a.stamps = (long long*)h->dTmp3.p;
   }
-  const size_t lds = (size_t)PB_LDS_BYTES + 128;
-  const void* fn = SH == 16 ? reinterpret_cast<const void*>(&small_factor_kernel<16>) : reinterpret_cast<const void*>(&small_factor_kernel<32>);
+  const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
+  const void* fn = reinterpret_cast<const void*>(&small_factor_kernel<16>);
   int rc0 = gps_dyn_lds(h, fn, (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_POTRF_BASE, (double)np * np * np / 3.0, 8.0 * np * np);
-  if (SH == 16) hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
-  else hipLaunchKernelGGL(small_factor_kernel<32>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
+  hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
   if (want_stamps) {
     std::vector<long long> st(stamp_words);
