@@ -704,8 +704,10 @@ def main():
                                         "statistic": "median of 5 calls", "cold_calls": cold, "warm_calls": warm},
                "fallback_counters": {"lookahead_retries": int(h.profile_get("lookahead_retries")["launches"]),
                                      "trsv_wave_fallbacks": int(h.profile_get("trsv_wave_fallbacks")["launches"]),
+                                     "small_n_fallbacks": int(h.profile_get("small_n_fallbacks")["launches"]),
                                      "note": "evaluations re-run without look-ahead after a missed hand-over / wavefront substitutions "
-                                             "that gave up, over the whole life of this process' handle (0 = the fast paths ran)"},
+                                             "that gave up / one-launch small-N factorisations that gave up, over the whole life of "
+                                             "this process' handle (0 = the fast paths ran)"},
                "predict_f_throughput": predict_tp,
                "lml_plus_gradient_ms": round(grad_ms, 2),
                "small_n_latency": small,

@@ -295,6 +295,7 @@ static int with_la_retry(gps_handle_t h, F&& body) {
   return rc;
 }
 
+static int gpr_lml_finish(gps_handle_t h, i64 r, double* lml);
 static int stage_time(gps_handle_t h, int a, int b, double* out) {
   float ms = 0.f;
   GPS_HIP(h, hipEventElapsedTime(&ms, h->ev[a], h->ev[b]));
@@ -335,7 +336,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
+                    &h->dDistScal, &h->dGradSums, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
   if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
@@ -380,6 +381,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
   h->dLaFlags.release();
   h->ring.release();
+  if (h->hRes) (void)hipHostFree(h->hRes);
   if (h->ev_la) (void)hipEventDestroy(h->ev_la);
   delete h;
   return GPS_OK;
@@ -767,6 +769,13 @@ extern "C" int gps_gpr_set_data(gps_handle_t h, const double* X, int64_t n, int6
   return GPS_OK;
 }
 
+// pinned host landing area of the small read-backs (a copy into pageable memory goes through a staging buffer of the
+// runtime and blocks the host for tens of microseconds)
+static int ensure_hres(gps_handle_t h) {
+  if (!h->hRes) GPS_HIP(h, hipHostMalloc(&h->hRes, GPS_HRES_BYTES, hipHostMallocDefault));
+  return GPS_OK;
+}
+
 // the transposed block inverses of the resident GPR factor, if the factorisation left them out (the one-launch small path)
 static int gpr_ensure_linvT(gps_handle_t h) {
   if (!h->gpr_linvT_stale) return GPS_OK;
@@ -836,8 +845,13 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     h->gpr_linvT_stale = true;
     if (rc == GPS_OK) {
       GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
-      double res[4] = {0.0, 0.0, 0.0, 1.0};
-      GPS_HIP(h, hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+      h->r = r;
+      if (h->small_defer) { h->small_pending = true; return GPS_OK; }      // (gps_gpr_lml_grad reads the results back itself, later)
+      int rch = ensure_hres(h);
+      if (rch) return rch;
+      double* res = (double*)h->hRes;
+      res[3] = 1.0;
+      GPS_HIP(h, hipMemcpyAsync(res, d_res, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       GPS_HIP(h, hipStreamSynchronize(h->stream));
       if (res[3] == 0.0) {
         const int v = (int)res[2];
@@ -911,6 +925,13 @@ extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   int rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
   if (info) *info = linfo;
   if (rc) return rc;
+  return gpr_lml_finish(h, r, lml);
+  });
+}
+
+// the likelihood from the resident factor and alpha (densities.py:92-94); stage times of the evaluation
+static int gpr_lml_finish(gps_handle_t h, i64 r, double* lml) {
+  int rc;
   const i64 n = h->n, np = h->npad;
   double slog = 0.0, ssq = 0.0;
   if (h->small_valid) {
@@ -936,7 +957,52 @@ extern "C" int gps_gpr_lml(gps_handle_t h, const gps_kern_node_t* prog, int n_no
   h->stage_ms[3] = 0.0;
   stage_time(h, 0, h->ev3_is_ev2 ? 2 : 3, &h->stage_ms[4]);
   return GPS_OK;
-  });
+}
+
+// What follows the (not yet read back) one-launch factorisation of a small problem in gps_gpr_lml_grad.  *done = false: a
+// bounded wait gave up, nothing of the outputs is valid.
+static int gpr_small_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, i64 r, double* lml, double* grad_slots,
+                               double* grad_noise, double* kinv_resid, int* info, bool* done) {
+  const i64 n = h->n, np = h->npad;
+  *done = false;
+  int rc = ensure_hres(h);
+  if (rc) return rc;
+  GPS_HIP(h, hipEventRecord(h->ev[5], h->stream));
+  GPS_HIP(h, h->dA.ensure((size_t)r * np * 8));
+  GPS_HIP(h, h->dY.ensure((size_t)np * np * 8));
+  GPS_HIP(h, h->dKinv.ensure((size_t)np * np * 8));
+  // dScal + 256: [0..3] the factorisation's results, [4] the inverse launch's abort word, [5 ..] the gradient sums
+  double* d_res = h->dScal.d() + 256;
+  rc = gps_launch_small_inverse(h, h->dK.d(), np, h->dLinv.d(), h->dAlpha.d(), r, h->dY.d(), h->dKinv.d(), h->dA.d(), d_res + 4);
+  if (rc) return rc;                   // (the factorisation took this shape: so does the inverse)
+  GradPost post;
+  rc = gps_grad_enqueue(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, d_res + 5, &post);
+  if (rc) return rc;
+  double* res = (double*)h->hRes;
+  double* kr = res + 256;
+  res[3] = 1.0; res[4] = 1.0;
+  GPS_HIP(h, hipMemcpyAsync(res, d_res, (size_t)(5 + GPS_GRAD_SUMS) * 8, hipMemcpyDeviceToHost, h->stream));
+  if (kinv_resid) {
+    GPS_HIP(h, h->dTmp3.ensure((size_t)n * r * 8));
+    rc = gps_launch_transpose(h, h->dA.d(), np, r, n, h->dTmp3.d(), r);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(kr, h->dTmp3.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  if (res[3] != 0.0 || res[4] != 0.0) return GPS_OK;
+  *done = true;
+  const int v = (int)res[2];
+  *info = (v == INT_MAX) ? 0 : v;
+  h->have_factor = (*info == 0);
+  h->small_valid = true; h->small_slog = res[0]; h->small_ssq = res[1];
+  if (*info) return GPS_OK;            // not positive definite: outputs undefined
+  rc = gpr_lml_finish(h, r, lml);
+  if (rc) return rc;
+  stage_time(h, 5, 6, &h->stage_ms[3]);
+  gps_grad_finish(post, res + 5, grad_slots, grad_noise);
+  if (kinv_resid) memcpy(kinv_resid, kr, (size_t)n * r * 8);
+  return GPS_OK;
 }
 
 // LML and its gradient: d/d(kernel parameter slots), d/d(noise variance), d/d(resid) = -K_y^-1 resid ... see header
@@ -956,36 +1022,89 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   if (n_slots_out) *n_slots_out = ns;
   if (ns > n_slots_cap) return gps_fail(h, GPS_ERR_ARG, "gps_gpr_lml_grad: grad_slots too small");
   int linfo = 0;
-  rc = gps_gpr_lml(h, prog, n_nodes, noise_var, resid, r, lml, &linfo);
+  // Small problems (the reference's own size: examples/gpr.py): factorisation, inverse and gradient sums are enqueued
+  // back to back -- six launches -- and everything the host needs comes back in one pinned copy behind ONE synchronisation.
+  h->small_defer = h->small_n > 0 && r <= 16 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)h->n * r * 8 <= GPS_HRES_BYTES / 2);
+  h->small_pending = false;
+  rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
+  h->small_defer = false;
+  if (rc) return rc;
+  if (h->small_pending) {
+    h->small_pending = false;
+    bool done = false;
+    rc = gpr_small_grad_tail(h, prog, n_nodes, r, lml, grad_slots, grad_noise, kinv_resid, &linfo, &done);
+    if (rc) return rc;
+    if (done) { if (info) *info = linfo; return GPS_OK; }
+    // a bounded wait of one of the two cooperative launches ran out (never seen): this evaluation again, launch by launch
+    h->small_fallbacks++;
+    rc = gps_small_factor_reset(h);
+    if (rc) return rc;
+    const int saved = h->small_n;
+    h->small_n = 0;
+    rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
+    h->small_n = saved;
+    if (rc) return rc;
+  }
   if (info) *info = linfo;
-  if (rc || linfo) return rc;
-  rc = gpr_ensure_linvT(h);
+  if (linfo) return GPS_OK;
+  rc = gpr_lml_finish(h, r, lml);
   if (rc) return rc;
   const i64 n = h->n, np = h->npad;
   GPS_HIP(h, hipEventRecord(h->ev[5], h->stream));
-  double* linv = h->dLinv.d();
-  HipOps ops{h, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
-  Blocked<HipOps> bl(ops);
-  // A = K_y^-1 resid = L^-T (L^-1 resid)
   GPS_HIP(h, h->dA.ensure((size_t)r * np * 8));
-  GPS_HIP(h, hipMemcpyAsync(h->dA.p, h->dAlpha.p, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
-  rc = trsv_backward(h, ops, h->dK.d(), np, np, h->dA.d(), np, r);
-  if (rc) return rc;
-  // K_y^-1 = L^-T L^-1
   GPS_HIP(h, h->dY.ensure((size_t)np * np * 8));
   GPS_HIP(h, h->dKinv.ensure((size_t)np * np * 8));
-  rc = bl.inv_t_rec(h->dK.d(), np, np, 0, h->dY.d(), np);
-  if (rc) return rc;
-  rc = bl.lauum_rec(h->dY.d(), np, np, h->dKinv.d(), np);
-  if (rc) return rc;
-  rc = gps_launch_grad(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, grad_slots,
-                       grad_noise);
-  if (rc) return rc;
-  if (kinv_resid) {
-    GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
-    rc = gps_launch_transpose(h, h->dA.d(), np, r, n, h->dTmp2.d(), r);
+  // K_y^-1 (lower triangle) and A = K_y^-1 resid.  After the one-launch factorisation of a small problem: one more
+  // cooperative launch (small_n.hip) instead of ~25 (the two recursions and the backward substitution below)
+  bool small_inv = h->small_valid && h->small_n > 0;
+  double* d_res1 = h->dScal.d() + 260;
+  if (small_inv) {
+    rc = gps_launch_small_inverse(h, h->dK.d(), np, h->dLinv.d(), h->dAlpha.d(), r, h->dY.d(), h->dKinv.d(), h->dA.d(), d_res1);
+    if (rc == GPS_ERR_UNSUPPORTED) small_inv = false;
+    else if (rc) return rc;
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    if (!small_inv) {
+      rc = gpr_ensure_linvT(h);
+      if (rc) return rc;
+      double* linv = h->dLinv.d();
+      HipOps ops{h, linv, linv + (np / GPS_TILE) * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
+      Blocked<HipOps> bl(ops);
+      // A = K_y^-1 resid = L^-T (L^-1 resid)
+      GPS_HIP(h, hipMemcpyAsync(h->dA.p, h->dAlpha.p, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
+      rc = trsv_backward(h, ops, h->dK.d(), np, np, h->dA.d(), np, r);
+      if (rc) return rc;
+      // K_y^-1 = L^-T L^-1
+      rc = bl.inv_t_rec(h->dK.d(), np, np, 0, h->dY.d(), np);
+      if (rc) return rc;
+      rc = bl.lauum_rec(h->dY.d(), np, np, h->dKinv.d(), np);
+      if (rc) return rc;
+    }
+    rc = gps_launch_grad(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, grad_slots,
+                         grad_noise);
     if (rc) return rc;
-    GPS_HIP(h, hipMemcpyAsync(kinv_resid, h->dTmp2.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
+    if (kinv_resid) {
+      GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
+      rc = gps_launch_transpose(h, h->dA.d(), np, r, n, h->dTmp2.d(), r);
+      if (rc) return rc;
+      GPS_HIP(h, hipMemcpyAsync(kinv_resid, h->dTmp2.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (!small_inv) break;
+    // (the launch-by-launch path touches neither the info word nor a hand-over: the only thing to read back is whether a
+    // bounded wait of the cooperative launch ran out -- never seen -- and then the same again launch by launch)
+    double ab = 1.0;
+    GPS_HIP(h, hipMemcpyAsync(&ab, d_res1, 8, hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    if (ab == 0.0) {
+      GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
+      GPS_HIP(h, hipEventSynchronize(h->ev[6]));
+      stage_time(h, 5, 6, &h->stage_ms[3]);
+      return GPS_OK;
+    }
+    h->small_fallbacks++;
+    rc = gps_small_factor_reset(h);
+    if (rc) return rc;
+    small_inv = false;
   }
   GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
   // synchronises, and surfaces a backward wavefront substitution that gave up (its result would poison dA and every
@@ -2517,7 +2636,7 @@ extern "C" int gps_device_bytes(gps_handle_t h, int64_t* bytes) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
+                    &h->dDistScal, &h->dGradSums, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
                     &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   int64_t tot = 0;
   for (DevBuf* b : bufs) tot += (int64_t)b->cap;

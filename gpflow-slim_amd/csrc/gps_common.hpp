@@ -222,6 +222,9 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
+  DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
+  void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
+  bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
   int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
@@ -331,6 +334,8 @@ static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var,
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows);
 int gps_small_factor_reset(gps_handle_t h);
+int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
+                             double* dY, double* dKinv, double* dA, double* d_res1);
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
                          int trans, int refine = 0);
@@ -390,6 +395,15 @@ int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int
 int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
                     double* grad_slots_host, double* grad_noise_host);
+// the same in two halves, for callers that read several results back with ONE synchronisation (gps_gpr_lml_grad, small N)
+#define GPS_GRAD_SUMS 161
+#define GPS_HRES_BYTES (192 * 1024)
+struct GradPost { int n_slots = 0; std::vector<double> ls_of_slot; };
+bool gps_grad_is_simple(const gps_kern_node_t* prog, int n_nodes);
+int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                     double* d_sums, GradPost* post);
+void gps_grad_finish(const GradPost& post, const double* sums, double* grad_slots_host, double* grad_noise_host);
 // grad_general.hip : programs grad.hip does not take (more than 4 primitives, neural-kernel-network layers)
 int gps_grad_general_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int* n_slots);
 int gps_launch_grad_general(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,

@@ -333,6 +333,21 @@ __global__ __launch_bounds__(256) void grad_kernel(GArgs a, GProg P) {
 // ---- host side ------------------------------------------------------------------------------------
 #define GRAD_BLOCKS 2048
 
+// the per-workgroup partial sums of one slot -> one number, in a fixed order (block s of the launch = slot s; the last = noise)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ partial, int nblocks, int n_slots, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int s = ((int)blockIdx.x < n_slots) ? (int)blockIdx.x : G_MAXSLOT;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) t += partial[(i64)b * (G_MAXSLOT + 1) + s];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[s] = red[0];
+}
+
 // programs this file's kernel does not take go to grad_general.hip
 static bool grad_needs_general(const gps_kern_node_t* prog, int n_nodes) {
   int prims = 0;
@@ -360,14 +375,19 @@ int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int
   return GPS_OK;
 }
 
-int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
-                    i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
-                    double* grad_slots_host, double* grad_noise_host) {
-  if (grad_needs_general(prog, n_nodes))
-    return gps_launch_grad_general(h, prog, n_nodes, dX, n, d_all, npad, dKinv, ldk, dA, lda, r, grad_slots_host, grad_noise_host);
+bool gps_grad_is_simple(const gps_kern_node_t* prog, int n_nodes) { return !grad_needs_general(prog, n_nodes); }
+
+// Everything of the gradient that runs on the device, without a synchronisation: feature table (pinned ring), features,
+// the tile sums, their reduction into d_sums[GPS_GRAD_SUMS] (slot s at [s], noise at [G_MAXSLOT]).  post: what the host
+// still has to do with the sums once it has them (gps_grad_finish).
+int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                     double* d_sums, GradPost* post) {
+  static_assert(GPS_GRAD_SUMS == G_MAXSLOT + 1, "GPS_GRAD_SUMS");
   GProg P;
   std::vector<GPrepFeat> feats;
-  std::vector<double> ls_of_slot;          // lengthscale that divides a per-dim slot
+  std::vector<double>& ls_of_slot = post->ls_of_slot;          // lengthscale that divides a per-dim slot
+  ls_of_slot.clear();
   P.n_nodes = n_nodes; P.n_prims = 0; P.n_slots = 0;
   if (n_nodes <= 0 || n_nodes > GRAD_MAX_NODES) return gps_fail(h, GPS_ERR_UNSUPPORTED, "gradient: program too long");
   for (int i = 0; i < n_nodes; ++i)
@@ -412,8 +432,7 @@ int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, co
   if (nfeat > 0) {
     GPS_HIP(h, h->dFeat.ensure((size_t)nfeat * npad * 8));
     GPS_HIP(h, h->dProg.ensure((size_t)nfeat * sizeof(GPrepFeat) + 64));
-    GPS_HIP(h, hipMemcpyAsync(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GPrepFeat), hipMemcpyHostToDevice, h->stream));
-    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    GPS_HIP(h, h->ring.upload(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GPrepFeat), h->stream));
     LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * nfeat);
     hipLaunchKernelGGL(gprep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
                        (const GPrepFeat*)h->dProg.p, nfeat, h->dFeat.d(), npad);
@@ -422,28 +441,49 @@ int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, co
   GArgs a;
   a.Ft = h->dFeat.d(); a.ldf = npad; a.Kinv = dKinv; a.ldk = ldk; a.A = dA; a.lda = lda; a.r = (int)r;
   a.n = n; a.npad = npad; a.tiles_r = (int)(npad / GT_R); a.tiles_c = (int)(npad / GT_C);
-  const size_t pbytes = (size_t)GRAD_BLOCKS * (G_MAXSLOT + 1) * 8;
+  const i64 ntiles = (i64)a.tiles_r * a.tiles_c;
+  const int nblocks = (int)(ntiles < GRAD_BLOCKS ? ntiles : GRAD_BLOCKS);
+  const size_t pbytes = (size_t)nblocks * (G_MAXSLOT + 1) * 8;
   GPS_HIP(h, h->dTmp2.ensure(pbytes));
   a.partial = h->dTmp2.d();
   {
     LaunchScope ls(h, KC_REDUCE, 0.5 * (double)npad * npad * (60.0 + 4.0 * nfeat), 4.0 * (double)npad * npad);
-    hipLaunchKernelGGL(grad_kernel, dim3(GRAD_BLOCKS), dim3(256), 0, h->stream, a, P);
+    hipLaunchKernelGGL(grad_kernel, dim3(nblocks), dim3(256), 0, h->stream, a, P);
     GPS_HIP(h, hipGetLastError());
   }
-  std::vector<double> part((size_t)GRAD_BLOCKS * (G_MAXSLOT + 1));
-  GPS_HIP(h, hipMemcpyAsync(part.data(), a.partial, pbytes, hipMemcpyDeviceToHost, h->stream));
-  GPS_HIP(h, hipStreamSynchronize(h->stream));
-  for (int s = 0; s <= G_MAXSLOT; ++s) {
-    if (s >= P.n_slots && s != G_MAXSLOT) continue;
-    double tot = 0.0;
-    for (int b = 0; b < GRAD_BLOCKS; ++b) tot += part[(size_t)b * (G_MAXSLOT + 1) + s];
-    if (s == G_MAXSLOT) { if (grad_noise_host) *grad_noise_host = tot; }
-    else {
-      // the kernel accumulated the FULL symmetric sum / 2 through c_ij (1 below, 1/2 on the diagonal):
-      // 1/2 sum_ij W dK = sum_{i>j} W dK + 1/2 sum_i W_ii dK_ii
-      if (ls_of_slot[s] > 0.0) tot /= ls_of_slot[s];       // -2 delta^2 / l_d : delta is already x/l
-      grad_slots_host[s] = tot;
-    }
+  {
+    // (2048 x 161 partial sums used to travel to the host, 2.6 MB per gradient: 48 us of copy at N = 512)
+    LaunchScope ls(h, KC_REDUCE, 0.0, (double)pbytes);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(P.n_slots + 1), dim3(256), 0, h->stream, a.partial, nblocks, P.n_slots, d_sums);
+    GPS_HIP(h, hipGetLastError());
   }
+  post->n_slots = P.n_slots;
+  return GPS_OK;
+}
+
+void gps_grad_finish(const GradPost& post, const double* sums, double* grad_slots_host, double* grad_noise_host) {
+  if (grad_noise_host) *grad_noise_host = sums[G_MAXSLOT];
+  for (int s = 0; s < post.n_slots; ++s) {
+    // the kernel accumulated the FULL symmetric sum / 2 through c_ij (1 below, 1/2 on the diagonal):
+    // 1/2 sum_ij W dK = sum_{i>j} W dK + 1/2 sum_i W_ii dK_ii
+    double tot = sums[s];
+    if (post.ls_of_slot[s] > 0.0) tot /= post.ls_of_slot[s];       // -2 delta^2 / l_d : delta is already x/l
+    grad_slots_host[s] = tot;
+  }
+}
+
+int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                    i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                    double* grad_slots_host, double* grad_noise_host) {
+  if (grad_needs_general(prog, n_nodes))
+    return gps_launch_grad_general(h, prog, n_nodes, dX, n, d_all, npad, dKinv, ldk, dA, lda, r, grad_slots_host, grad_noise_host);
+  GradPost post;
+  GPS_HIP(h, h->dGradSums.ensure((size_t)GPS_GRAD_SUMS * 8));
+  int rc = gps_grad_enqueue(h, prog, n_nodes, dX, n, d_all, npad, dKinv, ldk, dA, lda, r, h->dGradSums.d(), &post);
+  if (rc) return rc;
+  double sums[GPS_GRAD_SUMS];
+  GPS_HIP(h, hipMemcpyAsync(sums, h->dGradSums.p, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  gps_grad_finish(post, sums, grad_slots_host, grad_noise_host);
   return GPS_OK;
 }

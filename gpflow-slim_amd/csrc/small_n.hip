@@ -297,8 +297,8 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   pairs += aug_slabs * nblk;
   if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
   if (!h->dSmallSync.p) {
-    GPS_HIP(h, h->dSmallSync.ensure((size_t)SN_WORDS * 4));
-    GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4, h->stream));
+    GPS_HIP(h, h->dSmallSync.ensure((size_t)SN_WORDS * 4 * 2));                 // second half: the inverse launch (below)
+    GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4 * 2, h->stream));
   }
   SmallArgs a;
   a.K = dK; a.ld = np; a.Linv = linv; a.LinvT = linvT; a.resid = d_resid; a.n = (int)n; a.r = (int)r; a.nblk = nblk;
@@ -342,6 +342,186 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
 
 // after an aborted launch the counters are in an unknown state
 int gps_small_factor_reset(gps_handle_t h) {
-  if (h->dSmallSync.p) GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4, h->stream));
+  if (h->dSmallSync.p) GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4 * 2, h->stream));
+  return GPS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K_y^-1 (lower triangle) and K_y^-1 (Y - m) of a small problem from its factor, as ONE launch: what the gradient of the
+// likelihood needs (examples/gpr.py:53-54: tf.gradients through tf.cholesky), launch by launch ~25 launches at N = 512
+// (L^-T by recursion, K^-1 = L^-T L^-1 by recursion, the backward substitution).  With Y = L^-1 (lower, blocks Y_ij):
+//     Y_ii = W_i (the block inverses of the factorisation),   Y_ij = - sum_{k=j}^{i-1} (W_i L_ik) Y_kj   (i > j),
+//     K^-1_ab = sum_{i >= a} Y_ia^T Y_ib   (a >= b),          A^T = Y^T alpha.
+// Workgroup t is task t of stage 2 (block (a, b), 16-row slab sl of K^-1); the first 8 (nblk - 1) workgroups first do stage 1
+// for the 16-row slab (i, sl) of Y: M_ik = W_i L_ik for every k < i (no dependency: all of them at once), then Y_ij for
+// j = i-1 .. 0 -- which needs the block rows of Y above row i, published per block row (counter YROW).  M_ik is parked in the
+// unused upper block (k, i) of the Y buffer.  Stage 2 starts when every block row of Y is there; the first nblk workgroups
+// also compute one block of A^T.  Products as in the factorisation launch: operands through LDS, one column tile per wave.
+#define SI_YROW(i) ((i) * SN_LINE)
+#define SI_ABORT (8 * SN_LINE)            // (sn_wait's abort word is SN_ABORT of the buffer it is given: this launch passes a base shifted accordingly)
+#define SI_LSA 16                       // the 128 x 16 strip is read (4 s + fk) * 16 + fr: conflict-free; the per-wave 16 x 16 store staging too
+#define SI_AS_DOUBLES 2304                // >= 16 * SN_LS (16 rows of A) and >= 128 * SI_LSA (the strip)
+#define SI_LDS_BYTES ((128 * SN_LS + SI_AS_DOUBLES) * 8)      // a whole 128 x 128 B operand + the A operand (16 rows, or a 128 x 16 column strip)
+
+struct SmallInvArgs {
+  const double* L; i64 ld;        // factor (lower blocks), [np][ld]
+  const double* W;                // [nblk][128 * 128] block inverses
+  const double* alpha; i64 ld_alpha; int r;      // alpha^T [r][ld_alpha]
+  double* Y; i64 ldy;             // [np][ldy] work: Y (lower blocks), M (upper blocks)
+  double* Kinv; i64 ldk;          // out: lower blocks of K^-1
+  double* At; i64 lda;            // out: (K^-1 resid)^T [r][lda]
+  int nblk;
+  u32* sync;                      // zero on entry; zeroed again at the end
+  double* res;                    // [0] abort
+};
+
+// acc += A * B  with A [16 x 128] (rows in LDS, or AT: staged as its transpose's strip [128][16]) and B [128 x 128] given as B[k][n]
+template <bool AT>
+__device__ __forceinline__ void si_mma(v4d& acc, const double* As, const double* Bs, int wave, int fr, int fk) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const double a = AT ? As[(4 * s + fk) * SI_LSA + fr] : As[fr * SN_LS + 4 * s + fk];
+    const double b = Bs[(4 * s + fk) * SN_LS + 16 * wave + fr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+}
+// whole 128 x 128 block (rows of the source) -> Bs[128][SN_LS]: wave w its rows 16 w ..
+__device__ __forceinline__ void si_stage_B(double* Bs, const double* g, i64 ldg, int wave, int lane) {
+  sn_stage_rows<16>(Bs, g, ldg, 16 * wave, 16 * wave + 16, lane);
+}
+// 16 rows of A -> As[16][SN_LS] (wave w: rows 2 w, 2 w + 1)
+__device__ __forceinline__ void si_stage_A(double* As, const double* g, i64 ldg, int wave, int lane) {
+  sn_stage_rows<16>(As, g, ldg, 2 * wave, 2 * wave + 2, lane);
+}
+// column strip [128 rows][16 columns] -> As[128][SI_LSA]: 8 lanes per row, 16 bytes each
+__device__ __forceinline__ void si_stage_At(double* As, const double* g, i64 ldg, int wave, int lane) {
+  double2 v[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const double2*>(g + (i64)(16 * wave + 8 * u + (lane >> 3)) * ldg + 2 * (lane & 7));
+#pragma unroll
+  for (int u = 0; u < 2; ++u) *reinterpret_cast<double2*>(As + (16 * wave + 8 * u + (lane >> 3)) * SI_LSA + 2 * (lane & 7)) = v[u];
+}
+// the wave's 16 x 16 tile (accumulator layout) -> rows of C, whole 128-byte segments, write-through
+__device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, double sign, double* C, i64 ldc, int wave, int lane, int fr, int fk) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) scratch[(fk + 4 * rg) * SI_LSA + fr] = sign * acc[rg];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int hlf = 0; hlf < 2; ++hlf) {
+    const int row = 8 * hlf + (lane >> 3), col = 2 * (lane & 7);
+    const double2 v = *reinterpret_cast<const double2*>(scratch + row * SI_LSA + col);
+    pb_store16(&C[(i64)row * ldc + 16 * wave + col], v);
+  }
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_inverse_kernel(SmallInvArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Bs = reinterpret_cast<double*>(smem_raw);
+  double* As = Bs + 128 * SN_LS;
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + SI_LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nblk = g.nblk, t = (int)blockIdx.x;
+  u32* sync = g.sync;                       // (sn_wait looks for the abort word at sync + SN_ABORT)
+  double* scratch = As + 16 * SI_LSA * wave;          // per-wave 16 x 16 staging for the stores: inside the A region, used only between products
+  bool ok = true;
+
+  // ---- stage 1: slab (i, sl) of Y
+  if (t < 8 * (nblk - 1)) {
+    const int i = 1 + t / 8, sl = t % 8;
+    const i64 R = (i64)i * 128 + 16 * sl;
+    // M_ik = W_i[slab] L_ik  ->  upper block (k, i) of the Y buffer, rows 16 sl ..
+    for (int k = 0; k < i; ++k) {
+      si_stage_A(As, g.W + (i64)i * 128 * 128 + (i64)16 * sl * 128, 128, wave, lane);
+      si_stage_B(Bs, g.L + (i64)i * 128 * g.ld + (i64)k * 128, g.ld, wave, lane);
+      __syncthreads();
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      si_mma<false>(acc, As, Bs, wave, fr, fk);
+      __syncthreads();
+      si_store_tile(scratch, acc, 1.0, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane, fr, fk);
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this workgroup reads its own M slabs back below
+    __syncthreads();
+    for (int j = i - 1; j >= 0 && ok; --j) {
+      // (Y_i,i-1 needs no other block row; the others need the block rows j+1 .. i-1 of Y, i.e. every row above this one)
+      if (j == i - 2) {
+        for (int q = 1; q < i && ok; ++q) ok = sn_wait(sync, sync + SI_YROW(q), 8u, nullptr, 0u, s_flag_p);
+      }
+      if (!ok) break;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k) {
+        si_stage_A(As, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane);          // M_ik[slab]
+        if (k == j) si_stage_B(Bs, g.W + (i64)j * 128 * 128, 128, wave, lane);                              // Y_jj = W_j
+        else si_stage_B(Bs, g.Y + (i64)k * 128 * g.ldy + (i64)j * 128, g.ldy, wave, lane);                  // Y_kj
+        __syncthreads();
+        si_mma<false>(acc, As, Bs, wave, fr, fk);
+        __syncthreads();
+      }
+      si_store_tile(scratch, acc, -1.0, g.Y + R * g.ldy + (i64)j * 128, g.ldy, wave, lane, fr, fk);
+      __syncthreads();
+    }
+    if (ok) sn_publish(sync + SI_YROW(i), sync + SI_YROW(0));          // YROW(0) counts every finished slab of stage 1
+  }
+  // ---- stage 2: slab sl of block (a, b) of K^-1
+  if (ok) ok = sn_wait(sync, sync + SI_YROW(0), (u32)(8 * (nblk - 1)), nullptr, 0u, s_flag_p);
+  if (ok) {
+    int a = 0, rem = t / 8;
+    while (rem >= a + 1) { rem -= a + 1; ++a; }
+    const int b = rem, sl = t % 8;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int i = a; i < nblk; ++i) {
+      const double* Ya = (i == a) ? g.W + (i64)a * 128 * 128 + 16 * sl : g.Y + (i64)i * 128 * g.ldy + (i64)a * 128 + 16 * sl;
+      const double* Yb = (i == b) ? g.W + (i64)b * 128 * 128 : g.Y + (i64)i * 128 * g.ldy + (i64)b * 128;
+      si_stage_At(As, Ya, (i == a) ? 128 : g.ldy, wave, lane);
+      si_stage_B(Bs, Yb, (i == b) ? 128 : g.ldy, wave, lane);
+      __syncthreads();
+      si_mma<true>(acc, As, Bs, wave, fr, fk);
+      __syncthreads();
+    }
+    si_store_tile(scratch, acc, 1.0, g.Kinv + ((i64)a * 128 + 16 * sl) * g.ldk + (i64)b * 128, g.ldk, wave, lane, fr, fk);
+    // ---- A^T = Y^T alpha: workgroup t < nblk takes block t, thread c < 128 column c
+    if (t < nblk && tid < 128) {
+      for (int q = 0; q < g.r; ++q) {
+        double sum = 0.0;
+        for (int i = t; i < nblk; ++i) {
+          const double* Yc = (i == t) ? g.W + (i64)t * 128 * 128 + tid : g.Y + (i64)i * 128 * g.ldy + (i64)t * 128 + tid;
+          const i64 ldc = (i == t) ? 128 : g.ldy;
+          const double* al = g.alpha + (i64)q * g.ld_alpha + (i64)i * 128;
+          for (int m = 0; m < 128; ++m) sum = fma(Yc[(i64)m * ldc], al[m], sum);
+        }
+        g.At[(i64)q * g.lda + (i64)t * 128 + tid] = sum;
+      }
+    }
+  }
+  // ---- the last workgroup to finish leaves the counters zero for the next call and reports
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const u32 done = __hip_atomic_fetch_add(sync + SI_YROW(9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1 == gridDim.x) {
+      g.res[0] = (double)sn_load(sync + SN_ABORT);
+      if (sn_load(sync + SN_ABORT) == 0u) for (int w = 0; w < SN_WORDS; ++w) sync[w] = 0u;
+    }
+  }
+}
+
+// dK: the factor of gps_launch_small_factor; linv: its block inverses; d_alpha [r][np].  Fills dY (work), dKinv (lower blocks of
+// K^-1) and dA ([r][np]: K^-1 resid); res1 (device): abort flag.  GPS_ERR_UNSUPPORTED: not a shape for this path.
+int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
+                             double* dY, double* dKinv, double* dA, double* d_res1) {
+  if (np % 128 || np < 128 || np > 512 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
+  const int nblk = (int)(np / 128);
+  SmallInvArgs a;
+  a.L = dK; a.ld = np; a.W = linv; a.alpha = d_alpha; a.ld_alpha = np; a.r = (int)r;
+  a.Y = dY; a.ldy = np; a.Kinv = dKinv; a.ldk = np; a.At = dA; a.lda = np; a.nblk = nblk;
+  a.sync = (u32*)h->dSmallSync.p + SN_WORDS; a.res = d_res1;
+  const size_t lds = (size_t)SI_LDS_BYTES + 64;
+  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel), (int)lds);
+  if (rc0) return rc0;
+  LaunchScope ls(h, KC_GEMM, 2.0 * (double)np * np * np / 3.0, 16.0 * np * np);
+  hipLaunchKernelGGL(small_inverse_kernel, dim3(8 * nblk * (nblk + 1) / 2), dim3(NT), lds, h->stream, a);
+  GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
