@@ -35,6 +35,14 @@ struct Blocked {
   typedef int64_t i64;
 
   static i64 split(i64 n) { return ((n / GPS_TILE) / 2) * GPS_TILE; }   // n >= 256 -> 128 <= n1 < n
+  // the triangular solves: first parts that are multiples of 512 columns, so that their recursion ends in 512-column nodes
+  // (one launch each: Ops::trsm_leaf512) whatever the number of tiles
+  static i64 split_solve(i64 n) {
+    const i64 P = 4 * GPS_TILE;
+    if (n <= P) return split(n);
+    const i64 h = ((n / P) / 2) * P;
+    return h > P ? h : P;
+  }
 
   // A piece of the PARENT's panel solve handed down to a child node: solve  X L^T = B  for the first dn columns of the
   // child's matrix (B [dm, dn]: the parent's rows below, same columns).  The child issues it on the deferred stream as
@@ -271,7 +279,8 @@ struct Blocked {
   int trsm_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m, L, ldl);
-    const i64 n1 = split(n), n2 = n - n1;
+    if (n == 4 * GPS_TILE && ops.leaf512(m, 0)) return ops.trsm_leaf512(blk0, 0, B, ldb, m, L, ldl);
+    const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rec(L, ldl, n1, blk0, B, ldb, m);
     if (rc) return rc;
     rc = ops.gemm(0, 0, m, n2, n1, B, ldb, L + n1 * ldl, ldl, B + n1, ldb);   // B2 -= X1 L21^T
@@ -283,7 +292,8 @@ struct Blocked {
   int trsm_rn_rec(const double* U, i64 ldu, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m, U, ldu);
-    const i64 n1 = split(n), n2 = n - n1;
+    if (n == 4 * GPS_TILE && ops.leaf512(m, 1)) return ops.trsm_leaf512(blk0, 1, B, ldb, m, U, ldu);
+    const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rn_rec(U + n1 * ldu + n1, ldu, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
     if (rc) return rc;
     // B1 -= X2 L21 = X2 (U12)^T ; U12 = U[0:n1, n1:n]

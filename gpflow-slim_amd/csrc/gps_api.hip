@@ -68,6 +68,14 @@ struct HipOps {
     if (h->refine_now) return gps_launch_trsm_leaf_refine(h, B, ldb, m, W, D, ldd, transposed);
     return gps_launch_gemm_nt(h, /*op set*/ 1, 0, m, GPS_TILE, GPS_TILE, B, ldb, W, GPS_TILE, B, ldb);
   }
+  // four leaves and the updates between them as one launch (trsm_panel.hip); not for refined leaves
+  bool leaf512(i64 m, int transposed) const {
+    return h->trsm_panel > 0 && !h->refine_now && m >= 64 && m % 64 == 0 && (transposed ? linvT != nullptr : true);
+  }
+  int trsm_leaf512(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
+    const double* W = (transposed ? linvT : linv) + blk * GPS_TILE * GPS_TILE;
+    return gps_launch_trsm_panel(h, B, ldb, m, D, ldd, W, transposed);
+  }
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B,
            i64 ldb, double* C, i64 ldc) {
     return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
@@ -493,6 +501,11 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
+  if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
+  if (strcmp(key, "trsm_panel_rows") == 0) {
+    if (value != 0 && value != 32 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32 or 64");
+    h->trsm_panel_rows = (int)value; return GPS_OK;
+  }
   if (strcmp(key, "trsv_wave_refine") == 0) { h->trsv_wave_refine = (int)value; return GPS_OK; }
   return gps_fail(h, GPS_ERR_ARG, "unknown option");
 }
@@ -568,6 +581,71 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
 }
 
 // one 128-column leaf  X L11^T = B  (upper: X L11 = B through U = L^T) on m rows, timed over `reps` launches:
+// Diagnostics: the 512-column triangular solve of m rows, launch by launch (panel = 0) or as one launch (panel = 1,
+// trsm_panel.hip); backward: X L = B instead of X L^T = B.  maxdiff_out: largest |difference| between the two on the same input.
+extern "C" int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
+                                double* maxdiff_out) {
+  if (!h || m <= 0 || m % GPS_TILE || reps <= 0 || !us_per_solve) return GPS_ERR_ARG;
+  GPS_HIP(h, hipSetDevice(h->device));
+  const i64 T = GPS_TILE, n = 4 * T;
+  std::vector<double> L((size_t)n * n, 0.0), B((size_t)T * n);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0 - 0.5; };
+  for (i64 i = 0; i < n; ++i) for (i64 j = 0; j <= i; ++j) L[i * n + j] = (i == j) ? 2.0 + 0.5 * (rnd() + 0.5) : 0.1 * rnd();
+  for (auto& v : B) v = rnd();
+  GPS_HIP(h, h->dTmp.ensure((size_t)2 * n * n * 8));
+  GPS_HIP(h, h->dTmp3.ensure((size_t)8 * T * T * 8));
+  GPS_HIP(h, h->dB.ensure((size_t)m * n * 8 * 3));
+  double* dL = h->dTmp.d(); double* dU = dL + n * n; double* dInv = h->dTmp3.d(); double* dInvT = dInv + 4 * T * T;
+  double* dBm = h->dB.d(); double* dB0 = dBm + m * n; double* dB1 = dB0 + m * n;
+  GPS_HIP(h, hipMemcpyAsync(dL, L.data(), (size_t)n * n * 8, hipMemcpyHostToDevice, h->stream));
+  for (i64 q = 0; q < m / T; ++q) GPS_HIP(h, hipMemcpyAsync(dB0 + q * T * n, B.data(), (size_t)T * n * 8, hipMemcpyHostToDevice, h->stream));
+  int rc = gps_launch_transpose(h, dL, n, n, n, dU, n);
+  if (rc) return rc;
+  rc = gps_launch_fill_info(h, (int*)h->dInfo.p, INT_MAX);
+  if (rc) return rc;
+  HipOps ops{h, dInv, dInvT, (int*)h->dInfo.p};
+  ops.factor = 0;
+  for (i64 b = 0; b < 4 && !rc; ++b) rc = ops.potrf_base(dL + b * T * n + b * T, n, b, b * T);
+  if (rc) return rc;
+  Blocked<HipOps> bl(ops);
+  const bool saved_ref = h->refine_now; const int saved_panel = h->trsm_panel;
+  h->refine_now = false;
+  auto solve = [&](double* X) -> int { return backward ? bl.trsm_rn_rec(dU, n, n, 0, X, n, m) : bl.trsm_rec(dL, n, n, 0, X, n, m); };
+  hipEvent_t e0, e1;
+  GPS_HIP(h, hipEventCreate(&e0)); GPS_HIP(h, hipEventCreate(&e1));
+  float ms = 0.f;
+  h->trsm_panel = panel;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {            // pass 0 warms up
+    GPS_HIP(h, hipEventRecord(e0, h->stream));
+    for (int it = 0; it < reps && !rc; ++it) {
+      if (it == 0 || it == reps - 1) GPS_HIP(h, hipMemcpyAsync(dBm, dB0, (size_t)m * n * 8, hipMemcpyDeviceToDevice, h->stream));
+      rc = solve(dBm);
+    }
+    GPS_HIP(h, hipEventRecord(e1, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+    GPS_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+  }
+  if (!rc && maxdiff_out) {
+    h->trsm_panel = panel ? 0 : 1;
+    GPS_HIP(h, hipMemcpyAsync(dB1, dB0, (size_t)m * n * 8, hipMemcpyDeviceToDevice, h->stream));
+    rc = solve(dB1);
+    if (!rc) {
+      std::vector<double> x0((size_t)m * n), x1((size_t)m * n);
+      GPS_HIP(h, hipMemcpy(x0.data(), dBm, (size_t)m * n * 8, hipMemcpyDeviceToHost));
+      GPS_HIP(h, hipMemcpy(x1.data(), dB1, (size_t)m * n * 8, hipMemcpyDeviceToHost));
+      double w = 0.0;
+      for (size_t i = 0; i < x0.size(); ++i) { const double d = fabs(x0[i] - x1[i]); if (!(d <= w)) w = d; }
+      *maxdiff_out = w;
+    }
+  }
+  h->refine_now = saved_ref; h->trsm_panel = saved_panel;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  *us_per_solve = 1e3 * ms / reps;
+  return GPS_OK;
+}
+
 // mode 0 = product with the block inverse, 1 = refined (trsm_leaf.hip); resid_out = max |X T - B| / (|X| |T|)_max
 // of the last launch's first 128 rows (T = L11^T or L11), checked on the host
 extern "C" int gps_diag_trsm_leaf(gps_handle_t h, int64_t m, int mode, int upper, int reps, double* us_per_launch,

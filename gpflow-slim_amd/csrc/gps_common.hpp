@@ -222,6 +222,8 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
+  int trsm_panel = 1;         // 512-column triangular solves as one launch (trsm_panel.hip); 0: down to 128 columns launch by launch
+  int trsm_panel_rows = 0;    // rows per workgroup of that launch: 64, 32, or 0 = by the number of rows
   DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
@@ -334,6 +336,8 @@ static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var,
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows);
 int gps_small_factor_reset(gps_handle_t h);
+// trsm_panel.hip
+int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
                              double* dY, double* dKinv, double* dA, double* d_res1);
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch

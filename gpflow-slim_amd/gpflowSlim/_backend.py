@@ -134,6 +134,7 @@ _SIGNATURES = {
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
+    "gps_diag_trsm512": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
     "gps_diag_trsm_leaf": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
     "gps_diag_set_cu_mask": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int],
     "gps_diag_gemm_timeline": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, ctypes.c_int,
@@ -486,6 +487,13 @@ class Handle(object):
         self._check(self._lib.gps_diag_trsm_leaf(self._h, int(m), int(mode), int(bool(upper)), int(reps),
                                                  ctypes.byref(us), ctypes.byref(res)), "gps_diag_trsm_leaf")
         return us.value, res.value
+
+    def diag_trsm512(self, m, backward=False, panel=True, reps=20):
+        """(microseconds per 512-column solve of m rows, max |one launch - launch by launch|)."""
+        us, diff = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.gps_diag_trsm512(self._h, int(m), int(bool(backward)), int(bool(panel)), int(reps),
+                                               ctypes.byref(us), ctypes.byref(diff)), "gps_diag_trsm512")
+        return us.value, diff.value
 
     def diag_set_cu_mask(self, words):
         arr = (ctypes.c_uint32 * len(words))(*[int(w) & 0xffffffff for w in words])

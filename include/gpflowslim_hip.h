@@ -476,6 +476,11 @@ int gps_diag_set_cu_mask(gps_handle_t h, const uint32_t* mask, int n_words);
 /* phase timestamps (us) of one 128-block potrf_base launch; out7[0] = shader clock in MHz */
 int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
 
+/* Diagnostics: the 512-column triangular solve of m rows (m a multiple of 128) against a synthetic block, timed;
+ * panel = 1: as one launch (csrc/trsm_panel.hip), 0: launch by launch (blocked.hpp::trsm_rec).  backward: X L = B.
+ * maxdiff_out (optional): largest |difference| between the two forms on the same input. */
+int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
+                     double* maxdiff_out);
 /* one 128-column leaf of the triangular solves on m rows (device-resident synthetic block), average microseconds per
  * launch over `reps`: mode 0 = product with the explicit block inverse, 1 = refined against the factor's diagonal
  * block (what tf.matrix_triangular_solve's substitution delivers, conditionals.py:87,100); upper: the X L = B form;

@@ -13,6 +13,7 @@ static const i64 T = GPS_TILE;
 
 static i64 g_rl_group = 1;
 static int g_lookahead = 0;
+static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
 
 struct CpuOps {
@@ -128,6 +129,24 @@ struct CpuOps {
     const double* W = (transposed ? linvT.data() : linv.data()) + blk * T * T;
     return gemm(1, 0, m, T, T, B, ldb, W, T, B, ldb);
   }
+  // the 512-column node as the device does it (csrc/trsm_panel.hip): block substitution with the four block inverses and
+  // the off-diagonal blocks of D (forward: the lower block L; backward: U = L^T, blocks above the diagonal)
+  int n_leaf512 = 0;
+  bool leaf512(i64 m, int) const { return g_leaf512 != 0 && m % 64 == 0; }
+  int trsm_leaf512(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
+    ++n_leaf512;
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = transposed ? 3 - jj : jj;
+      int rc = trsm_base(blk + j, transposed, B + j * T, ldb, m);
+      if (rc) return rc;
+      for (int i = 0; i < 4; ++i) {
+        if (transposed ? (i >= j) : (i <= j)) continue;
+        rc = gemm(0, 0, m, T, T, B + j * T, ldb, D + i * T * ldd + j * T, ldd, B + i * T, ldb);      // B_i -= X_j D_ij^T
+        if (rc) return rc;
+      }
+    }
+    return 0;
+  }
   int trsv_base(i64 blk, double* y, i64 ldy, i64 r, const double* = nullptr, i64 = 0) {
     const double* W = linv.data() + blk * T * T;
     for (i64 q = 0; q < r; ++q) {
@@ -149,6 +168,7 @@ struct CpuOps {
 
 extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
+void emul_set_leaf512(int v) { g_leaf512 = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
 // the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only

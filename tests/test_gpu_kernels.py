@@ -188,6 +188,48 @@ def test_trsm_lower(handle, n, nrhs, trans):
     assert np.abs(X - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n,nrhs", [(512, 64), (512, 300), (1024, 1000), (1536, 130), (2048, 64)])
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("rows", [0, 32, 64])
+def test_trsm_512_column_solve_in_one_launch(handle, n, nrhs, trans, rows):
+    """csrc/trsm_panel.hip: every 512-column node of the blocked solve (blocked.hpp::trsm_rec / trsm_rn_rec) as one launch,
+    for both row-tile sizes of the launcher, against scipy; and against the launch-by-launch form of the same solve."""
+    rng = np.random.default_rng(n + nrhs)
+    G = rng.standard_normal((n, n))
+    L = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    B = rng.standard_normal((n, nrhs))
+    ref = sl.solve_triangular(L, B, lower=True, trans='T' if trans else 'N')
+    try:
+        handle.set_option("leaf_refine", 0)           # (refined leaves -- the default of this entry point -- stay launch by launch)
+        handle.set_option("trsm_panel_rows", rows)
+        before = handle.profile_get("gemm_f64")["launches"]
+        X = handle.trsm_lower(L, B, trans=trans)
+        mid = handle.profile_get("gemm_f64")["launches"]
+        handle.set_option("trsm_panel", 0)
+        X0 = handle.trsm_lower(L, B, trans=trans)
+        after = handle.profile_get("gemm_f64")["launches"]
+    finally:
+        handle.set_option("trsm_panel", 1); handle.set_option("trsm_panel_rows", 0); handle.set_option("leaf_refine", -1)
+    assert np.abs(X - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(X - X0).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # six launches fewer per 512 columns
+    assert (after - mid) - (mid - before) == 6 * (n // 512), (before, mid, after)
+
+
+def test_trsm_512_column_solve_many_rows(handle):
+    """The same launch on 128 .. 24576 rows (both row-tile sizes, both directions): identical to rounding with the
+    launch-by-launch solve of the same synthetic block (gps_diag_trsm512)."""
+    for m in (128, 4096, 16384, 24576):
+        for back in (False, True):
+            for rows in (32, 64):
+                handle.set_option("trsm_panel_rows", rows)
+                try:
+                    _, diff = handle.diag_trsm512(m, back, True, reps=1)
+                finally:
+                    handle.set_option("trsm_panel_rows", 0)
+                assert diff <= 1e-14, (m, back, rows, diff)
+
+
 def test_trsm_leaf_refined_residual(handle):
     """csrc/trsm_leaf.hip: the refined 128-column leaf (three triangular MFMA products in one launch) solves
     X L11^T = B and X L11 = B to a residual at rounding level for every row-tile size the launcher picks."""
