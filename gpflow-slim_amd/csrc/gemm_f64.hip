@@ -65,6 +65,9 @@ struct GemmArgs {
 
 // bijective XCD remap: blocks b, b+8, b+16 ... (same XCD) get consecutive ids
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
+#ifdef GPS_GEMM_NO_XCD_REMAP      // experiment (tools/power_vs_traffic.sh): neighbouring tiles on different XCDs -- every L2 fetches every panel
+  return b;
+#endif
   const int q = nb >> 3, r = nb & 7;
   const int x = b & 7, idx = b >> 3;
   const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
