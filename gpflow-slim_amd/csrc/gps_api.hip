@@ -344,7 +344,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dGradSums, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
+                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
   if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
@@ -901,7 +901,9 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
-    GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
+    // (through a pinned slot when small: a copy from pageable memory blocks the host for its staging)
+    if ((size_t)n * r * 8 <= (1u << 20)) GPS_HIP(h, h->ring.upload(h->dTmp2.p, resid, (size_t)n * r * 8, h->stream));
+    else GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
     if (!small) {
       double* dst = aug ? dAug : h->dAlpha.d();
       GPS_HIP(h, hipMemsetAsync(dst, 0, (size_t)(aug ? GPS_TILE : r) * np * 8, h->stream));
@@ -916,6 +918,10 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   int* d_info = (int*)h->dInfo.p;
   if (small) {
     double* d_res = h->dScal.d() + 256;
+    if (h->small_defer) {                 // (gps_gpr_lml_grad: with everything else it reads back, in one buffer)
+      GPS_HIP(h, h->dSmallOut.ensure((size_t)(5 + GPS_GRAD_SUMS + n * r) * 8));
+      d_res = h->dSmallOut.d();
+    }
     double* linv = h->dLinv.d();
     // (the transposed block inverses are not on the path of the likelihood: whoever needs them afterwards -- the gradient,
     // a prediction from this factor -- has them produced by one batched launch then: gpr_ensure_linvT)
@@ -1049,23 +1055,20 @@ static int gpr_small_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int 
   GPS_HIP(h, h->dA.ensure((size_t)r * np * 8));
   GPS_HIP(h, h->dY.ensure((size_t)np * np * 8));
   GPS_HIP(h, h->dKinv.ensure((size_t)np * np * 8));
-  // dScal + 256: [0..3] the factorisation's results, [4] the inverse launch's abort word, [5 ..] the gradient sums
-  double* d_res = h->dScal.d() + 256;
-  rc = gps_launch_small_inverse(h, h->dK.d(), np, h->dLinv.d(), h->dAlpha.d(), r, h->dY.d(), h->dKinv.d(), h->dA.d(), d_res + 4);
+  // dSmallOut: [0..3] the factorisation's results (already on their way), [4] the inverse launch's abort word, [5 ..] the
+  // gradient sums, then K^-1 resid as [n][r] -- one copy brings all of it back
+  double* d_res = h->dSmallOut.d();
+  double* d_kr = d_res + 5 + GPS_GRAD_SUMS;
+  rc = gps_launch_small_inverse(h, h->dK.d(), np, h->dLinv.d(), h->dAlpha.d(), r, h->dY.d(), h->dKinv.d(), h->dA.d(), d_res + 4,
+                                kinv_resid ? d_kr : nullptr, n);
   if (rc) return rc;                   // (the factorisation took this shape: so does the inverse)
   GradPost post;
   rc = gps_grad_enqueue(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, d_res + 5, &post);
   if (rc) return rc;
   double* res = (double*)h->hRes;
-  double* kr = res + 256;
+  double* kr = res + 5 + GPS_GRAD_SUMS;
   res[3] = 1.0; res[4] = 1.0;
-  GPS_HIP(h, hipMemcpyAsync(res, d_res, (size_t)(5 + GPS_GRAD_SUMS) * 8, hipMemcpyDeviceToHost, h->stream));
-  if (kinv_resid) {
-    GPS_HIP(h, h->dTmp3.ensure((size_t)n * r * 8));
-    rc = gps_launch_transpose(h, h->dA.d(), np, r, n, h->dTmp3.d(), r);
-    if (rc) return rc;
-    GPS_HIP(h, hipMemcpyAsync(kr, h->dTmp3.p, (size_t)n * r * 8, hipMemcpyDeviceToHost, h->stream));
-  }
+  GPS_HIP(h, hipMemcpyAsync(res, d_res, (size_t)(5 + GPS_GRAD_SUMS + (kinv_resid ? n * r : 0)) * 8, hipMemcpyDeviceToHost, h->stream));
   GPS_HIP(h, hipEventRecord(h->ev[6], h->stream));
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (res[3] != 0.0 || res[4] != 0.0) return GPS_OK;
@@ -1102,7 +1105,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   int linfo = 0;
   // Small problems (the reference's own size: examples/gpr.py): factorisation, inverse and gradient sums are enqueued
   // back to back -- six launches -- and everything the host needs comes back in one pinned copy behind ONE synchronisation.
-  h->small_defer = h->small_n > 0 && r <= 16 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)h->n * r * 8 <= GPS_HRES_BYTES / 2);
+  h->small_defer = h->small_n > 0 && r <= 16 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)(5 + GPS_GRAD_SUMS + h->n * r) * 8 <= GPS_HRES_BYTES);
   h->small_pending = false;
   rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
   h->small_defer = false;
@@ -2714,7 +2717,7 @@ extern "C" int gps_device_bytes(gps_handle_t h, int64_t* bytes) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dGradSums, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
+                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
                     &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   int64_t tot = 0;
   for (DevBuf* b : bufs) tot += (int64_t)b->cap;

@@ -224,6 +224,7 @@ struct gps_handle_s {
   DevBuf dTmp3;
   int trsm_panel = 1;         // 512-column triangular solves as one launch (trsm_panel.hip); 0: down to 128 columns launch by launch
   int trsm_panel_rows = 0;    // rows per workgroup of that launch: 64, 32, or 0 = by the number of rows
+  DevBuf dSmallOut;           // everything a small-N likelihood + gradient hands back, contiguous (one copy)
   DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
@@ -339,7 +340,7 @@ int gps_small_factor_reset(gps_handle_t h);
 // trsm_panel.hip
 int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
-                             double* dY, double* dKinv, double* dA, double* d_res1);
+                             double* dY, double* dKinv, double* dA, double* d_res1, double* dAT = nullptr, i64 n = 0);
 // trsv_wave.hip : L a = y / L^T a = y as one wavefront launch
 int gps_launch_trsv_wave(gps_handle_t h, const double* L, i64 ldl, i64 n, const double* W, double* y, i64 ldy, i64 r,
                          int trans, int refine = 0);

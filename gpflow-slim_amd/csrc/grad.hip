@@ -46,15 +46,18 @@ __device__ __forceinline__ double wave_sum64(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gprep_kernel(const double* __restrict__ X, i64 n, i64 d_all,
-                                                    i64 npad, const GPrepFeat* __restrict__ feats,
-                                                    int nfeat, double* __restrict__ Ft, i64 ldf) {
+#define GPREP_SMALL_F 24
+struct GPrepTabPtr { const GPrepFeat* f; };
+struct GPrepTabVal { GPrepFeat f[GPREP_SMALL_F]; };
+template <class Tab>
+__device__ __forceinline__ void gprep_body(const double* __restrict__ X, i64 n, i64 d_all, i64 npad, const Tab& tab, int nfeat,
+                                           double* __restrict__ Ft, i64 ldf) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
   for (int f = 0; f < nfeat; ++f) {
     double v = 0.0;
     if (i < n) {
-      const GPrepFeat pf = feats[f];
+      const GPrepFeat pf = tab.f[f];
       const double xv = X[i * d_all + pf.dim];
       if (pf.kind == 0) v = xv / pf.param;
       else {
@@ -64,6 +67,17 @@ __global__ __launch_bounds__(256) void gprep_kernel(const double* __restrict__ X
     }
     Ft[(i64)f * ldf + i] = v;
   }
+}
+__global__ __launch_bounds__(256) void gprep_kernel(const double* __restrict__ X, i64 n, i64 d_all,
+                                                    i64 npad, const GPrepFeat* __restrict__ feats,
+                                                    int nfeat, double* __restrict__ Ft, i64 ldf) {
+  const GPrepTabPtr tab{feats};
+  gprep_body(X, n, d_all, npad, tab, nfeat, Ft, ldf);
+}
+// (a small table travels in the kernel arguments: no copy command in front of the launch)
+__global__ __launch_bounds__(256) void gprep_args_kernel(const double* __restrict__ X, i64 n, i64 d_all, i64 npad, GPrepTabVal tab,
+                                                         int nfeat, double* __restrict__ Ft, i64 ldf) {
+  gprep_body(X, n, d_all, npad, tab, nfeat, Ft, ldf);
 }
 
 // value of the program with d(out)/d(prim p) by forward-mode: returns tangent
@@ -431,11 +445,19 @@ int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, c
   const int nfeat = (int)feats.size();
   if (nfeat > 0) {
     GPS_HIP(h, h->dFeat.ensure((size_t)nfeat * npad * 8));
-    GPS_HIP(h, h->dProg.ensure((size_t)nfeat * sizeof(GPrepFeat) + 64));
-    GPS_HIP(h, h->ring.upload(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GPrepFeat), h->stream));
     LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * nfeat);
-    hipLaunchKernelGGL(gprep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
-                       (const GPrepFeat*)h->dProg.p, nfeat, h->dFeat.d(), npad);
+    if (nfeat <= GPREP_SMALL_F) {
+      GPrepTabVal tab;
+      memset(&tab, 0, sizeof(tab));
+      for (int f = 0; f < nfeat; ++f) tab.f[f] = feats[f];
+      hipLaunchKernelGGL(gprep_args_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad, tab,
+                         nfeat, h->dFeat.d(), npad);
+    } else {
+      GPS_HIP(h, h->dProg.ensure((size_t)nfeat * sizeof(GPrepFeat) + 64));
+      GPS_HIP(h, h->ring.upload(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GPrepFeat), h->stream));
+      hipLaunchKernelGGL(gprep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
+                         (const GPrepFeat*)h->dProg.p, nfeat, h->dFeat.d(), npad);
+    }
     GPS_HIP(h, hipGetLastError());
   }
   GArgs a;

@@ -49,13 +49,16 @@ struct KmatArgs {
 };
 
 // ---- prep: one thread per point ------------------------------------------------------------
-__global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict__ X, i64 n,
-                                                        i64 d_all, i64 npts_pad,
-                                                        const PrepFeat* __restrict__ feats,
-                                                        int nfeat,
-                                                        const PrepNorm* __restrict__ norms,
-                                                        int nnorm, double* __restrict__ Ft,
-                                                        i64 ldf) {
+// The feature / norm tables either as device arrays (uploaded through the pinned ring) or, when they are small, by value in
+// the kernel arguments: no copy command in front of the launch (two of them were 14 us of a 200 us small-N evaluation).
+#define PREP_SMALL_F 24
+#define PREP_SMALL_N 8
+struct PrepTabPtr { const PrepFeat* f; const PrepNorm* n; };
+struct PrepTabVal { PrepFeat f[PREP_SMALL_F]; PrepNorm n[PREP_SMALL_N]; };
+
+template <class Tab>
+__device__ __forceinline__ void kmat_prep_body(const double* __restrict__ X, i64 n, i64 d_all, i64 npts_pad, const Tab& tab, int nfeat,
+                                               int nnorm, double* __restrict__ Ft, i64 ldf) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts_pad) return;
   if (i >= n) {
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict
   }
   const double* x = X + i * d_all;
   for (int f = 0; f < nfeat; ++f) {
-    const PrepFeat pf = feats[f];
+    const PrepFeat pf = tab.f[f];
     const double xv = x[pf.dim];
     double v;
     if (pf.kind == 0) v = xv / pf.param;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict
     Ft[(i64)f * ldf + i] = v;
   }
   for (int q = 0; q < nnorm; ++q) {
-    const PrepNorm pn = norms[q];
+    const PrepNorm pn = tab.n[q];
     double s = 0.0;
     for (int f = pn.f0; f < pn.f0 + pn.nf; ++f) {
       const double v = Ft[(i64)f * ldf + i];
@@ -83,6 +86,20 @@ __global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict
     }
     Ft[(i64)(nfeat + q) * ldf + i] = s;
   }
+}
+__global__ __launch_bounds__(256) void kmat_prep_kernel(const double* __restrict__ X, i64 n,
+                                                        i64 d_all, i64 npts_pad,
+                                                        const PrepFeat* __restrict__ feats,
+                                                        int nfeat,
+                                                        const PrepNorm* __restrict__ norms,
+                                                        int nnorm, double* __restrict__ Ft,
+                                                        i64 ldf) {
+  const PrepTabPtr tab{feats, norms};
+  kmat_prep_body(X, n, d_all, npts_pad, tab, nfeat, nnorm, Ft, ldf);
+}
+__global__ __launch_bounds__(256) void kmat_prep_args_kernel(const double* __restrict__ X, i64 n, i64 d_all, i64 npts_pad, PrepTabVal tab,
+                                                             int nfeat, int nnorm, double* __restrict__ Ft, i64 ldf) {
+  kmat_prep_body(X, n, d_all, npts_pad, tab, nfeat, nnorm, Ft, ldf);
 }
 
 // ---- exp(x) for x <= 0 (every kernel-matrix formula of kernels.py:436-439, 560-610, 813-819 has a non-positive argument up
@@ -988,6 +1005,17 @@ static int run_prep(gps_handle_t h, const KCompiled& kc, const double* dX, i64 n
   *ldf_out = npad;
   if (rows == 0) return GPS_OK;
   GPS_HIP(h, feat.ensure((size_t)rows * npad * sizeof(double)));
+  if (nfeat <= PREP_SMALL_F && nnorm <= PREP_SMALL_N) {
+    PrepTabVal tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int f = 0; f < nfeat; ++f) tab.f[f] = kc.feats[f];
+    for (int q = 0; q < nnorm; ++q) tab.n[q] = kc.norms[q];
+    LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * (double)(rows + d_all));
+    hipLaunchKernelGGL(kmat_prep_args_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad, tab,
+                       nfeat, nnorm, feat.d(), npad);
+    GPS_HIP(h, hipGetLastError());
+    return GPS_OK;
+  }
   const size_t fb = (size_t)nfeat * sizeof(PrepFeat), nb = (size_t)nnorm * sizeof(PrepNorm);
   GPS_HIP(h, tables.ensure(fb + nb + 64));
   // (through pinned slots: the host vectors die after return, and the stream is not synchronised)

@@ -353,13 +353,9 @@ int gps_small_factor_reset(gps_handle_t h) {
 // (L^-T by recursion, K^-1 = L^-T L^-1 by recursion, the backward substitution).  With Y = L^-1 (lower, blocks Y_ij):
 //     Y_ii = W_i (the block inverses of the factorisation),   Y_ij = - sum_{k=j}^{i-1} (W_i L_ik) Y_kj   (i > j),
 //     K^-1_ab = sum_{i >= a} Y_ia^T Y_ib   (a >= b),          A^T = Y^T alpha.
-// Workgroup t is task t of stage 2 (block (a, b), 16-row slab sl of K^-1); the first 8 (nblk - 1) workgroups first do stage 1
-// for the 16-row slab (i, sl) of Y: M_ik = W_i L_ik for every k < i (no dependency: all of them at once), then Y_ij for
-// j = i-1 .. 0 -- which needs the block rows of Y above row i, published per block row (counter YROW).  M_ik is parked in the
-// unused upper block (k, i) of the Y buffer.  Stage 2 starts when every block row of Y is there; the first nblk workgroups
-// also compute one block of A^T.  Products as in the factorisation launch: operands through LDS, one column tile per wave.
-#define SI_YROW(i) ((i) * SN_LINE)
-#define SI_ABORT (8 * SN_LINE)            // (sn_wait's abort word is SN_ABORT of the buffer it is given: this launch passes a base shifted accordingly)
+// Every product is one 16-row slab x one 128 x 128 block, as in the factorisation launch (operands through LDS, one column
+// tile per wave); the slabs are spread over the workgroups as a list of tasks with counters between them (below).  M_ik =
+// W_i L_ik is parked in the unused upper block (k, i) of the Y buffer.
 #define SI_LSA 16                       // the 128 x 16 strip is read (4 s + fk) * 16 + fr: conflict-free; the per-wave 16 x 16 store staging too
 #define SI_AS_DOUBLES 2304                // >= 16 * SN_LS (16 rows of A) and >= 128 * SI_LSA (the strip)
 #define SI_LDS_BYTES ((128 * SN_LS + SI_AS_DOUBLES) * 8)      // a whole 128 x 128 B operand + the A operand (16 rows, or a 128 x 16 column strip)
@@ -371,6 +367,7 @@ struct SmallInvArgs {
   double* Y; i64 ldy;             // [np][ldy] work: Y (lower blocks), M (upper blocks)
   double* Kinv; i64 ldk;          // out: lower blocks of K^-1
   double* At; i64 lda;            // out: (K^-1 resid)^T [r][lda]
+  double* AtT; int n;             // optional second home of the same, as [n][r] (what the host wants back)
   int nblk;
   u32* sync;                      // zero on entry; zeroed again at the end
   double* res;                    // [0] abort
@@ -415,6 +412,17 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
   }
 }
 
+// One workgroup = one task (blockIdx order = the order below; a task only waits for tasks before it):
+//   M (i, k, sl), k < i      : M_ik[slab] = W_i[slab] L_ik                                    -> counter SI_M(i, sl)  (i of them)
+//   Y (i, j, sl), j < i      : Y_ij[slab] = - sum_{k=j}^{i-1} M_ik[slab] Y_kj  (Y_jj = W_j)  -> counter SI_Y(i, j)   (8 slabs)
+//                              ordered by i - j: the blocks next to the diagonal need no other Y block
+//   K (a, b, sl), b <= a     : K^-1_ab[slab] = sum_{i >= a} Y_ia[:, slab]^T Y_ib
+//   A (t)                    : block t of (Y^T alpha)^T
+// Chain of dependent products at four blocks: M -> Y_10 -> Y_20 -> Y_30 -> K_00: five, against the nine plus four of a
+// workgroup that walks a whole slab of Y by itself.
+#define SI_M(i, sl) (((i) * 8 + (sl)) * SN_LINE)           // [4][8]
+#define SI_Y(i, j) ((32 + (i) * 4 + (j)) * SN_LINE)        // [4][4]
+#define SI_DONE (48 * SN_LINE)
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_inverse_kernel(SmallInvArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Bs = reinterpret_cast<double*>(smem_raw);
@@ -422,56 +430,61 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   int* const s_flag_p = reinterpret_cast<int*>(smem_raw + SI_LDS_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
-  const int nblk = g.nblk, t = (int)blockIdx.x;
+  const int nblk = g.nblk, npair = nblk * (nblk - 1) / 2;
   u32* sync = g.sync;                       // (sn_wait looks for the abort word at sync + SN_ABORT)
   double* scratch = As + 16 * SI_LSA * wave;          // per-wave 16 x 16 staging for the stores: inside the A region, used only between products
   bool ok = true;
+  int t = (int)blockIdx.x;
+  const int sl = t % 8;
 
-  // ---- stage 1: slab (i, sl) of Y
-  if (t < 8 * (nblk - 1)) {
-    const int i = 1 + t / 8, sl = t % 8;
-    const i64 R = (i64)i * 128 + 16 * sl;
-    // M_ik = W_i[slab] L_ik  ->  upper block (k, i) of the Y buffer, rows 16 sl ..
-    for (int k = 0; k < i; ++k) {
-      si_stage_A(As, g.W + (i64)i * 128 * 128 + (i64)16 * sl * 128, 128, wave, lane);
-      si_stage_B(Bs, g.L + (i64)i * 128 * g.ld + (i64)k * 128, g.ld, wave, lane);
+  if (t < 8 * npair) {
+    // ---- M (i, k, sl)
+    int i = 1, rem = t / 8;
+    while (rem >= i) { rem -= i; ++i; }
+    const int k = rem;
+    si_stage_A(As, g.W + (i64)i * 128 * 128 + (i64)16 * sl * 128, 128, wave, lane);
+    si_stage_B(Bs, g.L + (i64)i * 128 * g.ld + (i64)k * 128, g.ld, wave, lane);
+    __syncthreads();
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    si_mma<false>(acc, As, Bs, wave, fr, fk);
+    __syncthreads();
+    // parked in the unused upper block (k, i) of the Y buffer
+    si_store_tile(scratch, acc, 1.0, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane, fr, fk);
+    sn_publish(sync + SI_M(i, sl), nullptr);
+  } else if (t < 16 * npair) {
+    // ---- Y (i, j, sl): pairs by distance d = i - j, then by j
+    int d = 1, rem = (t - 8 * npair) / 8;
+    while (rem >= nblk - d) { rem -= nblk - d; ++d; }
+    const int j = rem, i = j + d;
+    ok = sn_wait(sync, sync + SI_M(i, sl), (u32)i, nullptr, 0u, s_flag_p);
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = j; k < i && ok; ++k) {
+      si_stage_A(As, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane);          // M_ik[slab]
+      if (k == j) {
+        si_stage_B(Bs, g.W + (i64)j * 128 * 128, 128, wave, lane);                                          // Y_jj = W_j
+      } else {
+        ok = sn_wait(sync, sync + SI_Y(k, j), 8u, nullptr, 0u, s_flag_p);
+        if (!ok) break;
+        si_stage_B(Bs, g.Y + (i64)k * 128 * g.ldy + (i64)j * 128, g.ldy, wave, lane);                      // Y_kj
+      }
       __syncthreads();
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
       si_mma<false>(acc, As, Bs, wave, fr, fk);
       __syncthreads();
-      si_store_tile(scratch, acc, 1.0, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane, fr, fk);
-      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this workgroup reads its own M slabs back below
-    __syncthreads();
-    for (int j = i - 1; j >= 0 && ok; --j) {
-      // (Y_i,i-1 needs no other block row; the others need the block rows j+1 .. i-1 of Y, i.e. every row above this one)
-      if (j == i - 2) {
-        for (int q = 1; q < i && ok; ++q) ok = sn_wait(sync, sync + SI_YROW(q), 8u, nullptr, 0u, s_flag_p);
-      }
-      if (!ok) break;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = j; k < i; ++k) {
-        si_stage_A(As, g.Y + ((i64)k * 128 + 16 * sl) * g.ldy + (i64)i * 128, g.ldy, wave, lane);          // M_ik[slab]
-        if (k == j) si_stage_B(Bs, g.W + (i64)j * 128 * 128, 128, wave, lane);                              // Y_jj = W_j
-        else si_stage_B(Bs, g.Y + (i64)k * 128 * g.ldy + (i64)j * 128, g.ldy, wave, lane);                  // Y_kj
-        __syncthreads();
-        si_mma<false>(acc, As, Bs, wave, fr, fk);
-        __syncthreads();
-      }
-      si_store_tile(scratch, acc, -1.0, g.Y + R * g.ldy + (i64)j * 128, g.ldy, wave, lane, fr, fk);
-      __syncthreads();
+    if (ok) {
+      si_store_tile(scratch, acc, -1.0, g.Y + ((i64)i * 128 + 16 * sl) * g.ldy + (i64)j * 128, g.ldy, wave, lane, fr, fk);
+      sn_publish(sync + SI_Y(i, j), nullptr);
     }
-    if (ok) sn_publish(sync + SI_YROW(i), sync + SI_YROW(0));          // YROW(0) counts every finished slab of stage 1
-  }
-  // ---- stage 2: slab sl of block (a, b) of K^-1
-  if (ok) ok = sn_wait(sync, sync + SI_YROW(0), (u32)(8 * (nblk - 1)), nullptr, 0u, s_flag_p);
-  if (ok) {
-    int a = 0, rem = t / 8;
+  } else if (t < 16 * npair + 8 * (npair + nblk)) {
+    // ---- K (a, b, sl)
+    int a = 0, rem = (t - 16 * npair) / 8;
     while (rem >= a + 1) { rem -= a + 1; ++a; }
-    const int b = rem, sl = t % 8;
+    const int b = rem;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    for (int i = a; i < nblk; ++i) {
+    for (int i = a; i < nblk && ok; ++i) {
+      if (i > a) ok = sn_wait(sync, sync + SI_Y(i, a), 8u, (i > b && b != a) ? sync + SI_Y(i, b) : nullptr, 8u, s_flag_p);
+      else if (b < a) ok = sn_wait(sync, sync + SI_Y(a, b), 8u, nullptr, 0u, s_flag_p);
+      if (!ok) break;
       const double* Ya = (i == a) ? g.W + (i64)a * 128 * 128 + 16 * sl : g.Y + (i64)i * 128 * g.ldy + (i64)a * 128 + 16 * sl;
       const double* Yb = (i == b) ? g.W + (i64)b * 128 * 128 : g.Y + (i64)i * 128 * g.ldy + (i64)b * 128;
       si_stage_At(As, Ya, (i == a) ? 128 : g.ldy, wave, lane);
@@ -480,18 +493,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       si_mma<true>(acc, As, Bs, wave, fr, fk);
       __syncthreads();
     }
-    si_store_tile(scratch, acc, 1.0, g.Kinv + ((i64)a * 128 + 16 * sl) * g.ldk + (i64)b * 128, g.ldk, wave, lane, fr, fk);
-    // ---- A^T = Y^T alpha: workgroup t < nblk takes block t, thread c < 128 column c
-    if (t < nblk && tid < 128) {
+    if (ok) si_store_tile(scratch, acc, 1.0, g.Kinv + ((i64)a * 128 + 16 * sl) * g.ldk + (i64)b * 128, g.ldk, wave, lane, fr, fk);
+  } else {
+    // ---- A^T = Y^T alpha, block tb: thread (c, part) sums a quarter of the rows of column c, LDS adds the quarters
+    const int tb = t - (16 * npair + 8 * (npair + nblk));
+    for (int i = tb + 1; i < nblk && ok; ++i) ok = sn_wait(sync, sync + SI_Y(i, tb), 8u, nullptr, 0u, s_flag_p);
+    if (ok) {
+      const int c = tid & 127, part = tid >> 7;
       for (int q = 0; q < g.r; ++q) {
         double sum = 0.0;
-        for (int i = t; i < nblk; ++i) {
-          const double* Yc = (i == t) ? g.W + (i64)t * 128 * 128 + tid : g.Y + (i64)i * 128 * g.ldy + (i64)t * 128 + tid;
-          const i64 ldc = (i == t) ? 128 : g.ldy;
+        for (int i = tb; i < nblk; ++i) {
+          const double* Yc = (i == tb) ? g.W + (i64)tb * 128 * 128 + c : g.Y + (i64)i * 128 * g.ldy + (i64)tb * 128 + c;
+          const i64 ldc = (i == tb) ? 128 : g.ldy;
           const double* al = g.alpha + (i64)q * g.ld_alpha + (i64)i * 128;
-          for (int m = 0; m < 128; ++m) sum = fma(Yc[(i64)m * ldc], al[m], sum);
+#pragma unroll 8
+          for (int m = 32 * part; m < 32 * part + 32; ++m) sum = fma(Yc[(i64)m * ldc], al[m], sum);
         }
-        g.At[(i64)q * g.lda + (i64)t * 128 + tid] = sum;
+        Bs[part * 128 + c] = sum;
+        __syncthreads();
+        if (part == 0) {
+          const double v = (Bs[c] + Bs[128 + c]) + (Bs[256 + c] + Bs[384 + c]);
+          g.At[(i64)q * g.lda + (i64)tb * 128 + c] = v;
+          if (g.AtT && tb * 128 + c < g.n) g.AtT[(i64)(tb * 128 + c) * g.r + q] = v;
+        }
+        __syncthreads();
       }
     }
   }
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const u32 done = __hip_atomic_fetch_add(sync + SI_YROW(9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 done = __hip_atomic_fetch_add(sync + SI_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done + 1 == gridDim.x) {
       g.res[0] = (double)sn_load(sync + SN_ABORT);
       if (sn_load(sync + SN_ABORT) == 0u) for (int w = 0; w < SN_WORDS; ++w) sync[w] = 0u;
@@ -508,20 +533,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // dK: the factor of gps_launch_small_factor; linv: its block inverses; d_alpha [r][np].  Fills dY (work), dKinv (lower blocks of
-// K^-1) and dA ([r][np]: K^-1 resid); res1 (device): abort flag.  GPS_ERR_UNSUPPORTED: not a shape for this path.
+// K^-1) and dA ([r][np]: K^-1 resid; dAT, if given: the same as [n][r]); res1 (device): abort flag.  GPS_ERR_UNSUPPORTED: not a shape for this path.
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
-                             double* dY, double* dKinv, double* dA, double* d_res1) {
+                             double* dY, double* dKinv, double* dA, double* d_res1, double* dAT, i64 n) {
   if (np % 128 || np < 128 || np > 512 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
   const int nblk = (int)(np / 128);
   SmallInvArgs a;
   a.L = dK; a.ld = np; a.W = linv; a.alpha = d_alpha; a.ld_alpha = np; a.r = (int)r;
-  a.Y = dY; a.ldy = np; a.Kinv = dKinv; a.ldk = np; a.At = dA; a.lda = np; a.nblk = nblk;
+  a.Y = dY; a.ldy = np; a.Kinv = dKinv; a.ldk = np; a.At = dA; a.lda = np; a.nblk = nblk; a.AtT = dAT; a.n = (int)n;
   a.sync = (u32*)h->dSmallSync.p + SN_WORDS; a.res = d_res1;
   const size_t lds = (size_t)SI_LDS_BYTES + 64;
   int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel), (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_GEMM, 2.0 * (double)np * np * np / 3.0, 16.0 * np * np);
-  hipLaunchKernelGGL(small_inverse_kernel, dim3(8 * nblk * (nblk + 1) / 2), dim3(NT), lds, h->stream, a);
+  const int npair = nblk * (nblk - 1) / 2;
+  const int grid = 16 * npair + 8 * (npair + nblk) + nblk;            // M, Y, K and A tasks: 180 at four blocks, all resident (one per CU)
+  if (grid > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(small_inverse_kernel, dim3(grid), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
