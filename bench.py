@@ -573,10 +573,18 @@ def main():
                     fn()
                     h.profile_enable(False)
                     launches = sum(h.profile_get(k)["launches"] for k in ("gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other"))
-                    row[what] = {"us_per_step": round(us, 1), "launches_per_step": int(launches), "steps_timed": reps}
+                    # the same through the C entry point alone (the drop-in boundary; no Python model layer around it)
+                    prog_s, resid_s = ks._program(d), msml._resid()
+                    cfn = (lambda: h.gpr_lml(prog_s, 0.1, resid_s)) if what == "lml" else (lambda: h.gpr_lml_grad(prog_s, 0.1, resid_s))
+                    cfn()
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for i in range(reps):
+                        cfn()
+                    torch.cuda.synchronize(); us_c = 1e6 * (time.perf_counter() - t1) / reps
+                    row[what] = {"us_per_step": round(us, 1), "c_entry_point_us": round(us_c, 1), "launches_per_step": int(launches), "steps_timed": reps}
                 small["n=%d" % ns_] = row
-            small["note"] = ("wall time per call through the Python API incl. the host round trip of the result; hyper-parameters "
-                             "change every step; D=%d RBF(ARD)" % d)
+            small["note"] = ("us_per_step: wall time per call through the Python API incl. the host round trip of the result, hyper-parameters "
+                             "changing every step; c_entry_point_us: gps_gpr_lml / gps_gpr_lml_grad alone; D=%d RBF(ARD)" % d)
 
         progress("gradient_and_small_n_done")
         roofline = None

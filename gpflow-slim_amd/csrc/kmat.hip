@@ -132,7 +132,18 @@ __device__ __forceinline__ ExpTab gps_exp_load() {
   return t;
 }
 __device__ __forceinline__ double gps_exp_nonpos(double x, const ExpTab& t) {        // exp(x) for x <= 0, <= 1 ulp-class error
+#ifndef GPS_EXP_LDEXP
+  // k = round(x log2 e) by adding 1.5 * 2^52: the sum's low mantissa bits ARE the integer k (two's complement), and 2^k is
+  // applied by adding k to the exponent field of the polynomial's value -- no v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64 (each
+  // a multi-cycle fp64 instruction; the kernel-matrix kernels are VALU-issue-bound).  Arguments below -708 (results below
+  // 2.2e-308, where exp() would go through the denormals) give 0.
+  const double magic = 6755399441055744.0;
+  const double kd = fma(fmax(x, -1100.0), t.c[13], magic);
+  const int ki = __double2loint(kd);
+  const double k = kd - magic;
+#else
   const double k = rint(x * t.c[13]);
+#endif
   double r = fma(-k, t.c[14], x);
   r = fma(-k, t.c[15], r);
   // Taylor to degree 13 on |r| <= ln2 / 2 (remainder 4e-18), Horner
@@ -142,7 +153,29 @@ __device__ __forceinline__ double gps_exp_nonpos(double x, const ExpTab& t) {   
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
+#ifndef GPS_EXP_LDEXP
+  const int hi = __double2hiint(p) + (ki << 20);         // p in [0.70, 1.42]: the exponent field cannot wrap for k >= -1021
+  const double v = __hiloint2double(hi, __double2loint(p));
+  return ki < -1021 ? 0.0 : v;
+#else
   return ldexp(p, (int)k);                          // k >= -1075: gradual underflow to 0 like exp()
+#endif
+}
+// sqrt(x) for x in [1e-12, huge): v_rsq_f64 and one coupled Newton step + a final correction (the library sqrt adds range
+// scaling and special cases around the same core)
+__device__ __forceinline__ double gps_sqrt_pos(double x) {
+#ifndef GPS_SQRT_LIB
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, hh = 0.5 * y;
+  const double e = fma(-hh, g, 0.5);
+  g = fma(g, e, g); hh = fma(hh, e, hh);
+  const double d = fma(-g, g, x);
+  g = fma(d, hh, g);
+  const double d2 = fma(-g, g, x);
+  return fma(d2, hh, g);
+#else
+  return sqrt(x);
+#endif
 }
 __device__ __forceinline__ double gps_exp_nonpos(double x) {        // (kernels that call it a few times only)
   const ExpTab t = gps_exp_load();
@@ -240,7 +273,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
           } else if (node.op == GPS_K_SQDIST) {
             val = node.variance * r2;                                    // kernels.py:408-421 as a callable
           } else {
-            const double r = sqrt(r2 + 1e-12);
+            const double r = gps_sqrt_pos(r2 + 1e-12);
             if (node.op == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
             else if (node.op == GPS_K_EUCLID) val = node.variance * r;    // kernels.py:424-426
             else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
@@ -336,7 +369,7 @@ __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDe
       if (OP == GPS_K_RBF) {
         val = node.variance * gps_exp_nonpos(-r2 / 2.0);
       } else {
-        const double r = sqrt(r2 + 1e-12);
+        const double r = gps_sqrt_pos(r2 + 1e-12);
         if (OP == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
         else if (OP == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
         else if (OP == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
@@ -437,7 +470,7 @@ __global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev
           if (node.op == GPS_K_RBF) {
             val = node.variance * gps_exp_nonpos(-r2 / 2.0);
           } else {
-            const double r = sqrt(r2 + 1e-12);
+            const double r = gps_sqrt_pos(r2 + 1e-12);
             if (node.op == GPS_K_MATERN12) val = node.variance * gps_exp_nonpos(-r);
             else if (node.op == GPS_K_EXPONENTIAL) val = node.variance * gps_exp_nonpos(-0.5 * r);
             else if (node.op == GPS_K_MATERN32) val = node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
@@ -498,7 +531,7 @@ __device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int o
   double r2 = -2.0 * dot + (ni + nj);                                                    // kernels.py:409-421
   r2 = on_diag ? 0.0 : fmax(r2, 0.0);
   if (o == GPS_K_RBF) return node.variance * gps_exp_nonpos(-0.5 * r2, et);
-  const double r = sqrt(r2 + 1e-12);
+  const double r = gps_sqrt_pos(r2 + 1e-12);
   if (o == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r, et);
   if (o == GPS_K_EXPONENTIAL) return node.variance * gps_exp_nonpos(-0.5 * r, et);
   if (o == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r, et);
@@ -681,7 +714,7 @@ __device__ __forceinline__ double prim_value(const KNodeDev& node, double dot, d
   double r2 = -2.0 * dot + (ni + nj);
   r2 = fmax(r2, 0.0);
   if (node.op == GPS_K_RBF) return node.variance * gps_exp_nonpos(-r2 / 2.0);
-  const double r = sqrt(r2 + 1e-12);
+  const double r = gps_sqrt_pos(r2 + 1e-12);
   if (node.op == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r);
   if (node.op == GPS_K_EXPONENTIAL) return node.variance * gps_exp_nonpos(-0.5 * r);
   if (node.op == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r);
