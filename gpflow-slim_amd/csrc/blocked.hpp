@@ -229,7 +229,7 @@ struct Blocked {
         double* Cn = A + (c + T) * lda + (c + T);      // the next block column / the remainder
         if (i + 1 < g) {
           // (the next block column was last written by the remainder update of the previous group)
-          if (pending) { rc = ops.chain_join(pending); pending = 0; if (rc) return rc; }
+          if (pending) { rc = ops.chain_join_next_gemm(pending); pending = 0; if (rc) return rc; }
           rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, Cn, lda);      // next block column
           if (rc) return rc;
           continue;

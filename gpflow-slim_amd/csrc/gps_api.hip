@@ -232,6 +232,14 @@ struct HipOps {
     if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) t = ~0ull;
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
   }
+  // the same join carried by the GEMM launched next on the chain (the caller guarantees that the next launch IS one): its
+  // workgroups wait for the ticket themselves -- one launch less between two potrf_base calls on every other step
+  int chain_join_next_gemm(unsigned long long t) {
+    if (!h->la_fused_join) return chain_join(t);
+    if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) t = ~0ull;
+    h->next_wait_ptr = la_flags() + 1; h->next_wait_val = t; h->next_wait_timeouts = la_flags() + 2;
+    return GPS_OK;
+  }
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     GPS_HIP(h, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)cols * 8, (size_t)rows, h->stream));
@@ -502,6 +510,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
+  if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
     if (value != 0 && value != 32 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32 or 64");
     h->trsm_panel_rows = (int)value; return GPS_OK;

@@ -136,6 +136,12 @@ struct gps_handle_s {
   int potrf_follower_cols = 512;               // ... in pieces of at least this many columns
   int potrf_follower = 1;                      // the parent's panel solve follows the sweep on the side stream (blocked.hpp)
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt
+  const unsigned long long* next_wait_ptr = nullptr; unsigned long long next_wait_val = 0;      // ... which first waits for this ticket
+  unsigned long long* next_wait_timeouts = nullptr;
+  // the chain's join with the side stream inside the GEMM that follows it instead of a la_wait launch of its own.  Off: measured
+  // SLOWER (N = 8192: 5.20 -> 5.29 ms, N = 32768: 180.2 -> 181.2 ms) -- the GEMM's waiting workgroups hold the slots the side
+  // stream's remainder update, which they are waiting for, needs to finish.
+  int la_fused_join = 0;
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned

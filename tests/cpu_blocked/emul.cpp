@@ -23,6 +23,7 @@ struct CpuOps {
   explicit CpuOps(i64 nblk) : linv(nblk * T * T, 0.0), linvT(nblk * T * T, 0.0) {}
 
   int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
+    if (join_armed) return -31;                 // a join handed to "the next GEMM" must be followed by one
     ++n_base;
     for (i64 j = 0; j < T; ++j) {
       double d = A[j * lda + j];
@@ -51,6 +52,7 @@ struct CpuOps {
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb,
            double* C, i64 ldc) {
     ++n_gemm;
+    join_armed = false;                         // (a pending fused join is consumed by this launch)
     if (M % T || N % T || K % 16) return -1;
     std::vector<double> out((size_t)M * N, 0.0);
     std::vector<char> done((size_t)M * N, 0);
@@ -115,6 +117,9 @@ struct CpuOps {
   int follower_publish() { if (!fol_open) return -11; ++fol_pub; return 0; }
   int follower_join() { if (open_side || fol_open || fol_pub == 0) return -12; return 0; }
   int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
+  // (the join carried by the next GEMM: that launch must follow at once)
+  bool join_armed = false;
+  int chain_join_next_gemm(unsigned long long t) { int rc = chain_join(t); join_armed = (rc == 0); return rc; }
   // forward substitution following the factorisation: sequential here; the hooks check pairing
   int y_opened = 0, y_sections = 0;
   int y_open() { if (y_opened || open_side || def_open || fol_open) return -21; y_opened = 1; ++y_sections; return 0; }
