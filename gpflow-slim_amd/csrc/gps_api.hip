@@ -510,6 +510,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
+  if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
     if (value != 0 && value != 32 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32 or 64");
@@ -911,7 +912,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
     GPS_HIP(h, h->dTmp2.ensure((size_t)n * r * 8));
     // (through a pinned slot when small: a copy from pageable memory blocks the host for its staging)
-    if ((size_t)n * r * 8 <= (1u << 20)) GPS_HIP(h, h->ring.upload(h->dTmp2.p, resid, (size_t)n * r * 8, h->stream));
+    if ((size_t)n * r * 8 <= (size_t)h->resid_ring_max) GPS_HIP(h, h->ring.upload(h->dTmp2.p, resid, (size_t)n * r * 8, h->stream));
     else GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, resid, (size_t)n * r * 8, hipMemcpyHostToDevice, h->stream));
     if (!small) {
       double* dst = aug ? dAug : h->dAlpha.d();

@@ -33,10 +33,30 @@ if [ "$what" = all ] || [ "$what" = stats ]; then
   (cd $R && python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids; GPS_PB_NO_T=1 python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids) > $OUT/potrf_base_stamps.txt || true
   [ -x $R/tools/bin/dpp_probe ] && $R/tools/bin/dpp_probe > $OUT/dpp_probe.txt 2>&1 || true
   (cd $R && GPS_SMALL_STAMPS=1 python3 tools/sn_once.py 2>&1 | grep -v amdgpu.ids | tail -16) > $OUT/small_n_stamps.txt || true
+  # timelines of one evaluation (kernel trace -> tools/eval_timeline.py): where the time of the chain and of the bulk goes
+  for n in 8192 32768; do
+    rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tl$n -- python3 $R/tools/one_eval.py $n 1 > $OUT/prof_tl$n.log 2>&1 || exit 1
+    python3 $R/tools/eval_timeline.py $(find $OUT/prof_tl$n -name "*kernel_trace.csv" | head -1) $([ $n = 8192 ] && echo 60 || echo 400) > $OUT/timeline_$n.txt || true
+  done
+  echo "timelines done"
+  # the 512-column triangular solve: one launch against launch by launch, 128 .. 262144 rows
+  (cd $R && python3 tools/trsm512.py 128 4096 16384 65536 262144 2>&1 | grep -v amdgpu.ids) > $OUT/trsm512.txt || true
+  (cd $R && python3 tools/kmat_ab.py 2>&1 | grep -v amdgpu.ids) > $OUT/kmat_ab.txt || true
+  # the bench line without a profiler around it (kernel tracing costs ~3 %)
+  (cd $R && python3 bench.py > $OUT/bench_unprofiled.log 2> $OUT/bench_unprofiled.err) || exit 1
+  echo "un-profiled bench done"
   for c in 2 4 5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg$c -- python3 $R/tools/configs.py $c > $OUT/prof_cfg$c.log 2>&1 || exit 1
     echo "cfg$c stats done"
   done
+fi
+if [ "$what" = all ] || [ "$what" = kmatpmc ]; then
+  # SQ counters of the kernel-matrix kernel of config 4 (five passes)
+  for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    n=$(echo $c | tr " " "_" | cut -c1-40)
+    GPS_LOOKAHEAD=0 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/kpmc_$n -- python3 $R/tools/kmat_once.py 16384 > $OUT/kpmc_$n.log 2>&1 || exit 1
+  done
+  echo "kmat counters done"
 fi
 if [ "$what" = all ] || [ "$what" = soak ]; then
   # long mixed run of every entry point on the final sources (summary -> gpurun_out/soak.json, copied by summarise_profiles.py)

@@ -42,8 +42,37 @@ for d, name in (("prof_bench", "bench"), ("prof_cfg2", "cfg2"), ("prof_cfg4", "c
             json.dump(j, open(os.path.join(PROF, "%s_%s.json" % (tag, name)), "w"), indent=1)
 
 
+f = os.path.join(OUT, "bench_unprofiled.log")
+if os.path.exists(f):
+    j = last_json(f)
+    if j:
+        j["kernel_source_sha"], j["commit"] = sha, commit
+        json.dump(j, open(os.path.join(PROF, "%s_bench_unprofiled.json" % tag), "w"), indent=1)
+
+# SQ counters of the config-4 kernel-matrix kernel (collect_profiles.sh kmatpmc)
+kc = {}
+for f in glob.glob(os.path.join(OUT, "kpmc_*", "**", "*counter_collection.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows if "kmat_mfma" in r["Kernel_Name"]})
+    if ids:
+        for r in rows:
+            if int(r["Dispatch_Id"]) == ids[-1]:
+                kc[r["Counter_Name"]] = float(r["Counter_Value"])
+if kc.get("SQ_INSTS_VALU") and kc.get("SQ_WAVES"):
+    aw = kc["SQ_WAVES"] * 0.5039           # lower triangle of the 256 x 256 tile grid (the other workgroups return at once)
+    json.dump({"what": "SQ counters of ONE launch of kmat_mfma_kernel<-1> (BASELINE config 4: Matern-5/2(ARD) + Periodic, N = 16384, D = 16; lower triangle), "
+                       "rocprofv3 --pmc, five passes (tools/kmat_once.py)", "counters": kc,
+               "derived": {"valu_instructions_per_active_wave": round(kc["SQ_INSTS_VALU"] / aw), "valu_instructions_per_entry": round(kc["SQ_INSTS_VALU"] / aw / 16, 1),
+                           "salu_instructions_per_active_wave": round(kc.get("SQ_INSTS_SALU", 0) / aw),
+                           "valu_issue_cycles_per_simd_at_4_per_instruction": round(kc["SQ_INSTS_VALU"] / 1024 * 4),
+                           "mfma_busy_cycles_per_simd": round(kc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024)},
+               "reading": "the build is VALU-issue-bound: ~115 VALU instructions per matrix entry (two in-line exponentials, sqrt, folds and selects) plus the fp64 MFMA "
+                          "feature products on the same double-precision pipe; see docs/LAB_NOTES.md (round 4)",
+               "kernel_source_sha": sha, "commit": commit}, open(os.path.join(PROF, "%s_kmat_cfg4_counters.json" % tag), "w"), indent=1)
+
 for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("dpp_probe.txt", "dpp_probe.txt"),
-                 ("small_n_stamps.txt", "small_n_stamps.txt")):
+                 ("small_n_stamps.txt", "small_n_stamps.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
+                 ("trsm512.txt", "trsm512.txt"), ("kmat_ab.txt", "kmat_ab.txt")):
     f = os.path.join(OUT, src)
     if os.path.exists(f):
         if src.endswith(".json"):
