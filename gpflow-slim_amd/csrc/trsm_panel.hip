@@ -11,8 +11,8 @@
 // Here a workgroup owns R = 16 RT rows of B and keeps all four 128-column blocks of them in MFMA accumulators for the whole
 // substitution (RT = 4: 128 VGPRs):
 //     for j: X_j = B_j W_j^T ;  B_i -= X_j L_ij^T  (i > j)             (backward: j = 3 .. 0, i < j, with U_ij)
-// B is read once and X written once.  Each product is [R x 128] x [128 x 128]^T on v_mfma_f64_16x16x4_f64, wave w = column
-// tile w of the 128 (so a wave needs only ITS 16 rows of the right-hand operand), RT row tiles each:
+// B is read once and X written once.  Each product is [R x 128] x [128 x 128]^T on v_mfma_f64_16x16x4_f64, one column
+// tile of the 128 per wave (so a wave needs only ITS 16 rows of the right-hand operand), RT row tiles each:
 //   * left operand (the current B_j, then X_j): accumulators -> LDS image As [R][130] (the accumulator layout is not the
 //     operand layout), read back by conflict-free ds_read_b64 -- shared by the eight waves;
 //   * right operand (rows 16 w .. of W_j / L_ij): streamed through a wave-private LDS region in two chunks of 64 k, the next
@@ -79,11 +79,11 @@ __device__ __forceinline__ void tp_product(v4d (&acc)[RT], const double* As, dou
 
 // accumulator tiles -> As (rows 16 t + fk + 4 rg, columns 16 w + fr)
 template <int RT>
-__device__ __forceinline__ void tp_to_lds(double* As, const v4d (&x)[RT], int wave, int fr, int fk) {
+__device__ __forceinline__ void tp_to_lds(double* As, const v4d (&x)[RT], int ct, int fr, int fk) {
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) As[(16 * t + fk + 4 * rg) * TP_LSA + 16 * wave + fr] = x[t][rg];
+    for (int rg = 0; rg < 4; ++rg) As[(16 * t + fk + 4 * rg) * TP_LSA + 16 * ct + fr] = x[t][rg];
 }
 
 template <int RT, bool RN>
@@ -94,12 +94,15 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   double* Bsw = As + R * TP_LSA + wave * TP_BS_WAVE;
+  // column tile of this wave: waves w and w + 4 share a SIMD, so they take the tiles w and 7 - w -- the triangular products skip
+  // 4 (7 - ct) (forward) / 4 ct (backward) of the 32 k-steps of tile ct, and every SIMD then carries the same 36
+  const int ct = (wave < 4) ? wave : 11 - wave;
   double* Brow = g.B + (i64)blockIdx.x * R * g.ldb;
 
   // the right operands in the order they are used: W_j, then the blocks L_ij still to be solved
-  auto w_rows = [&](int j) { return g.W + (i64)j * 128 * 128 + (i64)16 * wave * 128; };
+  auto w_rows = [&](int j) { return g.W + (i64)j * 128 * 128 + (i64)16 * ct * 128; };
   // forward: L_ij[c][k] = L[128 i + c][128 j + k] ; backward: U_ij[c][k] = U[128 i + c][128 j + k]  (i < j: above the diagonal)
-  auto l_rows = [&](int i, int j) { return g.L + (i64)(128 * i + 16 * wave) * g.ldl + 128 * j; };
+  auto l_rows = [&](int i, int j) { return g.L + (i64)(128 * i + 16 * ct) * g.ldl + 128 * j; };
   d2 v[8];
   tp_load_chunk(v, w_rows(RN ? 3 : 0), 128, 0, lane);
 
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) acc[i][t][rg] = Brow[(i64)(16 * t + fk + 4 * rg) * g.ldb + 128 * i + 16 * wave + fr];
+          for (int rg = 0; rg < 4; ++rg) acc[i][t][rg] = Brow[(i64)(16 * t + fk + 4 * rg) * g.ldb + 128 * i + 16 * ct + fr];
       }
     put_rows(t0);
     __syncthreads();
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int j = RN ? 3 - jj : jj;
     // B_j (updated) as left operand
     if (jj > 0) {
-      tp_to_lds<RT>(As, acc[j], wave, fr, fk);
+      tp_to_lds<RT>(As, acc[j], ct, fr, fk);
       __syncthreads();
     }
     // X_j = B_j W_j^T.  forward: W_j lower, W[c][k] = 0 for k > c: column tile w needs k <= 16 w + 15.  backward: upper, k >= 16 w.
@@ -146,10 +149,10 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       // what comes after this product: the first block still to be solved, or (last block) nothing -- any valid address
       const int i1 = RN ? j - 1 : j + 1;
       const double* nx = (jj < 3) ? l_rows(i1, j) : w_rows(j);
-      tp_product<RT, false>(x, As, Bsw, v, w_rows(j), 128, nx, (jj < 3) ? g.ldl : 128, RN ? 4 * wave : 0, RN ? 32 : 4 * (wave + 1), lane, fr, fk);
+      tp_product<RT, false>(x, As, Bsw, v, w_rows(j), 128, nx, (jj < 3) ? g.ldl : 128, RN ? 4 * ct : 0, RN ? 32 : 4 * (ct + 1), lane, fr, fk);
     }
     __syncthreads();                       // everybody has read B_j
-    tp_to_lds<RT>(As, x, wave, fr, fk);
+    tp_to_lds<RT>(As, x, ct, fr, fk);
     __syncthreads();
     // X_j is final: whole rows to HBM (wave w: rows 2 RT w ..), 1 KB per instruction
 #pragma unroll
