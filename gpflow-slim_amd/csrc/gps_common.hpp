@@ -129,6 +129,7 @@ struct gps_handle_s {
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
   int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
+  int small_fault_inject = 0;                  // diagnostics: the k-th cooperative small-N launch from now starts aborted
   int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"
   bool la_timed_out = false;                   // set by read_info when a hand-over wait gave up: the entry point re-runs without look-ahead
   long long la_retries = 0;                    // evaluations re-run that way (gps_profile_get "lookahead_retries")

@@ -312,6 +312,13 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
     GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, stamp_words * 8, h->stream));
     a.stamps = (long long*)h->dTmp3.p;
   }
+  // diagnostics ("small_fault_inject" = k): the k-th cooperative launch from now starts with its abort word set, as if one of
+  // its bounded waits had run out -- the evaluation must come back right through the launch-by-launch path
+  if (h->small_fault_inject > 0 && --h->small_fault_inject == 0) {
+    const u32 one = 1u;
+    GPS_HIP(h, hipMemcpyAsync((u32*)h->dSmallSync.p + SN_ABORT, &one, 4, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+  }
   const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
   const void* fn = reinterpret_cast<const void*>(&small_factor_kernel<16>);
   int rc0 = gps_dyn_lds(h, fn, (int)lds);
@@ -546,6 +553,11 @@ int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const dou
   int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel), (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_GEMM, 2.0 * (double)np * np * np / 3.0, 16.0 * np * np);
+  if (h->small_fault_inject > 0 && --h->small_fault_inject == 0) {
+    const u32 one = 1u;
+    GPS_HIP(h, hipMemcpyAsync((u32*)h->dSmallSync.p + SN_WORDS + SN_ABORT, &one, 4, hipMemcpyHostToDevice, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+  }
   const int npair = nblk * (nblk - 1) / 2;
   const int grid = 16 * npair + 8 * (npair + nblk) + nblk;            // M, Y, K and A tasks: 180 at four blocks, all resident (one per CU)
   if (grid > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;

@@ -446,6 +446,41 @@ def test_one_launch_factorisation_of_small_problems(handle, n, r):
     assert handle.profile_get("small_n_fallbacks")["launches"] == before
 
 
+@pytest.mark.parametrize("n", [300, 512])
+def test_small_launch_that_gives_up_is_redone_launch_by_launch(handle, n):
+    """A bounded wait of a cooperative small-N launch that runs out (injected: "small_fault_inject" = k makes the k-th such launch
+    start with its abort word set) must not surface: the evaluation comes back through the launch-by-launch path with the same
+    values, the give-up is counted, and the next evaluation takes the one-launch path again."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    d = 3
+    X, Y, _ = orc.synthetic_gpr_data(n, d, 0, seed=7 + n)
+    ls = np.linspace(0.9, 1.4, d)
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(d, variance=1.1, lengthscales=ls, ARD=True), obs_var=0.1)
+    spec = {"type": "rbf", "variance": orc.constrained(1.1), "lengthscales": orc.constrained(ls), "input_dim": d}
+    ref = orc.gpr_lml(spec, X, Y, orc.constrained(0.1))
+    lml0 = m.compute_log_likelihood()
+    lg0, grads0 = m.compute_log_likelihood_and_gradients()
+    g0 = np.concatenate([np.ravel(g) for _, g in grads0])
+    count = lambda: handle.profile_get("small_n_fallbacks")["launches"]
+    base = count()
+    # the likelihood alone: its one cooperative launch gives up
+    handle.set_option("small_fault_inject", 1)
+    assert abs(m.compute_log_likelihood() - ref) <= 1e-8 * abs(ref) and count() == base + 1
+    # likelihood + gradient: the factorisation launch gives up / the inverse launch gives up
+    for k in (1, 2):
+        handle.set_option("small_fault_inject", k)
+        lg, grads = m.compute_log_likelihood_and_gradients()
+        g = np.concatenate([np.ravel(x) for _, x in grads])
+        assert abs(lg - lg0) <= 1e-11 * abs(ref) and np.abs(g - g0).max() <= 1e-9 * max(1.0, np.abs(g0).max()), k
+    assert count() == base + 3
+    # and the fast path is back
+    handle.profile_reset()
+    assert abs(m.compute_log_likelihood() - lml0) <= 1e-13 * abs(ref)
+    assert sum(handle.profile_get(k)["launches"] for k in ("gemm_f64", "potrf_base", "kmat", "trsv", "reduce", "other")) <= 3
+    assert count() == base + 3
+
+
 def test_one_launch_factorisation_reports_not_positive_definite(handle):
     import gpflowSlim as gpf
     X = np.zeros((300, 2)); X[:, 0] = np.arange(300) % 7; Y = np.ones((300, 1))
