@@ -260,17 +260,18 @@ def primitive_node(op, variance, dims=(), lengthscales=(), period=0.0):
     nd.op = op
     nd.variance = float(variance)
     nd.period = float(period)
-    dims = list(dims)
-    if len(dims) > GPS_MAX_DIMS:
+    k = len(dims)
+    if k > GPS_MAX_DIMS:
         raise ValueError("a primitive kernel supports at most %d active dims" % GPS_MAX_DIMS)
-    nd.n_dims = len(dims)
-    for i, d in enumerate(dims):
-        nd.active_dims[i] = int(d)
-    ls = np.atleast_1d(np.asarray(lengthscales, dtype=np.float64))
-    if ls.size == 1 and len(dims) > 1:
-        ls = np.repeat(ls, len(dims))
-    for i in range(min(ls.size, GPS_MAX_DIMS)):
-        nd.lengthscales[i] = float(ls[i])
+    nd.n_dims = k
+    if k:
+        nd.active_dims[:k] = [int(d) for d in dims]      # (slice assignment: one call instead of one per element -- this runs every step)
+    ls = np.asarray(lengthscales, dtype=np.float64).ravel()
+    if ls.size == 1 and k > 1:
+        nd.lengthscales[:k] = [float(ls[0])] * k
+    elif ls.size:
+        m = min(ls.size, GPS_MAX_DIMS)
+        nd.lengthscales[:m] = ls[:m].tolist()
     return nd
 
 
