@@ -510,6 +510,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
+  if (strcmp(key, "small_kgen") == 0) { h->small_kgen = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
   if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
@@ -922,9 +923,23 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
       if (rc0) return rc0;
     }
   }
-  int rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np,
-                           np, np, /*lower_only*/ 1, /*identity_pad*/ 1);
-  if (rc) return rc;
+  // (small path, one RBF primitive: the cooperative launch generates K itself -- no kernel-matrix launches at all)
+  SmallKgen kg;
+  if (small && h->small_n >= 1 && h->small_kgen && n_nodes == 1 && prog[0].op == GPS_K_RBF && prog[0].n_dims >= 1 && prog[0].n_dims <= 16 &&
+      prog[0].variance > 0.0) {
+    kg.on = 1; kg.X = h->dX.d(); kg.d_all = (int)h->d_all; kg.nd = prog[0].n_dims; kg.variance = prog[0].variance; kg.noise = noise_var;
+    for (int d = 0; d < 16; ++d) { kg.dims[d] = 0; kg.inv_ls[d] = 0.0; }
+    for (int d = 0; d < kg.nd; ++d) {
+      kg.dims[d] = prog[0].active_dims[d]; kg.inv_ls[d] = 1.0 / prog[0].lengthscales[d];
+      if (kg.dims[d] < 0 || kg.dims[d] >= kg.d_all || !(prog[0].lengthscales[d] > 0.0)) kg.on = 0;       // (left to the ordinary build and its error text)
+    }
+  }
+  int rc = GPS_OK;
+  if (!kg.on) {
+    rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np,
+                         np, np, /*lower_only*/ 1, /*identity_pad*/ 1);
+    if (rc) return rc;
+  }
   GPS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   int* d_info = (int*)h->dInfo.p;
   if (small) {
@@ -936,7 +951,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     double* linv = h->dLinv.d();
     // (the transposed block inverses are not on the path of the likelihood: whoever needs them afterwards -- the gradient,
     // a prediction from this factor -- has them produced by one batched launch then: gpr_ensure_linvT)
-    rc = gps_launch_small_factor(h, h->dK.d(), np, linv, nullptr, h->dTmp2.d(), n, r, d_info, d_res, h->dAlpha.d(), np, r);
+    rc = gps_launch_small_factor(h, h->dK.d(), np, linv, nullptr, h->dTmp2.d(), n, r, d_info, d_res, h->dAlpha.d(), np, r, &kg);
     h->gpr_linvT_stale = true;
     if (rc == GPS_OK) {
       GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
@@ -968,7 +983,12 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
       return rc;
     }
     if (rc != GPS_ERR_UNSUPPORTED) return rc;
-    // (not a shape for that path after all: the residual still has to go where the launch-by-launch path expects it)
+    // (not a shape for that path after all: K, if the launch was to generate it, and the residual still have to go where the
+    // launch-by-launch path expects them)
+    if (kg.on) {
+      rc = gps_launch_kmat(h, prog, n_nodes, h->dX.d(), n, nullptr, n, h->d_all, noise_var, h->dK.d(), np, np, np, 1, 1);
+      if (rc) return rc;
+    }
     if (r > 0) {
       GPS_HIP(h, hipMemsetAsync(dAug, 0, (size_t)GPS_TILE * np * 8, h->stream));
       rc = gps_launch_transpose(h, h->dTmp2.d(), r, n, r, dAug, np);

@@ -129,6 +129,7 @@ struct gps_handle_s {
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
   int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
+  int small_kgen = 1;                          // the one-launch small-N path generates the kernel matrix of a single RBF primitive itself
   int small_fault_inject = 0;                  // diagnostics: the k-th cooperative small-N launch from now starts aborted
   int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"
   bool la_timed_out = false;                   // set by read_info when a hand-over wait gave up: the entry point re-runs without look-ahead
@@ -342,8 +343,10 @@ static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var,
 }
 
 // small_n.hip : the whole factorisation of a small problem as one cooperative launch
+// the kernel matrix generated inside the launch (one RBF primitive, at most 16 active dims): no kernel-matrix launches at all
+struct SmallKgen { int on = 0; const double* X = nullptr; int d_all = 0; int nd = 0; int dims[16]; double inv_ls[16]; double variance = 0.0, noise = 0.0; };
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
-                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows);
+                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen = nullptr);
 int gps_small_factor_reset(gps_handle_t h);
 // trsm_panel.hip
 int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);

@@ -45,6 +45,7 @@ struct SmallArgs {
   u32* sync;                     // SN_WORDS words, zero on entry
   double* res;                   // [0] sum log L_ii  [1] sum alpha^2  [2] info  [3] abort
   double* alpha; i64 ld_alpha; int alpha_rows;   // optional second home of alpha^T: [alpha_rows][ld_alpha]
+  SmallKgen kg;                  // kg.on: K is not in memory yet -- every pair generates its tile first (and block row 0 gets pairs for that)
   long long* stamps;             // diagnostics (GPS_SMALL_STAMPS): 100 MHz wall-clock stamps of the chain [0..63] and of the pairs of the first slab of each block row
 };
 
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
     SN_STAMP(0);
     for (int j = 0; j < nblk && ok; ++j) {
-      if (j > 0) ok = sn_wait(sync, sync + SN_D(j), (u32)(spb * j), nullptr, 0u, s_flag_p);
+      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
+      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
       if (!ok) break;
       SN_STAMP(1 + 3 * j);
       potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   // ------------------------------------------------------------------ a pair (row slab, block column)
   int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
-  for (int i = 1; i <= nblk && bi < 0; ++i) {
+  for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
     const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
     if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
   }
@@ -250,6 +252,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const i64 pt = (i64)k * 128 + c, out = (i64)sl * SH + q;
       C[(i64)q * ld + c] = (out < g.r && pt < g.n) ? g.resid[pt * g.r + out] : 0.0;
     }
+    __syncthreads();
+  }
+  if (!aug && g.kg.on) {
+    // this pair's tile of K + noise I (identity padded), kernels.py:436-439 with r2 = sum_d ((x_id - x_jd) / l_d)^2 (exactly 0 on
+    // the diagonal); thread: one column, four rows.  Block (0, 0) goes to the chain on another CU: write-through stores.
+    const SmallKgen& kg = g.kg;
+    const int c = tid & 127;
+    const i64 pj = (i64)k * 128 + c;
+    double xj[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) xj[d] = (d < kg.nd && pj < g.n) ? kg.X[pj * kg.d_all + kg.dims[d]] * kg.inv_ls[d] : 0.0;
+    for (int q = 0; q < SH * 128 / NT; ++q) {
+      const int row = (tid >> 7) + (NT >> 7) * q;
+      const i64 pi = r0 + row;
+      double v;
+      if (pi >= g.n || pj >= g.n) v = (pi == pj) ? 1.0 : 0.0;
+      else {
+        double r2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+          if (d < kg.nd) { const double dl = kg.X[pi * kg.d_all + kg.dims[d]] * kg.inv_ls[d] - xj[d]; r2 = fma(dl, dl, r2); }
+        v = (pi == pj) ? kg.variance + kg.noise : kg.variance * exp(-0.5 * r2);
+      }
+      sn_store(&C[(i64)row * ld + c], v);
+    }
+    if (bi == 0) { sn_publish(sync + SN_D(0), nullptr); return; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   const u32 my_slabs = (u32)(aug ? aug_slabs : spb);
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // augmented rows alpha^T, linv / linvT the block inverses, res4 (host) = {sum log L_ii, sum alpha^2, info, abort}.
 // GPS_ERR_UNSUPPORTED: not a shape for this path (the caller takes the launch-by-launch one).
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
-                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows) {
+                            int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen) {
   // (up to 512 padded rows in slabs of 16: 85 workgroups at most, so that two such launches of one process still fit the GPU side by side)
   if (np % 128 || np < 128 || np > 512 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
   if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
@@ -293,7 +322,8 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   const int SH = 16;
   const int spb = 128 / SH, aug_slabs = (int)((r + SH - 1) / SH);
   int pairs = 0;
-  for (int i = 1; i < nblk; ++i) pairs += spb * (i + 1);
+  const bool kg_on = kgen && kgen->on;
+  for (int i = kg_on ? 0 : 1; i < nblk; ++i) pairs += spb * (i + 1);
   pairs += aug_slabs * nblk;
   if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
   if (!h->dSmallSync.p) {
@@ -304,6 +334,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   a.K = dK; a.ld = np; a.Linv = linv; a.LinvT = linvT; a.resid = d_resid; a.n = (int)n; a.r = (int)r; a.nblk = nblk;
   a.info = d_info; a.sync = (u32*)h->dSmallSync.p; a.res = d_res4;
   a.alpha = d_alpha; a.ld_alpha = ld_alpha; a.alpha_rows = (int)alpha_rows;
+  if (kg_on) a.kg = *kgen; else a.kg.on = 0;
   a.stamps = nullptr;
   static const bool want_stamps = getenv("GPS_SMALL_STAMPS") != nullptr;
   const size_t stamp_words = 64 + 9 * 8 * 24;
