@@ -352,7 +352,7 @@ static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
+                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
   if (all) { h->dInfo.release(); h->dScal.release(); h->dWaveCtl.release(); }      // (allocated by gps_create; every reduction writes there)
@@ -923,11 +923,12 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
       if (rc0) return rc0;
     }
   }
-  // (small path, one RBF primitive: the cooperative launch generates K itself -- no kernel-matrix launches at all)
+  // (small path, one stationary primitive: the cooperative launch generates K itself -- no kernel-matrix launches at all)
   SmallKgen kg;
-  if (small && h->small_n >= 1 && h->small_kgen && n_nodes == 1 && prog[0].op == GPS_K_RBF && prog[0].n_dims >= 1 && prog[0].n_dims <= 16 &&
-      prog[0].variance > 0.0) {
-    kg.on = 1; kg.X = h->dX.d(); kg.d_all = (int)h->d_all; kg.nd = prog[0].n_dims; kg.variance = prog[0].variance; kg.noise = noise_var;
+  const int op0 = n_nodes == 1 ? prog[0].op : -1;
+  if (small && h->small_n >= 1 && h->small_kgen && (op0 == GPS_K_RBF || op0 == GPS_K_MATERN12 || op0 == GPS_K_MATERN32 || op0 == GPS_K_MATERN52 ||
+      op0 == GPS_K_EXPONENTIAL) && prog[0].n_dims >= 1 && prog[0].n_dims <= 16 && prog[0].variance > 0.0) {
+    kg.on = 1; kg.op = op0; kg.X = h->dX.d(); kg.d_all = (int)h->d_all; kg.nd = prog[0].n_dims; kg.variance = prog[0].variance; kg.noise = noise_var;
     for (int d = 0; d < 16; ++d) { kg.dims[d] = 0; kg.inv_ls[d] = 0.0; }
     for (int d = 0; d < kg.nd; ++d) {
       kg.dims[d] = prog[0].active_dims[d]; kg.inv_ls[d] = 1.0 / prog[0].lengthscales[d];
@@ -1093,6 +1094,7 @@ static int gpr_small_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int 
   rc = gps_launch_small_inverse(h, h->dK.d(), np, h->dLinv.d(), h->dAlpha.d(), r, h->dY.d(), h->dKinv.d(), h->dA.d(), d_res + 4,
                                 kinv_resid ? d_kr : nullptr, n);
   if (rc) return rc;                   // (the factorisation took this shape: so does the inverse)
+  // (launching the gradient kernel's features in front of the factorisation instead -- gps_grad_prepare -- was measured: no gain)
   GradPost post;
   rc = gps_grad_enqueue(h, prog, n_nodes, h->dX.d(), n, h->d_all, np, h->dKinv.d(), np, h->dA.d(), np, r, d_res + 5, &post);
   if (rc) return rc;
@@ -2748,7 +2750,7 @@ extern "C" int gps_device_bytes(gps_handle_t h, int64_t* bytes) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
                     &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
-                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
+                    &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dInfo, &h->dScal, &h->dWaveCtl, &h->dLaFlags,
                     &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   int64_t tot = 0;
   for (DevBuf* b : bufs) tot += (int64_t)b->cap;

@@ -234,6 +234,7 @@ struct gps_handle_s {
   int trsm_panel = 1;         // 512-column triangular solves as one launch (trsm_panel.hip); 0: down to 128 columns launch by launch
   int trsm_panel_rows = 0;    // rows per workgroup of that launch: 64, 32, or 0 = by the number of rows
   DevBuf dSmallOut;           // everything a small-N likelihood + gradient hands back, contiguous (one copy)
+  DevBuf dFeatG;              // features of the gradient kernel (its own buffer: they may be prepared before the kernel matrix is built)
   DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
@@ -343,8 +344,8 @@ static inline bool gps_gpr_needs_refine(const gps_handle_s* h, double noise_var,
 }
 
 // small_n.hip : the whole factorisation of a small problem as one cooperative launch
-// the kernel matrix generated inside the launch (one RBF primitive, at most 16 active dims): no kernel-matrix launches at all
-struct SmallKgen { int on = 0; const double* X = nullptr; int d_all = 0; int nd = 0; int dims[16]; double inv_ls[16]; double variance = 0.0, noise = 0.0; };
+// the kernel matrix generated inside the launch (one stationary primitive -- RBF, Matern-1/2, -3/2, -5/2, Exponential --, at most 16 active dims): no kernel-matrix launches at all
+struct SmallKgen { int on = 0; int op = 0; const double* X = nullptr; int d_all = 0; int nd = 0; int dims[16]; double inv_ls[16]; double variance = 0.0, noise = 0.0; };
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen = nullptr);
 int gps_small_factor_reset(gps_handle_t h);
@@ -414,7 +415,10 @@ int gps_launch_grad(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, co
 // the same in two halves, for callers that read several results back with ONE synchronisation (gps_gpr_lml_grad, small N)
 #define GPS_GRAD_SUMS 161
 #define GPS_HRES_BYTES (192 * 1024)
-struct GradPost { int n_slots = 0; std::vector<double> ls_of_slot; };
+struct GradPost { int n_slots = 0, nfeat = 0; std::vector<double> ls_of_slot; std::vector<char> blob; };   // blob: the device program (grad.hip)
+int gps_grad_prepare(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n, i64 d_all, i64 npad, GradPost* post);
+int gps_grad_run(gps_handle_t h, const GradPost& post, i64 n, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                 double* d_sums);
 bool gps_grad_is_simple(const gps_kern_node_t* prog, int n_nodes);
 int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
                      i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,

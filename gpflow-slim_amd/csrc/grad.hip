@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void grad_kernel(GArgs a, GProg P) {
 // ---- host side ------------------------------------------------------------------------------------
 #define GRAD_BLOCKS 2048
 
-// the per-workgroup partial sums of one slot -> one number, in a fixed order (block s of the launch = slot s; the last = noise)
+// the per-workgroup partial sums of one slot -> one number, in a fixed order (block s of the launch = slot s; the last = noise).
+// (Folding this into grad_kernel -- the workgroup that arrives last reduces -- was measured slower: one workgroup walking
+// 161 x nblocks partial sums takes longer than this launch costs: N = 512: +19 us, N = 2048: +150 us.)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ partial, int nblocks, int n_slots, double* __restrict__ out) {
   __shared__ double red[256];
   const int s = ((int)blockIdx.x < n_slots) ? (int)blockIdx.x : G_MAXSLOT;
@@ -391,14 +393,14 @@ int gps_grad_slots(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, int
 
 bool gps_grad_is_simple(const gps_kern_node_t* prog, int n_nodes) { return !grad_needs_general(prog, n_nodes); }
 
-// Everything of the gradient that runs on the device, without a synchronisation: feature table (pinned ring), features,
-// the tile sums, their reduction into d_sums[GPS_GRAD_SUMS] (slot s at [s], noise at [G_MAXSLOT]).  post: what the host
-// still has to do with the sums once it has them (gps_grad_finish).
-int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
-                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
-                     double* d_sums, GradPost* post) {
+// post: the analysed program, and what the host still has to do with the sums once it has them (gps_grad_finish).
+// The gradient in two halves for callers that want the features early (gps_gpr_lml_grad at small N launches gps_grad_prepare in
+// front of the factorisation, where it is off the chain): prepare = program analysis + feature launch (into dFeatG), run = the
+// tile sums and their reduction into d_sums[GPS_GRAD_SUMS] (slot s at [s], noise at [G_MAXSLOT]).  No synchronisation in either.
+int gps_grad_prepare(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n, i64 d_all, i64 npad, GradPost* post) {
   static_assert(GPS_GRAD_SUMS == G_MAXSLOT + 1, "GPS_GRAD_SUMS");
-  GProg P;
+  post->blob.resize(sizeof(GProg));
+  GProg& P = *reinterpret_cast<GProg*>(post->blob.data());
   std::vector<GPrepFeat> feats;
   std::vector<double>& ls_of_slot = post->ls_of_slot;          // lengthscale that divides a per-dim slot
   ls_of_slot.clear();
@@ -444,24 +446,32 @@ int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, c
 
   const int nfeat = (int)feats.size();
   if (nfeat > 0) {
-    GPS_HIP(h, h->dFeat.ensure((size_t)nfeat * npad * 8));
+    GPS_HIP(h, h->dFeatG.ensure((size_t)nfeat * npad * 8));
     LaunchScope ls(h, KC_KMAT, 0.0, 8.0 * (double)npad * nfeat);
     if (nfeat <= GPREP_SMALL_F) {
       GPrepTabVal tab;
       memset(&tab, 0, sizeof(tab));
       for (int f = 0; f < nfeat; ++f) tab.f[f] = feats[f];
       hipLaunchKernelGGL(gprep_args_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad, tab,
-                         nfeat, h->dFeat.d(), npad);
+                         nfeat, h->dFeatG.d(), npad);
     } else {
       GPS_HIP(h, h->dProg.ensure((size_t)nfeat * sizeof(GPrepFeat) + 64));
       GPS_HIP(h, h->ring.upload(h->dProg.p, feats.data(), (size_t)nfeat * sizeof(GPrepFeat), h->stream));
       hipLaunchKernelGGL(gprep_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, dX, n, d_all, npad,
-                         (const GPrepFeat*)h->dProg.p, nfeat, h->dFeat.d(), npad);
+                         (const GPrepFeat*)h->dProg.p, nfeat, h->dFeatG.d(), npad);
     }
     GPS_HIP(h, hipGetLastError());
   }
+  post->n_slots = P.n_slots; post->nfeat = nfeat;
+  return GPS_OK;
+}
+
+int gps_grad_run(gps_handle_t h, const GradPost& post, i64 n, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                 double* d_sums) {
+  const GProg& P = *reinterpret_cast<const GProg*>(post.blob.data());
+  const int nfeat = post.nfeat;
   GArgs a;
-  a.Ft = h->dFeat.d(); a.ldf = npad; a.Kinv = dKinv; a.ldk = ldk; a.A = dA; a.lda = lda; a.r = (int)r;
+  a.Ft = h->dFeatG.d(); a.ldf = npad; a.Kinv = dKinv; a.ldk = ldk; a.A = dA; a.lda = lda; a.r = (int)r;
   a.n = n; a.npad = npad; a.tiles_r = (int)(npad / GT_R); a.tiles_c = (int)(npad / GT_C);
   const i64 ntiles = (i64)a.tiles_r * a.tiles_c;
   const int nblocks = (int)(ntiles < GRAD_BLOCKS ? ntiles : GRAD_BLOCKS);
@@ -479,8 +489,15 @@ int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, c
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(P.n_slots + 1), dim3(256), 0, h->stream, a.partial, nblocks, P.n_slots, d_sums);
     GPS_HIP(h, hipGetLastError());
   }
-  post->n_slots = P.n_slots;
   return GPS_OK;
+}
+
+int gps_grad_enqueue(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, const double* dX, i64 n,
+                     i64 d_all, i64 npad, const double* dKinv, i64 ldk, const double* dA, i64 lda, i64 r,
+                     double* d_sums, GradPost* post) {
+  int rc = gps_grad_prepare(h, prog, n_nodes, dX, n, d_all, npad, post);
+  if (rc) return rc;
+  return gps_grad_run(h, *post, n, npad, dKinv, ldk, dA, lda, r, d_sums);
 }
 
 void gps_grad_finish(const GradPost& post, const double* sums, double* grad_slots_host, double* grad_noise_host) {

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
   }
   if (!aug && g.kg.on) {
-    // this pair's tile of K + noise I (identity padded), kernels.py:436-439 with r2 = sum_d ((x_id - x_jd) / l_d)^2 (exactly 0 on
+    // this pair's tile of K + noise I (identity padded), one stationary primitive with r2 = sum_d ((x_id - x_jd) / l_d)^2 (exactly 0 on
     // the diagonal); thread: one column, four rows.  Block (0, 0) goes to the chain on another CU: write-through stores.
     const SmallKgen& kg = g.kg;
     const int c = tid & 127;
@@ -273,7 +273,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int d = 0; d < 16; ++d)
           if (d < kg.nd) { const double dl = kg.X[pi * kg.d_all + kg.dims[d]] * kg.inv_ls[d] - xj[d]; r2 = fma(dl, dl, r2); }
-        v = (pi == pj) ? kg.variance + kg.noise : kg.variance * exp(-0.5 * r2);
+        // kernels.py:436-439 (RBF), 557-610 (Matern family, Exponential: r = sqrt(r2 + 1e-12), also on the diagonal)
+        const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
+        if (pi == pj) r2 = 0.0;
+        if (kg.op == GPS_K_RBF) v = kg.variance * exp(-0.5 * r2);
+        else {
+          const double rr = sqrt(r2 + 1e-12);
+          if (kg.op == GPS_K_MATERN12) v = kg.variance * exp(-rr);
+          else if (kg.op == GPS_K_EXPONENTIAL) v = kg.variance * exp(-0.5 * rr);
+          else if (kg.op == GPS_K_MATERN32) v = kg.variance * (1.0 + sq3 * rr) * exp(-sq3 * rr);
+          else v = kg.variance * (1.0 + sq5 * rr + 5.0 / 3.0 * (rr * rr)) * exp(-sq5 * rr);
+        }
+        if (pi == pj) v += kg.noise;
       }
       sn_store(&C[(i64)row * ld + c], v);
     }
