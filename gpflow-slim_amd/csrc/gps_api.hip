@@ -511,6 +511,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
   if (strcmp(key, "small_kgen") == 0) { h->small_kgen = (int)value; return GPS_OK; }
+  if (strcmp(key, "small_n_max") == 0) { h->small_n_max = (i64)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
   if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
@@ -908,7 +909,10 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // reductions of the likelihood as ONE cooperative launch (small_n.hip) -- three launches per evaluation with the two of the
   // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
   h->small_valid = false;
-  const bool small = h->small_n > 0 && aug && np <= 512 && r <= 16 && !h->refine_now && h->prop.multiProcessorCount >= 160;
+  // (up to 512 padded points with the gradient's second launch; up to small_n_max -- 896: seven blocks, 232 workgroups -- for
+  // the factorisation launch alone)
+  const bool small = h->small_n > 0 && aug && np <= (h->small_defer ? 512 : h->small_n_max) && r <= 16 && !h->refine_now &&
+                     h->prop.multiProcessorCount >= 160;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
@@ -1138,7 +1142,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   int linfo = 0;
   // Small problems (the reference's own size: examples/gpr.py): factorisation, inverse and gradient sums are enqueued
   // back to back -- six launches -- and everything the host needs comes back in one pinned copy behind ONE synchronisation.
-  h->small_defer = h->small_n > 0 && r <= 16 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)(5 + GPS_GRAD_SUMS + h->n * r) * 8 <= GPS_HRES_BYTES);
+  h->small_defer = h->small_n > 0 && r <= 16 && h->npad <= 512 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)(5 + GPS_GRAD_SUMS + h->n * r) * 8 <= GPS_HRES_BYTES);
   h->small_pending = false;
   rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
   h->small_defer = false;

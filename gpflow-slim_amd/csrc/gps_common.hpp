@@ -129,6 +129,7 @@ struct gps_handle_s {
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
   int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
+  i64 small_n_max = 896;                       // padded points up to which the factorisation is one cooperative launch
   int small_kgen = 1;                          // the one-launch small-N path generates the kernel matrix of a single RBF primitive itself
   int small_fault_inject = 0;                  // diagnostics: the k-th cooperative small-N launch from now starts aborted
   int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"

@@ -326,8 +326,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // GPS_ERR_UNSUPPORTED: not a shape for this path (the caller takes the launch-by-launch one).
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen) {
-  // (up to 512 padded rows in slabs of 16: 85 workgroups at most, so that two such launches of one process still fit the GPU side by side)
-  if (np % 128 || np < 128 || np > 512 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
+  // (up to 512 padded rows in slabs of 16: 93 workgroups at most, several such launches fit the GPU side by side; up to 896: 232,
+  // the whole GPU -- the workgroup count is checked against the CU count below)
+  if (np % 128 || np < 128 || np > 896 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
   if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
   const int nblk = (int)(np / 128);
   const int SH = 16;

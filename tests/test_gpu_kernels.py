@@ -409,9 +409,9 @@ def test_kernel_matrix_chain_kernel_equals_interpreter(handle, n, m):
         assert np.abs(out[1] - out[0]).max() <= 4e-15 * np.abs(out[0]).max()
 
 
-@pytest.mark.parametrize("n,r", [(1, 1), (2, 1), (50, 1), (128, 2), (129, 1), (300, 3), (455, 1), (512, 1), (640, 2), (768, 1)])
+@pytest.mark.parametrize("n,r", [(1, 1), (2, 1), (50, 1), (128, 2), (129, 1), (300, 3), (455, 1), (512, 1), (640, 2), (768, 1), (896, 1), (1000, 1)])
 def test_one_launch_factorisation_of_small_problems(handle, n, r):
-    """Problems of up to 512 padded rows (the reference's own example is N ~ 455, examples/gpr.py:36) are factored by ONE
+    """Problems of up to 896 padded rows (the reference's own example is N ~ 455, examples/gpr.py:36) are factored by ONE
     cooperative launch (csrc/small_n.hip): chain workgroup + slab workgroups, hand-overs through counters.  Same likelihood,
     predictions and gradient as the launch-by-launch path and as the oracle; three launches per evaluation; no fall-back."""
     import gpflowSlim as gpf
@@ -437,8 +437,8 @@ def test_one_launch_factorisation_of_small_problems(handle, n, r):
     handle.set_option("small_n", 1)
     one, many = res[1], res[0]
     assert abs(one[0] - ref) <= 1e-8 * abs(ref) and abs(one[0] - many[0]) <= 1e-11 * abs(ref)
-    if n <= 512:
-        assert one[5] <= 3 and (many[5] > one[5] or n <= 128), (one[5], many[5])          # kmat prep + kmat + the factorisation
+    if n <= 896:
+        assert one[5] <= 3 and (many[5] > one[5] or n <= 128), (one[5], many[5])          # the factorisation launch (+ kmat prep + kmat for programs it does not generate itself)
     rmu, rvar = orc.gpr_predict(spec, X, Y, orc.constrained(0.1), Xs)
     assert np.abs(one[1] - rmu).max() <= 1e-8 * max(1.0, np.abs(rmu).max()) and np.abs(one[2] - rvar).max() <= 1e-8 * np.abs(rvar).max()
     assert np.abs(one[1] - many[1]).max() <= 1e-10 * max(1.0, np.abs(rmu).max())
