@@ -35,6 +35,7 @@ typedef unsigned int u32;
 #define SN_ADONE ((16 + 72) * SN_LINE)                       // solves of the augmented rows
 #define SN_ABORT ((16 + 72 + 1) * SN_LINE)
 #define SN_WORDS ((16 + 72 + 2) * SN_LINE)
+#define SN_INV_WORDS (162 * SN_LINE)                         // the inverse launch's counters (SI_*, below)
 
 struct SmallArgs {
   double* K; i64 ld;             // [np + aug rows][ld]: K + noise (lower, identity padded), then the augmented rows
@@ -339,8 +340,8 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   pairs += aug_slabs * nblk;
   if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
   if (!h->dSmallSync.p) {
-    GPS_HIP(h, h->dSmallSync.ensure((size_t)SN_WORDS * 4 * 2));                 // second half: the inverse launch (below)
-    GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4 * 2, h->stream));
+    GPS_HIP(h, h->dSmallSync.ensure((size_t)(SN_WORDS + SN_INV_WORDS) * 4));    // behind the first SN_WORDS: the inverse launch (below)
+    GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)(SN_WORDS + SN_INV_WORDS) * 4, h->stream));
   }
   SmallArgs a;
   a.K = dK; a.ld = np; a.Linv = linv; a.LinvT = linvT; a.resid = d_resid; a.n = (int)n; a.r = (int)r; a.nblk = nblk;
@@ -392,7 +393,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
 
 // after an aborted launch the counters are in an unknown state
 int gps_small_factor_reset(gps_handle_t h) {
-  if (h->dSmallSync.p) GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)SN_WORDS * 4 * 2, h->stream));
+  if (h->dSmallSync.p) GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)(SN_WORDS + SN_INV_WORDS) * 4, h->stream));
   return GPS_OK;
 }
 
@@ -470,9 +471,14 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
 //   A (t)                    : block t of (Y^T alpha)^T
 // Chain of dependent products at four blocks: M -> Y_10 -> Y_20 -> Y_30 -> K_00: five, against the nine plus four of a
 // workgroup that walks a whole slab of Y by itself.
-#define SI_M(i, sl) (((i) * 8 + (sl)) * SN_LINE)           // [4][8]
-#define SI_Y(i, j) ((32 + (i) * 4 + (j)) * SN_LINE)        // [4][4]
-#define SI_DONE (48 * SN_LINE)
+// The tasks are drawn from a queue in that order by however many workgroups are resident (a task only waits for tasks drawn
+// before it, and whoever has drawn a task is running: no co-residency assumption at all).
+#define SI_M(i, sl) (((i) * 8 + (sl)) * SN_LINE)           // [8][8]     (line 89 is sn_wait's abort word: SN_ABORT)
+#define SI_Y(i, j) ((96 + (i) * 8 + (j)) * SN_LINE)        // [8][8]
+#define SI_QUEUE (160 * SN_LINE)
+#define SI_DONE (161 * SN_LINE)
+#define SI_WORDS (162 * SN_LINE)
+template <bool QUEUED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_inverse_kernel(SmallInvArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Bs = reinterpret_cast<double*>(smem_raw);
@@ -484,7 +490,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   u32* sync = g.sync;                       // (sn_wait looks for the abort word at sync + SN_ABORT)
   double* scratch = As + 16 * SI_LSA * wave;          // per-wave 16 x 16 staging for the stores: inside the A region, used only between products
   bool ok = true;
+  const int ntasks = 16 * npair + 8 * (npair + nblk) + nblk;
+  // (QUEUED = false: as many workgroups as tasks -- up to four blocks --, workgroup t is task t, nothing to draw.  A template
+  // parameter: as a run-time flag the loop around the tasks cost the straight-line form 11 us of its 38)
+  constexpr bool queued = QUEUED;
+  for (int round = 0;; ++round) {
   int t = (int)blockIdx.x;
+  if (queued) {
+    __syncthreads();                        // (the previous task's use of the LDS is over)
+    if (tid == 0) s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + SI_QUEUE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    t = s_flag_p[1];
+  } else if (round > 0) break;
+  if (t >= ntasks || !ok) break;
   const int sl = t % 8;
 
   if (t < 8 * npair) {
@@ -570,30 +588,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     }
   }
+  }   // task loop
   // ---- the last workgroup to finish leaves the counters zero for the next call and reports
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     const u32 done = __hip_atomic_fetch_add(sync + SI_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
     if (done + 1 == gridDim.x) {
-      g.res[0] = (double)sn_load(sync + SN_ABORT);
-      if (sn_load(sync + SN_ABORT) == 0u) for (int w = 0; w < SN_WORDS; ++w) sync[w] = 0u;
+      const u32 ab = sn_load(sync + SN_ABORT);
+      g.res[0] = (double)ab;
+      last = (ab == 0u) ? 1 : 0;
     }
+    s_flag_p[1] = last;
   }
+  __syncthreads();
+  if (s_flag_p[1]) for (int w = tid; w < SI_WORDS; w += NT) sync[w] = 0u;
 }
 
 // dK: the factor of gps_launch_small_factor; linv: its block inverses; d_alpha [r][np].  Fills dY (work), dKinv (lower blocks of
 // K^-1) and dA ([r][np]: K^-1 resid; dAT, if given: the same as [n][r]); res1 (device): abort flag.  GPS_ERR_UNSUPPORTED: not a shape for this path.
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
                              double* dY, double* dKinv, double* dA, double* d_res1, double* dAT, i64 n) {
-  if (np % 128 || np < 128 || np > 512 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
+  if (np % 128 || np < 128 || np > 896 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
   const int nblk = (int)(np / 128);
   SmallInvArgs a;
   a.L = dK; a.ld = np; a.W = linv; a.alpha = d_alpha; a.ld_alpha = np; a.r = (int)r;
   a.Y = dY; a.ldy = np; a.Kinv = dKinv; a.ldk = np; a.At = dA; a.lda = np; a.nblk = nblk; a.AtT = dAT; a.n = (int)n;
   a.sync = (u32*)h->dSmallSync.p + SN_WORDS; a.res = d_res1;
   const size_t lds = (size_t)SI_LDS_BYTES + 64;
-  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel), (int)lds);
+  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel<false>), (int)lds);
+  if (!rc0) rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_inverse_kernel<true>), (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_GEMM, 2.0 * (double)np * np * np / 3.0, 16.0 * np * np);
   if (h->small_fault_inject > 0 && --h->small_fault_inject == 0) {
@@ -602,9 +627,11 @@ int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const dou
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   const int npair = nblk * (nblk - 1) / 2;
-  const int grid = 16 * npair + 8 * (npair + nblk) + nblk;            // M, Y, K and A tasks: 180 at four blocks, all resident (one per CU)
-  if (grid > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(small_inverse_kernel, dim3(grid), dim3(NT), lds, h->stream, a);
+  const int ntasks = 16 * npair + 8 * (npair + nblk) + nblk;          // M, Y, K and A tasks: 180 at four blocks, 567 at seven
+  const int slots = h->prop.multiProcessorCount - 8;                  // one workgroup per CU (LDS); a few CUs left to whatever else runs
+  const int grid = ntasks < slots ? ntasks : slots;
+  if (grid == ntasks) hipLaunchKernelGGL(small_inverse_kernel<false>, dim3(grid), dim3(NT), lds, h->stream, a);
+  else hipLaunchKernelGGL(small_inverse_kernel<true>, dim3(grid), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

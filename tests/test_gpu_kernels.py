@@ -446,7 +446,7 @@ def test_one_launch_factorisation_of_small_problems(handle, n, r):
     assert handle.profile_get("small_n_fallbacks")["launches"] == before
 
 
-@pytest.mark.parametrize("n", [300, 512])
+@pytest.mark.parametrize("n", [300, 512, 768])
 def test_small_launch_that_gives_up_is_redone_launch_by_launch(handle, n):
     """A bounded wait of a cooperative small-N launch that runs out (injected: "small_fault_inject" = k makes the k-th such launch
     start with its abort word set) must not surface: the evaluation comes back through the launch-by-launch path with the same
