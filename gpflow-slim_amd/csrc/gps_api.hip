@@ -909,8 +909,8 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // reductions of the likelihood as ONE cooperative launch (small_n.hip) -- three launches per evaluation with the two of the
   // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
   h->small_valid = false;
-  // (up to small_n_max padded points; above seven blocks the launch draws its pairs from a queue)
-  const bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 4096 && r <= 16 && !h->refine_now &&
+  // (up to small_n_max -- 896 padded points: seven blocks, 232 workgroups)
+  const bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 896 && r <= 16 && !h->refine_now &&
                      h->prop.multiProcessorCount >= 160;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {

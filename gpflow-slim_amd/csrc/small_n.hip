@@ -29,16 +29,13 @@ typedef unsigned int u32;
 
 // sync words (u32), each counter on a 64-byte line of its own
 #define SN_LINE 16
-#define SN_MAXB 32                                           // block rows / columns the counters are laid out for (4096 padded points)
-#define SN_ABORT 0                                           // (first: sn_wait looks for it at this offset of whichever region it is given)
-#define SN_ADONE (1 * SN_LINE)                               // solves of the augmented rows
-#define SN_QUEUE (2 * SN_LINE)                               // next task (queued form)
-#define SN_F(j) ((3 + (j)) * SN_LINE)                        // [32]  block j factored and inverted
-#define SN_D(j) ((3 + SN_MAXB + (j)) * SN_LINE)              // [32]  update pieces applied to diagonal block j
-#define SN_XB(i, j) ((3 + 2 * SN_MAXB + (i) * SN_MAXB + (j)) * SN_LINE)   // [33][32] slabs of block row i (32 = the augmented rows) solved against panel j
-#define SN_WORDS ((3 + 2 * SN_MAXB + (SN_MAXB + 1) * SN_MAXB) * SN_LINE)
-#define SN_USED_WORDS(nblk) ((3 + 2 * SN_MAXB + ((nblk) + 1) * SN_MAXB) * SN_LINE)   // (the augmented rows are block row nblk)
-#define SN_INV_WORDS (131 * SN_LINE)                         // the inverse launch's counters (SI_*, below)
+#define SN_F(j) ((j) * SN_LINE)                              // [8]   block j factored and inverted
+#define SN_D(j) ((8 + (j)) * SN_LINE)                        // [8]   update pieces applied to diagonal block j
+#define SN_XB(i, j) ((16 + (i) * 8 + (j)) * SN_LINE)         // [9][8] slabs of block row i (8 = the augmented rows) solved against panel j
+#define SN_ADONE ((16 + 72) * SN_LINE)                       // solves of the augmented rows
+#define SN_ABORT ((16 + 72 + 1) * SN_LINE)
+#define SN_WORDS ((16 + 72 + 2) * SN_LINE)
+#define SN_INV_WORDS (162 * SN_LINE)                         // the inverse launch's counters (SI_*, below)
 
 struct SmallArgs {
   double* K; i64 ld;             // [np + aug rows][ld]: K + noise (lower, identity padded), then the augmented rows
@@ -175,15 +172,77 @@ __device__ __forceinline__ void sn_product(SnOwn<SH, SOLVE>& o, char* smem, cons
   __syncthreads();                                               // (the LDS regions are free again)
 }
 
-// One pair = one 16-row slab of block row bi (bi == nblk: the augmented rows) x block column k: generate (K inside the launch), update
-// with the columns j < k as they appear, solve against block k.
 template <int SH>
-__device__ __forceinline__ void sn_pair_task(const SmallArgs& g, char* smem_raw, int* s_flag_p, int bi, int sl, int k) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
+  // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
+  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
   const i64 ld = g.ld, np = (i64)nblk * 128;
   u32* sync = g.sync;
+
+  if (blockIdx.x == 0) {
+    // ---------------------------------------------------------------- the chain
+    if (tid == 0) *g.info = 0x7fffffff;
+    double slog = 0.0;
+    bool ok = true;
+#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
+    SN_STAMP(0);
+    for (int j = 0; j < nblk && ok; ++j) {
+      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
+      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
+      if (!ok) break;
+      SN_STAMP(1 + 3 * j);
+      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
+                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+      SN_STAMP(2 + 3 * j);
+      sn_publish(sync + SN_F(j), nullptr);
+      SN_STAMP(3 + 3 * j);
+      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
+      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
+    }
+    // sum alpha^2 once every slab of the augmented rows has been solved against every block
+    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+    SN_STAMP(30);
+    double ssq = 0.0;
+    if (ok) {
+      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
+        const i64 q = idx / np, i = idx - q * np;
+        const double v = g.K[(np + q) * ld + i];
+        ssq = fma(v, v, ssq);
+      }
+    }
+    // fixed-order reductions: lanes by shuffle, waves through LDS
+    for (int which = 0; which < 2; ++which) {
+      double v = which ? ssq : slog;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) s_red[wave] = v;
+      __syncthreads();
+      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      g.res[2] = (double)*g.info;
+      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
+    }
+    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
+    __syncthreads();
+    if (ok) for (int i = tid; i < SN_WORDS; i += NT) sync[i] = 0u;
+    SN_STAMP(31);
+    return;
+  }
+
+  // ------------------------------------------------------------------ a pair (row slab, block column)
+  int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
+  for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
+    const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
+    if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
+  }
+  if (bi < 0) return;
   const bool aug = bi == nblk;
   const i64 r0 = aug ? np + (i64)sl * SH : (i64)bi * 128 + (i64)sl * SH;
   double* C = g.K + r0 * ld + (i64)k * 128;
@@ -235,13 +294,13 @@ __device__ __forceinline__ void sn_pair_task(const SmallArgs& g, char* smem_raw,
     __syncthreads();
   }
   const u32 my_slabs = (u32)(aug ? aug_slabs : spb);
-  long long* ps = (g.stamps && sl == 0 && nblk <= 8) ? g.stamps + 64 + ((aug ? 8 : bi) * 8 + k) * 24 : nullptr;
+  long long* ps = (g.stamps && sl == 0) ? g.stamps + 64 + ((aug ? 8 : bi) * 8 + k) * 24 : nullptr;
 #define SN_PSTAMP(q) do { if (ps && tid == 0) ps[q] = (long long)wall_clock64(); } while (0)
   SN_PSTAMP(0);
   for (int j = 0; j < k; ++j) {
     SnOwn<SH, false> own;
     sn_own<SH, false>(own, smem_raw, nullptr, 0, C, ld, wave, lane, fr, fk);
-    if (!sn_wait(sync, sync + SN_XB(bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
+    if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
     SN_PSTAMP(1 + 2 * j);
     sn_product<SH, false>(own, smem_raw, g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0,
                           wave, lane, fr, fk, (ps && j == 0) ? ps + 12 : nullptr);
@@ -258,103 +317,8 @@ __device__ __forceinline__ void sn_pair_task(const SmallArgs& g, char* smem_raw,
     sn_product<SH, true>(own, smem_raw, C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH,
                          wave, lane, fr, fk, ps ? ps + 16 : nullptr);
     SN_PSTAMP(21);
-    sn_publish(sync + SN_XB(bi, k), aug ? sync + SN_ADONE : nullptr);
+    sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
     SN_PSTAMP(22);
-  }
-}
-
-template <int SH, bool QUEUED>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
-  // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
-  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
-  const i64 ld = g.ld, np = (i64)nblk * 128;
-  u32* sync = g.sync;
-
-  if (blockIdx.x == 0) {
-    // ---------------------------------------------------------------- the chain
-    if (tid == 0) *g.info = 0x7fffffff;
-    double slog = 0.0;
-    bool ok = true;
-#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
-    SN_STAMP(0);
-    for (int j = 0; j < nblk && ok; ++j) {
-      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
-      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
-      if (!ok) break;
-      SN_STAMP(1 + 3 * j);
-      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
-                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
-      SN_STAMP(2 + 3 * j);
-      sn_publish(sync + SN_F(j), nullptr);
-      SN_STAMP(3 + 3 * j);
-      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
-      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
-    }
-    // sum alpha^2 once every slab of the augmented rows has been solved against every block
-    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
-    SN_STAMP(30);
-    double ssq = 0.0;
-    if (ok) {
-      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
-        const i64 q = idx / np, i = idx - q * np;
-        const double v = g.K[(np + q) * ld + i];
-        ssq = fma(v, v, ssq);
-      }
-    }
-    // fixed-order reductions: lanes by shuffle, waves through LDS
-    for (int which = 0; which < 2; ++which) {
-      double v = which ? ssq : slog;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) s_red[wave] = v;
-      __syncthreads();
-      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      g.res[2] = (double)*g.info;
-      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
-    }
-    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
-    __syncthreads();
-    if (ok) for (int i = tid; i < SN_USED_WORDS(nblk); i += NT) sync[i] = 0u;
-    SN_STAMP(31);
-    return;
-  }
-
-  // ------------------------------------------------------------------ pairs (row slab, block column)
-  if (!QUEUED) {
-    // as many workgroups as pairs (up to seven blocks): workgroup p is pair p, block row by block row
-    int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
-    for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
-      const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
-      if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
-    }
-    if (bi >= 0) sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
-    return;
-  }
-  // More pairs than workgroups: drawn from a queue, block COLUMN by block column -- a pair of column k waits for pairs of the
-  // columns before it and for the chain only, so whoever has drawn a pair can finish it whatever else is resident.
-  for (;;) {
-    __syncthreads();
-    if (tid == 0) s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + SN_QUEUE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    int p = s_flag_p[1], bi = -1, sl = 0, k = 0;
-    for (int c = 0; c < nblk && bi < 0; ++c) {
-      const int first = (c == 0 && !g.kg.on) ? 1 : c;             // (block (0, 0) has a pair only when K is generated here)
-      const int cnt = spb * (nblk - first) + aug_slabs;
-      if (p < cnt) {
-        k = c;
-        if (p < spb * (nblk - first)) { bi = first + p / spb; sl = p % spb; } else { bi = nblk; sl = p - spb * (nblk - first); }
-      } else p -= cnt;
-    }
-    if (bi < 0) return;                                            // queue empty
-    if (sn_load(sync + SN_ABORT) != 0u) return;
-    sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
   }
 }
 
@@ -365,7 +329,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen) {
   // (up to 512 padded rows in slabs of 16: 93 workgroups at most, several such launches fit the GPU side by side; up to 896: 232,
   // the whole GPU -- the workgroup count is checked against the CU count below)
-  if (np % 128 || np < 128 || np > 128 * SN_MAXB || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
+  if (np % 128 || np < 128 || np > 896 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
   if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
   const int nblk = (int)(np / 128);
   const int SH = 16;
@@ -374,9 +338,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   const bool kg_on = kgen && kgen->on;
   for (int i = kg_on ? 0 : 1; i < nblk; ++i) pairs += spb * (i + 1);
   pairs += aug_slabs * nblk;
-  // as many workgroups as pairs while they all fit (one per CU: LDS) -- up to seven blocks --, a queue above
-  const bool queued = 1 + pairs > h->prop.multiProcessorCount;
-  const int grid = queued ? h->prop.multiProcessorCount - 8 : 1 + pairs;
+  if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
   if (!h->dSmallSync.p) {
     GPS_HIP(h, h->dSmallSync.ensure((size_t)(SN_WORDS + SN_INV_WORDS) * 4));    // behind the first SN_WORDS: the inverse launch (below)
     GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)(SN_WORDS + SN_INV_WORDS) * 4, h->stream));
@@ -389,7 +351,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   a.stamps = nullptr;
   static const bool want_stamps = getenv("GPS_SMALL_STAMPS") != nullptr;
   const size_t stamp_words = 64 + 9 * 8 * 24;
-  if (want_stamps && nblk <= 8) {
+  if (want_stamps) {
     GPS_HIP(h, h->dTmp3.ensure(stamp_words * 8));
     GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, stamp_words * 8, h->stream));
     a.stamps = (long long*)h->dTmp3.p;
@@ -402,14 +364,13 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
-  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16, false>), (int)lds);
-  if (!rc0) rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16, true>), (int)lds);
+  const void* fn = reinterpret_cast<const void*>(&small_factor_kernel<16>);
+  int rc0 = gps_dyn_lds(h, fn, (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_POTRF_BASE, (double)np * np * np / 3.0, 8.0 * np * np);
-  if (queued) hipLaunchKernelGGL((small_factor_kernel<16, true>), dim3(grid), dim3(NT), lds, h->stream, a);
-  else hipLaunchKernelGGL((small_factor_kernel<16, false>), dim3(grid), dim3(NT), lds, h->stream, a);
+  hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
-  if (want_stamps && nblk <= 8) {
+  if (want_stamps) {
     std::vector<long long> st(stamp_words);
     GPS_HIP(h, hipMemcpyAsync(st.data(), h->dTmp3.p, stamp_words * 8, hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
@@ -512,11 +473,11 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
 // workgroup that walks a whole slab of Y by itself.
 // The tasks are drawn from a queue in that order by however many workgroups are resident (a task only waits for tasks drawn
 // before it, and whoever has drawn a task is running: no co-residency assumption at all).
-#define SI_QUEUE (1 * SN_LINE)                             // (line 0 is sn_wait's abort word: SN_ABORT)
-#define SI_DONE (2 * SN_LINE)
-#define SI_M(i, sl) ((3 + (i) * 8 + (sl)) * SN_LINE)       // [8][8]
-#define SI_Y(i, j) ((67 + (i) * 8 + (j)) * SN_LINE)        // [8][8]
-#define SI_WORDS (131 * SN_LINE)
+#define SI_M(i, sl) (((i) * 8 + (sl)) * SN_LINE)           // [8][8]     (line 89 is sn_wait's abort word: SN_ABORT)
+#define SI_Y(i, j) ((96 + (i) * 8 + (j)) * SN_LINE)        // [8][8]
+#define SI_QUEUE (160 * SN_LINE)
+#define SI_DONE (161 * SN_LINE)
+#define SI_WORDS (162 * SN_LINE)
 template <bool QUEUED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_inverse_kernel(SmallInvArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
