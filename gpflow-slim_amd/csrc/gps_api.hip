@@ -909,8 +909,8 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // reductions of the likelihood as ONE cooperative launch (small_n.hip) -- three launches per evaluation with the two of the
   // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
   h->small_valid = false;
-  // (up to small_n_max -- 896 padded points: seven blocks, 232 workgroups)
-  const bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 896 && r <= 16 && !h->refine_now &&
+  // (up to small_n_max padded points; above seven blocks the launch draws all its work from a queue)
+  const bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 4096 && r <= 16 && !h->refine_now &&
                      h->prop.multiProcessorCount >= 160;
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
@@ -1141,7 +1141,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
   int linfo = 0;
   // Small problems (the reference's own size: examples/gpr.py): factorisation, inverse and gradient sums are enqueued
   // back to back -- six launches -- and everything the host needs comes back in one pinned copy behind ONE synchronisation.
-  h->small_defer = h->small_n > 0 && r <= 16 && h->npad <= 896 && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)(5 + GPS_GRAD_SUMS + h->n * r) * 8 <= GPS_HRES_BYTES);
+  h->small_defer = h->small_n > 0 && r <= 16 && h->npad <= 2048 && h->npad <= h->small_n_max && gps_grad_is_simple(prog, n_nodes) && (!kinv_resid || (size_t)(5 + GPS_GRAD_SUMS + h->n * r) * 8 <= GPS_HRES_BYTES);
   h->small_pending = false;
   rc = gpr_factor(h, prog, n_nodes, noise_var, resid, r, &linfo);
   h->small_defer = false;

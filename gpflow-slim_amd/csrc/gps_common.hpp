@@ -129,7 +129,10 @@ struct gps_handle_s {
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
   int la_fault_inject = 0;                     // diagnostics: see HipOps::chain_join
-  i64 small_n_max = 896;                       // padded points up to which the factorisation is one cooperative launch
+  // padded points up to which the factorisation is one cooperative launch (as many workgroups as pairs up to 896, everything
+  // drawn from a queue above; against launch by launch: N = 1024 / 1536 / 2048: -17 / -14 / -11 % per likelihood, 3072: -2 %,
+  // 4096: +35 % -- the 16-row-slab products are no match for the GEMM kernel once the bulk outweighs the chain)
+  i64 small_n_max = 2048;
   int small_kgen = 1;                          // the one-launch small-N path generates the kernel matrix of a single RBF primitive itself
   int small_fault_inject = 0;                  // diagnostics: the k-th cooperative small-N launch from now starts aborted
   int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"

@@ -29,13 +29,17 @@ typedef unsigned int u32;
 
 // sync words (u32), each counter on a 64-byte line of its own
 #define SN_LINE 16
-#define SN_F(j) ((j) * SN_LINE)                              // [8]   block j factored and inverted
-#define SN_D(j) ((8 + (j)) * SN_LINE)                        // [8]   update pieces applied to diagonal block j
-#define SN_XB(i, j) ((16 + (i) * 8 + (j)) * SN_LINE)         // [9][8] slabs of block row i (8 = the augmented rows) solved against panel j
-#define SN_ADONE ((16 + 72) * SN_LINE)                       // solves of the augmented rows
-#define SN_ABORT ((16 + 72 + 1) * SN_LINE)
-#define SN_WORDS ((16 + 72 + 2) * SN_LINE)
-#define SN_INV_WORDS (162 * SN_LINE)                         // the inverse launch's counters (SI_*, below)
+#define SN_MAXB 32                                           // block rows / columns the counters are laid out for (4096 padded points)
+#define SN_ABORT 0                                           // (first: sn_wait looks for it at this offset of whichever region it is given)
+#define SN_ADONE (1 * SN_LINE)                               // solves of the augmented rows
+#define SN_QUEUE (2 * SN_LINE)                               // next task (queued form)
+#define SN_DONE (3 * SN_LINE)                                // workgroups that have left (queued form)
+#define SN_F(j) ((5 + (j)) * SN_LINE)                        // [32]  block j factored and inverted
+#define SN_D(j) ((5 + SN_MAXB + (j)) * SN_LINE)              // [32]  update pieces applied to diagonal block j
+#define SN_XB(i, j) ((5 + 2 * SN_MAXB + (i) * SN_MAXB + (j)) * SN_LINE)   // [33][32] slabs of block row i (nblk = the augmented rows) solved against panel j
+#define SN_WORDS ((5 + 2 * SN_MAXB + (SN_MAXB + 1) * SN_MAXB) * SN_LINE)
+#define SN_USED_WORDS(nblk) ((5 + 2 * SN_MAXB + ((nblk) + 1) * SN_MAXB) * SN_LINE)   // (the augmented rows are block row nblk)
+#define SN_INV_WORDS ((3 + 8 * 16 + 16 * 16) * SN_LINE)      // the inverse launch's counters (SI_*, below)
 
 struct SmallArgs {
   double* K; i64 ld;             // [np + aug rows][ld]: K + noise (lower, identity padded), then the augmented rows
@@ -172,77 +176,15 @@ __device__ __forceinline__ void sn_product(SnOwn<SH, SOLVE>& o, char* smem, cons
   __syncthreads();                                               // (the LDS regions are free again)
 }
 
+// One pair = one 16-row slab of block row bi (bi == nblk: the augmented rows) x block column k: generate (K inside the launch), update
+// with the columns j < k as they appear, solve against block k.
 template <int SH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
-  // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
-  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
+__device__ __forceinline__ void sn_pair_task(const SmallArgs& g, char* smem_raw, int* s_flag_p, int bi, int sl, int k) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
   const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
   const i64 ld = g.ld, np = (i64)nblk * 128;
   u32* sync = g.sync;
-
-  if (blockIdx.x == 0) {
-    // ---------------------------------------------------------------- the chain
-    if (tid == 0) *g.info = 0x7fffffff;
-    double slog = 0.0;
-    bool ok = true;
-#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
-    SN_STAMP(0);
-    for (int j = 0; j < nblk && ok; ++j) {
-      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
-      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
-      if (!ok) break;
-      SN_STAMP(1 + 3 * j);
-      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
-                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
-      SN_STAMP(2 + 3 * j);
-      sn_publish(sync + SN_F(j), nullptr);
-      SN_STAMP(3 + 3 * j);
-      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
-      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
-    }
-    // sum alpha^2 once every slab of the augmented rows has been solved against every block
-    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
-    SN_STAMP(30);
-    double ssq = 0.0;
-    if (ok) {
-      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
-        const i64 q = idx / np, i = idx - q * np;
-        const double v = g.K[(np + q) * ld + i];
-        ssq = fma(v, v, ssq);
-      }
-    }
-    // fixed-order reductions: lanes by shuffle, waves through LDS
-    for (int which = 0; which < 2; ++which) {
-      double v = which ? ssq : slog;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) s_red[wave] = v;
-      __syncthreads();
-      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      g.res[2] = (double)*g.info;
-      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
-    }
-    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
-    __syncthreads();
-    if (ok) for (int i = tid; i < SN_WORDS; i += NT) sync[i] = 0u;
-    SN_STAMP(31);
-    return;
-  }
-
-  // ------------------------------------------------------------------ a pair (row slab, block column)
-  int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
-  for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
-    const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
-    if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
-  }
-  if (bi < 0) return;
   const bool aug = bi == nblk;
   const i64 r0 = aug ? np + (i64)sl * SH : (i64)bi * 128 + (i64)sl * SH;
   double* C = g.K + r0 * ld + (i64)k * 128;
@@ -294,13 +236,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
   }
   const u32 my_slabs = (u32)(aug ? aug_slabs : spb);
-  long long* ps = (g.stamps && sl == 0) ? g.stamps + 64 + ((aug ? 8 : bi) * 8 + k) * 24 : nullptr;
+  long long* ps = (g.stamps && sl == 0 && nblk <= 8) ? g.stamps + 64 + ((aug ? 8 : bi) * 8 + k) * 24 : nullptr;
 #define SN_PSTAMP(q) do { if (ps && tid == 0) ps[q] = (long long)wall_clock64(); } while (0)
   SN_PSTAMP(0);
   for (int j = 0; j < k; ++j) {
     SnOwn<SH, false> own;
     sn_own<SH, false>(own, smem_raw, nullptr, 0, C, ld, wave, lane, fr, fk);
-    if (!sn_wait(sync, sync + SN_XB(aug ? 8 : bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
+    if (!sn_wait(sync, sync + SN_XB(bi, j), my_slabs, sync + SN_XB(k, j), (u32)spb, s_flag_p)) return;
     SN_PSTAMP(1 + 2 * j);
     sn_product<SH, false>(own, smem_raw, g.K + r0 * ld + (i64)j * 128, ld, g.K + (i64)k * 128 * ld + (i64)j * 128, ld, C, ld, nullptr, 0, 0,
                           wave, lane, fr, fk, (ps && j == 0) ? ps + 12 : nullptr);
@@ -317,9 +259,172 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     sn_product<SH, true>(own, smem_raw, C, ld, g.Linv + (i64)k * 128 * 128, 128, C, ld, mirror, g.ld_alpha, g.alpha_rows - sl * SH,
                          wave, lane, fr, fk, ps ? ps + 16 : nullptr);
     SN_PSTAMP(21);
-    sn_publish(sync + SN_XB(aug ? 8 : bi, k), aug ? sync + SN_ADONE : nullptr);
+    sn_publish(sync + SN_XB(bi, k), aug ? sync + SN_ADONE : nullptr);
     SN_PSTAMP(22);
   }
+}
+
+template <int SH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
+  // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
+  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
+  const i64 ld = g.ld, np = (i64)nblk * 128;
+  u32* sync = g.sync;
+
+  if (blockIdx.x == 0) {
+    // ---------------------------------------------------------------- the chain
+    if (tid == 0) *g.info = 0x7fffffff;
+    double slog = 0.0;
+    bool ok = true;
+#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
+    SN_STAMP(0);
+    for (int j = 0; j < nblk && ok; ++j) {
+      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
+      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
+      if (!ok) break;
+      SN_STAMP(1 + 3 * j);
+      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
+                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+      SN_STAMP(2 + 3 * j);
+      sn_publish(sync + SN_F(j), nullptr);
+      SN_STAMP(3 + 3 * j);
+      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
+      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
+    }
+    // sum alpha^2 once every slab of the augmented rows has been solved against every block
+    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+    SN_STAMP(30);
+    double ssq = 0.0;
+    if (ok) {
+      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
+        const i64 q = idx / np, i = idx - q * np;
+        const double v = g.K[(np + q) * ld + i];
+        ssq = fma(v, v, ssq);
+      }
+    }
+    // fixed-order reductions: lanes by shuffle, waves through LDS
+    for (int which = 0; which < 2; ++which) {
+      double v = which ? ssq : slog;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) s_red[wave] = v;
+      __syncthreads();
+      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      g.res[2] = (double)*g.info;
+      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
+    }
+    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
+    __syncthreads();
+    if (ok) for (int i = tid; i < SN_USED_WORDS(nblk); i += NT) sync[i] = 0u;
+    SN_STAMP(31);
+    return;
+  }
+
+  // ------------------------------------------------------------------ pairs: workgroup p is pair p, block row by block row
+  int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
+  for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
+    const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
+    if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
+  }
+  if (bi >= 0) sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
+}
+
+// More pairs than CUs (above seven blocks): the work is drawn from one queue by however many workgroups are resident.  Task 0
+// is the CHAIN -- block after block: wait for its updates, factor + invert, publish -- taken by whoever draws it (so the chain
+// is resident by construction; a first version that gave it to workgroup 0 stalled for the full bounded wait when several such
+// launches of one process were in flight: workgroup 0 need not be the first to become resident, docs/LAB_NOTES.md); the other
+// tasks are the pairs, block column by block column and the DIAGONAL pairs of a column first.  A pair waits for pairs drawn
+// before it and for the chain's block k; the chain waits for the diagonal pairs of column k, which are drawn before every pair
+// that waits for block k: whatever part of the launch is resident makes progress.  The workgroup that leaves last reports the
+// abort word and leaves the counters zero (not the chain: others may still be drawing from the queue when it has finished).
+template <int SH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_queue_kernel(SmallArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
+  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
+  const i64 ld = g.ld, np = (i64)nblk * 128;
+  u32* sync = g.sync;
+  const bool kgen = g.kg.on != 0;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + SN_QUEUE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int p = s_flag_p[1];
+    if (sn_load(sync + SN_ABORT) != 0u) break;
+    if (p == 0) {
+      // ---------------------------------------------------------------- the chain
+      if (tid == 0) *g.info = 0x7fffffff;
+      double slog = 0.0;
+      bool ok = true;
+      for (int j = 0; j < nblk && ok; ++j) {
+        if (j > 0 || kgen) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
+        if (!ok) break;
+        potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
+                        g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+        sn_publish(sync + SN_F(j), nullptr);
+        if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
+      }
+      if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+      if (!ok) break;
+      double ssq = 0.0;
+      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
+        const i64 q = idx / np, i = idx - q * np;
+        const double x = g.K[(np + q) * ld + i];
+        ssq = fma(x, x, ssq);
+      }
+      for (int which = 0; which < 2; ++which) {
+        double v = which ? ssq : slog;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
+      }
+      if (tid == 0) g.res[2] = (double)*g.info;
+      continue;
+    }
+    // ---------------------------------------------------------------- a pair: column by column, the diagonal pairs first
+    p -= 1;
+    int k = -1, bi = 0, sl = 0;
+    for (int c = 0; c < nblk && k < 0; ++c) {
+      const int nd = (c == 0 && !kgen) ? 0 : spb;
+      const int nrow = spb * (nblk - 1 - c);
+      const int cnt = nd + nrow + aug_slabs;
+      if (p < cnt) {
+        k = c;
+        if (p < nd) { bi = c; sl = p; }
+        else if (p - nd < nrow) { bi = c + 1 + (p - nd) / spb; sl = (p - nd) % spb; }
+        else { bi = nblk; sl = p - nd - nrow; }
+      } else p -= cnt;
+    }
+    if (k < 0) break;                                     // the queue is empty
+    sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
+  }
+  // ---- the workgroup that leaves last reports and leaves the counters zero for the next call
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const u32 done = __hip_atomic_fetch_add(sync + SN_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
+    if (done + 1 == gridDim.x) {
+      const u32 ab = sn_load(sync + SN_ABORT);
+      g.res[3] = (double)ab;
+      last = (ab == 0u) ? 1 : 0;
+    }
+    s_flag_p[1] = last;
+  }
+  __syncthreads();
+  if (s_flag_p[1]) for (int w = tid; w < SN_USED_WORDS(nblk); w += NT) sync[w] = 0u;
 }
 
 // K (lower, + noise, identity padded) is in dK [np + 128][np]; resid [n][r] on the device.  On success dK holds L and the
@@ -329,7 +434,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen) {
   // (up to 512 padded rows in slabs of 16: 93 workgroups at most, several such launches fit the GPU side by side; up to 896: 232,
   // the whole GPU -- the workgroup count is checked against the CU count below)
-  if (np % 128 || np < 128 || np > 896 || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
+  if (np % 128 || np < 128 || np > 128 * SN_MAXB || r < 1 || r > 16) return GPS_ERR_UNSUPPORTED;
   if (h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;           // every workgroup must be resident (one per CU)
   const int nblk = (int)(np / 128);
   const int SH = 16;
@@ -338,7 +443,12 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   const bool kg_on = kgen && kgen->on;
   for (int i = kg_on ? 0 : 1; i < nblk; ++i) pairs += spb * (i + 1);
   pairs += aug_slabs * nblk;
-  if (1 + pairs > h->prop.multiProcessorCount) return GPS_ERR_UNSUPPORTED;
+  // as many workgroups as pairs (+ the chain) while they all fit, one per CU (LDS) -- up to seven blocks --; above, every
+  // piece of the work is a task of one queue
+  const bool queued = 1 + pairs > h->prop.multiProcessorCount;
+  const int ntasks = 1 + pairs;                        // the chain + the pairs
+  const int slots = h->prop.multiProcessorCount - 8;
+  const int grid = queued ? (ntasks < slots ? ntasks : slots) : 1 + pairs;
   if (!h->dSmallSync.p) {
     GPS_HIP(h, h->dSmallSync.ensure((size_t)(SN_WORDS + SN_INV_WORDS) * 4));    // behind the first SN_WORDS: the inverse launch (below)
     GPS_HIP(h, hipMemsetAsync(h->dSmallSync.p, 0, (size_t)(SN_WORDS + SN_INV_WORDS) * 4, h->stream));
@@ -351,7 +461,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
   a.stamps = nullptr;
   static const bool want_stamps = getenv("GPS_SMALL_STAMPS") != nullptr;
   const size_t stamp_words = 64 + 9 * 8 * 24;
-  if (want_stamps) {
+  if (want_stamps && nblk <= 8) {
     GPS_HIP(h, h->dTmp3.ensure(stamp_words * 8));
     GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, stamp_words * 8, h->stream));
     a.stamps = (long long*)h->dTmp3.p;
@@ -364,13 +474,14 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
-  const void* fn = reinterpret_cast<const void*>(&small_factor_kernel<16>);
-  int rc0 = gps_dyn_lds(h, fn, (int)lds);
+  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16>), (int)lds);
+  if (!rc0) rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_queue_kernel<16>), (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_POTRF_BASE, (double)np * np * np / 3.0, 8.0 * np * np);
-  hipLaunchKernelGGL(small_factor_kernel<16>, dim3(1 + pairs), dim3(NT), lds, h->stream, a);
+  if (queued) hipLaunchKernelGGL(small_factor_queue_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
+  else hipLaunchKernelGGL(small_factor_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
-  if (want_stamps) {
+  if (want_stamps && nblk <= 8) {
     std::vector<long long> st(stamp_words);
     GPS_HIP(h, hipMemcpyAsync(st.data(), h->dTmp3.p, stamp_words * 8, hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
@@ -473,11 +584,12 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
 // workgroup that walks a whole slab of Y by itself.
 // The tasks are drawn from a queue in that order by however many workgroups are resident (a task only waits for tasks drawn
 // before it, and whoever has drawn a task is running: no co-residency assumption at all).
-#define SI_M(i, sl) (((i) * 8 + (sl)) * SN_LINE)           // [8][8]     (line 89 is sn_wait's abort word: SN_ABORT)
-#define SI_Y(i, j) ((96 + (i) * 8 + (j)) * SN_LINE)        // [8][8]
-#define SI_QUEUE (160 * SN_LINE)
-#define SI_DONE (161 * SN_LINE)
-#define SI_WORDS (162 * SN_LINE)
+#define SI_QUEUE (1 * SN_LINE)                             // (line 0 is sn_wait's abort word: SN_ABORT)
+#define SI_DONE (2 * SN_LINE)
+#define SI_MAXB 16                                         // blocks the counters are laid out for (2048 padded points)
+#define SI_M(i, sl) ((3 + (i) * 8 + (sl)) * SN_LINE)       // [16][8]
+#define SI_Y(i, j) ((3 + 8 * SI_MAXB + (i) * SI_MAXB + (j)) * SN_LINE)        // [16][16]
+#define SI_WORDS ((3 + 8 * SI_MAXB + SI_MAXB * SI_MAXB) * SN_LINE)
 template <bool QUEUED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_inverse_kernel(SmallInvArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -610,7 +722,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // K^-1) and dA ([r][np]: K^-1 resid; dAT, if given: the same as [n][r]); res1 (device): abort flag.  GPS_ERR_UNSUPPORTED: not a shape for this path.
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,
                              double* dY, double* dKinv, double* dA, double* d_res1, double* dAT, i64 n) {
-  if (np % 128 || np < 128 || np > 896 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
+  if (np % 128 || np < 128 || np > 128 * 16 || r < 1 || !h->dSmallSync.p) return GPS_ERR_UNSUPPORTED;
   const int nblk = (int)(np / 128);
   SmallInvArgs a;
   a.L = dK; a.ld = np; a.W = linv; a.alpha = d_alpha; a.ld_alpha = np; a.r = (int)r;
