@@ -312,6 +312,13 @@ static int with_la_retry(gps_handle_t h, F&& body) {
 }
 
 static int gpr_lml_finish(gps_handle_t h, i64 r, double* lml);
+// a cooperative launch of the small-N path gave up: counted; the fourth in a row sends the handle's next 256 evaluations of
+// that size launch by launch (a GPU shared with something that holds its CUs must not cost a bounded wait per optimiser step;
+// option "small_cooldown" reads / sets what is left of the back-off)
+static void small_gave_up(gps_handle_t h) {
+  h->small_fallbacks++;
+  if (++h->small_consec >= 4) { h->small_cooldown = 256; h->small_consec = 0; }
+}
 static int stage_time(gps_handle_t h, int a, int b, double* out) {
   float ms = 0.f;
   GPS_HIP(h, hipEventElapsedTime(&ms, h->ev[a], h->ev[b]));
@@ -448,6 +455,11 @@ extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launc
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
     return GPS_OK;
   }
+  if (strcmp(klass, "small_n_cooldown") == 0) {       // evaluations the small-N back-off (small_gave_up) still sends launch by launch
+    if (launches) *launches = (int64_t)h->small_cooldown;
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   if (strcmp(klass, "trsv_wave_fallbacks") == 0) {    // wavefront substitutions that gave up (handle fell back to the recursive one)
     if (launches) *launches = (int64_t)h->wave_fallbacks;
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
@@ -510,6 +522,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
+  if (strcmp(key, "small_cooldown") == 0) { h->small_cooldown = (int)value; h->small_consec = 0; return GPS_OK; }
   if (strcmp(key, "small_kgen") == 0) { h->small_kgen = (int)value; return GPS_OK; }
   if (strcmp(key, "small_n_max") == 0) { h->small_n_max = (i64)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
@@ -910,8 +923,9 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // kernel-matrix build, no memset, no transposition, one 32-byte read-back.  Not for refined leaves (ill-conditioned K).
   h->small_valid = false;
   // (up to small_n_max padded points; above seven blocks the launch draws all its work from a queue)
-  const bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 4096 && r <= 16 && !h->refine_now &&
-                     h->prop.multiProcessorCount >= 160;
+  bool small = h->small_n > 0 && aug && np <= h->small_n_max && np <= 4096 && r <= 16 && !h->refine_now &&
+               h->prop.multiProcessorCount >= 160;
+  if (small && h->small_cooldown > 0) { --h->small_cooldown; small = false; }      // (back-off after give-ups in a row: small_gave_up)
   // residual, transposed to [r][np] and zero padded
   if (r > 0) {
     GPS_HIP(h, h->dAlpha.ensure((size_t)r * np * 8));
@@ -973,11 +987,12 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
         h->r = r;
         h->small_valid = true; h->small_slog = res[0]; h->small_ssq = res[1];
         h->have_factor = (info == nullptr) || (*info == 0);
+        h->small_consec = 0;
         return GPS_OK;
       }
       // a bounded wait of the launch ran out (never seen; e.g. several such launches of one process interleaved on the GPU
       // so that none was fully resident): counters back to zero, this evaluation again launch by launch
-      h->small_fallbacks++;
+      small_gave_up(h);
       rc = gps_small_factor_reset(h);
       if (rc) return rc;
       const int saved = h->small_n;
@@ -1109,6 +1124,7 @@ static int gpr_small_grad_tail(gps_handle_t h, const gps_kern_node_t* prog, int 
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (res[3] != 0.0 || res[4] != 0.0) return GPS_OK;
   *done = true;
+  h->small_consec = 0;
   const int v = (int)res[2];
   *info = (v == INT_MAX) ? 0 : v;
   h->have_factor = (*info == 0);
@@ -1153,7 +1169,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
     if (rc) return rc;
     if (done) { if (info) *info = linfo; return GPS_OK; }
     // a bounded wait of one of the two cooperative launches ran out (never seen): this evaluation again, launch by launch
-    h->small_fallbacks++;
+    small_gave_up(h);
     rc = gps_small_factor_reset(h);
     if (rc) return rc;
     const int saved = h->small_n;
@@ -1218,7 +1234,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
       stage_time(h, 5, 6, &h->stage_ms[3]);
       return GPS_OK;
     }
-    h->small_fallbacks++;
+    small_gave_up(h);
     rc = gps_small_factor_reset(h);
     if (rc) return rc;
     small_inv = false;

@@ -245,6 +245,8 @@ struct gps_handle_s {
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
   int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
+  int small_consec = 0;            // give-ups in a row; two of them send the next small_cooldown evaluations launch by launch
+  int small_cooldown = 0;          // (back-off: a device that something else keeps busy must not cost a bounded wait per step)
   bool small_valid = false; double small_slog = 0.0, small_ssq = 0.0;   // reductions the last small launch produced
   bool ev3_is_ev2 = false;
   bool gpr_linvT_stale = false;    // the resident GPR factor's transposed block inverses have not been produced yet (gpr_ensure_linvT)

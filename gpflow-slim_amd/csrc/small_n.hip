@@ -1,26 +1,29 @@
-// Exact-GP factorisation of a SMALL covariance (up to 512 padded rows) as ONE launch.
+// Exact-GP factorisation of a SMALL covariance (up to SN_MAXB = 32 blocks of 128 padded rows; the entry points use it up to
+// "small_n_max" = 2048) as ONE launch.
 //
 // The reference's own workload is this size (examples/gpr.py:36,48-61: N ~ 455, 20 000 optimiser steps; each step
 // tf.cholesky + tf.matrix_triangular_solve, models/gpr.py:70, densities.py:82).  Launch by launch (blocked.hpp) such a
 // factorisation is a chain of potrf_base / panel solve / update launches, each at the launch-latency floor: 14 launches at
 // N = 512.  Here the whole of
 //     L = chol(K),  inv of the diagonal blocks,  alpha^T = (Y - m)^T L^-T  (augmented rows),  sum log L_ii,  sum alpha^2
-// runs in one persistent launch of 1 + P workgroups (all resident: one per CU), synchronised by monotone counters in HBM:
+// runs in one persistent launch of 1 + P tasks, synchronised by monotone counters in HBM.  Every workgroup DRAWS its task from
+// one counter (sn_draw) -- nothing is derived from blockIdx, so nothing is assumed about which workgroups are resident:
 //
-//   workgroup 0, the CHAIN: for every 128-column block j: wait until the updates of the panels before it have reached the
+//   task 0, the CHAIN: for every 128-column block j: wait until the updates of the panels before it have reached the
 //     diagonal block, factor + invert it (potrf_base_body: the kernel of potrf_base.hip as a device function), publish F[j].
-//   workgroup 1 + p, a PAIR (row slab s of SH rows, block column k): owns the SH x 128 piece of the matrix at (s, k) for the
+//   task 1 + p, a PAIR (row slab s of SH rows, block column k): owns the SH x 128 piece of the matrix at (s, k) for the
 //     whole launch -- applies panel j = 0 .. k-1 to it as soon as the slabs it needs are solved (U: C -= X_s,j X_k,j^T),
 //     then, once F[k] is there, solves it against the block's inverse (S: X <- X W_k^T) and publishes that.  The pieces
 //     of a diagonal block only take the updates (and count them for the chain); the augmented rows (Y - m)^T are one more
 //     block row of slabs that is never factored.  Every product is a [SH x 128] x [128 x 128]^T MFMA product with both
-//     operands straight from L2 into registers.
+//     operands staged through LDS.  Order of the pairs: column by column, the diagonal pairs of a column first (sn_decode) --
+//     in that order every task waits only for tasks drawn before it.
 //
 // Hand-overs (cdna_hip_programming.md, Guideline 16): producer -- every storing wave drains its stores, workgroup barrier, one
 // lane's agent-scope release fence, relaxed agent-scope add on the counter; consumer -- one lane polls (relaxed, s_sleep,
 // bounded by the wall clock), agent-scope acquire, barrier, plain loads.  A wait that runs out sets the abort word: every
-// workgroup leaves, the host falls back to the launch-by-launch path (and counts it).  The counters are zeroed by the chain
-// at the very end (nobody reads them any more), so an evaluation costs no memset.
+// workgroup leaves, the host falls back to the launch-by-launch path (and counts it).  The counters are zeroed at the very end
+// by the chain (as many workgroups as tasks) or by the workgroup that leaves last (queued form), so an evaluation costs no memset.
 #define GPS_PB_DEVICE_ONLY
 #define GPS_PB_WT 1            // the chain's results leave with write-through stores
 #include "potrf_base.hip"
@@ -264,153 +267,133 @@ __device__ __forceinline__ void sn_pair_task(const SmallArgs& g, char* smem_raw,
   }
 }
 
-template <int SH>
+// Draw the next task of the launch: one lane takes a ticket and reads the abort word, everybody gets both through LDS (so that
+// all waves of the workgroup take the same branch whatever another workgroup does to the abort word in between).
+__device__ __forceinline__ int sn_draw(u32* sync, int queue_word, int* s_flag_p, bool* aborted) {
+  __syncthreads();                                                 // (the previous task's use of the LDS words is over)
+  if (threadIdx.x == 0) {
+    s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + queue_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag_p[3] = (sn_load(sync + SN_ABORT) != 0u) ? 1 : 0;
+  }
+  __syncthreads();
+  *aborted = s_flag_p[3] != 0;
+  return s_flag_p[1];
+}
+
+// The CHAIN: block after block -- wait for its updates, factor + invert, publish --, then the two sums of the likelihood.
+__device__ __forceinline__ bool sn_chain(const SmallArgs& g, char* smem_raw, int* s_flag_p, double* s_red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = g.nblk, spb = 128 / 16, aug_slabs = (g.r + 15) / 16;
+  const i64 ld = g.ld, np = (i64)nblk * 128;
+  u32* sync = g.sync;
+  if (tid == 0) *g.info = 0x7fffffff;
+  double slog = 0.0;
+  bool ok = true;
+#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
+  SN_STAMP(0);
+  for (int j = 0; j < nblk && ok; ++j) {
+    // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
+    if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
+    if (!ok) break;
+    SN_STAMP(1 + 3 * j);
+    potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
+                    g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
+    SN_STAMP(2 + 3 * j);
+    sn_publish(sync + SN_F(j), nullptr);
+    SN_STAMP(3 + 3 * j);
+    // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
+    if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
+  }
+  // sum alpha^2 once every slab of the augmented rows has been solved against every block
+  if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
+  SN_STAMP(30);
+  if (!ok) return false;
+  double ssq = 0.0;
+  for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
+    const i64 q = idx / np, i = idx - q * np;
+    const double v = g.K[(np + q) * ld + i];
+    ssq = fma(v, v, ssq);
+  }
+  // fixed-order reductions: lanes by shuffle, waves through LDS
+  for (int which = 0; which < 2; ++which) {
+    double v = which ? ssq : slog;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
+  }
+  if (tid == 0) g.res[2] = (double)*g.info;
+  return true;
+}
+
+// Task p >= 1 of the launch -> (block row bi, slab sl, block column k): column by column, the DIAGONAL pairs of a column first
+// (without the in-launch kernel matrix block (0, 0) has none), then the slabs of the rows below, then the augmented rows.
+__device__ __forceinline__ bool sn_decode(int p, int nblk, int spb, int aug_slabs, bool kgen, int* bi, int* sl, int* k) {
+  p -= 1;
+  for (int c = 0; c < nblk; ++c) {
+    const int nd = (c == 0 && !kgen) ? 0 : spb;
+    const int nrow = spb * (nblk - 1 - c);
+    const int cnt = nd + nrow + aug_slabs;
+    if (p < cnt) {
+      *k = c;
+      if (p < nd) { *bi = c; *sl = p; }
+      else if (p - nd < nrow) { *bi = c + 1 + (p - nd) / spb; *sl = (p - nd) % spb; }
+      else { *bi = nblk; *sl = p - nd - nrow; }
+      return true;
+    }
+    p -= cnt;
+  }
+  return false;                                            // the queue is empty
+}
+
+// Every workgroup DRAWS its task (a ticket from one counter) instead of deriving it from blockIdx: task 0 is the chain, the
+// others are the pairs in sn_decode's order.  In that order a pair waits only for pairs drawn before it and for the chain's
+// block k, and the chain waits only for the diagonal pairs of column k, which are drawn before every pair that waits for block
+// k -- and whoever has drawn a task is running.  So whatever part of the launch is resident makes progress: no assumption about
+// which workgroups of a launch become resident first, or together (round 4 gave the chain to workgroup 0 and the pairs to
+// workgroup 1 + p, block row by block row: with several such launches of one process in flight a launch whose workgroup 0 was
+// not resident stalled for the full bounded wait, docs/LAB_NOTES.md).
+//   QUEUED = false: as many workgroups as tasks (up to seven blocks: one per CU), one draw each; the chain, which finishes
+//     last by construction, reports and leaves the counters zero.
+//   QUEUED = true : more tasks than CUs -- a workgroup keeps drawing until the queue is empty (the chain is run straight-line in
+//     front of the loop: inside it the compiler spilled 44 VGPRs and 459 SGPRs); the workgroup that leaves last reports and zeroes.
+template <int SH, bool QUEUED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_kernel(SmallArgs g) {
   // (no static __shared__: it would sit in front of the dynamic region and push the image off its 16-byte alignment)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;       // the chain's image / a pair's operand regions
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
+  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);        // [0] sn_wait  [1] ticket  [2] last to leave  [3] aborted
   double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x;
   const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
-  const i64 ld = g.ld, np = (i64)nblk * 128;
-  u32* sync = g.sync;
-
-  if (blockIdx.x == 0) {
-    // ---------------------------------------------------------------- the chain
-    if (tid == 0) *g.info = 0x7fffffff;
-    double slog = 0.0;
-    bool ok = true;
-#define SN_STAMP(q) do { if (g.stamps && tid == 0) g.stamps[q] = (long long)wall_clock64(); } while (0)
-    SN_STAMP(0);
-    for (int j = 0; j < nblk && ok; ++j) {
-      // (with the kernel matrix generated in this launch block 0 is stored by its eight pairs first)
-      if (j > 0 || g.kg.on) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
-      if (!ok) break;
-      SN_STAMP(1 + 3 * j);
-      potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
-                      g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
-      SN_STAMP(2 + 3 * j);
-      sn_publish(sync + SN_F(j), nullptr);
-      SN_STAMP(3 + 3 * j);
-      // log of the diagonal from the image the body leaves in LDS (identity padding: log 1 = 0)
-      if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
-    }
-    // sum alpha^2 once every slab of the augmented rows has been solved against every block
-    if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
-    SN_STAMP(30);
-    double ssq = 0.0;
-    if (ok) {
-      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
-        const i64 q = idx / np, i = idx - q * np;
-        const double v = g.K[(np + q) * ld + i];
-        ssq = fma(v, v, ssq);
-      }
-    }
-    // fixed-order reductions: lanes by shuffle, waves through LDS
-    for (int which = 0; which < 2; ++which) {
-      double v = which ? ssq : slog;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) s_red[wave] = v;
-      __syncthreads();
-      if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      g.res[2] = (double)*g.info;
-      g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
-    }
-    // nobody reads the counters any more (the last waits above were the last of the launch): leave them zero for the next call
-    __syncthreads();
-    if (ok) for (int i = tid; i < SN_USED_WORDS(nblk); i += NT) sync[i] = 0u;
-    SN_STAMP(31);
-    return;
-  }
-
-  // ------------------------------------------------------------------ pairs: workgroup p is pair p, block row by block row
-  int p = (int)blockIdx.x - 1, bi = -1, sl = 0, k = 0;
-  for (int i = g.kg.on ? 0 : 1; i <= nblk && bi < 0; ++i) {
-    const int slabs = (i < nblk) ? spb : aug_slabs, cols = (i < nblk) ? i + 1 : nblk;
-    if (p < slabs * cols) { bi = i; sl = p / cols; k = p - sl * cols; } else p -= slabs * cols;
-  }
-  if (bi >= 0) sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
-}
-
-// More pairs than CUs (above seven blocks): the work is drawn from one queue by however many workgroups are resident.  Task 0
-// is the CHAIN -- block after block: wait for its updates, factor + invert, publish -- taken by whoever draws it (so the chain
-// is resident by construction; a first version that gave it to workgroup 0 stalled for the full bounded wait when several such
-// launches of one process were in flight: workgroup 0 need not be the first to become resident, docs/LAB_NOTES.md); the other
-// tasks are the pairs, block column by block column and the DIAGONAL pairs of a column first.  A pair waits for pairs drawn
-// before it and for the chain's block k; the chain waits for the diagonal pairs of column k, which are drawn before every pair
-// that waits for block k: whatever part of the launch is resident makes progress.  The workgroup that leaves last reports the
-// abort word and leaves the counters zero (not the chain: others may still be drawing from the queue when it has finished).
-template <int SH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void small_factor_queue_kernel(SmallArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);
-  double* const s_red = reinterpret_cast<double*>(smem_raw + LDS_MAIN + 16);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = g.nblk, spb = 128 / SH, aug_slabs = (g.r + SH - 1) / SH;
-  const i64 ld = g.ld, np = (i64)nblk * 128;
   u32* sync = g.sync;
   const bool kgen = g.kg.on != 0;
-  for (;;) {
-    __syncthreads();
-    if (tid == 0) s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + SN_QUEUE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    int p = s_flag_p[1];
-    if (sn_load(sync + SN_ABORT) != 0u) break;
-    if (p == 0) {
-      // ---------------------------------------------------------------- the chain
-      if (tid == 0) *g.info = 0x7fffffff;
-      double slog = 0.0;
-      bool ok = true;
-      for (int j = 0; j < nblk && ok; ++j) {
-        if (j > 0 || kgen) ok = sn_wait(sync, sync + SN_D(j), (u32)(j > 0 ? spb * j : spb), nullptr, 0u, s_flag_p);
-        if (!ok) break;
-        potrf_base_body(smem_raw, g.K + (i64)j * 128 * ld + (i64)j * 128, ld, g.Linv + (i64)j * 128 * 128,
-                        g.LinvT ? g.LinvT + (i64)j * 128 * 128 : nullptr, g.info, j * 128, 1, nullptr);
-        sn_publish(sync + SN_F(j), nullptr);
-        if (tid < PB) { const double* a = reinterpret_cast<const double*>(smem_raw); slog += log(a[tid * PS + tid]); }
-      }
-      if (ok) ok = sn_wait(sync, sync + SN_ADONE, (u32)(aug_slabs * nblk), nullptr, 0u, s_flag_p);
-      if (!ok) break;
-      double ssq = 0.0;
-      for (i64 idx = tid; idx < (i64)g.r * np; idx += NT) {
-        const i64 q = idx / np, i = idx - q * np;
-        const double x = g.K[(np + q) * ld + i];
-        ssq = fma(x, x, ssq);
-      }
-      for (int which = 0; which < 2; ++which) {
-        double v = which ? ssq : slog;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        __syncthreads();
-        if (lane == 0) s_red[wave] = v;
-        __syncthreads();
-        if (tid == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_red[w]; g.res[which] = t; }
-      }
-      if (tid == 0) g.res[2] = (double)*g.info;
-      continue;
+  bool aborted = false;
+  int p = sn_draw(sync, SN_QUEUE, s_flag_p, &aborted);
+  if (p == 0) {
+    const bool ok = !aborted && sn_chain(g, smem_raw, s_flag_p, s_red);
+    if (!QUEUED) {
+      if (tid == 0) g.res[3] = ok ? (double)sn_load(sync + SN_ABORT) : 1.0;
+      // nobody reads the counters any more (every pair is needed by something the chain has waited for, so every ticket has
+      // been drawn and the last waits above were the last of the launch): leave them zero for the next call
+      __syncthreads();
+      if (ok) for (int i = tid; i < SN_USED_WORDS(nblk); i += NT) sync[i] = 0u;
+      if (g.stamps && tid == 0) g.stamps[31] = (long long)wall_clock64();
+      return;
     }
-    // ---------------------------------------------------------------- a pair: column by column, the diagonal pairs first
-    p -= 1;
-    int k = -1, bi = 0, sl = 0;
-    for (int c = 0; c < nblk && k < 0; ++c) {
-      const int nd = (c == 0 && !kgen) ? 0 : spb;
-      const int nrow = spb * (nblk - 1 - c);
-      const int cnt = nd + nrow + aug_slabs;
-      if (p < cnt) {
-        k = c;
-        if (p < nd) { bi = c; sl = p; }
-        else if (p - nd < nrow) { bi = c + 1 + (p - nd) / spb; sl = (p - nd) % spb; }
-        else { bi = nblk; sl = p - nd - nrow; }
-      } else p -= cnt;
-    }
-    if (k < 0) break;                                     // the queue is empty
-    sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
+    if (ok) p = sn_draw(sync, SN_QUEUE, s_flag_p, &aborted); else aborted = true;
   }
-  // ---- the workgroup that leaves last reports and leaves the counters zero for the next call
+  while (!aborted) {
+    int bi = 0, sl = 0, k = 0;
+    if (!sn_decode(p, nblk, spb, aug_slabs, kgen, &bi, &sl, &k)) break;
+    sn_pair_task<SH>(g, smem_raw, s_flag_p, bi, sl, k);
+    if (!QUEUED) return;
+    p = sn_draw(sync, SN_QUEUE, s_flag_p, &aborted);
+  }
+  if (!QUEUED) return;
+  // ---- the workgroup that leaves last reports and leaves the counters zero for the next call (not the chain: others may still
+  // be drawing from the queue when it has finished)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -421,10 +404,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       g.res[3] = (double)ab;
       last = (ab == 0u) ? 1 : 0;
     }
-    s_flag_p[1] = last;
+    s_flag_p[2] = last;
   }
   __syncthreads();
-  if (s_flag_p[1]) for (int w = tid; w < SN_USED_WORDS(nblk); w += NT) sync[w] = 0u;
+  if (s_flag_p[2]) for (int w = tid; w < SN_USED_WORDS(nblk); w += NT) sync[w] = 0u;
 }
 
 // K (lower, + noise, identity padded) is in dK [np + 128][np]; resid [n][r] on the device.  On success dK holds L and the
@@ -474,12 +457,12 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
     GPS_HIP(h, hipStreamSynchronize(h->stream));
   }
   const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
-  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16>), (int)lds);
-  if (!rc0) rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_queue_kernel<16>), (int)lds);
+  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16, false>), (int)lds);
+  if (!rc0) rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&small_factor_kernel<16, true>), (int)lds);
   if (rc0) return rc0;
   LaunchScope ls(h, KC_POTRF_BASE, (double)np * np * np / 3.0, 8.0 * np * np);
-  if (queued) hipLaunchKernelGGL(small_factor_queue_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
-  else hipLaunchKernelGGL(small_factor_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
+  if (queued) hipLaunchKernelGGL((small_factor_kernel<16, true>), dim3(grid), dim3(NT), lds, h->stream, a);
+  else hipLaunchKernelGGL((small_factor_kernel<16, false>), dim3(grid), dim3(NT), lds, h->stream, a);
   GPS_HIP(h, hipGetLastError());
   if (want_stamps && nblk <= 8) {
     std::vector<long long> st(stamp_words);
@@ -574,7 +557,7 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
   }
 }
 
-// One workgroup = one task (blockIdx order = the order below; a task only waits for tasks before it):
+// One workgroup = one task at a time (ticket order = the order below; a task only waits for tasks before it):
 //   M (i, k, sl), k < i      : M_ik[slab] = W_i[slab] L_ik                                    -> counter SI_M(i, sl)  (i of them)
 //   Y (i, j, sl), j < i      : Y_ij[slab] = - sum_{k=j}^{i-1} M_ik[slab] Y_kj  (Y_jj = W_j)  -> counter SI_Y(i, j)   (8 slabs)
 //                              ordered by i - j: the blocks next to the diagonal need no other Y block
@@ -583,7 +566,8 @@ __device__ __forceinline__ void si_store_tile(double* scratch, const v4d& acc, d
 // Chain of dependent products at four blocks: M -> Y_10 -> Y_20 -> Y_30 -> K_00: five, against the nine plus four of a
 // workgroup that walks a whole slab of Y by itself.
 // The tasks are drawn from a queue in that order by however many workgroups are resident (a task only waits for tasks drawn
-// before it, and whoever has drawn a task is running: no co-residency assumption at all).
+// before it, and whoever has drawn a task is running: no co-residency assumption at all) -- also when there are as many
+// workgroups as tasks (round 5: that form took its task from blockIdx before).
 #define SI_QUEUE (1 * SN_LINE)                             // (line 0 is sn_wait's abort word: SN_ABORT)
 #define SI_DONE (2 * SN_LINE)
 #define SI_MAXB 16                                         // blocks the counters are laid out for (2048 padded points)
@@ -603,17 +587,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* scratch = As + 16 * SI_LSA * wave;          // per-wave 16 x 16 staging for the stores: inside the A region, used only between products
   bool ok = true;
   const int ntasks = 16 * npair + 8 * (npair + nblk) + nblk;
-  // (QUEUED = false: as many workgroups as tasks -- up to four blocks --, workgroup t is task t, nothing to draw.  A template
-  // parameter: as a run-time flag the loop around the tasks cost the straight-line form 11 us of its 38)
+  // (QUEUED = false: as many workgroups as tasks -- up to four blocks --, one draw each.  A template parameter: as a run-time
+  // flag the loop around the tasks cost the straight-line form 11 us of its 38)
   constexpr bool queued = QUEUED;
   for (int round = 0;; ++round) {
-  int t = (int)blockIdx.x;
-  if (queued) {
-    __syncthreads();                        // (the previous task's use of the LDS is over)
-    if (tid == 0) s_flag_p[1] = (int)__hip_atomic_fetch_add(sync + SI_QUEUE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    t = s_flag_p[1];
-  } else if (round > 0) break;
+  // the task is DRAWN (both forms; QUEUED = false: exactly once), never derived from blockIdx: a task only waits for tasks
+  // drawn before it, and whoever has drawn a task is running -- no co-residency assumption at all
+  if (!queued && round > 0) break;
+  bool aborted = false;
+  const int t = sn_draw(sync, SI_QUEUE, s_flag_p, &aborted);
+  if (aborted) break;
   if (t >= ntasks || !ok) break;
   const int sl = t % 8;
 
@@ -712,10 +695,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       g.res[0] = (double)ab;
       last = (ab == 0u) ? 1 : 0;
     }
-    s_flag_p[1] = last;
+    s_flag_p[2] = last;
   }
   __syncthreads();
-  if (s_flag_p[1]) for (int w = tid; w < SI_WORDS; w += NT) sync[w] = 0u;
+  if (s_flag_p[2]) for (int w = tid; w < SI_WORDS; w += NT) sync[w] = 0u;
 }
 
 // dK: the factor of gps_launch_small_factor; linv: its block inverses; d_alpha [r][np].  Fills dY (work), dKinv (lower blocks of
