@@ -57,6 +57,30 @@ struct Blocked {
   // current column range, [r][ldy], in place.
   struct YFollow { double* y; i64 ldy, r; };
 
+  // CROSS-LEVEL look-ahead (round 5).  The sweeps are latency chains that leave most of the GPU idle (a 4096-column sweep
+  // holds 0.3 ms of GEMM work and takes 1.6 - 1.9 ms); the big GEMMs of the levels above have slack.  Two kinds of BULK work
+  // are therefore taken out of the calling stream's order and issued on a stream of their own (Ops::bulk_open / bulk_close,
+  // joined by Ops::bulk_join before the first launch that needs their result; one piece in flight at a time: Ops::bulk()):
+  //  (a) the REST of a trailing update.  A22 -= A21 A21^T is split at A22's own split point: its leading n2a columns (all
+  //      rows) on the calling stream, the lower-right block -- which the child potrf_rec(A22) does not touch before its own
+  //      trailing update -- on the bulk stream, beside the child's first half (sweeps, panel solve).  The child is told by
+  //      `pend` and joins before that update.
+  //  (b) the first rows of a node's panel solve, beside the LAST sweep of the node's first half (the one with nothing of
+  //      its own to run beside): rows [0, rows) of  X L^T = A21  against the first n1a columns -- final since the first
+  //      half of A11 was factored -- are issued by the leaf that is about to start that sweep (`last` is handed down the
+  //      right spine); the node then solves the other rows itself, joins and carries on as after a handed-down piece.
+  struct Last { const double* L; i64 ldl, n, blk0; double* B; i64 ldb, rows; bool issued; };
+  int issue_last(Last* last) {
+    if (!last || last->issued || last->rows <= 0 || !ops.bulk()) return 0;
+    int rc = ops.bulk_open();
+    if (rc) return rc;
+    rc = trsm_rec(last->L, last->ldl, last->n, last->blk0, last->B, last->ldb, last->rows);
+    const int rc2 = ops.bulk_close();
+    if (rc || rc2) return rc ? rc : rc2;
+    last->issued = true;
+    return 0;
+  }
+
   // blk0: index of the first 128-block of this sub-matrix in the block-inverse array;
   // row0: global row of A's first row (for info reporting)
   // e: AUGMENTED rows -- e more rows stored directly below A (same leading dimension, a multiple of 128) that are not
@@ -75,7 +99,10 @@ struct Blocked {
     return rc ? rc : rc2;
   }
 
-  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr, i64 e = 0, const YFollow* yf = nullptr) {
+  // pend: a bulk piece (a) is in flight that writes this node's A22 -- join before the trailing update
+  // last: a bulk piece (b) to issue right before the last sweep of this sub-matrix
+  int potrf_rec(double* A, i64 lda, i64 n, i64 blk0, i64 row0, Deferred* dj = nullptr, i64 e = 0, const YFollow* yf = nullptr,
+                bool pend = false, Last* last = nullptr) {
     if (n <= 0) return 0;
     if (n == GPS_TILE) {
       int rc = ops.potrf_base(A, lda, blk0, row0);
@@ -84,7 +111,9 @@ struct Blocked {
       return y_block(A, lda, n, blk0, yf);
     }
     if (n <= ops.rl_max()) {
-      int rc = ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0, nullptr, 0, 0, e) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0, e);
+      int rc = issue_last(last);
+      if (rc) return rc;
+      rc = ops.rl_group() > 1 ? potrf_rl_groups(A, lda, n, ops.rl_group(), blk0, row0, nullptr, 0, 0, e) : potrf_rl(A, lda, n, GPS_TILE, blk0, row0, e);
       if (rc) return rc;
       return y_block(A, lda, n, blk0, yf);
     }
@@ -98,6 +127,7 @@ struct Blocked {
       // A11 is factored by the sweep: the solve of A21 against it follows the sweep on the side stream
       // ... and so does the trailing update of A22: every solved column block of A21 is applied to A22 at once, behind
       // the sweep, instead of as one update after it (below: skipped)
+      if (pend && ops.trail_follows()) { rc = ops.bulk_join(); if (rc) return rc; pend = false; }     // (the follower writes A22)
       rc = potrf_rl_groups(A, lda, n1, ops.rl_group(), blk0, row0, A21, lda, m2, 0, ops.trail_follows() ? A22 : nullptr, lda, n2);
       if (rc) return rc;
       trailing_done = ops.trail_follows();
@@ -117,9 +147,22 @@ struct Blocked {
       const i64 n1a = split(n1);
       Deferred job{A21, lda, m2, n1a, false};
       const bool hand_down = n1 > ops.rl_max() && n1a > GPS_TILE && n1a <= ops.rl_max() && ops.rl_group() > 1 && ops.follower() && ops.deferred();
-      rc = potrf_rec(A, lda, n1, blk0, row0, hand_down ? &job : nullptr, 0, yf);
+      // (b): a first half of at least four sweeps has a last sweep with nothing to run beside -- the first rows of this
+      // node's panel solve against its first n1a columns go there
+      Last mine{A, lda, n1a, blk0, A21, lda, 0, false};
+      if (!hand_down && n1a > ops.rl_max()) mine.rows = ops.bulk_rows(n1a, m2);
+      rc = potrf_rec(A, lda, n1, blk0, row0, hand_down ? &job : nullptr, 0, yf, false, mine.rows > 0 ? &mine : nullptr);
       if (rc) return rc;
-      if (hand_down && job.issued) {
+      if (mine.issued) {
+        // rows [0, rows) of the first n1a columns are on the bulk stream: the other rows here, then as after a handed-down piece
+        rc = trsm_rec(A, lda, n1a, blk0, A21 + mine.rows * lda, lda, m2 - mine.rows);
+        if (rc) return rc;
+        rc = ops.bulk_join();
+        if (rc) return rc;
+        rc = ops.gemm(0, 0, m2, n1 - n1a, n1a, A21, lda, A + n1a * lda, lda, A21 + n1a, lda);
+        if (rc) return rc;
+        rc = trsm_rec(A + n1a * lda + n1a, lda, n1 - n1a, blk0 + n1a / GPS_TILE, A21 + n1a, lda, m2);
+      } else if (hand_down && job.issued) {
         // trsm_rec(A, n1) = trsm_rec(first n1a columns) [done on the deferred stream] ; update ; trsm_rec(the others)
         rc = ops.deferred_join();
         if (rc) return rc;
@@ -141,11 +184,32 @@ struct Blocked {
       const int rc2 = ops.y_close();
       if (rc || rc2) return rc ? rc : rc2;
     }
+    if (pend) { rc = ops.bulk_join(); if (rc) return rc; }         // the rest of the parent's update of this A22 has landed
+    bool pend2 = false;
     if (!trailing_done) {
-      rc = ops.gemm(/*op sub*/ 0, /*lower (trapezoid when e > 0)*/ 1, m2, n2, n1, A21, lda, A21, lda, A22, lda);
-      if (rc) return rc;
+      const i64 n2a = split(n2);
+      if (n2 > ops.rl_max() && n2a >= GPS_TILE && ops.bulk_rest()) {
+        // (a): the columns the child factors first on this stream, the block it does not touch before its own trailing
+        // update on the bulk stream
+        rc = ops.gemm(0, 1, m2, n2a, n1, A21, lda, A21, lda, A22, lda);
+        if (rc) return rc;
+        rc = ops.bulk_open();
+        if (rc) return rc;
+        // (in K chunks: workgroups that live tens of microseconds instead of milliseconds, so that the kernels of the
+        // chain find slots as they arrive -- Ops::bulk_chunk)
+        double* R = A21 + n2a * lda;
+        const i64 kc = ops.bulk_chunk(n1);
+        for (i64 k0 = 0; k0 < n1 && !rc; k0 += kc)
+          rc = ops.gemm(0, 1, m2 - n2a, n2 - n2a, (n1 - k0 < kc) ? n1 - k0 : kc, R + k0, lda, R + k0, lda, A22 + n2a * lda + n2a, lda);
+        const int rc2 = ops.bulk_close();
+        if (rc || rc2) return rc ? rc : rc2;
+        pend2 = true;
+      } else {
+        rc = ops.gemm(/*op sub*/ 0, /*lower (trapezoid when e > 0)*/ 1, m2, n2, n1, A21, lda, A21, lda, A22, lda);
+        if (rc) return rc;
+      }
     }
-    return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1, nullptr, e, yf ? &y2 : nullptr);
+    return potrf_rec(A22, lda, n2, blk0 + n1 / GPS_TILE, row0 + n1, nullptr, e, yf ? &y2 : nullptr, pend2, last);
   }
 
   // Right-looking sweep over nbp-column panels.

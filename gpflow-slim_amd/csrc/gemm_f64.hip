@@ -490,12 +490,16 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     if (ns > h->gemm_tail_max_slices) ns = h->gemm_tail_max_slices;
     while (ns > 1 && (g.K / BK_MIN) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
     if (nfull >= slots && ns > 1) {
-      GPS_HIP(h, h->dGemmWs.ensure((size_t)r * ns * BM * BN * sizeof(double)));
-      if (h->dGemmCnt.cap == 0) {
-        GPS_HIP(h, h->dGemmCnt.ensure(512 * sizeof(unsigned)));
-        GPS_HIP(h, hipMemsetAsync(h->dGemmCnt.p, 0, 512 * sizeof(unsigned), h->stream));
+      // (the bulk stream's GEMMs run beside the main stream's: a work space of their own)
+      const bool on_bulk = h->bulk_stream != nullptr && h->stream == h->bulk_stream;
+      DevBuf& ws = on_bulk ? h->dGemmWsB : h->dGemmWs;
+      DevBuf& cnt = on_bulk ? h->dGemmCntB : h->dGemmCnt;
+      GPS_HIP(h, ws.ensure((size_t)r * ns * BM * BN * sizeof(double)));
+      if (cnt.cap == 0) {
+        GPS_HIP(h, cnt.ensure(512 * sizeof(unsigned)));
+        GPS_HIP(h, hipMemsetAsync(cnt.p, 0, 512 * sizeof(unsigned), h->stream));
       }
-      g.nfull = nfull; g.nsplit = ns; g.ws = h->dGemmWs.d(); g.cnt = (unsigned*)h->dGemmCnt.p;
+      g.nfull = nfull; g.nsplit = ns; g.ws = ws.d(); g.cnt = (unsigned*)cnt.p;
     }
   }
   // scheduled K loop (see the kernel) for the square 128x128 and 64x64 tiles; "gemm_pipe" = 0 keeps the compiler's order

@@ -226,6 +226,67 @@ struct HipOps {
     GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_def_join, 0));
     return GPS_OK;
   }
+  // ---- bulk stream: cross-level look-ahead (blocked.hpp: pieces (a) and (b)); coarse (milliseconds of GEMM work): events
+  bool bulk_busy = false;
+  hipStream_t saved_stream_b = nullptr;
+  bool bulk() {
+    if (!h->potrf_bulk || bulk_busy || !lookahead()) return false;
+    if (!h->bulk_stream) {
+      hipError_t e;
+      if (h->potrf_bulk_prio) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // (lo: numerically greatest = least urgent)
+        e = hipStreamCreateWithPriority(&h->bulk_stream, hipStreamNonBlocking, lo);
+      } else if (h->prop.multiProcessorCount == 256) {
+        // (mask word w = CUs 4 w .. 4 w + 3 of every XCD, one per shader engine: the chain's kernels are dealt out over all XCDs
+        // and must find free CUs in each of them)
+        uint32_t mask[8];
+        for (int w = 0; w < 8; ++w) mask[w] = (w < h->potrf_bulk_reserve) ? 0u : 0xffffffffu;
+        e = hipExtStreamCreateWithCUMask(&h->bulk_stream, 8, mask);
+      } else {
+        e = hipStreamCreateWithFlags(&h->bulk_stream, hipStreamNonBlocking);
+      }
+      if (e != hipSuccess) { h->bulk_stream = nullptr; return false; }
+      if ((!h->ev_bulk_fork && hipEventCreateWithFlags(&h->ev_bulk_fork, hipEventDisableTiming) != hipSuccess) ||
+          (!h->ev_bulk_join && hipEventCreateWithFlags(&h->ev_bulk_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(h->bulk_stream);
+        h->bulk_stream = nullptr;
+        return false;
+      }
+    }
+    if (h->bulk_pending) {
+      // a piece an earlier call left behind (it returned early with an error): nothing of this call may overtake it
+      if (hipStreamSynchronize(h->bulk_stream) != hipSuccess) return false;
+      h->bulk_pending = false;
+    }
+    return true;
+  }
+  bool bulk_rest() { return (h->potrf_bulk & 1) && bulk(); }     // piece (a)
+  i64 bulk_chunk(i64 k) const { return (h->potrf_bulk_kc >= 128 && h->potrf_bulk_kc < k) ? (i64)h->potrf_bulk_kc : k; }
+  i64 bulk_rows(i64 n1a, i64 m) {            // rows of a (b) piece: potrf_bulk_flop of GEMM work, whole tiles
+    if (!(h->potrf_bulk & 2) || !bulk()) return 0;
+    i64 rows = (i64)(h->potrf_bulk_flop / ((double)n1a * (double)n1a)) / GPS_TILE * GPS_TILE;
+    if (rows < 4 * GPS_TILE) rows = 4 * GPS_TILE;
+    return rows < m ? rows : m;
+  }
+  int bulk_open() {
+    GPS_HIP(h, hipEventRecord(h->ev_bulk_fork, h->stream));
+    GPS_HIP(h, hipStreamWaitEvent(h->bulk_stream, h->ev_bulk_fork, 0));
+    saved_stream_b = h->stream; h->stream = h->bulk_stream;
+    bulk_busy = true; h->bulk_pending = true;
+    return GPS_OK;
+  }
+  int bulk_close() {
+    hipError_t e = hipEventRecord(h->ev_bulk_join, h->bulk_stream);
+    h->stream = saved_stream_b; saved_stream_b = nullptr;
+    GPS_HIP(h, e);
+    return GPS_OK;
+  }
+  int bulk_join() {
+    GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_bulk_join, 0));
+    bulk_busy = false; h->bulk_pending = false;
+    return GPS_OK;
+  }
   int chain_join(unsigned long long t) {
     // diagnostics ("la_fault_inject" = k): the k-th join from now waits for a ticket that never comes, i.e. takes the
     // time-out path of a missed hand-over (tests/test_gpu_kernels.py::test_lookahead_timeout_is_retried)
@@ -345,6 +406,10 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   }
   if (const char* m0 = getenv("GPS_LA_MASK0")) h->la_mask_word0 = (uint32_t)strtoul(m0, nullptr, 0);     // diagnostics
   if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
+  if (const char* v = getenv("GPS_BULK")) h->potrf_bulk = atoi(v);                                       // diagnostics
+  if (const char* v = getenv("GPS_BULK_RESERVE")) h->potrf_bulk_reserve = atoi(v);                       // diagnostics
+  if (const char* v = getenv("GPS_BULK_KC")) h->potrf_bulk_kc = atoi(v);                                 // diagnostics
+  if (const char* v = getenv("GPS_BULK_PRIO")) h->potrf_bulk_prio = atoi(v);                             // diagnostics
   if (const char* v = getenv("GPS_TRSV_WAVE")) h->trsv_wave = atoi(v);                                   // (same switches as
   if (const char* v = getenv("GPS_LEAF_PERSISTENT")) h->leaf_persistent = atoi(v);                       //  gps_set_option,
   if (const char* v = getenv("GPS_SMALL_N")) h->small_n = atoi(v);
@@ -358,7 +423,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
 static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB,
                     &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
@@ -374,6 +439,7 @@ extern "C" int gps_release_buffers(gps_handle_t h) {
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (h->side_stream) GPS_HIP(h, hipStreamSynchronize(h->side_stream));
   if (h->def_stream) GPS_HIP(h, hipStreamSynchronize(h->def_stream));
+  if (h->bulk_stream) GPS_HIP(h, hipStreamSynchronize(h->bulk_stream));
   if (h->y_stream) GPS_HIP(h, hipStreamSynchronize(h->y_stream));
   gps_profile_collect(h);
   release_work_buffers(h, false);
@@ -394,6 +460,7 @@ extern "C" int gps_destroy(gps_handle_t h) {
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }
+  if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); }
   if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); }
   if (h->dist_chain) { (void)hipStreamSynchronize(h->dist_chain); (void)hipStreamDestroy(h->dist_chain); }
   if (h->dist_bulk_own) { (void)hipStreamSynchronize(h->dist_bulk_own); (void)hipStreamDestroy(h->dist_bulk_own); }
@@ -402,6 +469,8 @@ extern "C" int gps_destroy(gps_handle_t h) {
   if (h->ev_y_join) (void)hipEventDestroy(h->ev_y_join);
   if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
   if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
+  if (h->ev_bulk_fork) (void)hipEventDestroy(h->ev_bulk_fork);
+  if (h->ev_bulk_join) (void)hipEventDestroy(h->ev_bulk_join);
   h->dLaFlags.release();
   h->ring.release();
   if (h->hRes) (void)hipHostFree(h->hRes);
@@ -510,11 +579,21 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "dist_partitioned") == 0) { h->dist_partitioned = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_bulk") == 0) { h->potrf_bulk = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_bulk_flop") == 0) { h->potrf_bulk_flop = value; return GPS_OK; }
+  if (strcmp(key, "potrf_bulk_reserve") == 0) {   // takes effect when the bulk stream is (re)created
+    const int v = (int)value < 1 ? 1 : ((int)value > 6 ? 6 : (int)value);
+    if (v == h->potrf_bulk_reserve) return GPS_OK;
+    h->potrf_bulk_reserve = v;
+    if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; h->bulk_pending = false; }
+    return GPS_OK;
+  }
   if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
     if (h->la_mask_word0 == (uint32_t)value) return GPS_OK;
     h->la_mask_word0 = (uint32_t)value;
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
     if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); h->def_stream = nullptr; }
+    if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; h->bulk_pending = false; }
     if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); h->y_stream = nullptr; }
     return GPS_OK;
   }
@@ -2268,6 +2347,11 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
       (void)hipStreamSynchronize(h->y_stream);
       (void)hipStreamDestroy(h->y_stream);
       h->y_stream = nullptr;
+    }
+    if (h->bulk_stream) {
+      (void)hipStreamSynchronize(h->bulk_stream);
+      (void)hipStreamDestroy(h->bulk_stream);
+      h->bulk_stream = nullptr; h->bulk_pending = false;
     }
   } else if (h->ext_stream) {
     h->stream = h->own_stream; h->ext_stream = false;

@@ -108,6 +108,26 @@ struct gps_handle_s {
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
   int potrf_deferred = 1;
+  // cross-level look-ahead (blocked.hpp: "bulk" pieces (a) and (b)): a CU-masked, event-ordered stream of its own; one piece
+  // in flight at a time.  potrf_bulk: bit 0 = (a) the rest of a trailing update beside the child's first half, bit 1 = (b) the
+  // first rows of a panel solve beside the last sweep of the first half; potrf_bulk_flop: GEMM work of a (b) piece.
+  // OFF: built, correct (CPU emulation with a region race detector, same LML on the GPU) and measured slower in every form
+  // tried on MI355X -- N = 32768, same-process A/B, potrf stage: 180.2 -> 183.3 (a) / 181.5 (b) / 184.5 ms (both); with 8 / 12 /
+  // 16 / 24 CUs of every XCD kept from the bulk stream: +2.2 .. +43 ms; pieces cut into K = 256 .. 2048 launches on a
+  // lowest-priority un-masked stream: +1.5 .. +4.5 ms.  The kernel trace shows why: the chain's own launches keep their pace
+  // beside a resident GEMM (potrf_base 30 us, panel solve 19, block column 24 against 18), but every launch of the sweep's
+  // side and follower streams waits for workgroups of the bulk GEMM to retire (they live 3.5 ms at K = 16384) or shares its
+  // CUs: remainder updates 65 -> 480 us, follower pieces 2 x; and a potrf(8192) window already holds 4.5 ms of GEMM work in
+  // its 8.4 ms, so a static split of the CUs cannot pay either (docs/LAB_NOTES.md, round 5).
+  hipStream_t bulk_stream = nullptr;
+  hipEvent_t ev_bulk_fork = nullptr, ev_bulk_join = nullptr;
+  bool bulk_pending = false;                   // a piece has been issued and not yet joined
+  int potrf_bulk = 0;
+  int potrf_bulk_kc = 0;                       // K chunk of a piece (a)'s launches (0: one launch)
+  int potrf_bulk_prio = 0;                     // 1: the bulk stream is an un-masked stream of the lowest priority instead of a CU-masked one
+  int potrf_bulk_reserve = 2;                  // CU-mask words (4 CUs of every XCD each) the bulk stream leaves to the chain
+  double potrf_bulk_flop = 1.2e11;
+  DevBuf dGemmWsB, dGemmCntB;                  // the tail split's work space of GEMMs on the bulk stream (they run beside the main stream's)
   // forward substitution of gps_gpr_lml following the factorisation on a stream of its own (blocked.hpp: YFollow).
   // Off: measured on MI355X, ~500 small kernels dribbling in beside the 128x128 GEMM rounds (which own every register of
   // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).

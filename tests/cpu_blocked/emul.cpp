@@ -15,6 +15,9 @@ static i64 g_rl_group = 1;
 static int g_lookahead = 0;
 static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
+static int g_bulk = 0;        // emul_set_bulk: cross-level look-ahead -- bit 0: piece (a), bit 1: piece (b); rows of a (b) piece below
+static i64 g_bulk_rows = 256;
+static int g_bulk_pieces = 0, g_bulk_bad = 0;      // pieces issued / pairing or race violations seen (read by the tests)
 
 struct CpuOps {
   std::vector<double> linv, linvT;
@@ -25,6 +28,7 @@ struct CpuOps {
   int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
     if (join_armed) return -31;                 // a join handed to "the next GEMM" must be followed by one
     ++n_base;
+    touch(A, lda, T, T, true);
     for (i64 j = 0; j < T; ++j) {
       double d = A[j * lda + j];
       for (i64 k = 0; k < j; ++k) d -= A[j * lda + k] * A[j * lda + k];
@@ -54,6 +58,8 @@ struct CpuOps {
     ++n_gemm;
     join_armed = false;                         // (a pending fused join is consumed by this launch)
     if (M % T || N % T || K % 16) return -1;
+    touch(A, lda, M, K, false); touch(B, ldb, N, K, false); touch(C, ldc, M, N, true);
+    if (op != 1 && op != 3) touch(C, ldc, M, N, false);
     std::vector<double> out((size_t)M * N, 0.0);
     std::vector<char> done((size_t)M * N, 0);
     for (i64 i = 0; i < M; ++i)
@@ -116,6 +122,36 @@ struct CpuOps {
   int follower_close() { if (!fol_open) return -17; fol_open = 0; return 0; }
   int follower_publish() { if (!fol_open) return -11; ++fol_pub; return 0; }
   int follower_join() { if (open_side || fol_open || fol_pub == 0) return -12; return 0; }
+  // cross-level look-ahead (blocked.hpp: pieces (a) and (b)).  Sequential here -- a piece is executed when it is issued --, so
+  // what the hooks check is (i) the pairing: one piece in flight at a time, every piece joined, and (ii) a race detector by
+  // regions: every rectangle of the matrix a piece reads or writes is recorded, and until the join no operation of the
+  // calling stream may write a rectangle the piece touches or read one it writes (touch()).
+  int bulk_state = 0;            // 0 idle, 1 open (launches go to the bulk stream), 2 in flight (closed, not joined)
+  struct Rect { i64 r0, c0, nr, nc; };
+  std::vector<Rect> bulk_reads, bulk_writes;
+  const double* base = nullptr; i64 base_ld = 0, base_rows = 0;        // the matrix being factored (set by the entry points below)
+  static bool overlap(const Rect& a, const Rect& b) { return a.r0 < b.r0 + b.nr && b.r0 < a.r0 + a.nr && a.c0 < b.c0 + b.nc && b.c0 < a.c0 + a.nc; }
+  void touch(const double* p, i64 ld, i64 nr, i64 nc, bool write) {
+    if (!base || ld != base_ld || p < base || p >= base + base_rows * base_ld) return;      // (block inverses etc.: not in the matrix)
+    const Rect r{(i64)((p - base) / base_ld), (i64)((p - base) % base_ld), nr, nc};
+    if (bulk_state == 1) { (write ? bulk_writes : bulk_reads).push_back(r); return; }
+    if (bulk_state != 2) return;
+    for (const Rect& w : bulk_writes) if (overlap(r, w)) ++g_bulk_bad;
+    if (write) for (const Rect& q : bulk_reads) if (overlap(r, q)) ++g_bulk_bad;
+  }
+  bool bulk() { return g_bulk != 0 && bulk_state == 0; }
+  bool bulk_rest() { return (g_bulk & 1) && bulk(); }
+  i64 bulk_chunk(i64 k) const { return k > 256 ? 256 : k; }
+  i64 bulk_rows(i64, i64 m) { if (!(g_bulk & 2) || !bulk()) return 0; return g_bulk_rows < m ? g_bulk_rows : m; }
+  int n_bulk_open = 0;
+  int bulk_open() { if (bulk_state != 0 || open_side || def_open || fol_open) { ++g_bulk_bad; return -41; } bulk_state = 1; ++n_bulk_open; return 0; }
+  int bulk_close() { if (bulk_state != 1) { ++g_bulk_bad; return -42; } bulk_state = 2; return 0; }
+  int bulk_join() {
+    if (bulk_state != 2) { ++g_bulk_bad; return -43; }
+    bulk_reads.clear(); bulk_writes.clear();
+    bulk_state = 0;
+    return 0;
+  }
   int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
   // (the join carried by the next GEMM: that launch must follow at once)
   bool join_armed = false;
@@ -176,6 +212,37 @@ void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_leaf512(int v) { g_leaf512 = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
+void emul_set_bulk(int v, i64 rows) { g_bulk = v; g_bulk_rows = rows; g_bulk_pieces = g_bulk_bad = 0; }
+void emul_bulk_counts(int* pieces, int* bad) { *pieces = g_bulk_pieces; *bad = g_bulk_bad; }
+// the race detector itself: a piece that writes a block the calling stream then reads before the join must be flagged (1),
+// the same with the join in between must not (0)
+int emul_bulk_selftest(int with_join) {
+  const i64 n = 3 * T;
+  std::vector<double> A((size_t)n * n, 1.0);
+  CpuOps ops(n / T);
+  ops.base = A.data(); ops.base_ld = n; ops.base_rows = n;
+  g_bulk_bad = 0;
+  const int saved = g_bulk; g_bulk = 3;
+  int rc = ops.bulk_open();
+  if (!rc) rc = ops.gemm(0, 0, T, T, T, A.data() + T * n, n, A.data() + T * n, n, A.data() + 2 * T * n + 2 * T, n);     // piece writes block (2, 2)
+  if (!rc) rc = ops.bulk_close();
+  if (!rc && with_join) rc = ops.bulk_join();
+  if (!rc) rc = ops.gemm(0, 0, T, T, T, A.data() + 2 * T * n + 2 * T, n, A.data(), n, A.data() + T * n, n);               // calling stream reads block (2, 2)
+  g_bulk = saved;
+  return rc ? -1 : (g_bulk_bad > 0 ? 1 : 0);
+}
+// A [(n + e), n] in place with the cross-level look-ahead hooks armed: factor (+ augmented rows), count the bulk pieces and
+// the violations of the race detector; a piece still in flight at the end is a violation
+int emul_potrf_bulk(double* A, i64 n, i64 e, int* info) {
+  CpuOps ops(n / T);
+  ops.base = A; ops.base_ld = n; ops.base_rows = n + e;
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, e);
+  *info = ops.info;
+  g_bulk_pieces += ops.n_bulk_open;
+  if (ops.bulk_state != 0) ++g_bulk_bad;
+  return rc;
+}
 // the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only
 int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
   CpuOps ops(n / T);

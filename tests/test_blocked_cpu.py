@@ -183,3 +183,40 @@ def test_forward_substitution_follows_the_factorisation(emul, n, r, rl_max, grou
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
     assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
     assert sections.value >= 1
+
+
+@pytest.mark.parametrize("n,e,rl_max,bulk,expect", [(1024, 0, 256, 1, 1), (1536, 128, 256, 1, 3), (1280, 0, 256, 3, 3), (2048, 0, 256, 1, 3), (2048, 0, 256, 2, 1),
+                                                    (2048, 128, 256, 3, 4), (2304, 0, 256, 3, 6), (1024, 0, 512, 3, 0)])
+def test_cross_level_lookahead_schedule(emul, n, e, rl_max, bulk, expect):
+    """blocked.hpp, round 5: (a) the rest of a trailing update and (b) the first rows of a panel solve leave the calling stream's
+    order (Ops::bulk_*) to run beside the sweeps.  As index logic on the CPU: the factor (and the augmented rows) still match
+    LAPACK; the expected number of pieces was issued, every one joined; and the emulation's region race detector saw no
+    operation of the calling stream touch what a piece in flight reads or writes."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(1)
+    emul.emul_set_rl_group(ctypes.c_int64(2))
+    emul.emul_set_bulk(bulk, ctypes.c_int64(256))
+    try:
+        rng = np.random.default_rng(n + e + bulk)
+        G = rng.standard_normal((n, n)); K = G @ G.T + n * np.eye(n)
+        E = rng.standard_normal((e, n))
+        A = np.ascontiguousarray(np.vstack([K, E]))
+        info = ctypes.c_int(0)
+        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        rc = emul.emul_potrf_bulk(p(A), ctypes.c_int64(n), ctypes.c_int64(e), ctypes.byref(info))
+        pieces, bad = ctypes.c_int(0), ctypes.c_int(0)
+        emul.emul_bulk_counts(ctypes.byref(pieces), ctypes.byref(bad))
+    finally:
+        emul.emul_set_bulk(0, ctypes.c_int64(256)); emul.emul_set_lookahead(0)
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(K, lower=True)
+    assert np.abs(np.tril(A[:n]) - L).max() <= 1e-12 * np.abs(L).max()
+    if e:
+        assert np.abs(A[n:] - sl.solve_triangular(L, E.T, lower=True).T).max() <= 1e-11
+    assert bad.value == 0
+    # (n = 2048 with 256-column sweeps is N = 32768 with 4096-column sweeps in small: three rests (a) and one row piece (b))
+    assert pieces.value == expect, pieces.value
+
+
+def test_cross_level_lookahead_race_detector_detects(emul):
+    assert emul.emul_bulk_selftest(0) == 1 and emul.emul_bulk_selftest(1) == 0
