@@ -241,6 +241,35 @@ def progress(tag):
             f.write("%s %.3f\n" % (tag, time.time()))
 
 
+class alive:
+    """Heartbeat for a phase of a rank process that can take longer than --stall without being hung and that cannot hang on
+    the GPU or in a collective with work outstanding: the CPU stand-in timed on rank 0's host cores (44 s with 128 BLAS threads,
+    several times that with the cores shared by 8 ranks), and the other ranks' wait for rank 0 in the last barrier (they have
+    finished; if rank 0 fails or stalls its own supervisor says so and the attempt ends for everybody).  A progress mark every
+    `period` seconds while inside; everything else stays under the supervisor's stall clock."""
+
+    period = 15.0          # (main() lowers it to a third of --stall)
+
+    def __init__(self, tag):
+        import threading
+        self.tag, self.stop = tag, threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop.wait(self.period):
+            progress(self.tag)
+
+    def __enter__(self):
+        progress(self.tag)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.thread.join()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +309,7 @@ def main():
     ap.add_argument("--cfg5-m", type=int, default=4096)
     ap.add_argument("--cfg5-n", type=int, default=1000000)
     args = ap.parse_args()
+    alive.period = max(0.5, min(15.0, args.stall / 3.0))
 
     if args.gpus > 1 and not os.environ.get("GPS_BENCH_CHILD"):
         # Not a rank process yet: be the GPU-free supervisor of the rank processes (before torch / the library / any GPU call).
@@ -295,8 +325,12 @@ def main():
         if len(attempts) > 1:
             # a launcher started one bench.py per rank: each becomes the supervisor of its own rank process; the supervisors of
             # the run meet in a directory named after what they share (the launcher's pid and rendezvous port; same node)
+            # (+ the launcher's run id and restart count: a launcher that restarts its workers keeps pid and port, and the
+            # files of the previous round -- an old port, old verdicts -- must not be found by the new one)
             rdv = os.environ.get("GPS_BENCH_RDV_DIR") or os.path.join(
-                "/tmp", "gps_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+                "/tmp", "gps_bench_%d_%s_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                                   "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:24],
+                                                   os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
             r = int(os.environ.get("RANK", "0"))
             sys.exit(supervise([r], args.gpus, sys.argv[1:], attempts, rdv, args.first_stall, args.stall, False))
         args.attempt_name = attempts[0]          # one configuration only: the launcher's rank process runs it itself
@@ -605,20 +639,25 @@ def main():
             # the algorithmic work of the class is the potrf's N^3/3 (all of it lands in this kernel)
             alg = n ** 3 / 3.0
             achieved = alg / (g["ms"] * 1e-3) / 1e12
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_total, traffic_launches = None, None, None, None
             import glob
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_f64_hbm_bytes_per_launch.json")), reverse=True):
                 if not (n == 32768 and d == 8):
                     break
                 with open(pmc) as f:
                     rec = json.load(f)
-                if rec.get("kernel_source_sha") == kernel_source_sha():      # measured on exactly these device sources
-                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
+                # measured on exactly these device sources, over exactly this launch set (the KC_GEMM class: gemm_nt_f64_kernel<*>
+                # and trsm_panel_kernel<*>): traffic x launches == traffic_total_bytes
+                if rec.get("kernel_source_sha") == kernel_source_sha() and int(rec.get("launches", -1)) == int(g["launches"]):
+                    traffic_total, traffic_launches = rec.get("hbm_bytes_total"), int(rec["launches"])
+                    traffic, traffic_src = traffic_total / traffic_launches, "profiles/" + os.path.basename(pmc)
                     break
             peak_meas, _ = h.diag_mfma_f64(2)
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel", "achieved": round(achieved, 3),
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (+ trsm_panel_kernel, the 512-column solve built from the same MFMA products: the library's GEMM class)",
+                        "achieved": round(achieved, 3),
                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": traffic, "traffic_source": traffic_src, "launches": g["launches"],
+                        "traffic": traffic, "traffic_total_bytes": traffic_total, "traffic_launches": traffic_launches,
+                        "traffic_source": traffic_src, "launches": g["launches"],
                         "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 3),
                         "algorithmic_flops_per_launch": alg / max(g["launches"], 1),
                         "launch_counted": {"flops": g["flops"], "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 3),
@@ -628,7 +667,10 @@ def main():
                                        "tflops": round(flops_eval / (stages["total"] * 1e-3) / 1e12, 3),
                                        "frac": round(flops_eval / (stages["total"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                                        "ms": round(stages["total"], 3)},
-                        "per_class_ms": {k: round(v["ms"], 3) for k, v in classes.items()},
+                        "per_class_ms": dict({k: round(v["ms"], 3) for k, v in classes.items()},
+                                             schedule="look-ahead OFF: the instrumented pass (every launch bracketed by events, launches serialised)"),
+                        "stage_ms": dict({k: round(v, 3) for k, v in stages.items()},
+                                         schedule="look-ahead ON: stage events of a timed evaluation (what value / ms_per_step measure)"),
                         "kernel_source_sha": kernel_source_sha(),
                         "note": "instrumented evaluation with the look-ahead off (launches serialised); value / ms_per_step are measured with it on"}
             # the HBM-bound kernels of the evaluation: algorithmic bytes / class time
@@ -673,8 +715,11 @@ def main():
             ns = min(args.cpu_sample_n, n)
             Xc, Yc = X[:ns], Y[:ns]
             spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls0), "input_dim": d}
-            ref_lml, tm = orc.gpr_lml_timed(spec, Xc, Yc, orc.constrained(0.1))
-            t1 = time.perf_counter(); orc.rbf_K_inplace(spec, Xc); kin = time.perf_counter() - t1
+            with alive("cpu_baseline_running"):
+                # (testing: GPS_BENCH_TEST_SLOW_TAIL = seconds rank 0 spends here on top, as if its host cores were shared)
+                time.sleep(float(os.environ.get("GPS_BENCH_TEST_SLOW_TAIL", "0")))
+                ref_lml, tm = orc.gpr_lml_timed(spec, Xc, Yc, orc.constrained(0.1))
+                t1 = time.perf_counter(); orc.rbf_K_inplace(spec, Xc); kin = time.perf_counter() - t1
             # parity gate on the very sample that is timed
             kern._ls.assign(ls0); kern._variance.assign(1.0)
             ms = gpf.models.GPR(Xc, Yc, kern, obs_var=0.1)
@@ -726,7 +771,8 @@ def main():
         progress("cpu_baseline_done")
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        with alive("last_barrier"):          # (ranks != 0 wait here while rank 0 runs its single-GPU tail and the CPU stand-in)
+            dist.barrier()
         state["done"] = True
         timer.cancel()
         dist.destroy_process_group()

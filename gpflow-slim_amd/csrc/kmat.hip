@@ -156,7 +156,9 @@ __device__ __forceinline__ double gps_exp_nonpos(double x, const ExpTab& t) {   
 #ifndef GPS_EXP_LDEXP
   const int hi = __double2hiint(p) + (ki << 20);         // p in [0.70, 1.42]: the exponent field cannot wrap for k >= -1021
   const double v = __hiloint2double(hi, __double2loint(p));
-  return ki < -1021 ? 0.0 : v;
+  // (a NaN argument -- NaN in X or in a hyper-parameter -- is clamped to -1100 above: hand it through, as tf.exp and the
+  // small-N path's exp() do, instead of returning 0 and a finite kernel matrix)
+  return ki < -1021 ? (x == x ? 0.0 : x) : v;
 #else
   return ldexp(p, (int)k);                          // k >= -1075: gradual underflow to 0 like exp()
 #endif

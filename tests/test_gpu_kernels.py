@@ -409,6 +409,31 @@ def test_kernel_matrix_chain_kernel_equals_interpreter(handle, n, m):
         assert np.abs(out[1] - out[0]).max() <= 4e-15 * np.abs(out[0]).max()
 
 
+def test_nan_inputs_propagate_through_the_kernel_matrix(handle):
+    """tf.exp propagates NaN (kernels.py:439, 576-610): a NaN coordinate must poison its row and column of K on every build
+    path (the exponent-injection exp returned 0 for a NaN argument), and the likelihood must not come back finite."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((300, 3)); X[17, 1] = np.nan
+    for kern in (gpf.kernels.RBF(3, lengthscales=1.1), gpf.kernels.Matern52(3, lengthscales=0.9),
+                 gpf.kernels.Matern32(3) + gpf.kernels.Periodic(3, period=2.0)):
+        K = kern.K(X)
+        bad = np.isnan(K)
+        assert bad[17, :].all() and bad[:, 17].all() and not np.delete(np.delete(bad, 17, 0), 17, 1).any()
+    Y = rng.standard_normal((300, 1))
+    for small in (1, 0):
+        handle.set_option("small_n", small)
+        try:
+            m = gpf.models.GPR(X, Y, gpf.kernels.RBF(3, lengthscales=1.1), obs_var=0.1)
+            try:
+                v = m.compute_log_likelihood()
+            except gpf.NotPositiveDefiniteError:
+                v = np.nan
+            assert not np.isfinite(v)
+        finally:
+            handle.set_option("small_n", 1)
+
+
 @pytest.mark.parametrize("n,r", [(1, 1), (2, 1), (50, 1), (128, 2), (129, 1), (300, 3), (455, 1), (512, 1), (640, 2), (768, 1), (896, 1), (1000, 1), (1300, 2), (2048, 1), (2100, 1)])
 def test_one_launch_factorisation_of_small_problems(handle, n, r):
     """Problems of up to 2048 padded rows (the reference's own example is N ~ 455, examples/gpr.py:36) are factored by ONE

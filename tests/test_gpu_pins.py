@@ -1,0 +1,200 @@
+"""Pins of the HIP path that do NOT go through oracle/ (round 5).
+
+Parity is unpinned by the reference (it holds no numeric vectors and cannot run here), so the oracle must not be the only thing
+between the product and the truth.  Three kinds of pins, every one compared with the HIP path directly, through the C ABI:
+  (a) the reference's own two structural tests (gpflowSlim/models/gpr.py:135-203 TestPredict, gpflowSlim/densities.py:159-174
+      Test_multivariate_normal_feature) restated on the product's entry points: the Cholesky forms computed by gps_potrf /
+      gps_trsm_lower / densities.multivariate_normal against the Woodbury forms computed here in numpy;
+  (b) 50-digit mpmath evaluations of the reference's formulas (tests/golden/mp/*.npz, generator committed beside them);
+  (c) analytic known answers: N = 1, N = 2, far-apart points, multi-output additivity, prediction far from the data.
+Nothing in this file imports oracle."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+MP = os.path.join(HERE, "golden", "mp")
+
+
+# ---------------------------------------------------------------- (a) the reference's structural tests on the product path
+@pytest.mark.parametrize("n", [20, 300, 2000])
+def test_cholesky_predictor_equals_woodbury_predictor(handle, n):
+    """models/gpr.py:135-203 (TestPredict): K = feat feat^T + 2 I.  "standard one" (:183-196) through gps_potrf and
+    gps_trsm_lower, "use feature" (:152-181) in numpy; the reference asserts 1e-4 in fp32, fp64 gives 1e-9."""
+    rng = np.random.default_rng(10 + n)
+    nn, d, variance = 10, 5, 2.0
+    mX = rng.standard_normal((n, 1)); m_new = rng.standard_normal((nn, 1))
+    Y = rng.standard_normal((n, 1))
+    feat = rng.standard_normal((n, d)); feat_new = rng.standard_normal((nn, d))
+    # ---- standard one, on the device
+    Kx = feat @ feat_new.T
+    K = feat @ feat.T + np.eye(n) * variance
+    L = handle.potrf(K)                                         # tf.cholesky                      :186
+    A = handle.trsm_lower(L, Kx)                                # tf.matrix_triangular_solve        :187
+    V = handle.trsm_lower(L, Y - mX)                            #                                   :188
+    standard_fmean = A.T @ V + m_new
+    standard_fvar_full = feat_new @ feat_new.T - A.T @ A
+    standard_fvar_diag = np.diag(feat_new @ feat_new.T) - np.sum(np.square(A), 0)
+    # ---- use feature (Woodbury), in numpy
+    CtC_I = feat.T @ feat + np.eye(d) * variance
+    tmp = (feat.T @ feat) @ (np.linalg.inv(CtC_I) @ feat.T)
+    Ct_CCT_I_inv = (feat.T - tmp) / variance
+    fmean = feat_new @ (Ct_CCT_I_inv @ (Y - mX)) + m_new
+    fvar_full = feat_new @ feat_new.T - feat_new @ ((Ct_CCT_I_inv @ feat) @ feat_new.T)
+    fvar_diag = np.sum(feat_new ** 2, -1) - np.sum((feat_new @ (Ct_CCT_I_inv @ feat)) * feat_new, -1)
+    assert np.allclose(np.tril(L) @ np.tril(L).T, K, rtol=0, atol=1e-11 * n)
+    assert np.allclose(fmean, standard_fmean, rtol=1e-9, atol=1e-10)
+    assert np.allclose(fvar_full, standard_fvar_full, rtol=1e-9, atol=1e-9)
+    assert np.allclose(fvar_diag, standard_fvar_diag, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,k,r", [(10, 5, 1), (300, 7, 1), (2000, 12, 3)])
+def test_cholesky_logp_equals_feature_logp(handle, n, k, r):
+    """densities.py:159-174 (Test_multivariate_normal_feature.test_logp): multivariate_normal with the Cholesky factor of
+    C C^T + var I -- factor by gps_potrf, density by the product's densities.multivariate_normal (gps_trsm_lower) -- against
+    multivariate_normal_feature (densities.py:98-124) restated in numpy (r > 1: columns independent, :93)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(9 + n)
+    C = rng.standard_normal((n, k)); var = 2.0
+    x = rng.standard_normal((n, r)); mu = np.zeros((n, r))
+    L = handle.potrf(C @ C.T + var * np.eye(n))
+    logp1 = gpf.densities.multivariate_normal(x, mu, np.tril(L))
+    CtC = C.T @ C + var * np.eye(k)
+    Lf = np.linalg.cholesky(CtC)
+    logdet = 2.0 * np.sum(np.log(np.diag(Lf))) + (n - k) * np.log(var)
+    logp2 = 0.0
+    for q in range(r):
+        Ctx = C.T @ x[:, q]
+        sq = (np.sum(x[:, q] ** 2) - np.sum(np.linalg.solve(Lf, Ctx) ** 2)) / var
+        logp2 += -0.5 * (sq + n * np.log(2.0 * np.pi) + logdet)
+    assert logp1 == pytest.approx(logp2, rel=1e-10)
+
+
+# ---------------------------------------------------------------- (b) 50-digit values, straight against the HIP path
+def _build(gpf, spec):
+    k = gpf.kernels
+    t = spec["type"]
+    if t == "sum" or t == "product":
+        parts = [_build(gpf, ch) for ch in spec["children"]]
+        out = parts[0]
+        for p in parts[1:]:
+            out = out + p if t == "sum" else out * p
+        return out
+    if t == "constant":
+        return k.Constant(4, variance=spec["variance"])
+    d = spec["input_dim"]
+    ad = spec.get("active_dims")
+    if t == "periodic":
+        return k.Periodic(d, period=spec["period"], variance=spec["variance"], lengthscales=spec["lengthscales"], active_dims=ad)
+    cls = {"rbf": k.RBF, "matern12": k.Matern12, "matern32": k.Matern32, "matern52": k.Matern52}[t]
+    ls = spec["lengthscales"]
+    return cls(d, variance=spec["variance"], lengthscales=np.asarray(ls, dtype=float) if np.ndim(ls) else ls, ARD=bool(np.ndim(ls)), active_dims=ad)
+
+
+def _mp_specs():
+    sys.path.insert(0, MP)
+    try:
+        import make_mp_golden
+    finally:
+        sys.path.remove(MP)
+    return make_mp_golden.SPECS
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(MP, "*.npz"))))
+def test_hip_path_matches_50_digit_evaluation(handle, path):
+    """LML, posterior mean and variance of the HIP path against mpmath at 50 digits (tests/golden/mp/make_mp_golden.py), 1e-8."""
+    import gpflowSlim as gpf
+    g = np.load(path)
+    name = os.path.basename(path)[:-4].rsplit("_n", 1)[0]
+    spec = _mp_specs()[name]
+    m = gpf.models.GPR(g["X"], g["Y"], _build(gpf, spec), obs_var=float(g["noise_var"]))
+    assert abs(float(np.squeeze(m.likelihood.variance)) - float(g["noise_var"])) <= 1e-15
+    lml = m.compute_log_likelihood()
+    assert abs(lml - float(g["lml"])) <= 1e-8 * abs(float(g["lml"]))
+    mu, var = m.predict_f(g["Xs"])
+    assert mu.shape == g["mu"].shape and var.shape == g["mu"].shape
+    assert np.abs(mu - g["mu"]).max() <= 1e-8 * max(1.0, np.abs(g["mu"]).max())
+    assert np.abs(var - g["var"][:, None]).max() <= 1e-8 * max(1.0, np.abs(g["var"]).max())
+
+
+# ---------------------------------------------------------------- (c) analytic known answers on the HIP path itself
+def _vals(m):
+    return float(np.squeeze(m.kern.variance)), float(np.squeeze(m.likelihood.variance))
+
+
+def test_kat_single_point(handle):
+    """N = 1: lml = -1/2 log 2pi - 1/2 log(s2 + s2n) - y^2 / (2 (s2 + s2n)); predicting at the point itself."""
+    import gpflowSlim as gpf
+    X = np.array([[0.3, -1.2]]); Y = np.array([[0.7]])
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2, variance=1.7, lengthscales=0.9), obs_var=0.25)
+    s2, s2n = _vals(m)
+    ref = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(s2 + s2n) - 0.7 ** 2 / (2 * (s2 + s2n))
+    assert m.compute_log_likelihood() == pytest.approx(ref, rel=1e-13)
+    mu, var = m.predict_f(X)
+    assert mu[0, 0] == pytest.approx(s2 * 0.7 / (s2 + s2n), rel=1e-13)
+    assert var[0, 0] == pytest.approx(s2 - s2 * s2 / (s2 + s2n), rel=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern12", "matern32", "matern52"])
+def test_kat_two_points(handle, kind):
+    """N = 2 in closed form: K = [[a, b], [b, a]], a = k(x, x) + s2n, b = k(x1, x2) -- with the reference's
+    r = sqrt(r2 + 1e-12) for the Matern family, whose diagonal is therefore not the variance (kernels.py:426)."""
+    import gpflowSlim as gpf
+    X = np.array([[0.0], [0.8]]); Y = np.array([[0.4], [-1.1]])
+    cls = {"rbf": gpf.kernels.RBF, "matern12": gpf.kernels.Matern12, "matern32": gpf.kernels.Matern32, "matern52": gpf.kernels.Matern52}[kind]
+    m = gpf.models.GPR(X, Y, cls(1, variance=1.4, lengthscales=0.6), obs_var=0.2)
+    s2, s2n = _vals(m)
+    ell = float(np.squeeze(m.kern.lengthscales))
+
+    def k(r2):
+        if kind == "rbf":
+            return s2 * np.exp(-0.5 * r2)
+        r = np.sqrt(r2 + 1e-12)
+        if kind == "matern12":
+            return s2 * np.exp(-r)
+        if kind == "matern32":
+            return s2 * (1 + np.sqrt(3.) * r) * np.exp(-np.sqrt(3.) * r)
+        return s2 * (1 + np.sqrt(5.) * r + 5. / 3. * r * r) * np.exp(-np.sqrt(5.) * r)
+    a, b = k(0.0) + s2n, k((0.8 / ell) ** 2)
+    det = a * a - b * b
+    quad = (a * 0.4 ** 2 + 2 * b * 0.4 * 1.1 + a * 1.1 ** 2) / det
+    ref = -np.log(2 * np.pi) - 0.5 * np.log(det) - 0.5 * quad
+    assert m.compute_log_likelihood() == pytest.approx(ref, rel=1e-12)
+
+
+@pytest.mark.parametrize("n", [3, 200, 700])
+def test_kat_far_apart_points_and_far_prediction(handle, n):
+    """Points 1e3 length-scales apart: K = s2 I exactly (exp underflows), so the likelihood is n independent Gaussians of
+    variance s2 + s2n; a test point far from all of them sees the prior: (mean function, s2)."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n)
+    X = 1e3 * np.arange(n, dtype=float)[:, None] * np.ones((1, 2))
+    Y = rng.standard_normal((n, 1))
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(2, variance=0.8, lengthscales=1.0), obs_var=0.3,
+                       mean_function=gpf.mean_functions.Constant(np.array([0.25])))
+    s2, s2n = _vals(m)
+    res = Y - 0.25
+    ref = -0.5 * n * np.log(2 * np.pi) - 0.5 * n * np.log(s2 + s2n) - 0.5 * np.sum(res ** 2) / (s2 + s2n)
+    assert m.compute_log_likelihood() == pytest.approx(ref, rel=1e-13)
+    mu, var = m.predict_f(np.array([[-5e4, 7e4]]))
+    assert mu[0, 0] == pytest.approx(0.25, abs=1e-14) and var[0, 0] == pytest.approx(s2, rel=1e-14)
+    # ... and AT a data point: the one-point posterior of that point alone
+    mu, var = m.predict_f(X[1:2])
+    assert mu[0, 0] == pytest.approx(0.25 + s2 * res[1, 0] / (s2 + s2n), rel=1e-12)
+    assert var[0, 0] == pytest.approx(s2 - s2 * s2 / (s2 + s2n), rel=1e-12)
+
+
+@pytest.mark.parametrize("n", [20, 600, 3000])
+def test_kat_multi_output_counts_logdet_r_times(handle, n):
+    """densities.py:93: R outputs share one factor -- the log-determinant counts R times, the quadratic forms add."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 2)); Y = rng.standard_normal((n, 3))
+    kern = lambda: gpf.kernels.Matern32(2, variance=1.0, lengthscales=1.0)
+    total = gpf.models.GPR(X, Y, kern(), obs_var=0.1).compute_log_likelihood()
+    parts = sum(gpf.models.GPR(X, Y[:, j:j + 1], kern(), obs_var=0.1).compute_log_likelihood() for j in range(3))
+    assert total == pytest.approx(parts, rel=1e-12)

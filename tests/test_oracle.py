@@ -181,6 +181,22 @@ def test_oracle_matches_50_digit_evaluation(name, n):
     assert np.abs(ovar[:, 0] - var).max() <= tol * max(1.0, np.abs(var).max())
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mp", "*.npz"))))
+def test_oracle_matches_committed_50_digit_fixtures(path):
+    """tests/golden/mp/*.npz (make_mp_golden.py: mpmath only, no oracle): the same fixtures the HIP path is compared with
+    directly in tests/test_gpu_pins.py."""
+    import importlib.util
+    spec_mod = importlib.util.spec_from_file_location("make_mp_golden", os.path.join(GOLD, "mp", "make_mp_golden.py"))
+    mod = importlib.util.module_from_spec(spec_mod); spec_mod.loader.exec_module(mod)
+    g = np.load(path)
+    spec = mod.SPECS[os.path.basename(path)[:-4].rsplit("_n", 1)[0]]
+    s2 = float(g["noise_var"])
+    assert orc.gpr_lml(spec, g["X"], g["Y"], s2) == pytest.approx(float(g["lml"]), rel=1e-8)
+    omu, ovar = orc.gpr_predict(spec, g["X"], g["Y"], s2, g["Xs"])
+    assert np.abs(omu - g["mu"]).max() <= 1e-8 * max(1.0, np.abs(g["mu"]).max())
+    assert np.abs(ovar - g["var"][:, None]).max() <= 1e-8 * max(1.0, np.abs(g["var"]).max())
+
+
 # ---- independent implementation: scikit-learn -------------------------------------------------
 def test_sklearn_cross_check_rbf_and_matern():
     from sklearn.gaussian_process import GaussianProcessRegressor
