@@ -127,7 +127,7 @@ struct HipOps {
       // hipMemset goes to the legacy default stream and is asynchronous to the host: it runs whenever every blocking
       // stream of the process -- other handles' CU-masked side streams -- has drained, which with several handles in
       // one process could be after this handle's first tickets, or its time-out count, had been written: found with
-      // four handles in four host threads, tools/concurrent_handles2.py.)
+      // four handles in four host threads, a round-3 probe; tests/test_gpu_kernels.py::test_concurrent_small_launches runs that regime now.)
       if (h->dLaFlags.ensure(64) != hipSuccess || hipMemsetAsync(h->dLaFlags.p, 0, 64, h->stream) != hipSuccess ||
           hipStreamSynchronize(h->stream) != hipSuccess ||
           (!h->ev_la && hipEventCreateWithFlags(&h->ev_la, hipEventDisableTiming) != hipSuccess)) {

@@ -103,7 +103,7 @@ def test_bench_slow_rank0_tail_does_not_trip_the_stall_supervisor():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["GPS_BENCH_TEST_SLOW_TAIL"] = "30"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo",
-           "--force-device", "0", "--npoints", "2048", "--dist-nb", "256", "--num-new-throughput", "256", "--dist-timeout", "200",
+           "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "256", "--dist-timeout", "200",
            "--no-dist-autotune", "--independent-steps", "0", "--cpu-sample-n", "512", "--small-n", "", "--stall", "12"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])

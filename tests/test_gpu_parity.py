@@ -367,7 +367,7 @@ def test_full_size_block_separable(handle):
 def test_maximum_size_block_separable(handle):
     """N = 131072 on one GPU (K: 137 GB of the 288 GB HBM; every index beyond 2^32 elements): 128 exactly independent
     clusters of 1024 points, interleaved in memory, so the factorisation is a dense N x N one and
-    LML(X, Y) = sum of the clusters' oracle LMLs.  (tools/big_n.py runs the same check at N = 180224 = 260 GB:
+    LML(X, Y) = sum of the clusters' oracle LMLs.  (a one-off probe, round 2, ran the same check at N = 180224 = 260 GB:
     profiles/r02_big_n.json.)"""
     import torch
     import gpflowSlim as gpf
