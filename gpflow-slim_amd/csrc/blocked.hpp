@@ -259,7 +259,10 @@ struct Blocked {
     const i64 T = GPS_TILE;
     const bool la = (g >= 2) && ops.lookahead();
     const bool fol = la && FB != nullptr && fm > 0;
-    unsigned long long pending = 0;              // join ticket of a remainder update still running on the side stream
+    // join values of a remainder update still running on the side stream (they grow: 2 t after its FIRST block column -- the
+    // one the next group's first block-column update writes --, 2 t + 1 after the rest, which nothing touches before the next
+    // group's second update: one more step of the chain for the side stream to finish in)
+    unsigned long long pending = 0, pending2 = 0;
     bool forked = false, fforked = false;        // a hand-over to the side / follower stream has already happened in this sweep
     i64 fdone = 0;                               // columns of the follower solve issued so far
     auto follower_piece = [&](i64 c_lo, i64 c_hi) -> int {          // columns [c_lo, c_hi) of  X L^T = FB
@@ -271,28 +274,56 @@ struct Blocked {
       return ops.gemm(0, 1, fm, tn, c_hi - c_lo, FB + c_lo, ldfb, FB + c_lo, ldfb, TR, ldt);
     };
     auto finish = [&]() -> int {
+      if (pending2) pending = pending2;          // (values grow: the later one covers the earlier)
       int rc = pending ? ops.chain_join(pending) : 0;
-      pending = 0;
+      pending = 0; pending2 = 0;
       if (rc || FB == nullptr) return rc;
       if (fol && fdone > 0) { rc = ops.follower_join(); if (rc) return rc; }
       return fdone < n ? follower_piece(fdone, n) : 0;               // the rest (all of it without look-ahead) on the chain
     };
+    // One launch per 128 columns (Ops::step, round 5): the panel solve, the update of the next block column and the NEXT
+    // block's potrf_base as one launch (the next diagonal block only needs the top tile of the first two).  have_diag: the
+    // block this iteration starts with was factored by the previous iteration's launch.  The launch publishes the fork ticket
+    // when the panel is solved (what the start of the next-block-column GEMM used to signal) and awaits a pending join inside.
+    const bool fused = la && ops.fused_step();
+    bool have_diag = false;
     for (i64 c0 = 0; c0 < n; c0 += g * T) {
       for (i64 i = 0; i < g; ++i) {
         const i64 c = c0 + i * T;
         if (c >= n) return finish();
         double* Acc = A + c * lda + c;
-        int rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
+        int rc = 0;
+        if (!have_diag) rc = ops.potrf_base(Acc, lda, blk0 + c / T, row0 + c);
+        have_diag = false;
         if (rc) return rc;
         const i64 sq = n - c - T, m = sq + e;          // columns right of this block ; rows below it
         if (m == 0) return finish();
-        rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m, Acc, lda);
-        if (rc) return rc;
-        if (sq == 0) return finish();
+        const bool fuse = fused && sq > 0;
+        if (!fuse) {
+          rc = ops.trsm_base(blk0 + c / T, 0, Acc + T * lda, lda, m, Acc, lda);
+          if (rc) return rc;
+          if (sq == 0) return finish();
+        }
         double* P = A + (c + T) * lda + c0;            // the group's panels so far, rows below this block: [m, (i+1) 128]
         double* Cn = A + (c + T) * lda + (c + T);      // the next block column / the remainder
+        // (second panel of a group: its update writes the first column of the REST of the previous group's remainder update)
+        if (i == 1 && pending2) { rc = fuse ? ops.step_join(pending2) : ops.chain_join(pending2); pending2 = 0; if (rc) return rc; }
+        // Joins CARRIED by a step (Ops::step_exit_join): the step launched for this panel awaits, before it ends, the join
+        // value the NEXT panel's step needs -- first panel of a group: the rest of the previous remainder update (pending2);
+        // last panel: the first block column of the remainder update forked right behind this step (its value is known now).
+        const bool carry = fuse && ops.step_exit_join() && sq > T;       // (there is a next step)
         if (i + 1 < g) {
           // (the next block column was last written by the remainder update of the previous group)
+          if (fuse) {
+            // (Ops::step_join: awaited inside the launch, or -- its workgroups would hold their CUs while they wait for an
+            // update that needs CUs -- by a launch of its own in front of it)
+            if (pending) { rc = ops.step_join(pending); pending = 0; if (rc) return rc; }
+            if (carry && i == 0 && pending2) { rc = ops.step_carry_join(pending2); pending2 = 0; if (rc) return rc; }
+            rc = ops.step(blk0 + c / T, Acc + T * lda, lda, m, i * T, row0 + c + T);
+            if (rc) return rc;
+            have_diag = true;
+            continue;
+          }
           if (pending) { rc = ops.chain_join_next_gemm(pending); pending = 0; if (rc) return rc; }
           rc = ops.gemm(0, 0, m, T, (i + 1) * T, P, lda, P, lda, Cn, lda);      // next block column
           if (rc) return rc;
@@ -301,7 +332,14 @@ struct Blocked {
         // ---- last panel of the group
         const bool split = la && sq - T >= ops.lookahead_min_rows();
         if (!split && !fol) {
-          rc = ops.gemm(0, 1, m, sq, g * T, P, lda, P, lda, Cn, lda);           // remainder
+          if (fuse) {
+            rc = ops.step(blk0 + c / T, Acc + T * lda, lda, m, i * T, row0 + c + T);
+            if (rc) return rc;
+            have_diag = true;
+            if (sq > T) rc = ops.gemm(0, 1, m - T, sq - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);   // the rest of the remainder
+          } else {
+            rc = ops.gemm(0, 1, m, sq, g * T, P, lda, P, lda, Cn, lda);         // remainder
+          }
           if (rc) return rc;
           continue;
         }
@@ -310,16 +348,36 @@ struct Blocked {
         // stream beside the next group's first potrf_base / panel solve; its join is awaited before the next group's
         // first block-column update, the first launch that touches what the side stream writes.
         const unsigned long long t = ops.la_fork();      // (also when only the follower needs it)
-        if (split) rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
+        const bool two = split && ops.two_stage_join() && sq - T >= 2 * T;
+        bool carried = false;
+        if (fuse) {
+          // (not with the sweep's FIRST hand-over: the side stream is then parked behind an event recorded after this launch
+          // -- Ops::side_open --, i.e. it starts when this launch has ENDED: the launch would wait for itself)
+          if (carry && split && forked) { rc = ops.step_carry_join(two ? 2 * t : 2 * t + 1); carried = true; if (rc) return rc; }
+          rc = ops.step(blk0 + c / T, Acc + T * lda, lda, m, i * T, row0 + c + T);       // (carries the fork ticket)
+          if (rc) return rc;
+          have_diag = true;
+          if (!split && sq > T) rc = ops.gemm(0, 1, m - T, sq - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+        } else if (split) rc = ops.gemm(0, 0, m, T, g * T, P, lda, P, lda, Cn, lda);
         else rc = ops.gemm(0, 1, m, sq, g * T, P, lda, P, lda, Cn, lda);
         if (rc) return rc;
         if (split) {
           rc = ops.side_open(t, !forked);
           forked = true;
           if (rc) return rc;
-          rc = ops.gemm(0, 1, m - T, sq - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
-          if (!rc) rc = ops.side_publish_join(t);
-          pending = t;
+          if (two) {
+            // the remainder's first block column, which the next group's first update writes, then the rest -- which nothing
+            // touches before the next group's second update
+            rc = ops.gemm(0, 0, m - T, T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+            if (!rc) rc = ops.side_publish_join(2 * t);
+            if (!rc) rc = ops.gemm(0, 1, m - 2 * T, sq - 2 * T, g * T, P + 2 * T * lda, lda, P + 2 * T * lda, lda, Cn + 2 * T * lda + 2 * T, lda);
+            if (!rc) rc = ops.side_publish_join(2 * t + 1);
+            pending = carried ? 0 : 2 * t; pending2 = 2 * t + 1;
+          } else {
+            rc = ops.gemm(0, 1, m - T, sq - T, g * T, P + T * lda, lda, P + T * lda, lda, Cn + T * lda + T, lda);
+            if (!rc) rc = ops.side_publish_join(2 * t + 1);
+            pending = carried ? 0 : 2 * t + 1;
+          }
           const int rc2 = ops.side_close();
           if (rc || rc2) return rc ? rc : rc2;
         }

@@ -19,6 +19,27 @@ struct HipOps {
                                  (linvT && store_T) ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
                                  factor);
   }
+  // ---- one launch per 128 columns of the sweep (small_n.hip: sweep_step_kernel): the solve of the rows below block `blk`, the
+  // update of the next block column with the group's panels, and the next diagonal block's potrf_base
+  bool fused_step() { return h->potrf_fused_step != 0 && !h->refine_now && factor == 1 && h->prop.multiProcessorCount >= 160 && lookahead(); }
+  int step(i64 blk, double* B, i64 ldb, i64 m, i64 kprev, i64 row0_next) {
+    double* ln = linv + (blk + 1) * GPS_TILE * GPS_TILE;
+    double* lt = (linvT && store_T) ? linvT + (blk + 1) * GPS_TILE * GPS_TILE : nullptr;
+    return gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, ln, lt, d_info, row0_next, factor);
+  }
+  // The join with the side stream before a step whose next block column the side stream's last remainder update wrote: a wait
+  // launch in front of the step.  (Awaited INSIDE the step launch -- built, round 5 -- it deadlocks: the step's workgroups
+  // hold one CU each (150 KB of LDS) while they wait, and the update they wait for needs CUs to finish.)
+  int step_join(unsigned long long t) { return chain_join(t); }
+  // ... or carried by the step launched BEFORE the one that needs it: its chain workgroup awaits the value before it leaves
+  // (blocked.hpp: exit_join), so that no wait launch sits between two steps
+  bool step_exit_join() const { return h->potrf_fused_step >= 2; }
+  int step_carry_join(unsigned long long v) {
+    if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) v = ~0ull;
+    h->next_wait_ptr = la_flags() + 1; h->next_wait_val = v; h->next_wait_timeouts = la_flags() + 2;
+    return GPS_OK;
+  }
+  bool two_stage_join() const { return h->potrf_two_stage_join != 0; }
   // ---- forward substitution following the factorisation (blocked.hpp: YFollow): its own stream, ordered behind the
   // calling stream by one event per section
   hipStream_t saved_stream_y = nullptr;
@@ -344,10 +365,20 @@ static int read_info(gps_handle_t h, int* d_info, int* info) {
     return gps_fail(h, GPS_ERR_STATE, "trsv wavefront timed out (result invalid)");
   }
   if (la_timeouts) {
+    if (getenv("GPS_STEP_DEBUG") && h->dStepSync.p) {      // diagnostics: where the one-launch sweep steps stand
+      unsigned long long c[40];
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(c, h->dStepSync.p, sizeof(c), hipMemcpyDeviceToHost);
+      unsigned long long f[4] = {0, 0, 0, 0};
+      (void)hipMemcpy(f, h->dLaFlags.p, sizeof(f), hipMemcpyDeviceToHost);
+      fprintf(stderr, "time-outs %llu | step counters: abort %llu  Q %llu (%llu)  XN %llu (%llu)  DN %llu (%llu)  SD %llu (%llu) | la flags: fork %llu (host %llu) join %llu follower %llu (host %llu)\n",
+              la_timeouts, c[0], c[8], h->step_q, c[16], h->step_xn, c[24], h->step_dn, c[32], h->step_sd, f[0], h->la_ticket, f[1], f[3], h->fol_ticket);
+    }
     // not sticky: the counter is cleared (stream-ordered) so that the handle is usable again; the entry point re-runs
     // the evaluation once without look-ahead (with_la_retry)
     (void)hipMemsetAsync((unsigned long long*)h->dLaFlags.p + 2, 0, 8, h->stream);
     h->la_timed_out = true;
+    h->step_dirty = true;               // (the one-launch sweep steps count their time-outs there too: their counters start over)
     return gps_fail(h, GPS_ERR_STATE, "look-ahead hand-over timed out (result invalid)");
   }
   return GPS_OK;
@@ -364,6 +395,9 @@ static int with_la_retry(gps_handle_t h, F&& body) {
     h->la_timed_out = false;
     h->la_retries++;
     (void)hipDeviceSynchronize();
+    // (kernels of the side streams that were still waiting for a hand-over of the failed attempt ran into their own bounds
+    // after the counter was cleared: clear it again now that everything has drained)
+    if (h->dLaFlags.p) { (void)hipMemsetAsync((unsigned long long*)h->dLaFlags.p + 2, 0, 8, h->stream); (void)hipStreamSynchronize(h->stream); }
     const int saved = h->potrf_lookahead;
     h->potrf_lookahead = 0;
     rc = body();
@@ -407,6 +441,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   if (const char* m0 = getenv("GPS_LA_MASK0")) h->la_mask_word0 = (uint32_t)strtoul(m0, nullptr, 0);     // diagnostics
   if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
   if (const char* v = getenv("GPS_BULK")) h->potrf_bulk = atoi(v);                                       // diagnostics
+  if (const char* v = getenv("GPS_FUSED_STEP")) h->potrf_fused_step = atoi(v);                           // diagnostics
   if (const char* v = getenv("GPS_BULK_RESERVE")) h->potrf_bulk_reserve = atoi(v);                       // diagnostics
   if (const char* v = getenv("GPS_BULK_KC")) h->potrf_bulk_kc = atoi(v);                                 // diagnostics
   if (const char* v = getenv("GPS_BULK_PRIO")) h->potrf_bulk_prio = atoi(v);                             // diagnostics
@@ -423,7 +458,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
 static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync,
                     &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
@@ -580,6 +615,8 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk") == 0) { h->potrf_bulk = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_fused_step") == 0) { h->potrf_fused_step = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_two_stage_join") == 0) { h->potrf_two_stage_join = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk_flop") == 0) { h->potrf_bulk_flop = value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk_reserve") == 0) {   // takes effect when the bulk stream is (re)created
     const int v = (int)value < 1 ? 1 : ((int)value > 6 ? 6 : (int)value);

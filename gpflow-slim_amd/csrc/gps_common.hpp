@@ -262,6 +262,11 @@ struct gps_handle_s {
   DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
+  DevBuf dStepSync;           // counters of the one-launch sweep step (small_n.hip: sweep_step_kernel); monotone, their host-side values below
+  unsigned long long step_q = 0, step_xn = 0, step_dn = 0, step_sd = 0;
+  bool step_dirty = false;    // a bounded wait of such a launch ran out: the area is cleared before the next one
+  int potrf_two_stage_join = 1;   // option: the side stream's remainder update publishes its first block column before the rest (blocked.hpp)
+  int potrf_fused_step = 2;   // option: panel solve + next block column + next potrf_base of the sweep as ONE launch per 128 columns (1), which also awaits the NEXT step's join with the side stream before it ends (2)
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
   int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
@@ -375,6 +380,8 @@ struct SmallKgen { int on = 0; int op = 0; const double* X = nullptr; int d_all 
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen = nullptr);
 int gps_small_factor_reset(gps_handle_t h);
+int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const double* W, i64 kprev, double* Linv_next, double* LinvT_next,
+                          int* d_info, i64 row0_next, int factor);
 // trsm_panel.hip
 int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,

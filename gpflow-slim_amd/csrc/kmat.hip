@@ -124,6 +124,8 @@ __constant__ double gps_exp_tab[16] = {
     1.4426950408889634,            // [13] log2(e)
     6.93147180369123816490e-01,    // [14] ln2 high
     1.90821492927058770002e-10};   // [15] ln2 low
+// max(r2, 0) of kernels.py:421 the way tf.maximum does it: a NaN argument stays NaN (fmax would return the 0)
+__device__ __forceinline__ double gps_clamp0(double r2) { return (r2 < 0.0) ? 0.0 : r2; }
 struct ExpTab { double c[16]; };
 __device__ __forceinline__ ExpTab gps_exp_load() {
   ExpTab t;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
         for (int e = 0; e < 16; ++e) {
           const double ni = nr_s[ty * 4 + (e >> 2)], nj = nc_s[tx * 4 + (e & 3)];
           double r2 = -2.0 * dot[e] + (ni + nj);
-          r2 = fmax(r2, 0.0);
+          r2 = gps_clamp0(r2);
           double val;
           if (node.op == GPS_K_RBF) {
             val = node.variance * gps_exp_nonpos(-r2 / 2.0);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDe
     for (int c = 0; c < 4; ++c) {
       const i64 gj = a.col_off + gj0 + tx * 4 + c;
       double r2 = -2.0 * dot[q * 4 + c] + (ni + nc_s[tx * 4 + c]);        // kernels.py:409-421, same op order as the interpreter
-      r2 = fmax(r2, 0.0);
+      r2 = gps_clamp0(r2);
       double val;
       if (OP == GPS_K_RBF) {
         val = node.variance * gps_exp_nonpos(-r2 / 2.0);
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev
         for (int e = 0; e < 16; ++e) {
           const double ni = nr_s[ty * 4 + (e >> 2)], nj = nc_s[tx * 4 + (e & 3)];
           double r2 = -2.0 * v[e] + (ni + nj);
-          r2 = fmax(r2, 0.0);
+          r2 = gps_clamp0(r2);
           double val;
           if (node.op == GPS_K_RBF) {
             val = node.variance * gps_exp_nonpos(-r2 / 2.0);
@@ -531,7 +533,7 @@ __device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int o
     return node.variance * gps_exp_nonpos(arg, et);                             // (no clamp: kernels.py:817-819)
   }
   double r2 = -2.0 * dot + (ni + nj);                                                    // kernels.py:409-421
-  r2 = on_diag ? 0.0 : fmax(r2, 0.0);
+  r2 = on_diag ? r2 * 0.0 : gps_clamp0(r2);      // (exactly 0 on the diagonal -- NaN stays NaN)
   if (o == GPS_K_RBF) return node.variance * gps_exp_nonpos(-0.5 * r2, et);
   const double r = gps_sqrt_pos(r2 + 1e-12);
   if (o == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r, et);
@@ -714,7 +716,7 @@ __device__ __forceinline__ double prim_value(const KNodeDev& node, double dot, d
   }
   const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
   double r2 = -2.0 * dot + (ni + nj);
-  r2 = fmax(r2, 0.0);
+  r2 = gps_clamp0(r2);
   if (node.op == GPS_K_RBF) return node.variance * gps_exp_nonpos(-r2 / 2.0);
   const double r = gps_sqrt_pos(r2 + 1e-12);
   if (node.op == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r);

@@ -15,8 +15,10 @@ static i64 g_rl_group = 1;
 static int g_lookahead = 0;
 static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
+static int g_fused = 0;       // emul_set_fused: the sweep's one-launch steps (Ops::step)
 static int g_bulk = 0;        // emul_set_bulk: cross-level look-ahead -- bit 0: piece (a), bit 1: piece (b); rows of a (b) piece below
 static i64 g_bulk_rows = 256;
+static int g_side_bad = 0;    // operations of the chain that touched what a side section had written and the chain had not joined yet
 static int g_bulk_pieces = 0, g_bulk_bad = 0;      // pieces issued / pairing or race violations seen (read by the tests)
 
 struct CpuOps {
@@ -98,6 +100,28 @@ struct CpuOps {
     for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) Y[i * ldy + c] = W[i * T + c];
     return 0;
   }
+  // one launch per 128 columns (blocked.hpp: Ops::step): here the three operations it stands for, in order
+  int n_step = 0;
+  bool fused_step() { return (g_fused & 1) != 0; }
+  bool two_stage_join() const { return (g_fused & 2) != 0; }
+  int step_join(unsigned long long t) { return chain_join(t); }
+  // a join value the NEXT step needs, awaited by this step before it ends (after its own work): it takes effect when the
+  // step has run AND the value has been published, whichever comes last
+  unsigned long long carry = 0;
+  bool carry_armed = false;                                     // step_carry_join must be followed by the step that carries it
+  bool step_exit_join() const { return (g_fused & 8) != 0; }
+  int step_carry_join(unsigned long long v) { if (carry || v <= joined) return -52; carry = v; carry_armed = true; return 0; }
+  void apply_carry() { if (carry && !carry_armed && published >= carry) { (void)chain_join(carry); carry = 0; } }
+  int step(i64 blk, double* B, i64 ldb, i64 m, i64 kprev, i64 row0_next) {
+    if (m < T || open_side || fol_open || def_open) return -51;
+    ++n_step;
+    int rc = trsm_base(blk, 0, B, ldb, m);
+    if (!rc) rc = gemm(0, 0, m, T, kprev + T, B - kprev, ldb, B - kprev, ldb, B + T, ldb);
+    if (!rc) rc = potrf_base(B + T, ldb, blk + 1, row0_next);
+    carry_armed = false;
+    apply_carry();
+    return rc;
+  }
   i64 rl_max() const { return g_rl_max; }
   i64 rl_group() const { return g_rl_group; }
   // look-ahead hooks: the host emulation is sequential; the hooks check that forks, side sections and joins pair up
@@ -114,9 +138,26 @@ struct CpuOps {
   i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
   bool trail_follows() const { return g_lookahead == 2; }        // (both forms of the trailing update are emulated)
   unsigned long long fol_pub = 0;
+  // side sections: what they write stays "in flight" until the chain has joined the join value published after it (values
+  // grow: a section may publish several, e.g. after the first block column of a remainder update and after the rest); until
+  // then no operation of the chain may touch it (touch(), g_side_bad)
+  struct Rect { i64 r0, c0, nr, nc; };
+  unsigned long long published = 0, joined = 0;
+  struct SideRect { Rect r; unsigned long long v; bool rd; };       // v = 0: touched, not yet published; rd: only read
+  std::vector<SideRect> side_pending;
   int side_open(unsigned long long t, bool) { if (open_side || t != ticket) return -7; open_side = t; return 0; }
-  int side_publish_join(unsigned long long t) { if (open_side != t || unjoined) return -8; unjoined = t; return 0; }
-  int side_close() { if (!open_side) return -10; open_side = 0; return 0; }
+  int side_publish_join(unsigned long long v) {
+    if (!open_side || v <= published) return -8;
+    published = v;
+    for (auto& q : side_pending) if (q.v == 0) q.v = v;
+    apply_carry();
+    return 0;
+  }
+  int side_close() {
+    if (!open_side) return -10;
+    for (auto& q : side_pending) if (q.v == 0) return -18;           // (something written in the section was never published)
+    open_side = 0; return 0;
+  }
   int fol_open = 0;
   int follower_open(unsigned long long t, bool) { if (fol_open || def_open || t != ticket) return -16; fol_open = 1; return 0; }
   int follower_close() { if (!fol_open) return -17; fol_open = 0; return 0; }
@@ -127,13 +168,15 @@ struct CpuOps {
   // regions: every rectangle of the matrix a piece reads or writes is recorded, and until the join no operation of the
   // calling stream may write a rectangle the piece touches or read one it writes (touch()).
   int bulk_state = 0;            // 0 idle, 1 open (launches go to the bulk stream), 2 in flight (closed, not joined)
-  struct Rect { i64 r0, c0, nr, nc; };
   std::vector<Rect> bulk_reads, bulk_writes;
   const double* base = nullptr; i64 base_ld = 0, base_rows = 0;        // the matrix being factored (set by the entry points below)
   static bool overlap(const Rect& a, const Rect& b) { return a.r0 < b.r0 + b.nr && b.r0 < a.r0 + a.nr && a.c0 < b.c0 + b.nc && b.c0 < a.c0 + a.nc; }
   void touch(const double* p, i64 ld, i64 nr, i64 nc, bool write) {
     if (!base || ld != base_ld || p < base || p >= base + base_rows * base_ld) return;      // (block inverses etc.: not in the matrix)
     const Rect r{(i64)((p - base) / base_ld), (i64)((p - base) % base_ld), nr, nc};
+    if (open_side) { side_pending.push_back(SideRect{r, 0, !write}); return; }
+    if (!fol_open && !def_open && bulk_state != 1)             // an operation of the chain
+      for (const SideRect& q : side_pending) if ((write || !q.rd) && overlap(r, q.r)) ++g_side_bad;
     if (bulk_state == 1) { (write ? bulk_writes : bulk_reads).push_back(r); return; }
     if (bulk_state != 2) return;
     for (const Rect& w : bulk_writes) if (overlap(r, w)) ++g_bulk_bad;
@@ -152,7 +195,15 @@ struct CpuOps {
     bulk_state = 0;
     return 0;
   }
-  int chain_join(unsigned long long t) { if (unjoined != t) return -9; unjoined = 0; return 0; }
+  int chain_join(unsigned long long v) {
+    if (g_fused & 4) return 0;                                  // (self-test of the race detector: an Ops that forgets to join)
+    if (v > published || v <= joined) return -9;              // a join for something that was never published / joined twice
+    joined = v;
+    std::vector<SideRect> keep;
+    for (auto& q : side_pending) if (q.v > v) keep.push_back(q);
+    side_pending.swap(keep);
+    return 0;
+  }
   // (the join carried by the next GEMM: that launch must follow at once)
   bool join_armed = false;
   int chain_join_next_gemm(unsigned long long t) { int rc = chain_join(t); join_armed = (rc == 0); return rc; }
@@ -212,6 +263,8 @@ void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_leaf512(int v) { g_leaf512 = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
+void emul_set_fused(int v) { g_fused = v; }
+int emul_side_bad(int reset) { const int v = g_side_bad; if (reset) g_side_bad = 0; return v; }
 void emul_set_bulk(int v, i64 rows) { g_bulk = v; g_bulk_rows = rows; g_bulk_pieces = g_bulk_bad = 0; }
 void emul_bulk_counts(int* pieces, int* bad) { *pieces = g_bulk_pieces; *bad = g_bulk_bad; }
 // the race detector itself: a piece that writes a block the calling stream then reads before the join must be flagged (1),
@@ -254,6 +307,7 @@ int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
 // A [n,n] in place -> L (lower valid); B [m,n]: X L^T = B ; B2 [m,n]: X L = B ; y [r][n]: L a = y
 int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, int* info) {
   CpuOps ops(n / T);
+  ops.base = A; ops.base_ld = n; ops.base_rows = n;
   Blocked<CpuOps> bl(ops);
   int rc = bl.potrf_rec(A, n, n, 0, 0);
   if (rc) return rc;
@@ -269,6 +323,7 @@ int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, i
 // A [(n + e), n] in place: rows 0..n-1 SPD -> L, rows n..n+e-1 (e a multiple of 128) -> E L^-T  (augmented rows)
 int emul_potrf_aug(double* A, i64 n, i64 e, int* info) {
   CpuOps ops(n / T);
+  ops.base = A; ops.base_ld = n; ops.base_rows = n + e;
   Blocked<CpuOps> bl(ops);
   int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, e);
   *info = ops.info;

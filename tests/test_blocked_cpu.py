@@ -220,3 +220,64 @@ def test_cross_level_lookahead_schedule(emul, n, e, rl_max, bulk, expect):
 
 def test_cross_level_lookahead_race_detector_detects(emul):
     assert emul.emul_bulk_selftest(0) == 1 and emul.emul_bulk_selftest(1) == 0
+
+
+@pytest.mark.parametrize("n,m,e", [(256, 128, 0), (640, 128, 128), (1024, 256, 0), (1408, 128, 128)])
+@pytest.mark.parametrize("fused", [1, 2, 3, 9, 11])
+@pytest.mark.parametrize("rl_max,group,la", [(256, 2, 1), (512, 2, 1), (1024, 2, 2), (1024, 3, 1), (2048, 4, 2)])
+def test_one_launch_sweep_steps_as_index_logic(emul, n, m, e, rl_max, group, la, fused):
+    """blocked.hpp::potrf_rl_groups with Ops::step (round 5: panel solve + next block column + next potrf_base as ONE launch per
+    128 columns, csrc/small_n.hip::sweep_step_kernel; fused & 1) and with the side stream's remainder update joined in two
+    stages (first block column, then the rest one step later; fused & 2), the joins carried by the step before the one that needs
+    them (fused & 8): which rows, which earlier panels of the group, which
+    block is factored next, where the fork ticket and the joins go -- against LAPACK, with and without augmented rows,
+    followers on; the emulation's race detector checks that the chain touches nothing a side section wrote (or writes what it
+    read) before the matching join."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(la)
+    emul.emul_set_rl_group(ctypes.c_int64(group))
+    emul.emul_set_fused(fused)
+    emul.emul_side_bad(1)
+    try:
+        rng = np.random.default_rng(n + m + e)
+        G = rng.standard_normal((n, n)); K = G @ G.T + n * np.eye(n)
+        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        info = ctypes.c_int(0)
+        if e:
+            E = rng.standard_normal((e, n))
+            A = np.ascontiguousarray(np.vstack([K, E]))
+            rc = emul.emul_potrf_aug(p(A), ctypes.c_int64(n), ctypes.c_int64(e), ctypes.byref(info))
+            assert rc == 0 and info.value == 0
+            L = sl.cholesky(K, lower=True)
+            assert np.abs(np.tril(A[:n]) - L).max() <= 1e-12 * np.abs(L).max()
+            assert np.abs(A[n:] - sl.solve_triangular(L, E.T, lower=True).T).max() <= 1e-11
+        else:
+            A = K.copy(); B = rng.standard_normal((m, n)); B2 = B.copy(); y = rng.standard_normal((1, n))
+            B0, y0 = B.copy(), y.copy()
+            rc = emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(m), p(y), ctypes.c_int64(1), ctypes.byref(info))
+            assert rc == 0 and info.value == 0
+            L = sl.cholesky(K, lower=True)
+            assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
+            assert np.abs(B - sl.solve_triangular(L, B0.T, lower=True).T).max() <= 1e-12
+        assert emul.emul_side_bad(0) == 0
+    finally:
+        emul.emul_set_fused(0); emul.emul_set_lookahead(0)
+
+
+def test_side_stream_race_detector_detects(emul):
+    """The detector behind the test above, firing: with the lookahead_min threshold of the emulation every group forks a side
+    section; an Ops that "forgets" the joins (emul_set_fused bit 2) must be flagged."""
+    emul.emul_set_rl_max(ctypes.c_int64(1024)); emul.emul_set_lookahead(1); emul.emul_set_rl_group(ctypes.c_int64(2))
+    emul.emul_set_fused(4)
+    emul.emul_side_bad(1)
+    try:
+        n = 1024
+        rng = np.random.default_rng(n)
+        G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+        B = rng.standard_normal((128, n)); B2 = B.copy(); y = rng.standard_normal((1, n))
+        info = ctypes.c_int(0)
+        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
+        assert emul.emul_side_bad(0) > 0
+    finally:
+        emul.emul_set_fused(0); emul.emul_set_lookahead(0)
