@@ -458,7 +458,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
 static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync, &h->dStepScratch,
                     &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
@@ -616,6 +616,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk") == 0) { h->potrf_bulk = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_fused_step") == 0) { h->potrf_fused_step = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_step_helpers") == 0) { h->potrf_step_helpers = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_two_stage_join") == 0) { h->potrf_two_stage_join = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk_flop") == 0) { h->potrf_bulk_flop = value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk_reserve") == 0) {   // takes effect when the bulk stream is (re)created

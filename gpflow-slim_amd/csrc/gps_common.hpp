@@ -103,7 +103,7 @@ struct gps_handle_s {
   // look-ahead of the sweep (potrf_rl_groups): the remainder update of a pair of panels runs on side_stream (one CU per
   // XCD left free for potrf_base) and is handed over through two monotone device counters instead of events
   int potrf_lookahead = 1;
-  int potrf_lookahead_min = 1024;              // rows of that remainder from which the hand-over pays
+  int potrf_lookahead_min = 256;               // rows of that remainder from which the hand-over pays (round 5, with the one-launch steps: 1024 -> 256, N = 8192 -2 %)
   hipStream_t side_stream = nullptr;
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
@@ -263,7 +263,9 @@ struct gps_handle_s {
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
   DevBuf dStepSync;           // counters of the one-launch sweep step (small_n.hip: sweep_step_kernel); monotone, their host-side values below
-  unsigned long long step_q = 0, step_xn = 0, step_dn = 0, step_sd = 0;
+  unsigned long long step_q = 0, step_xn = 0, step_dn = 0, step_sd = 0, step_tp = 0;
+  DevBuf dStepScratch;        // [128][128]: the helper tasks' product for the top tile
+  int potrf_step_helpers = 1; // option: the earlier panels' product of the top tile by eight more workgroups of the step launch
   bool step_dirty = false;    // a bounded wait of such a launch ran out: the area is cleared before the next one
   int potrf_two_stage_join = 1;   // option: the side stream's remainder update publishes its first block column before the rest (blocked.hpp)
   int potrf_fused_step = 2;   // option: panel solve + next block column + next potrf_base of the sweep as ONE launch per 128 columns (1), which also awaits the NEXT step's join with the side stream before it ends (2)

@@ -449,14 +449,16 @@ typedef unsigned long long u64;
 #define ST_XN 16
 #define ST_DN 24
 #define ST_SD 32
-#define ST_WORDS 40
+#define ST_TP 40
+#define ST_WORDS 48
 
 struct StepArgs {
   double* B; i64 lda; int m;          // the rows below the block just factored, its 128 columns: solved in place.  m: multiple of 16, >= 128
   const double* W;                    // that block's inverse [128][128]
   int kprev;                          // columns of the group's earlier panels directly left of B (their update of the next block column is due too)
   double* Linv_next; double* LinvT_next; int* info; int row0_next; int factor;       // potrf_base of the next diagonal block (B's rows 0 .. 127, columns 128 .. 255)
-  u64* sync; u64 q0, xn0, dn0, sd0;   // the counters and their values at launch
+  u64* sync; u64 q0, xn0, dn0, sd0, tp0;   // the counters and their values at launch
+  double* scratch;                    // [128][128]: the earlier panels' product for the top tile, by helper tasks (or null: the top slabs do it themselves)
   u64* sig; u64 sig_val;              // fork ticket to publish when every slab is solved (or null)
   const u64* exit_wait; u64 exit_val; // join value of the side stream the NEXT step needs: awaited by the chain workgroup before it leaves (or null)
   u64* timeouts;
@@ -489,6 +491,30 @@ __device__ __forceinline__ bool st_wait(const StepArgs& g, const u64* c, u64 tar
   return ok != 0;
 }
 
+// Helper task hs (second panel of a group onwards, 8 of them): - P_prev[slab hs] Pn_prev^T of the TOP tile into the scratch tile,
+// beside the top slabs' own solve -- the next diagonal block waits for the top tile's update, and this half of it needs
+// nothing of this launch (3.5 us off the chain on those steps).
+template <int SH>
+__device__ __forceinline__ void st_helper_task(const StepArgs& g, char* smem, int hs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const i64 ld = g.lda;
+  SnOwn<SH, false> own;
+#pragma unroll
+  for (int t = 0; t < SH / 16; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] = 0.0;
+  const double* Pslab = g.B + (i64)hs * SH * ld - g.kprev;
+  for (int kb = 0; kb < g.kprev; kb += 128) {
+    sn_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+    __syncthreads();
+  }
+  sn_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, nullptr, 0, 0, wave, lane, fr, fk);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(g.sync + ST_TP, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int SH>
 __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int* s_flag_p, int s, int nslabs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -518,9 +544,20 @@ __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int*
   // ---- U: Cn -= [P_prev | X] [Pn_prev | Xn]^T  (Pn, Xn: the top tile's rows of the same columns)
   SnOwn<SH, false> own;
   sn_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
-  for (int kb = 0; kb < g.kprev; kb += 128) {         // the group's earlier panels: final since the previous launches, no wait
-    sn_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
-    __syncthreads();                                  // (everybody has read the staged rows: the next product restages them)
+  const bool helped = top && g.scratch != nullptr && g.kprev > 0;
+  if (helped) {
+    // (the top tile's share of the earlier panels' product comes from the helper tasks)
+    if (!st_wait(g, g.sync + ST_TP, g.tp0 + (u64)(128 / SH), s_flag_p)) return;
+    const double* T = g.scratch + (i64)s * SH * 128;
+#pragma unroll
+    for (int t = 0; t < SH / 16; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] += T[(16 * t + fk + 4 * rg) * 128 + 16 * wave + fr];
+  } else {
+    for (int kb = 0; kb < g.kprev; kb += 128) {       // the group's earlier panels: final since the previous launches, no wait
+      sn_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+      __syncthreads();                                // (everybody has read the staged rows: the next product restages them)
+    }
   }
   ST_STAMP(2);
   if (!st_wait(g, g.sync + ST_XN, g.xn0 + (u64)(128 / SH), s_flag_p)) return;
@@ -542,7 +579,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;
   int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);        // [0] waits  [1] ticket  [3] aborted
   const int tid = threadIdx.x;
-  const int nslabs = g.m / SH, top = 128 / SH, ntasks = nslabs + 1;
+  // tasks: 0 .. 7 the top slabs, 8 the chain, then (with helpers) 8 helper tasks, then the other slabs
+  const int nslabs = g.m / SH, top = 128 / SH, nh = (g.scratch && g.kprev > 0) ? top : 0, ntasks = nslabs + 1 + nh;
   const bool one_each = (int)gridDim.x >= ntasks;     // as many workgroups as tasks: one draw each
   auto draw = [&]() -> int {                          // next task, -1: nothing left / aborted
     __syncthreads();
@@ -559,9 +597,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     return (s_flag_p[3] || t >= ntasks) ? -1 : t;
   };
   // (the chain is straight-line code between two copies of the slab loop: inside ONE loop with it the compiler spills)
+  auto slab_or_helper = [&](int t) {
+    if (t > top && t <= top + nh) st_helper_task<SH>(g, smem_raw, t - top - 1);
+    else st_slab_task<SH>(g, smem_raw, s_flag_p, t < top ? t : t - 1 - nh, nslabs);
+  };
   int t = draw();
   while (t >= 0 && t != top) {
-    st_slab_task<SH>(g, smem_raw, s_flag_p, t < top ? t : t - 1, nslabs);
+    slab_or_helper(t);
     if (one_each) return;
     t = draw();
   }
@@ -578,7 +620,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (g.exit_wait && !st_wait(g, g.exit_wait, g.exit_val, s_flag_p)) return;
   if (g.stamps && tid == 0) g.stamps[8 * top + 3] = (long long)wall_clock64();
   if (one_each) return;
-  for (t = draw(); t >= 0; t = draw()) st_slab_task<SH>(g, smem_raw, s_flag_p, t - 1, nslabs);
+  for (t = draw(); t >= 0; t = draw()) slab_or_helper(t);
 }
 
 // S + U + the next block's potrf_base of one step of the sweep (see above).  B: rows below the factored block, its columns
@@ -588,19 +630,26 @@ int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const doubl
                           int* d_info, i64 row0_next, int factor) {
   if (m < 128 || m % 16 || kprev % 128 || kprev < 0 || h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;
   const int SH = 16;
-  const int nslabs = (int)(m / SH), ntasks = nslabs + 1;
+  const bool helpers = kprev > 0 && h->potrf_step_helpers != 0;
+  const int nslabs = (int)(m / SH), ntasks = nslabs + 1 + (helpers ? 128 / SH : 0);
   const int slots = h->prop.multiProcessorCount - 8;          // one workgroup per CU (LDS)
   const int grid = ntasks < slots ? ntasks : slots;
   if (!h->dStepSync.p || h->step_dirty) {
     GPS_HIP(h, h->dStepSync.ensure((size_t)ST_WORDS * 8));
     GPS_HIP(h, hipMemsetAsync(h->dStepSync.p, 0, (size_t)ST_WORDS * 8, h->stream));
-    h->step_q = h->step_xn = h->step_dn = h->step_sd = 0;
+    h->step_q = h->step_xn = h->step_dn = h->step_sd = h->step_tp = 0;
     h->step_dirty = false;
   }
   StepArgs a;
   a.B = B; a.lda = lda; a.m = (int)m; a.W = W; a.kprev = (int)kprev;
   a.Linv_next = Linv_next; a.LinvT_next = LinvT_next; a.info = d_info; a.row0_next = (int)row0_next; a.factor = factor;
-  a.sync = (u64*)h->dStepSync.p; a.q0 = h->step_q; a.xn0 = h->step_xn; a.dn0 = h->step_dn; a.sd0 = h->step_sd;
+  a.sync = (u64*)h->dStepSync.p; a.q0 = h->step_q; a.xn0 = h->step_xn; a.dn0 = h->step_dn; a.sd0 = h->step_sd; a.tp0 = h->step_tp;
+  a.scratch = nullptr;
+  if (helpers) {
+    GPS_HIP(h, h->dStepScratch.ensure((size_t)128 * 128 * 8));
+    a.scratch = h->dStepScratch.d();
+    h->step_tp += 128 / SH;
+  }
   a.sig = h->next_sig_ptr; a.sig_val = h->next_sig_val; h->next_sig_ptr = nullptr;         // consumed by this launch
   a.exit_wait = h->next_wait_ptr; a.exit_val = h->next_wait_val; h->next_wait_ptr = nullptr;
   a.timeouts = h->dLaFlags.p ? (u64*)h->dLaFlags.p + 2 : nullptr;
@@ -628,24 +677,24 @@ int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const doubl
   }
   const bool dbg = dbg_mode == 1;
   if (want_stamps) {
+    const int ns1 = nslabs + 1;                       // stamp slots: slab s -> s (top) / s + 1, the chain -> 8
     std::vector<long long> st((size_t)8 * (ntasks + 1));
     GPS_HIP(h, hipMemcpyAsync(st.data(), h->dTmp3.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
-    long long t0 = LLONG_MAX, t_end = 0;
-    for (int t = 0; t < ntasks; ++t) if (st[8 * t] && st[8 * t] < t0) t0 = st[8 * t];
+    long long t0 = LLONG_MAX;
+    for (int t = 0; t < ns1; ++t) if (st[8 * t] && st[8 * t] < t0) t0 = st[8 * t];
     auto us = [&](long long v) { return v ? (v - t0) * 0.01 : -1.0; };
     double s_done = 0, u_done = 0, start_max = 0;
-    for (int t = 0; t < ntasks; ++t) {
+    for (int t = 0; t < ns1; ++t) {
       if (t == 8) continue;
       if (us(st[8 * t]) > start_max) start_max = us(st[8 * t]);
       if (us(st[8 * t + 1]) > s_done) s_done = us(st[8 * t + 1]);
       if (us(st[8 * t + 4]) > u_done) u_done = us(st[8 * t + 4]);
     }
-    (void)t_end;
     fprintf(stderr, "step m=%lld kprev=%lld tasks=%d grid=%d | top slab 0: start %.1f S done %.1f prev-U done %.1f XN seen %.1f U done %.1f DN counted %.1f | slab %d: start %.1f S %.1f XN %.1f U %.1f | "
                     "all slabs: last start %.1f last S %.1f last U %.1f | chain: start %.1f DN seen %.1f factored %.1f next join seen %.1f\n",
             (long long)m, (long long)kprev, ntasks, grid, us(st[0]), us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]),
-            ntasks - 2, us(st[8 * (ntasks - 1)]), us(st[8 * (ntasks - 1) + 1]), us(st[8 * (ntasks - 1) + 3]), us(st[8 * (ntasks - 1) + 4]),
+            nslabs - 1, us(st[8 * (ns1 - 1)]), us(st[8 * (ns1 - 1) + 1]), us(st[8 * (ns1 - 1) + 3]), us(st[8 * (ns1 - 1) + 4]),
             start_max, s_done, u_done, us(st[64]), us(st[65]), us(st[66]), us(st[67]));
   }
   if (dbg) {

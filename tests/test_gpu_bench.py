@@ -99,12 +99,12 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
 def test_bench_slow_rank0_tail_does_not_trip_the_stall_supervisor():
     """ranks != 0 finish early and wait in the last barrier while rank 0 runs its single-GPU tail and the CPU
     stand-in; with a stall limit shorter than that tail the supervisor used to kill the waiting (healthy) ranks.  They now
-    send a heartbeat from the barrier, and rank 0 one from the CPU stand-in: --stall 12 against a 30-s tail must succeed."""
+    send a heartbeat from the barrier, and rank 0 one from the CPU stand-in: --stall 6 against a 15-s tail must succeed."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env["GPS_BENCH_TEST_SLOW_TAIL"] = "30"
+    env["GPS_BENCH_TEST_SLOW_TAIL"] = "15"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo",
            "--force-device", "0", "--npoints", "4096", "--dist-nb", "256", "--num-new-throughput", "256", "--dist-timeout", "200",
-           "--no-dist-autotune", "--independent-steps", "0", "--cpu-sample-n", "512", "--small-n", "", "--stall", "12"]
+           "--no-dist-autotune", "--independent-steps", "0", "--cpu-sample-n", "512", "--small-n", "", "--stall", "6"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     out = _last_json(p.stdout)

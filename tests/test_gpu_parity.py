@@ -133,9 +133,13 @@ def solve_tol(K):
     return max(RTOL, 2.0 * EPS * float(np.linalg.cond(K)))
 
 
+# (N = 4096 at the two ends and right behind the refinement switch only -- the oracle's dense solves are what the cases cost:
+# the suite has to stay well inside the driver's limit; N = 1024 runs every ratio, N = 16384 below the hardest one)
+_LOW_NOISE = [(n, r) for n in (1024, 4096) for r in (1e-5, 1e-4, 9e-4, 1.1e-3, 5e-3, 1e-2) if n == 1024 or r in (1e-5, 1.1e-3, 1e-2)]
+
+
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
-@pytest.mark.parametrize("n", [1024, 4096])
-@pytest.mark.parametrize("ratio", [1e-5, 1e-4, 9e-4, 1.1e-3, 5e-3, 1e-2])
+@pytest.mark.parametrize("n,ratio", _LOW_NOISE)
 def test_gpr_low_noise_sweep(handle, kind, n, ratio):
     """The GPR rows at the noise levels a fit actually reaches (the reference trains the likelihood variance down towards
     its 1e-6 floor, likelihoods.py:162; models/gpr.py:69-72,119-131): noise / Kdiag from 1e-5 to 1e-2 on two-dimensional
@@ -240,7 +244,7 @@ def test_gpr_not_positive_definite_raises(handle):
         m.compute_log_likelihood()
 
 
-@pytest.mark.parametrize("ratio", [1e-5, 1e-4])
+@pytest.mark.parametrize("ratio", [1e-5])
 def test_gpr_low_noise_sweep_large(handle, ratio):
     """The low-noise end of the sweep above at N = 16384 (the regime a fit ends in, at a size where the substitution is a
     wavefront over 128 blocks): refined leaves in the factorisation AND the refined wavefront substitution (trsv_wave.hip,
