@@ -700,6 +700,64 @@ int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds_, i64 rows, 
   return GPS_OK;
 }
 
+// kappa_2 of every 128 x 128 diagonal block of a factor, from the block and its explicit inverse W_j: ||L_jj||_2 ||W_j||_2 with both
+// norms by 16 steps of power iteration on A^T A (from the all-ones vector; it converges from below, hence the factor 1.5),
+// capped by the rigorous bound sqrt(||A||_1 ||A||_inf) of each norm (the norm bounds alone are 6 - 50 x too pessimistic on the
+// blocks of an RBF Gram matrix).  One workgroup per block, thread t: row t / column t.  What decides, per leaf, whether the
+// product with the explicit inverse IS the solve or only its preconditioner (gps_api.hip: classify_blocks).
+__device__ __forceinline__ double bc_norm2(const double* __restrict__ A, i64 lda, double* x, double* y, double* red, int t) {
+  // A lower triangular [128][128]; returns min(1.5 * power-iteration estimate of ||A||_2, sqrt(||A||_1 ||A||_inf))
+  double cs = 0.0, rs = 0.0;
+  for (int r = t; r < 128; ++r) cs += fabs(A[(i64)r * lda + t]);
+  for (int q = 0; q <= t; ++q) rs += fabs(A[(i64)t * lda + q]);
+  red[t] = cs; red[128 + t] = rs;
+  x[t] = 1.0;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if (t < off) { red[t] = fmax(red[t], red[t + off]); red[128 + t] = fmax(red[128 + t], red[128 + t + off]); }
+    __syncthreads();
+  }
+  const double bound = sqrt(red[0] * red[128]);
+  __syncthreads();
+  double est = 0.0;
+  for (int it = 0; it < 16; ++it) {
+    double s = 0.0;
+    for (int q = 0; q <= t; ++q) s = fma(A[(i64)t * lda + q], x[q], s);          // y = A x
+    y[t] = s;
+    __syncthreads();
+    double z = 0.0;
+    for (int r = t; r < 128; ++r) z = fma(A[(i64)r * lda + t], y[r], z);         // z = A^T y
+    red[t] = z * z; red[128 + t] = x[t] * x[t];
+    __syncthreads();
+    for (int off = 64; off > 0; off >>= 1) {
+      if (t < off) { red[t] += red[t + off]; red[128 + t] += red[128 + t + off]; }
+      __syncthreads();
+    }
+    const double nz = sqrt(red[0]), nx = sqrt(red[128]);
+    est = sqrt(nz / nx);                                                          // ||A^T A x|| / ||x|| -> sigma_max^2
+    __syncthreads();
+    x[t] = z / nz;
+    __syncthreads();
+  }
+  return fmin(1.5 * est, bound);
+}
+
+__global__ __launch_bounds__(128) void block_cond_kernel(const double* __restrict__ L, i64 ldl, const double* __restrict__ W, double* __restrict__ out) {
+  __shared__ double x[128], y[128], red[256];
+  const int j = blockIdx.x, t = threadIdx.x;
+  const double nl = bc_norm2(L + (i64)j * 128 * ldl + (i64)j * 128, ldl, x, y, red, t);
+  const double nw = bc_norm2(W + (i64)j * 128 * 128, 128, x, y, red, t);
+  if (t == 0) out[j] = nl * nw;
+}
+
+int gps_launch_block_cond(gps_handle_t h, const double* L, i64 ldl, const double* W, i64 nblk, double* d_out) {
+  if (nblk <= 0) return GPS_OK;
+  LaunchScope ls(h, KC_OTHER, 0.0, 2.0 * 8.0 * 128 * 128 * nblk);
+  hipLaunchKernelGGL(block_cond_kernel, dim3((unsigned)nblk), dim3(128), 0, h->stream, L, ldl, W, d_out);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
 int gps_launch_transpose_blocks(gps_handle_t h, const double* src, double* dst, i64 nblk) {
   if (nblk <= 0) return GPS_OK;
   LaunchScope ls(h, KC_OTHER, 0.0, 16.0 * 128 * 128 * nblk);

@@ -401,7 +401,7 @@ struct Blocked {
   int trsm_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m, L, ldl);
-    if (n == 4 * GPS_TILE && ops.leaf512(m, 0)) return ops.trsm_leaf512(blk0, 0, B, ldb, m, L, ldl);
+    if (n == 4 * GPS_TILE && ops.leaf512(m, 0, blk0)) return ops.trsm_leaf512(blk0, 0, B, ldb, m, L, ldl);
     const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rec(L, ldl, n1, blk0, B, ldb, m);
     if (rc) return rc;
@@ -414,7 +414,7 @@ struct Blocked {
   int trsm_rn_rec(const double* U, i64 ldu, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m, U, ldu);
-    if (n == 4 * GPS_TILE && ops.leaf512(m, 1)) return ops.trsm_leaf512(blk0, 1, B, ldb, m, U, ldu);
+    if (n == 4 * GPS_TILE && ops.leaf512(m, 1, blk0)) return ops.trsm_leaf512(blk0, 1, B, ldb, m, U, ldu);
     const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rn_rec(U + n1 * ldu + n1, ldu, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
     if (rc) return rc;

@@ -15,6 +15,7 @@ struct HipOps {
   bool store_T = true;   // potrf_base also stores the transposed inverse (false: produced later by transpose_blocks)
 
   int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
+    if (h->plain_linv == linv) h->plain_linv = nullptr;         // (these block inverses are being produced anew: classify_blocks again)
     return gps_launch_potrf_base(h, A, lda, linv + blk * GPS_TILE * GPS_TILE,
                                  (linvT && store_T) ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
                                  factor);
@@ -23,6 +24,7 @@ struct HipOps {
   // update of the next block column with the group's panels, and the next diagonal block's potrf_base
   bool fused_step() { return h->potrf_fused_step != 0 && !h->refine_now && factor == 1 && h->prop.multiProcessorCount >= 160 && lookahead(); }
   int step(i64 blk, double* B, i64 ldb, i64 m, i64 kprev, i64 row0_next) {
+    if (h->plain_linv == linv) h->plain_linv = nullptr;
     double* ln = linv + (blk + 1) * GPS_TILE * GPS_TILE;
     double* lt = (linvT && store_T) ? linvT + (blk + 1) * GPS_TILE * GPS_TILE : nullptr;
     return gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, ln, lt, d_info, row0_next, factor);
@@ -86,14 +88,22 @@ struct HipOps {
   // D: the diagonal block the leaf solves against (lower block of L, or the upper block of U = L^T when transposed)
   int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
     const double* W = (transposed ? linvT : linv) + blk * GPS_TILE * GPS_TILE;
-    if (h->refine_now) return gps_launch_trsm_leaf_refine(h, B, ldb, m, W, D, ldd, transposed);
+    if (h->refine_now && !plain_ok(blk, 1)) { h->leaves_refined++; return gps_launch_trsm_leaf_refine(h, B, ldb, m, W, D, ldd, transposed); }
+    if (h->refine_now) h->leaves_plain++;
     return gps_launch_gemm_nt(h, /*op set*/ 1, 0, m, GPS_TILE, GPS_TILE, B, ldb, W, GPS_TILE, B, ldb);
   }
+  // refine mode: blocks blk .. blk + cnt - 1 of THIS factor have been classified well conditioned (classify_blocks): plain leaves
+  bool plain_ok(i64 blk, i64 cnt) const {
+    if (h->plain_linv != linv || blk < 0 || (size_t)(blk + cnt) > h->plain_flags.size()) return false;
+    for (i64 b = blk; b < blk + cnt; ++b) if (!h->plain_flags[(size_t)b]) return false;
+    return true;
+  }
   // four leaves and the updates between them as one launch (trsm_panel.hip); not for refined leaves
-  bool leaf512(i64 m, int transposed) const {
-    return h->trsm_panel > 0 && !h->refine_now && m >= 64 && m % 64 == 0 && (transposed ? linvT != nullptr : true);
+  bool leaf512(i64 m, int transposed, i64 blk) const {
+    return h->trsm_panel > 0 && (!h->refine_now || plain_ok(blk, 4)) && m >= 64 && m % 64 == 0 && (transposed ? linvT != nullptr : true);
   }
   int trsm_leaf512(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
+    if (h->refine_now) h->leaves_plain += 4;
     const double* W = (transposed ? linvT : linv) + blk * GPS_TILE * GPS_TILE;
     return gps_launch_trsm_panel(h, B, ldb, m, D, ldd, W, transposed);
   }
@@ -406,6 +416,24 @@ static int with_la_retry(gps_handle_t h, F&& body) {
   return rc;
 }
 
+// Refine mode, after a factorisation: kappa_1 of every diagonal block from the factor and its block inverses (one small launch,
+// one read-back); blocks at or below "leaf_plain_kappa" are solved against by the plain product from now on (HipOps::plain_ok).
+static int classify_blocks(gps_handle_t h, const HipOps& ops, const double* L, i64 ldl, i64 n) {
+  h->plain_linv = nullptr;
+  if (!h->refine_now || !(h->leaf_plain_kappa > 0.0) || n < GPS_TILE) return GPS_OK;
+  const i64 nblk = n / GPS_TILE;
+  GPS_HIP(h, h->dBlkCond.ensure((size_t)nblk * 8));
+  int rc = gps_launch_block_cond(h, L, ldl, ops.linv, nblk, h->dBlkCond.d());
+  if (rc) return rc;
+  std::vector<double> k((size_t)nblk);
+  GPS_HIP(h, hipMemcpyAsync(k.data(), h->dBlkCond.p, (size_t)nblk * 8, hipMemcpyDeviceToHost, h->stream));
+  GPS_HIP(h, hipStreamSynchronize(h->stream));
+  h->plain_flags.assign((size_t)nblk, 0);
+  for (i64 b = 0; b < nblk; ++b) h->plain_flags[(size_t)b] = (k[(size_t)b] == k[(size_t)b] && k[(size_t)b] <= h->leaf_plain_kappa) ? 1 : 0;   // (NaN: not positive definite -- refine)
+  h->plain_linv = ops.linv;
+  return GPS_OK;
+}
+
 static int gpr_lml_finish(gps_handle_t h, i64 r, double* lml);
 // a cooperative launch of the small-N path gave up: counted; the fourth in a row sends the handle's next 256 evaluations of
 // that size launch by launch (a GPU shared with something that holds its CUs must not cost a bounded wait per optimiser step;
@@ -458,7 +486,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
 static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync, &h->dStepScratch,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync, &h->dStepScratch, &h->dBlkCond,
                     &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
@@ -559,6 +587,11 @@ extern "C" int gps_profile_get(gps_handle_t h, const char* klass, int64_t* launc
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
     return GPS_OK;
   }
+  if (strcmp(klass, "leaves_plain") == 0 || strcmp(klass, "leaves_refined") == 0) {     // leaf launches in refine mode, by kind
+    if (launches) *launches = (int64_t)(klass[7] == 'p' ? h->leaves_plain : h->leaves_refined);
+    if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
+    return GPS_OK;
+  }
   if (strcmp(klass, "small_n_cooldown") == 0) {       // evaluations the small-N back-off (small_gave_up) still sends launch by launch
     if (launches) *launches = (int64_t)h->small_cooldown;
     if (ms) *ms = 0.0; if (flops) *flops = 0.0; if (bytes) *bytes = 0.0;
@@ -616,6 +649,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk") == 0) { h->potrf_bulk = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_fused_step") == 0) { h->potrf_fused_step = (int)value; return GPS_OK; }
+  if (strcmp(key, "leaf_plain_kappa") == 0) { h->leaf_plain_kappa = value; h->plain_linv = nullptr; return GPS_OK; }
   if (strcmp(key, "potrf_step_helpers") == 0) { h->potrf_step_helpers = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_two_stage_join") == 0) { h->potrf_two_stage_join = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_bulk_flop") == 0) { h->potrf_bulk_flop = value; return GPS_OK; }
@@ -1151,6 +1185,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     if (followed) rc = fops.y_join();
     else rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
     if (rc) return rc;
+    if (h->refine_now) { rc = classify_blocks(h, ops, h->dK.d(), np, np); if (rc) return rc; }      // (low noise: the predictions' solves)
   }
   Blocked<HipOps> bl(ops);
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
@@ -1532,6 +1567,8 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
   Blocked<HipOps> bl(ops);
   rc = bl.potrf_rec(c.Kmm, mp, mp, 0, 0);                          // Lm   conditionals.py:84
   if (rc) return rc;
+  rc = classify_blocks(h, ops, c.Kmm, mp, mp);                     // (refined leaves only against ill-conditioned diagonal blocks)
+  if (rc) return rc;
   rc = bl.trsm_rec(c.Kmm, mp, mp, 0, c.Bt, mp, nsp);               // A^T  conditionals.py:87
   if (rc) return rc;
 
@@ -1907,6 +1944,8 @@ static int svgp_whiten(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   if (rc) return rc;
   rc = read_info(h, d_info, info);
   if (rc || (info && *info)) return rc;
+  rc = classify_blocks(h, ops, h->dK.d(), mp, mp);
+  if (rc) return rc;
   // m_w^T = (Lm^-1 q_mu)^T : right-hand sides as rows
   std::vector<double> buf((size_t)GPS_TILE * mp, 0.0);
   for (i64 j = 0; j < m; ++j) for (i64 q = 0; q < k; ++q) buf[(size_t)q * mp + j] = q_mu[j * k + q];
@@ -2941,6 +2980,8 @@ static int sparse_gpr_impl(gps_handle_t h, int fitc, const gps_kern_node_t* prog
   HipOps opsL{h, h->dLinv.d(), h->dLinv.d() + blk_bytes / 8, d_info};
   Blocked<HipOps> blL(opsL);
   rc = blL.potrf_rec(h->dK.d(), mp, mp, 0, 0);
+  if (rc) return rc;
+  rc = classify_blocks(h, opsL, h->dK.d(), mp, mp);
   if (rc) return rc;
   // At = K(X, Z) L^-T  = (L^-1 Kuf)^T   [np, mp]                         (sgpr.py:139, without the 1/sigma)
   rc = gps_launch_kmat(h, prog, n_nodes, h->dXnew.d(), n, h->dX.d(), m, d_all, 0.0, h->dS1.d(), mp, np, mp, 0, 0);

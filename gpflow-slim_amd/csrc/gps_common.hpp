@@ -178,6 +178,16 @@ struct gps_handle_s {
   int leaf_refine = -1;
   double leaf_refine_cond = 2e6;
   bool refine_now = false;       // resolved at every API entry
+  // Per-block refinement (round 5): where leaves are to be refined, a leaf whose diagonal block is well conditioned
+  // (kappa_2(L_jj) = ||L_jj||_2 ||W_j||_2, by power iteration with a safety factor, capped by the 1- / inf-norm bound; <= leaf_plain_kappa) takes the plain product with the explicit inverse anyway: its
+  // error, eps kappa(L_jj) kappa(L), stays a tenth below what a backward-stable solve leaves (2 eps kappa(L)^2, or the 1e-8
+  // contract) as long as kappa(L_jj) <= 1000 -- BASELINE config 5 (M = 4096 inducing points in 8 dimensions, cond(Kuu) 1.7e9):
+  // every block has kappa_2 <= 160, so none of its 32 x 1.3 ms refined leaves was buying anything.  plain_linv: the block
+  // inverses the flags belong to (cleared when a factorisation writes them again).
+  const double* plain_linv = nullptr;
+  std::vector<unsigned char> plain_flags;
+  double leaf_plain_kappa = 1000.0;   // option "leaf_plain_kappa" (0: refine every leaf, as before round 5)
+  long long leaves_plain = 0, leaves_refined = 0;      // leaf launches of either kind in refine mode (gps_profile_get "leaves_plain" / "leaves_refined")
   bool factor_refine = false;    // what the resident GPR factor was built with (warm predict_f keeps it)
   int kmat_fast = 1;             // one-primitive stationary programs: the stack-free kernel-matrix kernel (kmat.hip)
   int kmat_mfma = 1;             // chains of primitives (Sum / Product): the feature dot products on the matrix pipe (kmat_mfma_kernel); 2: one-primitive programs too
@@ -264,6 +274,7 @@ struct gps_handle_s {
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
   DevBuf dStepSync;           // counters of the one-launch sweep step (small_n.hip: sweep_step_kernel); monotone, their host-side values below
   unsigned long long step_q = 0, step_xn = 0, step_dn = 0, step_sd = 0, step_tp = 0;
+  DevBuf dBlkCond;            // kappa_1 of the diagonal blocks (classify_blocks)
   DevBuf dStepScratch;        // [128][128]: the helper tasks' product for the top tile
   int potrf_step_helpers = 1; // option: the earlier panels' product of the top tile by eight more workgroups of the step launch
   bool step_dirty = false;    // a bounded wait of such a launch ran out: the area is cleared before the next one
@@ -427,6 +438,7 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
 int gps_launch_transpose_blocks(gps_handle_t h, const double* src, double* dst, i64 nblk);
+int gps_launch_block_cond(gps_handle_t h, const double* L, i64 ldl, const double* W, i64 nblk, double* d_out);
 int gps_launch_scale_rows(gps_handle_t h, double* A, i64 lda, i64 rows, i64 cols, const double* sc);
 int gps_launch_scale_cols(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols, const double* sc,
                           double* dst, i64 ldd);

@@ -224,7 +224,7 @@ struct CpuOps {
   // the 512-column node as the device does it (csrc/trsm_panel.hip): block substitution with the four block inverses and
   // the off-diagonal blocks of D (forward: the lower block L; backward: U = L^T, blocks above the diagonal)
   int n_leaf512 = 0;
-  bool leaf512(i64 m, int) const { return g_leaf512 != 0 && m % 64 == 0; }
+  bool leaf512(i64 m, int, i64) const { return g_leaf512 != 0 && m % 64 == 0; }
   int trsm_leaf512(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
     ++n_leaf512;
     for (int jj = 0; jj < 4; ++jj) {

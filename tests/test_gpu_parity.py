@@ -949,6 +949,44 @@ def test_ill_conditioned_conditional_against_exact_arithmetic(handle):
     assert gm(plain) >= 3.0 * gm(errs), (gm(plain), gm(errs))               # the refinement is what buys the digit
 
 
+def test_refinement_only_against_ill_conditioned_blocks(handle):
+    """Round 5 (gps_common.hpp: leaf_plain_kappa): in refine mode a leaf whose diagonal block has kappa_1 <= 1000 takes the plain
+    product with the explicit inverse -- its error eps kappa(L_jj) kappa(L) stays a tenth below what a backward-stable solve
+    leaves.  Inducing points in 8 dimensions (BASELINE config 5's geometry: cond(Kuu) ~ 1e9, every diagonal block of the
+    factor kappa_2 <= 160): no refined leaf, and the result within the conditioning-derived gate of the oracle AND of the
+    every-leaf-refined solve; inducing points on a line (cond ~ 1e8 inside every block): the leaves are refined as before."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(11)
+    count = lambda k: handle.profile_get(k)["launches"]
+    # ---- config 5's geometry
+    m, d, n = 1024, 8, 3000
+    Z = rng.standard_normal((m, d)); Xn = rng.standard_normal((n, d)); f = rng.standard_normal((m, 2))
+    ls = np.sqrt(d) * np.ones(d)
+    kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=ls, ARD=True)
+    spec = {"type": "rbf", "variance": orc.constrained(1.0), "lengthscales": orc.constrained(ls), "input_dim": d}
+    tol = solve_tol(orc.K(spec, Z) + 1e-6 * np.eye(m))
+    p0, r0 = count("leaves_plain"), count("leaves_refined")
+    mu, var = gpf.conditionals.conditional(Xn, Z, kern, f, white=False)
+    # (the factorisation's own panel solves come before the classification: m / 128 - 1 refined leaves; the solve against the
+    # n test points -- two 512-column nodes -- is plain)
+    assert count("leaves_plain") - p0 == 8 and count("leaves_refined") - r0 == m // 128 - 1
+    rmu, rvar = orc.conditional(Xn, Z, spec, f, white=False)
+    assert np.abs(mu - rmu).max() <= tol * max(1.0, np.abs(rmu).max()) and np.abs(var - rvar).max() <= tol * max(1.0, np.abs(rvar).max())
+    handle.set_option("leaf_plain_kappa", 0.0)
+    try:
+        mu_r, var_r = gpf.conditionals.conditional(Xn, Z, kern, f, white=False)
+    finally:
+        handle.set_option("leaf_plain_kappa", 1000.0)
+    assert count("leaves_refined") > r0
+    assert np.abs(mu - mu_r).max() <= 0.2 * tol * max(1.0, np.abs(rmu).max())
+    # ---- points on a line: every block ill conditioned
+    Z1 = np.sort(rng.uniform(-2.0, 2.0, (512, 1)), axis=0); X1 = rng.uniform(-2.0, 2.0, (700, 1)); f1 = rng.standard_normal((512, 1))
+    k1 = gpf.kernels.RBF(1, variance=1.3, lengthscales=0.7)
+    p1, r1 = count("leaves_plain"), count("leaves_refined")
+    gpf.conditionals.conditional(X1, Z1, k1, f1, white=False)
+    assert count("leaves_refined") > r1
+
+
 def test_kernel_helper_methods(handle):
     """The reference's eager helpers on the kernel objects (kernels.py:68-75 compute_K / compute_K_symm / compute_Kdiag,
     :217-253 _slice, :287-306 Kdim, :441-444 dimwise): thin, but part of the surface a user of the reference calls."""
