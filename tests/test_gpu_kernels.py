@@ -604,3 +604,50 @@ def test_concurrent_small_launches(n, threads):
         assert t_max < 0.25 and slow <= 2, "thread %d: slowest step %.1f ms, %d steps over 50 ms" % (t, 1e3 * t_max, slow)
         # every thread computes the same bits as every other
         assert out[t][0][0] == out[0][0][0] and np.array_equal(out[t][0][1], out[0][0][1])
+
+
+@pytest.mark.parametrize("n", [3000, 5200])
+def test_concurrent_sweep_step_launches(n):
+    """The one-launch sweep steps (csrc/small_n.hip::sweep_step_kernel: workgroups that hold a whole CU each, synchronised through
+    counters in HBM, the chain workgroup awaiting the side stream's join before it leaves) with four factorisations in flight at
+    once: four handles in four host threads, 25 likelihood evaluations each at a size that takes the sweep (N > 2048).  Every
+    thread: bit-identical results step after step and across threads, equal to LAPACK on the oracle's kernel matrix to 1e-8,
+    no evaluation re-run without look-ahead (a bounded wait that ran out), no stalled step."""
+    import threading
+    import time
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    from gpflowSlim import _backend as be
+    d, steps, threads = 6, 25, 4
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
+    ls = np.sqrt(d) * np.linspace(0.8, 1.2, d)
+    prog = gpf.kernels.RBF(d, variance=1.1, lengthscales=ls, ARD=True)._program(d)
+    ref = orc.gpr_lml({"type": "rbf", "variance": 1.1, "lengthscales": ls, "input_dim": d}, X, Y, 0.1)
+    out, errors = {}, []
+
+    def run(t):
+        try:
+            h = be.Handle(0)
+            h.gpr_set_data(X, X)
+            vals, t_max = [], 0.0
+            for i in range(steps):
+                t0 = time.perf_counter()
+                vals.append(h.gpr_lml(prog, 0.1, Y))
+                if i >= 2:
+                    t_max = max(t_max, time.perf_counter() - t0)
+            out[t] = (vals, t_max, h.profile_get("lookahead_retries")["launches"])
+            h.close()
+        except Exception as e:
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(threads)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errors, errors
+    for t in range(threads):
+        vals, t_max, retries = out[t]
+        assert all(v == vals[0] for v in vals), "thread %d: the likelihood changed between steps" % t
+        assert vals[0] == out[0][0][0]
+        assert abs(vals[0] - ref) <= 1e-8 * abs(ref)
+        assert retries == 0 and t_max < 0.5, (t, retries, t_max)
