@@ -423,7 +423,16 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)
  *   "potrf_lookahead" 1 (default): that remainder update runs on a second stream beside the next potrf_base, handed over
  *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
- *                     from which it is used (default 1024)
+ *                     from which it is used (default 256; 1024 before round 5)
+ *   "potrf_fused_step" 2 (default): every 128 columns of that sweep are ONE launch -- the solve of the rows below, the update of
+ *                     the next block column and the NEXT diagonal block's factorisation (small_n.hip: sweep_step_kernel) --
+ *                     whose chain workgroup also awaits, before it leaves, the join with the second stream that the next
+ *                     step needs; 1: the join by a wait launch of its own; 0: three launches per 128 columns (round 4)
+ *   "potrf_two_stage_join" 1 (default): the second stream publishes the FIRST block column of its remainder update before
+ *                     the rest (which nothing touches for one more step); "potrf_step_helpers" 1 (default): the earlier
+ *                     panel's share of the next diagonal tile's update by eight more workgroups of the step launch
+ *   "potrf_bulk"      0 (default) / bit 0, bit 1: cross-level look-ahead -- the rest of a trailing update / the first rows of a
+ *                     panel solve on a stream of their own beside the sweeps (measured slower on MI355X: DESIGN.md section 0)
  *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
  *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512)
  *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
@@ -435,7 +444,9 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when the bound
  *                     cond_2(K + noise I) <= (N Kdiag + noise) / noise exceeds "leaf_refine_cond" (default 2e6: the plain
  *                     products are ~7 u cond from exact, 1e-8 holds up to cond 1.3e7); 0: plain products with the block
- *                     inverses; 1: always
+ *                     inverses; 1: always.  "leaf_plain_kappa" (default 1000): in that mode a leaf whose diagonal block has
+ *                     kappa_2 <= this (estimated per block after the factorisation) takes the plain product anyway -- its
+ *                     error eps kappa(L_jj) kappa(L) stays a tenth below a backward-stable solve's; 0: refine every leaf
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always
