@@ -27,7 +27,12 @@ struct HipOps {
     if (h->plain_linv == linv) h->plain_linv = nullptr;
     double* ln = linv + (blk + 1) * GPS_TILE * GPS_TILE;
     double* lt = (linvT && store_T) ? linvT + (blk + 1) * GPS_TILE * GPS_TILE : nullptr;
-    return gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, ln, lt, d_info, row0_next, factor);
+    // "potrf_fused_step" = 3: solve + update as one lean launch (its workgroups share their CUs with the side streams' GEMMs),
+    // the next diagonal block by a potrf_base launch behind it; 1 / 2: all three in one launch of whole-CU workgroups
+    if (h->potrf_fused_step != 3) return gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, ln, lt, d_info, row0_next, factor, 1);
+    int rc = gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, nullptr, nullptr, d_info, row0_next, factor, 0);
+    if (rc) return rc;
+    return gps_launch_potrf_base(h, B + GPS_TILE, ldb, ln, lt, d_info, row0_next, factor);
   }
   // The join with the side stream before a step whose next block column the side stream's last remainder update wrote: a wait
   // launch in front of the step.  (Awaited INSIDE the step launch -- built, round 5 -- it deadlocks: the step's workgroups
@@ -35,7 +40,7 @@ struct HipOps {
   int step_join(unsigned long long t) { return chain_join(t); }
   // ... or carried by the step launched BEFORE the one that needs it: its chain workgroup awaits the value before it leaves
   // (blocked.hpp: exit_join), so that no wait launch sits between two steps
-  bool step_exit_join() const { return h->potrf_fused_step >= 2; }
+  bool step_exit_join() const { return h->potrf_fused_step == 2; }
   int step_carry_join(unsigned long long v) {
     if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) v = ~0ull;
     h->next_wait_ptr = la_flags() + 1; h->next_wait_val = v; h->next_wait_timeouts = la_flags() + 2;

@@ -103,7 +103,7 @@ struct gps_handle_s {
   // look-ahead of the sweep (potrf_rl_groups): the remainder update of a pair of panels runs on side_stream (one CU per
   // XCD left free for potrf_base) and is handed over through two monotone device counters instead of events
   int potrf_lookahead = 1;
-  int potrf_lookahead_min = 256;               // rows of that remainder from which the hand-over pays (round 5, with the one-launch steps: 1024 -> 256, N = 8192 -2 %)
+  int potrf_lookahead_min = 1024;              // rows of that remainder from which the hand-over pays
   hipStream_t side_stream = nullptr;
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
@@ -278,8 +278,18 @@ struct gps_handle_s {
   DevBuf dStepScratch;        // [128][128]: the helper tasks' product for the top tile
   int potrf_step_helpers = 1; // option: the earlier panels' product of the top tile by eight more workgroups of the step launch
   bool step_dirty = false;    // a bounded wait of such a launch ran out: the area is cleared before the next one
-  int potrf_two_stage_join = 1;   // option: the side stream's remainder update publishes its first block column before the rest (blocked.hpp)
-  int potrf_fused_step = 2;   // option: panel solve + next block column + next potrf_base of the sweep as ONE launch per 128 columns (1), which also awaits the NEXT step's join with the side stream before it ends (2)
+  // One launch per 128 columns of the sweep (small_n.hip: sweep_step_kernel), round 5 -- BUILT, TESTED, OFF: in isolation the
+  // launch replaces 52.7 us of launches by 44.8, but what the sweep gains depends on the box: same-process A/B of the final
+  // form against the round-4 schedule on six MI355X boxes: N = 4096 -4 / -1 / +4 / +3.5 / +3.5 / +3 %, N = 8192 -2.3 / -1.5 /
+  // 0 / +1.5 / +1.3 %, N = 32768 -0.4 ... +0.4 % (docs/LAB_NOTES.md).  The chain and the side stream's remainder updates
+  // form a cycle; shortening one of them moves the wait, not the sweep.
+  //   potrf_fused_step  1: solve + next block column + next potrf_base as one launch; 2: ... whose chain workgroup also awaits the
+  //                     NEXT step's join with the side stream before it leaves; 3: solve + update as one LEAN launch (51 KB of
+  //                     LDS instead of 150: shares its CUs), potrf_base launched behind it; 0 (default): three launches
+  //   potrf_two_stage_join  the side stream publishes the first block column of its remainder update before the rest
+  //   potrf_step_helpers    the earlier panel's share of the next diagonal tile's update by eight more workgroups of the launch
+  int potrf_two_stage_join = 0;
+  int potrf_fused_step = 0;
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
   int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
@@ -394,7 +404,7 @@ int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, do
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen = nullptr);
 int gps_small_factor_reset(gps_handle_t h);
 int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const double* W, i64 kprev, double* Linv_next, double* LinvT_next,
-                          int* d_info, i64 row0_next, int factor);
+                          int* d_info, i64 row0_next, int factor, int chain);
 // trsm_panel.hip
 int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,

@@ -196,6 +196,82 @@ __device__ __forceinline__ void sn_product(SnOwn<SH, SOLVE>& o, char* smem, cons
   sn_store_tile<SH, SOLVE>(o, smem, C, ldc, C2, ldc2, c2_rows, wave, lane, fr, fk);
 }
 
+// LEAN variants of the above for launches whose workgroups must leave room on their CU (sweep_step_kernel without the chain):
+// the B operand is staged in K-quarters -- each wave its 16 rows x 32 columns, 4.3 KB instead of 16.6 -- into a region only that
+// wave reads (no workgroup barrier between quarters, the next quarter's rows are fetched behind the current one's MFMAs); 51 KB of
+// LDS per workgroup instead of 150: three workgroups per CU, and GEMM workgroups of the side streams beside them.
+#define LN_BS 34                                       // row stride of a wave's quarter region (doubles)
+#define LN_AS_OFF (8 * 16 * LN_BS)
+#define LN_LDS_BYTES ((LN_AS_OFF + 16 * SN_LS) * 8)
+
+// this wave's two of the slab's 16 rows of A -> As[row][SN_LS]
+__device__ __forceinline__ void ln_stage_a(double* As, const double* g, i64 ldg, int wave, int lane) {
+  const double2 v0 = *reinterpret_cast<const double2*>(g + (i64)(2 * wave) * ldg + 2 * lane);
+  const double2 v1 = *reinterpret_cast<const double2*>(g + (i64)(2 * wave + 1) * ldg + 2 * lane);
+  *reinterpret_cast<double2*>(As + (2 * wave) * SN_LS + 2 * lane) = v0;
+  *reinterpret_cast<double2*>(As + (2 * wave + 1) * SN_LS + 2 * lane) = v1;
+}
+
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void ln_own(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* C, i64 ldc,
+                                       int wave, int lane, int fr, int fk) {
+  double* As = reinterpret_cast<double*>(smem) + LN_AS_OFF;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) o.acc[0][rg] = SOLVE ? 0.0 : C[(i64)(fk + 4 * rg) * ldc + 16 * wave + fr];
+  if (SOLVE) ln_stage_a(As, A, lda, wave, lane);
+}
+
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void ln_mma(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* __restrict__ Bm,
+                                       i64 ldb, int wave, int lane, int fr, int fk) {
+  static_assert(SH == 16, "lean products: 16-row slabs");
+  double* Bs = reinterpret_cast<double*>(smem) + wave * 16 * LN_BS;
+  double* As = reinterpret_cast<double*>(smem) + LN_AS_OFF;
+  if (!SOLVE) ln_stage_a(As, A, lda, wave, lane);
+  const int nq = SOLVE ? (16 * (wave + 1) + 31) / 32 : 4;       // (W lower triangular: columns beyond the tile's last are zero)
+  const int r = lane >> 2, c0 = (lane & 3) * 8;                 // this lane's 64 bytes of the quarter: row r, columns c0 .. c0 + 7
+  const double* src = Bm + (i64)(16 * wave + r) * ldb + c0;
+  double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2),
+          v2 = *reinterpret_cast<const double2*>(src + 4), v3 = *reinterpret_cast<const double2*>(src + 6);
+  __syncthreads();                                              // the rows of A are in LDS
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < nq) {
+      *reinterpret_cast<double2*>(Bs + r * LN_BS + c0) = v0; *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 2) = v1;
+      *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 4) = v2; *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 6) = v3;
+      if (q < 3) {            // (the next quarter's rows, unconditionally: named registers, not an array the compiler parks in scratch)
+        const double* nx = src + 32 * (q + 1);
+        v0 = *reinterpret_cast<const double2*>(nx); v1 = *reinterpret_cast<const double2*>(nx + 2);
+        v2 = *reinterpret_cast<const double2*>(nx + 4); v3 = *reinterpret_cast<const double2*>(nx + 6);
+      }
+      // (the region belongs to this wave alone and a wave's LDS operations complete in order: no barrier)
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const double b = Bs[fr * LN_BS + 4 * s2 + fk];
+        const double a = As[fr * SN_LS + 32 * q + 4 * s2 + fk];
+        if (!SOLVE || 32 * q + 4 * s2 < 16 * (wave + 1))
+          o.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? a : -a, b, o.acc[0], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this quarter's fragment reads are done before the region is overwritten
+    }
+  }
+}
+
+template <int SH, bool SOLVE>
+__device__ __forceinline__ void ln_store_tile(SnOwn<SH, SOLVE>& o, char* smem, double* C, i64 ldc, int wave, int lane, int fr, int fk) {
+  double* Bs = reinterpret_cast<double*>(smem) + wave * 16 * LN_BS;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) Bs[(fk + 4 * rg) * LN_BS + fr] = o.acc[0][rg];
+#pragma unroll
+  for (int hlf = 0; hlf < 2; ++hlf) {
+    const int row = 8 * hlf + (lane >> 3), col = 2 * (lane & 7);
+    const double2 v = *reinterpret_cast<const double2*>(Bs + row * LN_BS + col);
+    pb_store16(&C[(i64)row * ldc + 16 * wave + col], v);
+  }
+  __syncthreads();                                               // (the rows of A may be restaged)
+}
+
 // One pair = one 16-row slab of block row bi (bi == nblk: the augmented rows) x block column k: generate (K inside the launch), update
 // with the columns j < k as they appear, solve against block k.
 template <int SH>
@@ -494,7 +570,7 @@ __device__ __forceinline__ bool st_wait(const StepArgs& g, const u64* c, u64 tar
 // Helper task hs (second panel of a group onwards, 8 of them): - P_prev[slab hs] Pn_prev^T of the TOP tile into the scratch tile,
 // beside the top slabs' own solve -- the next diagonal block waits for the top tile's update, and this half of it needs
 // nothing of this launch (3.5 us off the chain on those steps).
-template <int SH>
+template <int SH, bool LEAN>
 __device__ __forceinline__ void st_helper_task(const StepArgs& g, char* smem, int hs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
@@ -506,16 +582,18 @@ __device__ __forceinline__ void st_helper_task(const StepArgs& g, char* smem, in
     for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] = 0.0;
   const double* Pslab = g.B + (i64)hs * SH * ld - g.kprev;
   for (int kb = 0; kb < g.kprev; kb += 128) {
-    sn_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+    if (LEAN) ln_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+    else sn_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
     __syncthreads();
   }
-  sn_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, nullptr, 0, 0, wave, lane, fr, fk);
+  if (LEAN) ln_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, wave, lane, fr, fk);
+  else sn_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, nullptr, 0, 0, wave, lane, fr, fk);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) __hip_atomic_fetch_add(g.sync + ST_TP, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int SH>
+template <int SH, bool LEAN>
 __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int* s_flag_p, int s, int nslabs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
@@ -529,8 +607,15 @@ __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int*
   // ---- S: X <- X W^T (W lower triangular: k-steps beyond the tile's last column are skipped)
   {
     SnOwn<SH, true> own;
-    sn_own<SH, true>(own, smem, X, ld, X, ld, wave, lane, fr, fk);
-    sn_product<SH, true>(own, smem, X, ld, g.W, 128, X, ld, nullptr, 0, 0, wave, lane, fr, fk);
+    if (LEAN) {
+      ln_own<SH, true>(own, smem, X, ld, X, ld, wave, lane, fr, fk);
+      ln_mma<SH, true>(own, smem, X, ld, g.W, 128, wave, lane, fr, fk);
+      __syncthreads();                                // (everybody has read the rows about to be overwritten)
+      ln_store_tile<SH, true>(own, smem, X, ld, wave, lane, fr, fk);
+    } else {
+      sn_own<SH, true>(own, smem, X, ld, X, ld, wave, lane, fr, fk);
+      sn_product<SH, true>(own, smem, X, ld, g.W, 128, X, ld, nullptr, 0, 0, wave, lane, fr, fk);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -543,7 +628,8 @@ __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int*
   ST_STAMP(1);
   // ---- U: Cn -= [P_prev | X] [Pn_prev | Xn]^T  (Pn, Xn: the top tile's rows of the same columns)
   SnOwn<SH, false> own;
-  sn_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
+  if (LEAN) ln_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
+  else sn_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
   const bool helped = top && g.scratch != nullptr && g.kprev > 0;
   if (helped) {
     // (the top tile's share of the earlier panels' product comes from the helper tasks)
@@ -555,15 +641,16 @@ __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int*
       for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] += T[(16 * t + fk + 4 * rg) * 128 + 16 * wave + fr];
   } else {
     for (int kb = 0; kb < g.kprev; kb += 128) {       // the group's earlier panels: final since the previous launches, no wait
-      sn_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+      if (LEAN) ln_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
+      else sn_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
       __syncthreads();                                // (everybody has read the staged rows: the next product restages them)
     }
   }
   ST_STAMP(2);
   if (!st_wait(g, g.sync + ST_XN, g.xn0 + (u64)(128 / SH), s_flag_p)) return;
   ST_STAMP(3);
-  sn_mma<SH, false>(own, smem, X, ld, g.B, ld, wave, lane, fr, fk);
-  sn_store_tile<SH, false>(own, smem, Cn, ld, nullptr, 0, 0, wave, lane, fr, fk);
+  if (LEAN) { ln_mma<SH, false>(own, smem, X, ld, g.B, ld, wave, lane, fr, fk); ln_store_tile<SH, false>(own, smem, Cn, ld, wave, lane, fr, fk); }
+  else { sn_mma<SH, false>(own, smem, X, ld, g.B, ld, wave, lane, fr, fk); sn_store_tile<SH, false>(own, smem, Cn, ld, nullptr, 0, 0, wave, lane, fr, fk); }
   ST_STAMP(4);
   if (top) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -573,14 +660,17 @@ __device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int*
   }
 }
 
-template <int SH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sweep_step_kernel(StepArgs g) {
+// CHAIN = true: the launch described above (150 KB of LDS per workgroup: one per CU).  CHAIN = false: S and U only, with the lean
+// products (51 KB: the workgroups share their CUs with each other and with the side streams' GEMMs); the next diagonal block is
+// factored by a potrf_base launch behind it ("potrf_fused_step" = 3).
+template <int SH, bool CHAIN>
+__device__ __forceinline__ void sweep_step_body(const StepArgs& g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int LDS_MAIN = (PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES;
+  constexpr int LDS_MAIN = CHAIN ? ((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) : LN_LDS_BYTES;
   int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);        // [0] waits  [1] ticket  [3] aborted
   const int tid = threadIdx.x;
-  // tasks: 0 .. 7 the top slabs, 8 the chain, then (with helpers) 8 helper tasks, then the other slabs
-  const int nslabs = g.m / SH, top = 128 / SH, nh = (g.scratch && g.kprev > 0) ? top : 0, ntasks = nslabs + 1 + nh;
+  // tasks: 0 .. 7 the top slabs, [8 the chain,] then (with helpers) 8 helper tasks, then the other slabs
+  const int nslabs = g.m / SH, top = 128 / SH, nh = (g.scratch && g.kprev > 0) ? top : 0, nc = CHAIN ? 1 : 0, ntasks = nslabs + nc + nh;
   const bool one_each = (int)gridDim.x >= ntasks;     // as many workgroups as tasks: one draw each
   auto draw = [&]() -> int {                          // next task, -1: nothing left / aborted
     __syncthreads();
@@ -596,18 +686,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (s_flag_p[3] && t == 0 && tid == 0 && g.sig) __hip_atomic_store(g.sig, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return (s_flag_p[3] || t >= ntasks) ? -1 : t;
   };
-  // (the chain is straight-line code between two copies of the slab loop: inside ONE loop with it the compiler spills)
   auto slab_or_helper = [&](int t) {
-    if (t > top && t <= top + nh) st_helper_task<SH>(g, smem_raw, t - top - 1);
-    else st_slab_task<SH>(g, smem_raw, s_flag_p, t < top ? t : t - 1 - nh, nslabs);
+    if (t >= top + nc && t < top + nc + nh) st_helper_task<SH, !CHAIN>(g, smem_raw, t - top - nc);
+    else st_slab_task<SH, !CHAIN>(g, smem_raw, s_flag_p, t < top ? t : t - nc - nh, nslabs);
   };
+  // (the chain is straight-line code between two copies of the slab loop: inside ONE loop with it the compiler spills)
   int t = draw();
-  while (t >= 0 && t != top) {
+  while (t >= 0 && (!CHAIN || t != top)) {
     slab_or_helper(t);
     if (one_each) return;
     t = draw();
   }
-  if (t != top) return;
+  if (!CHAIN || t != top) return;
   // ---- the chain: the next diagonal block, as soon as its eight slabs have taken this panel
   if (g.stamps && tid == 0) g.stamps[8 * top] = (long long)wall_clock64();
   if (!st_wait(g, g.sync + ST_DN, g.dn0 + (u64)top, s_flag_p)) return;
@@ -623,16 +713,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (t = draw(); t >= 0; t = draw()) slab_or_helper(t);
 }
 
+template <int SH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sweep_step_kernel(StepArgs g) { sweep_step_body<SH, true>(g); }
+template <int SH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 4))) void sweep_su_kernel(StepArgs g) { sweep_step_body<SH, false>(g); }
+
 // S + U + the next block's potrf_base of one step of the sweep (see above).  B: rows below the factored block, its columns
 // (m rows, m >= 128: there is a next block); W: the block's inverse; kprev: columns of earlier panels of the group left of B.
 // GPS_ERR_UNSUPPORTED: not a shape / device for this path (the caller launches the three kernels).
 int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const double* W, i64 kprev, double* Linv_next, double* LinvT_next,
-                          int* d_info, i64 row0_next, int factor) {
+                          int* d_info, i64 row0_next, int factor, int chain) {
   if (m < 128 || m % 16 || kprev % 128 || kprev < 0 || h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;
   const int SH = 16;
   const bool helpers = kprev > 0 && h->potrf_step_helpers != 0;
-  const int nslabs = (int)(m / SH), ntasks = nslabs + 1 + (helpers ? 128 / SH : 0);
-  const int slots = h->prop.multiProcessorCount - 8;          // one workgroup per CU (LDS)
+  const int nslabs = (int)(m / SH), ntasks = nslabs + (chain ? 1 : 0) + (helpers ? 128 / SH : 0);
+  const int slots = chain ? h->prop.multiProcessorCount - 8 : 2 * h->prop.multiProcessorCount;      // one workgroup per CU (LDS) / three fit
   const int grid = ntasks < slots ? ntasks : slots;
   if (!h->dStepSync.p || h->step_dirty) {
     GPS_HIP(h, h->dStepSync.ensure((size_t)ST_WORDS * 8));
@@ -656,7 +751,7 @@ int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const doubl
   if (!a.timeouts) return GPS_ERR_UNSUPPORTED;
   // what the launch will add to the counters: every workgroup draws until it sees a ticket >= ntasks
   h->step_q += (u64)ntasks + (u64)(grid >= ntasks ? 0 : grid);
-  h->step_xn += 128 / SH; h->step_dn += 128 / SH; h->step_sd += (u64)nslabs;
+  h->step_xn += 128 / SH; h->step_dn += 128 / SH; h->step_sd += (u64)nslabs;        // (the top slabs count DN in either form)
   a.stamps = nullptr;
   static const bool want_stamps = getenv("GPS_STEP_DEBUG") && atoi(getenv("GPS_STEP_DEBUG")) == 3;
   if (want_stamps) {
@@ -664,12 +759,16 @@ int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const doubl
     GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, (size_t)8 * (ntasks + 1) * 8, h->stream));
     a.stamps = (long long*)h->dTmp3.p;
   }
-  const size_t lds = (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) + 128;
-  int rc0 = gps_dyn_lds(h, reinterpret_cast<const void*>(&sweep_step_kernel<16>), (int)lds);
+  const size_t lds = (chain ? (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) : (size_t)LN_LDS_BYTES) + 128;
+  int rc0 = chain ? gps_dyn_lds(h, reinterpret_cast<const void*>(&sweep_step_kernel<16>), (int)lds)
+                  : gps_dyn_lds(h, reinterpret_cast<const void*>(&sweep_su_kernel<16>), (int)lds);
   if (rc0) return rc0;
-  LaunchScope ls(h, KC_POTRF_BASE, 2.0 * 128 * 128 * 128 / 3.0 + 2.0 * (double)m * 128.0 * (128.0 + (double)kprev), 3.0 * 8.0 * (double)m * 128.0);
-  hipLaunchKernelGGL(sweep_step_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
-  GPS_HIP(h, hipGetLastError());
+  {
+    LaunchScope ls(h, chain ? KC_POTRF_BASE : KC_GEMM, (chain ? 2.0 * 128 * 128 * 128 / 3.0 : 0.0) + 2.0 * (double)m * 128.0 * (128.0 + (double)kprev), 3.0 * 8.0 * (double)m * 128.0);
+    if (chain) hipLaunchKernelGGL(sweep_step_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
+    else hipLaunchKernelGGL(sweep_su_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
+    GPS_HIP(h, hipGetLastError());
+  }
   static const int dbg_mode = getenv("GPS_STEP_DEBUG") ? atoi(getenv("GPS_STEP_DEBUG")) : 0;
   if (dbg_mode == 3) {
     // diagnostics: stamps of every task of this launch (the launch above ran without them: run it again?  no -- this mode

@@ -423,14 +423,15 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)
  *   "potrf_lookahead" 1 (default): that remainder update runs on a second stream beside the next potrf_base, handed over
  *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
- *                     from which it is used (default 256; 1024 before round 5)
- *   "potrf_fused_step" 2 (default): every 128 columns of that sweep are ONE launch -- the solve of the rows below, the update of
- *                     the next block column and the NEXT diagonal block's factorisation (small_n.hip: sweep_step_kernel) --
- *                     whose chain workgroup also awaits, before it leaves, the join with the second stream that the next
- *                     step needs; 1: the join by a wait launch of its own; 0: three launches per 128 columns (round 4)
- *   "potrf_two_stage_join" 1 (default): the second stream publishes the FIRST block column of its remainder update before
- *                     the rest (which nothing touches for one more step); "potrf_step_helpers" 1 (default): the earlier
- *                     panel's share of the next diagonal tile's update by eight more workgroups of the step launch
+ *                     from which it is used (default 1024)
+ *   "potrf_fused_step" 0 (default): three launches per 128 columns of that sweep; 1: ONE launch -- the solve of the rows below, the
+ *                     update of the next block column and the NEXT diagonal block's factorisation (small_n.hip:
+ *                     sweep_step_kernel); 2: ... whose chain workgroup also awaits, before it leaves, the join with the second
+ *                     stream that the next step needs; 3: solve + update as one lean launch, potrf_base behind it.  Measured on
+ *                     six MI355X boxes: -4 ... +4 % at N = 4096, +-0.4 % at N = 32768 -- off
+ *   "potrf_two_stage_join" 0 (default) / 1: the second stream publishes the FIRST block column of its remainder update before
+ *                     the rest (which nothing touches for one more step); "potrf_step_helpers" 1: the earlier panel's share
+ *                     of the next diagonal tile's update by eight more workgroups of the step launch
  *   "potrf_bulk"      0 (default) / bit 0, bit 1: cross-level look-ahead -- the rest of a trailing update / the first rows of a
  *                     panel solve on a stream of their own beside the sweeps (measured slower on MI355X: DESIGN.md section 0)
  *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on

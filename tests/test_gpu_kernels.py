@@ -606,13 +606,40 @@ def test_concurrent_small_launches(n, threads):
         assert out[t][0][0] == out[0][0][0] and np.array_equal(out[t][0][1], out[0][0][1])
 
 
-@pytest.mark.parametrize("n", [3000, 5200])
-def test_concurrent_sweep_step_launches(n):
-    """The one-launch sweep steps (csrc/small_n.hip::sweep_step_kernel: workgroups that hold a whole CU each, synchronised through
-    counters in HBM, the chain workgroup awaiting the side stream's join before it leaves) with four factorisations in flight at
-    once: four handles in four host threads, 25 likelihood evaluations each at a size that takes the sweep (N > 2048).  Every
-    thread: bit-identical results step after step and across threads, equal to LAPACK on the oracle's kernel matrix to 1e-8,
-    no evaluation re-run without look-ahead (a bounded wait that ran out), no stalled step."""
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("n", [2304, 4096, 5000, 8192])
+def test_sweep_step_modes_agree_with_the_three_launch_sweep(handle, n, mode):
+    """Option "potrf_fused_step" (csrc/small_n.hip::sweep_step_kernel; off by default -- its gain depends on the box): every 128
+    columns of a sweep as ONE launch (1), with the next step's join carried by its chain workgroup (2), or solve + update as one
+    lean launch and potrf_base behind it (3), with the side stream's two-stage join: same likelihood, predictions and gradient
+    as the three-launch sweep -- with and without augmented rows (5000 < 6200 <= 8192), queued (4096) and one task per workgroup."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    X, Y, Xs = orc.synthetic_gpr_data(n, 5, 64, seed=n)
+    m = gpf.models.GPR(X, Y, gpf.kernels.Matern52(5, lengthscales=1.7) + gpf.kernels.RBF(5, variance=0.4, lengthscales=0.9), obs_var=0.05)
+    res = {}
+    try:
+        for md in (0, mode):
+            handle.set_option("potrf_fused_step", md); handle.set_option("potrf_two_stage_join", 1 if md else 0)
+            before = handle.profile_get("lookahead_retries")["launches"]
+            lml = m.compute_log_likelihood()
+            mu, var = m.predict_f(Xs)
+            res[md] = (lml, mu, var)
+            assert handle.profile_get("lookahead_retries")["launches"] == before
+    finally:
+        handle.set_option("potrf_fused_step", 0); handle.set_option("potrf_two_stage_join", 0)
+    a, b = res[0], res[mode]
+    assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0])
+    assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(1.0, np.abs(a[1]).max()) and np.abs(a[2] - b[2]).max() <= 1e-10 * np.abs(a[2]).max()
+
+
+@pytest.mark.parametrize("n,mode", [(3000, 2), (5200, 2), (5200, 3)])
+def test_concurrent_sweep_step_launches(n, mode):
+    """The one-launch sweep steps (option "potrf_fused_step"; csrc/small_n.hip::sweep_step_kernel: workgroups synchronised through
+    counters in HBM, mode 2: whole-CU workgroups and a chain workgroup that awaits the side stream's join before it leaves) with
+    four factorisations in flight at once: four handles in four host threads, 25 likelihood evaluations each at a size that takes
+    the sweep (N > 2048).  Every thread: bit-identical results step after step and across threads, equal to LAPACK on the
+    oracle's kernel matrix to 1e-8, no evaluation re-run without look-ahead (a bounded wait that ran out), no stalled step."""
     import threading
     import time
     import gpflowSlim as gpf
@@ -629,6 +656,7 @@ def test_concurrent_sweep_step_launches(n):
     def run(t):
         try:
             h = be.Handle(0)
+            h.set_option("potrf_fused_step", mode); h.set_option("potrf_two_stage_join", 1)
             h.gpr_set_data(X, X)
             vals, t_max = [], 0.0
             for i in range(steps):
