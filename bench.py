@@ -352,8 +352,9 @@ def main():
     os.environ["GPFLOWSLIM_DEVICE"] = str(local_rank)
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
+    with alive("importing_torch"):          # (minutes on a freshly provisioned box, and nothing a GPU can hang)
+        import torch
+        import torch.distributed as dist
     progress("torch_imported")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback")
