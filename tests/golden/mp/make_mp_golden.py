@@ -1,8 +1,9 @@
 """50-digit pins of the GPR path, independent of oracle/ (imports numpy and mpmath only).
 
 The formulas of SURVEY section 9 -- kernels.py:408-439, 557-610, 806-819, 1071-1084; models/gpr.py:69-72, 119-131;
-densities.py:81-94 of the reference -- evaluated with mpmath at 50 digits on small seeded inputs: log-marginal likelihood,
-posterior mean and variance.  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
+densities.py:81-94, conditionals.py:24-121 of the reference -- evaluated with mpmath at 50 digits on small seeded inputs:
+log-marginal likelihood, posterior mean and variance of GPR; mean and (co)variance of conditional() for q_sqrt None / [M, K] /
+[M, M, K], whitened or not (conditional.npz).  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
 tests/test_gpu_pins.py feeds exactly those to the HIP path and compares at 1e-8, with no oracle in between.
     python tests/golden/mp/make_mp_golden.py        # rewrites tests/golden/mp/*.npz
 """
@@ -101,7 +102,93 @@ def mp_gpr(spec, X, Y, s2, Xs, dps=50):
     return float(lml), mu, var
 
 
+def mp_conditional(spec, Z, Xn, f, q_sqrt, white, full_cov, jitter=1e-6, dps=50):
+    """conditionals.py:24-66 + 80-121 at working precision: Kmm = K(Z) + jitter I, Kmn = K(Z, Xnew), Knn = Kdiag(Xnew) or K(Xnew);
+    q_sqrt None, [M, K] (standard deviations) or [M, M, K] (lower-triangular factors).  Returns fmean [N, K], fvar [N, K] or [N, N, K]."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    M, N, K = Z.shape[0], Xn.shape[0], f.shape[1]
+    Kmm = mp.matrix(M, M)
+    for i in range(M):
+        for j in range(M):
+            Kmm[i, j] = mp_kernel(mp, spec, Z[i], Z[j], i == j) + (mp.mpf(jitter) if i == j else 0)
+    Kmn = mp.matrix(M, N)
+    for i in range(M):
+        for j in range(N):
+            Kmn[i, j] = mp_kernel(mp, spec, Z[i], Xn[j], False)
+    Lm = mp.cholesky(Kmm)                                                    # :84
+    A = mp.matrix(M, N)
+    for j in range(N):
+        col = mp.lu_solve(Lm, Kmn[:, j])                                     # :87
+        for i in range(M):
+            A[i, j] = col[i]
+    if full_cov:                                                              # :90-96
+        base = mp.matrix(N, N)
+        for a in range(N):
+            for b in range(N):
+                base[a, b] = mp_kernel(mp, spec, Xn[a], Xn[b], a == b) - sum(A[i, a] * A[i, b] for i in range(M))
+    else:
+        base = [mp_kdiag(mp, spec) - sum(A[i, j] * A[i, j] for i in range(M)) for j in range(N)]
+    if not white:                                                             # :99-100
+        A2 = mp.matrix(M, N)
+        for j in range(N):
+            col = mp.lu_solve(Lm.T, A[:, j])
+            for i in range(M):
+                A2[i, j] = col[i]
+        A = A2
+    fmean = np.zeros((N, K))
+    fvar = np.zeros((N, N, K) if full_cov else (N, K))
+    for k in range(K):
+        for j in range(N):
+            fmean[j, k] = float(sum(A[i, j] * mp.mpf(float(f[i, k])) for i in range(M)))      # :103
+        if q_sqrt is None:
+            LTA = None
+        elif q_sqrt.ndim == 2:                                                # :106-107
+            LTA = mp.matrix(M, N)
+            for i in range(M):
+                for j in range(N):
+                    LTA[i, j] = A[i, j] * mp.mpf(float(q_sqrt[i, k]))
+        else:                                                                 # :108-111 (lower band of q_sqrt[:, :, k], transposed)
+            LTA = mp.matrix(M, N)
+            for i in range(M):
+                for j in range(N):
+                    LTA[i, j] = sum(mp.mpf(float(q_sqrt[r, i, k])) * A[r, j] for r in range(i, M))
+        if full_cov:
+            for a in range(N):
+                for b in range(N):
+                    v = base[a, b] + (sum(LTA[i, a] * LTA[i, b] for i in range(M)) if LTA is not None else 0)
+                    fvar[a, b, k] = float(v)
+        else:
+            for j in range(N):
+                fvar[j, k] = float(base[j] + (sum(LTA[i, j] * LTA[i, j] for i in range(M)) if LTA is not None else 0))
+    return fmean, fvar
+
+
+COND_CASES = [(name, white, q, fc) for name in ("rbf_ard", "matern52", "sum") for white in (True, False)
+              for q, fc in (("none", False), ("diag", False), ("full", False), ("full", True))]
+
+
+def cond_inputs(name):
+    rng = np.random.default_rng(77 + len(name))
+    M, N, K = 14, 6, 2
+    Z = rng.standard_normal((M, 4)); Xn = rng.standard_normal((N, 4)); f = rng.standard_normal((M, K))
+    q_diag = np.abs(rng.standard_normal((M, K))) * 0.3 + 0.05
+    q_full = np.tril(rng.standard_normal((K, M, M)) * 0.05 + np.eye(M) * 0.2).transpose(1, 2, 0).copy()
+    return Z, Xn, f, q_diag, q_full
+
+
 def main():
+    out = {}
+    for name in ("rbf_ard", "matern52", "sum"):
+        Z, Xn, f, q_diag, q_full = cond_inputs(name)
+        out.update({"%s_Z" % name: Z, "%s_Xn" % name: Xn, "%s_f" % name: f, "%s_qdiag" % name: q_diag, "%s_qfull" % name: q_full})
+    for name, white, q, fc in COND_CASES:
+        Z, Xn, f, q_diag, q_full = cond_inputs(name)
+        mu, var = mp_conditional(SPECS[name], Z, Xn, f, {"none": None, "diag": q_diag, "full": q_full}[q], white, fc)
+        tag = "%s_%s_%s_%s" % (name, "white" if white else "unwhite", q, "fullcov" if fc else "diag")
+        out[tag + "_mu"] = mu; out[tag + "_var"] = var
+        print("conditional", tag, float(mu.sum()), float(var.sum()))
+    np.savez(os.path.join(HERE, "conditional.npz"), **out)
     for name, spec in sorted(SPECS.items()):
         for n in (4, 16, 32):
             rng = np.random.default_rng(1000 + n)

@@ -5,7 +5,8 @@ between the product and the truth.  Three kinds of pins, every one compared with
   (a) the reference's own two structural tests (gpflowSlim/models/gpr.py:135-203 TestPredict, gpflowSlim/densities.py:159-174
       Test_multivariate_normal_feature) restated on the product's entry points: the Cholesky forms computed by gps_potrf /
       gps_trsm_lower / densities.multivariate_normal against the Woodbury forms computed here in numpy;
-  (b) 50-digit mpmath evaluations of the reference's formulas (tests/golden/mp/*.npz, generator committed beside them);
+  (b) 50-digit mpmath evaluations of the reference's formulas (tests/golden/mp/*.npz, generator committed beside them): the GPR
+      likelihood and posterior, and conditional() with every form of q_sqrt;
   (c) analytic known answers: N = 1, N = 2, far-apart points, multi-output additivity, prediction far from the data.
 Nothing in this file imports oracle."""
 import glob
@@ -104,7 +105,7 @@ def _mp_specs():
     return make_mp_golden.SPECS
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(MP, "*.npz"))))
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(MP, "*_n*.npz"))))
 def test_hip_path_matches_50_digit_evaluation(handle, path):
     """LML, posterior mean and variance of the HIP path against mpmath at 50 digits (tests/golden/mp/make_mp_golden.py), 1e-8."""
     import gpflowSlim as gpf
@@ -119,6 +120,32 @@ def test_hip_path_matches_50_digit_evaluation(handle, path):
     assert mu.shape == g["mu"].shape and var.shape == g["mu"].shape
     assert np.abs(mu - g["mu"]).max() <= 1e-8 * max(1.0, np.abs(g["mu"]).max())
     assert np.abs(var - g["var"][:, None]).max() <= 1e-8 * max(1.0, np.abs(g["var"]).max())
+
+
+def _cond_cases():
+    sys.path.insert(0, MP)
+    try:
+        import make_mp_golden
+    finally:
+        sys.path.remove(MP)
+    return make_mp_golden.COND_CASES
+
+
+@pytest.mark.parametrize("name,white,q,full_cov", _cond_cases())
+def test_conditional_matches_50_digit_evaluation(handle, name, white, q, full_cov):
+    """conditional() (conditionals.py:24-121: Kmm + jitter, Lm, A, the unwhitened back-solve, the q_sqrt terms) against the same
+    formulas at 50 digits (tests/golden/mp/conditional.npz): q_sqrt None / [M, K] / [M, M, K], whitened or not, marginal and
+    full covariance -- M = 14 inducing points in 4 dimensions, where fp64 itself is good for 1e-8."""
+    import gpflowSlim as gpf
+    g = np.load(os.path.join(MP, "conditional.npz"))
+    kern = _build(gpf, _mp_specs()[name])
+    qs = {"none": None, "diag": g[name + "_qdiag"], "full": g[name + "_qfull"]}[q]
+    mu, var = gpf.conditionals.conditional(g[name + "_Xn"], g[name + "_Z"], kern, g[name + "_f"], full_cov=full_cov, q_sqrt=qs, white=white)
+    tag = "%s_%s_%s_%s" % (name, "white" if white else "unwhite", q, "fullcov" if full_cov else "diag")
+    rmu, rvar = g[tag + "_mu"], g[tag + "_var"]
+    assert mu.shape == rmu.shape and var.shape == rvar.shape
+    assert np.abs(mu - rmu).max() <= 1e-8 * max(1.0, np.abs(rmu).max())
+    assert np.abs(var - rvar).max() <= 1e-8 * max(1.0, np.abs(rvar).max())
 
 
 # ---------------------------------------------------------------- (c) analytic known answers on the HIP path itself

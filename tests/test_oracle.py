@@ -181,7 +181,21 @@ def test_oracle_matches_50_digit_evaluation(name, n):
     assert np.abs(ovar[:, 0] - var).max() <= tol * max(1.0, np.abs(var).max())
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mp", "*.npz"))))
+def test_oracle_conditional_matches_committed_50_digit_fixtures():
+    """tests/golden/mp/conditional.npz: conditional() at 50 digits (q_sqrt None / [M, K] / [M, M, K], whitened or not)."""
+    import importlib.util
+    spec_mod = importlib.util.spec_from_file_location("make_mp_golden", os.path.join(GOLD, "mp", "make_mp_golden.py"))
+    mod = importlib.util.module_from_spec(spec_mod); spec_mod.loader.exec_module(mod)
+    g = np.load(os.path.join(GOLD, "mp", "conditional.npz"))
+    for name, white, q, fc in mod.COND_CASES:
+        qs = {"none": None, "diag": g[name + "_qdiag"], "full": g[name + "_qfull"]}[q]
+        mu, var = orc.conditional(g[name + "_Xn"], g[name + "_Z"], mod.SPECS[name], g[name + "_f"], full_cov=fc, q_sqrt=qs, white=white)
+        tag = "%s_%s_%s_%s" % (name, "white" if white else "unwhite", q, "fullcov" if fc else "diag")
+        assert np.abs(mu - g[tag + "_mu"]).max() <= 1e-8 * max(1.0, np.abs(g[tag + "_mu"]).max()), tag
+        assert np.abs(var - g[tag + "_var"]).max() <= 1e-8 * max(1.0, np.abs(g[tag + "_var"]).max()), tag
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mp", "*_n*.npz"))))
 def test_oracle_matches_committed_50_digit_fixtures(path):
     """tests/golden/mp/*.npz (make_mp_golden.py: mpmath only, no oracle): the same fixtures the HIP path is compared with
     directly in tests/test_gpu_pins.py."""
