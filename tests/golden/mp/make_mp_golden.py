@@ -3,7 +3,7 @@
 The formulas of SURVEY section 9 -- kernels.py:408-439, 557-610, 806-819, 1071-1084; models/gpr.py:69-72, 119-131;
 densities.py:81-94, conditionals.py:24-121 of the reference -- evaluated with mpmath at 50 digits on small seeded inputs:
 log-marginal likelihood, posterior mean and variance of GPR; mean and (co)variance of conditional() for q_sqrt None / [M, K] /
-[M, M, K], whitened or not (conditional.npz).  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
+[M, M, K], whitened or not (conditional.npz); gauss_kl and the SVGP bound with the Gaussian likelihood (svgp.npz).  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
 tests/test_gpu_pins.py feeds exactly those to the HIP path and compares at 1e-8, with no oracle in between.
     python tests/golden/mp/make_mp_golden.py        # rewrites tests/golden/mp/*.npz
 """
@@ -164,6 +164,68 @@ def mp_conditional(spec, Z, Xn, f, q_sqrt, white, full_cov, jitter=1e-6, dps=50)
     return fmean, fvar
 
 
+def mp_gauss_kl(spec, Z, q_mu, q_sqrt, white, jitter=1e-6, dps=50):
+    """kullback_leiblers.py:26-105: KL[N(q_mu, q_sqrt q_sqrt^T) || N(0, K)] summed over the columns; K = K(Z) + jitter I
+    (models/svgp.py:101-106), or the identity when whitened.  q_sqrt [M, K] (diagonal) or [M, M, K] (lower factors)."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    M, K = q_mu.shape
+    if not white:
+        Kmm = mp.matrix(M, M)
+        for i in range(M):
+            for j in range(M):
+                Kmm[i, j] = mp_kernel(mp, spec, Z[i], Z[j], i == j) + (mp.mpf(jitter) if i == j else 0)
+        Lp = mp.cholesky(Kmm)
+    total = mp.mpf(0)
+    for k in range(K):
+        mu = mp.matrix([float(v) for v in q_mu[:, k]])
+        alpha = mu if white else mp.lu_solve(Lp, mu)
+        maha = sum(a * a for a in alpha)
+        if q_sqrt.ndim == 2:
+            Lq = mp.diag([float(v) for v in q_sqrt[:, k]])
+        else:
+            Lq = mp.matrix(M, M)
+            for i in range(M):
+                for j in range(i + 1):
+                    Lq[i, j] = mp.mpf(float(q_sqrt[i, j, k]))
+        logdet_q = sum(mp.log(Lq[i, i] ** 2) for i in range(M))
+        if white:
+            trace = sum(Lq[i, j] ** 2 for i in range(M) for j in range(M))
+        else:
+            trace = mp.mpf(0)
+            for j in range(M):
+                col = mp.lu_solve(Lp, Lq[:, j])                       # Lp^-1 Lq, column by column (the diagonal form is the same sum)
+                trace += sum(c * c for c in col)
+        two = maha - M - logdet_q + trace
+        if not white:
+            two += sum(mp.log(Lp[i, i] ** 2) for i in range(M))
+        total += two / 2
+    return float(total)
+
+
+def svgp_inputs(name):
+    rng = np.random.default_rng(177 + len(name))
+    N, M, K = 24, 10, 2
+    X = rng.standard_normal((N, 4)); Y = rng.standard_normal((N, K)); Z = rng.standard_normal((M, 4))
+    q_mu = rng.standard_normal((M, K)) * 0.5
+    q_diag = np.abs(rng.standard_normal((M, K))) * 0.3 + 0.05
+    q_full = np.tril(rng.standard_normal((K, M, M)) * 0.05 + np.eye(M) * 0.3).transpose(1, 2, 0).copy()
+    return X, Y, Z, q_mu, q_diag, q_full
+
+
+SVGP_CASES = [(name, white, q) for name in ("rbf_ard", "matern52") for white in (True, False) for q in ("diag", "full")]
+SVGP_NOISE, SVGP_NUM_DATA = 0.2, 72
+
+
+def mp_svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, white):
+    """models/svgp.py:108-125 with the Gaussian likelihood (likelihoods.py:186-188): sum of the variational expectations, scaled by
+    num_data / N, minus the KL.  (The conditional and the KL at 50 digits; the N x K expectations summed in fp64.)"""
+    fmean, fvar = mp_conditional(spec, Z, X, q_mu, q_sqrt, white, False)
+    ve = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(SVGP_NOISE) - 0.5 * ((Y - fmean) ** 2 + fvar) / SVGP_NOISE
+    kl = mp_gauss_kl(spec, Z, q_mu, q_sqrt, white)
+    return float(ve.sum()) * SVGP_NUM_DATA / X.shape[0] - kl, kl
+
+
 COND_CASES = [(name, white, q, fc) for name in ("rbf_ard", "matern52", "sum") for white in (True, False)
               for q, fc in (("none", False), ("diag", False), ("full", False), ("full", True))]
 
@@ -189,6 +251,17 @@ def main():
         out[tag + "_mu"] = mu; out[tag + "_var"] = var
         print("conditional", tag, float(mu.sum()), float(var.sum()))
     np.savez(os.path.join(HERE, "conditional.npz"), **out)
+    out = {}
+    for name in ("rbf_ard", "matern52"):
+        X, Y, Z, q_mu, q_diag, q_full = svgp_inputs(name)
+        out.update({"%s_X" % name: X, "%s_Y" % name: Y, "%s_Z" % name: Z, "%s_qmu" % name: q_mu, "%s_qdiag" % name: q_diag, "%s_qfull" % name: q_full})
+    for name, white, q in SVGP_CASES:
+        X, Y, Z, q_mu, q_diag, q_full = svgp_inputs(name)
+        elbo, kl = mp_svgp_elbo(SPECS[name], X, Y, Z, q_mu, q_diag if q == "diag" else q_full, white)
+        tag = "%s_%s_%s" % (name, "white" if white else "unwhite", q)
+        out[tag + "_elbo"] = elbo; out[tag + "_kl"] = kl
+        print("svgp", tag, elbo, kl)
+    np.savez(os.path.join(HERE, "svgp.npz"), **out)
     for name, spec in sorted(SPECS.items()):
         for n in (4, 16, 32):
             rng = np.random.default_rng(1000 + n)

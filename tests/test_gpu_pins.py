@@ -148,6 +148,37 @@ def test_conditional_matches_50_digit_evaluation(handle, name, white, q, full_co
     assert np.abs(var - rvar).max() <= 1e-8 * max(1.0, np.abs(rvar).max())
 
 
+def _mp_module():
+    sys.path.insert(0, MP)
+    try:
+        import make_mp_golden
+    finally:
+        sys.path.remove(MP)
+    return make_mp_golden
+
+
+@pytest.mark.parametrize("name,white,q", _mp_module().SVGP_CASES)
+def test_svgp_bound_and_kl_match_50_digit_evaluation(handle, name, white, q):
+    """gauss_kl (kullback_leiblers.py:26-105) and the SVGP bound with the Gaussian likelihood (models/svgp.py:101-125,
+    likelihoods.py:186-188), both parametrisations, diagonal and full q_sqrt, two latent functions, minibatch scale 3: the
+    device-resident bound and the stand-alone KL against 50-digit values (tests/golden/mp/svgp.npz)."""
+    import gpflowSlim as gpf
+    mod = _mp_module()
+    g = np.load(os.path.join(MP, "svgp.npz"))
+    kern = _build(gpf, mod.SPECS[name])
+    X, Y, Z, q_mu = g[name + "_X"], g[name + "_Y"], g[name + "_Z"], g[name + "_qmu"]
+    qs = g[name + ("_qdiag" if q == "diag" else "_qfull")]
+    tag = "%s_%s_%s" % (name, "white" if white else "unwhite", q)
+    Kuu = None if white else kern.K(Z) + 1e-6 * np.eye(Z.shape[0])
+    kl = gpf.kullback_leiblers.gauss_kl(q_mu, qs, Kuu)
+    assert abs(kl - float(g[tag + "_kl"])) <= 1e-8 * abs(float(g[tag + "_kl"]))
+    sv = gpf.models.SVGP(X, Y, kern, gpf.likelihoods.Gaussian(mod.SVGP_NOISE), Z=Z, q_diag=(q == "diag"), whiten=white, num_data=mod.SVGP_NUM_DATA)
+    sv._q_mu.assign(q_mu); sv._q_sqrt.assign(qs)
+    assert abs(float(np.squeeze(sv.likelihood.variance)) - mod.SVGP_NOISE) <= 1e-15
+    elbo = sv.compute_log_likelihood()
+    assert abs(elbo - float(g[tag + "_elbo"])) <= 1e-8 * abs(float(g[tag + "_elbo"]))
+
+
 # ---------------------------------------------------------------- (c) analytic known answers on the HIP path itself
 def _vals(m):
     return float(np.squeeze(m.kern.variance)), float(np.squeeze(m.likelihood.variance))

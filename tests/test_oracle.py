@@ -195,6 +195,22 @@ def test_oracle_conditional_matches_committed_50_digit_fixtures():
         assert np.abs(var - g[tag + "_var"]).max() <= 1e-8 * max(1.0, np.abs(g[tag + "_var"]).max()), tag
 
 
+def test_oracle_svgp_bound_matches_committed_50_digit_fixtures():
+    """tests/golden/mp/svgp.npz: gauss_kl and the SVGP bound (Gaussian likelihood) at 50 digits."""
+    import importlib.util
+    spec_mod = importlib.util.spec_from_file_location("make_mp_golden", os.path.join(GOLD, "mp", "make_mp_golden.py"))
+    mod = importlib.util.module_from_spec(spec_mod); spec_mod.loader.exec_module(mod)
+    g = np.load(os.path.join(GOLD, "mp", "svgp.npz"))
+    for name, white, q in mod.SVGP_CASES:
+        X, Y, Z, q_mu = g[name + "_X"], g[name + "_Y"], g[name + "_Z"], g[name + "_qmu"]
+        qs = g[name + ("_qdiag" if q == "diag" else "_qfull")]
+        tag = "%s_%s_%s" % (name, "white" if white else "unwhite", q)
+        Kp = None if white else orc.K(mod.SPECS[name], Z) + 1e-6 * np.eye(Z.shape[0])
+        assert orc.gauss_kl(q_mu, qs, Kp) == pytest.approx(float(g[tag + "_kl"]), rel=1e-8), tag
+        el = orc.svgp_elbo(mod.SPECS[name], X, Y, Z, q_mu, qs, mod.SVGP_NOISE, whiten=white, num_data=mod.SVGP_NUM_DATA)
+        assert el == pytest.approx(float(g[tag + "_elbo"]), rel=1e-8), tag
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mp", "*_n*.npz"))))
 def test_oracle_matches_committed_50_digit_fixtures(path):
     """tests/golden/mp/*.npz (make_mp_golden.py: mpmath only, no oracle): the same fixtures the HIP path is compared with
