@@ -3,7 +3,8 @@
 The formulas of SURVEY section 9 -- kernels.py:408-439, 557-610, 806-819, 1071-1084; models/gpr.py:69-72, 119-131;
 densities.py:81-94, conditionals.py:24-121 of the reference -- evaluated with mpmath at 50 digits on small seeded inputs:
 log-marginal likelihood, posterior mean and variance of GPR; mean and (co)variance of conditional() for q_sqrt None / [M, K] /
-[M, M, K], whitened or not (conditional.npz); gauss_kl and the SVGP bound with the Gaussian likelihood (svgp.npz).  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
+[M, M, K], whitened or not (conditional.npz); gauss_kl and the SVGP bound with the Gaussian likelihood, the SGPR bound and the FITC likelihood from their dense
+definitions (svgp.npz); the gradient of the GPR likelihood by 1e-25 central differences of the 60-digit likelihood (gradient.npz).  The fp64 parameter values stored in the fixture are the ones the formulas were evaluated with;
 tests/test_gpu_pins.py feeds exactly those to the HIP path and compares at 1e-8, with no oracle in between.
     python tests/golden/mp/make_mp_golden.py        # rewrites tests/golden/mp/*.npz
 """
@@ -29,8 +30,13 @@ SPECS = {
 NOISE = 0.1
 
 
+def _mpf(mp, v):
+    return v if isinstance(v, mp.mpf) else mp.mpf(float(v))
+
+
 def mp_kernel(mp, spec, x, y, same):
-    """k(x, y) at working precision; same: x and y are the same data point (White, and r2 = 0 exactly)."""
+    """k(x, y) at working precision; same: x and y are the same data point (White, and r2 = 0 exactly).  Parameter values may be
+    fp64 numbers or mpmath numbers (the gradient pins perturb them by 1e-25)."""
     t = spec["type"]
     if t == "sum":
         return sum(mp_kernel(mp, ch, x, y, same) for ch in spec["children"])
@@ -39,7 +45,7 @@ def mp_kernel(mp, spec, x, y, same):
         for ch in spec["children"]:
             out *= mp_kernel(mp, ch, x, y, same)
         return out
-    v = mp.mpf(float(spec["variance"]))
+    v = _mpf(mp, spec["variance"])
     if t == "white":
         return v if same else mp.mpf(0)
     if t == "constant":
@@ -47,10 +53,11 @@ def mp_kernel(mp, spec, x, y, same):
     ad = spec.get("active_dims") or list(range(spec["input_dim"]))
     xs = [mp.mpf(float(x[d])) for d in ad]; ys = [mp.mpf(float(y[d])) for d in ad]
     if t == "periodic":                                   # kernels.py:806-819
-        p, l = mp.mpf(float(spec["period"])), mp.mpf(float(spec["lengthscales"]))
+        p, l = _mpf(mp, spec["period"]), _mpf(mp, spec["lengthscales"])
         return v * mp.exp(-sum((mp.sin(mp.pi * (a - b) / p) / l) ** 2 for a, b in zip(xs, ys)) / 2)
-    ls = np.broadcast_to(np.asarray(spec["lengthscales"], dtype=float), (len(ad),))
-    r2 = sum(((a - b) / mp.mpf(float(l))) ** 2 for a, b, l in zip(xs, ys, ls))      # kernels.py:408-421
+    ls = spec["lengthscales"]
+    ls = list(ls) if isinstance(ls, (list, tuple, np.ndarray)) else [ls] * len(ad)
+    r2 = sum(((a - b) / _mpf(mp, l)) ** 2 for a, b, l in zip(xs, ys, ls))      # kernels.py:408-421
     if t == "rbf":
         return v * mp.exp(-r2 / 2)                        # :439
     r = mp.sqrt(r2 + mp.mpf("1e-12"))                     # :426
@@ -100,6 +107,48 @@ def mp_gpr(spec, X, Y, s2, Xs, dps=50):
             mu[s, q] = float(sum(a[i] * alphas[q][i] for i in range(n)))       # :124
         var[s] = float(mp_kdiag(mp, spec) - sum(a[i] * a[i] for i in range(n)))    # :130
     return float(lml), mu, var
+
+
+def mp_lml(mp, spec, X, Y, s2):
+    """log-marginal likelihood (densities.py:81-94) as an mpmath number; spec and s2 may hold mpmath values"""
+    n, r = Y.shape
+    Km = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(n):
+            Km[i, j] = mp_kernel(mp, spec, X[i], X[j], i == j) + (_mpf(mp, s2) if i == j else 0)
+    L = mp.cholesky(Km)
+    out = -mp.mpf(n * r) / 2 * mp.log(2 * mp.pi) - r * sum(mp.log(L[i, i]) for i in range(n))
+    for q in range(r):
+        a = mp.lu_solve(L, mp.matrix([float(v) for v in Y[:, q]]))
+        out -= sum(x * x for x in a) / 2
+    return out
+
+
+# parameter vectors of the gradient pins: theta -> spec, in the slot order of gps_gpr_lml_grad (per primitive: variance, then the
+# length-scales [, period])
+GRAD_SPECS = {
+    "rbf_ard": ([1.3, 0.7, 1.1, 1.6, 2.0], lambda t: {"type": "rbf", "variance": t[0], "lengthscales": list(t[1:5]), "input_dim": 4}),
+    "matern52": ([0.9, 1.4], lambda t: {"type": "matern52", "variance": t[0], "lengthscales": t[1], "input_dim": 4}),
+    "periodic": ([1.1, 1.3, 2.5], lambda t: {"type": "periodic", "variance": t[0], "lengthscales": t[1], "period": t[2], "input_dim": 4}),
+}
+
+
+def mp_lml_grad(name, X, Y, s2, dps=60):
+    """d LML / d theta and d LML / d noise by central differences of the 60-digit likelihood with a step of 1e-25: exact to
+    ~1e-40 -- independent of every derivative formula (what TF autodiff supplies to examples/gpr.py:53-54)."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    theta0, fn = GRAD_SPECS[name]
+    h = mp.mpf("1e-25")
+    grads = []
+    for i in range(len(theta0)):
+        tp = [mp.mpf(float(v)) for v in theta0]; tm = list(tp)
+        tp[i] += h; tm[i] -= h
+        grads.append(float((mp_lml(mp, fn(tp), X, Y, s2) - mp_lml(mp, fn(tm), X, Y, s2)) / (2 * h)))
+    s = mp.mpf(float(s2))
+    spec = fn([mp.mpf(float(v)) for v in theta0])
+    gn = float((mp_lml(mp, spec, X, Y, s + h) - mp_lml(mp, spec, X, Y, s - h)) / (2 * h))
+    return np.array(grads), gn, float(mp_lml(mp, spec, X, Y, s))
 
 
 def mp_conditional(spec, Z, Xn, f, q_sqrt, white, full_cov, jitter=1e-6, dps=50):
@@ -226,6 +275,50 @@ def mp_svgp_elbo(spec, X, Y, Z, q_mu, q_sqrt, white):
     return float(ve.sum()) * SVGP_NUM_DATA / X.shape[0] - kl, kl
 
 
+def mp_sparse_bounds(spec, X, Y, Z, s2, jitter=1e-6, dps=50):
+    """The SGPR bound (models/sgpr.py:121-155) and the FITC likelihood (:229-282) from their DEFINITIONS rather than the
+    reference's Woodbury algebra: with Qff = Kfu (Kuu + jitter I)^-1 Kuf,
+        SGPR  = sum_r log N(y_r | 0, Qff + s2 I) - R / (2 s2) tr(Kff - Qff)            (Titsias 2009)
+        FITC  = sum_r log N(y_r | 0, Qff + diag(Kff - Qff) + s2 I)
+    as dense N x N problems at working precision (Kff only through its diagonal = Kdiag, kernels.py:428-429)."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    N, R = Y.shape
+    M = Z.shape[0]
+    Kuu = mp.matrix(M, M)
+    for i in range(M):
+        for j in range(M):
+            Kuu[i, j] = mp_kernel(mp, spec, Z[i], Z[j], i == j) + (mp.mpf(jitter) if i == j else 0)
+    Kuf = mp.matrix(M, N)
+    for i in range(M):
+        for j in range(N):
+            Kuf[i, j] = mp_kernel(mp, spec, Z[i], X[j], False)
+    Lu = mp.cholesky(Kuu)
+    V = mp.matrix(M, N)
+    for j in range(N):
+        col = mp.lu_solve(Lu, Kuf[:, j])
+        for i in range(M):
+            V[i, j] = col[i]
+    Qff = V.T * V
+    kd = mp_kdiag(mp, spec)
+    s2m = mp.mpf(float(s2))
+
+    def logpdf(C):
+        L = mp.cholesky(C)
+        ld = 2 * sum(mp.log(L[i, i]) for i in range(N))
+        tot = mp.mpf(0)
+        for r in range(R):
+            a = mp.lu_solve(L, mp.matrix([float(v) for v in Y[:, r]]))
+            tot += -mp.mpf(N) / 2 * mp.log(2 * mp.pi) - ld / 2 - sum(x * x for x in a) / 2
+        return tot
+    C1 = Qff.copy(); C2 = Qff.copy()
+    for i in range(N):
+        C1[i, i] += s2m
+        C2[i, i] = kd + s2m                                   # Qff_ii + (Kff_ii - Qff_ii) + s2
+    tr = sum(kd - Qff[i, i] for i in range(N))
+    return float(logpdf(C1) - R * tr / (2 * s2m)), float(logpdf(C2))
+
+
 COND_CASES = [(name, white, q, fc) for name in ("rbf_ard", "matern52", "sum") for white in (True, False)
               for q, fc in (("none", False), ("diag", False), ("full", False), ("full", True))]
 
@@ -261,7 +354,20 @@ def main():
         tag = "%s_%s_%s" % (name, "white" if white else "unwhite", q)
         out[tag + "_elbo"] = elbo; out[tag + "_kl"] = kl
         print("svgp", tag, elbo, kl)
+    for name in ("rbf_ard", "matern52"):
+        X, Y, Z, _, _, _ = svgp_inputs(name)
+        sg, fi = mp_sparse_bounds(SPECS[name], X, Y, Z, SVGP_NOISE)
+        out[name + "_sgpr_bound"] = sg; out[name + "_fitc_lml"] = fi
+        print("sparse", name, sg, fi)
     np.savez(os.path.join(HERE, "svgp.npz"), **out)
+    out = {}
+    for name in sorted(GRAD_SPECS):
+        rng = np.random.default_rng(31 + len(name))
+        X = rng.standard_normal((16, 4)); Y = rng.standard_normal((16, 2))
+        g, gn, lml = mp_lml_grad(name, X, Y, NOISE)
+        out.update({name + "_X": X, name + "_Y": Y, name + "_grad": g, name + "_grad_noise": gn, name + "_lml": lml})
+        print("gradient", name, lml, g, gn)
+    np.savez(os.path.join(HERE, "gradient.npz"), **out)
     for name, spec in sorted(SPECS.items()):
         for n in (4, 16, 32):
             rng = np.random.default_rng(1000 + n)

@@ -179,6 +179,42 @@ def test_svgp_bound_and_kl_match_50_digit_evaluation(handle, name, white, q):
     assert abs(elbo - float(g[tag + "_elbo"])) <= 1e-8 * abs(float(g[tag + "_elbo"]))
 
 
+@pytest.mark.parametrize("name", ["rbf_ard", "matern52"])
+def test_sgpr_bound_and_fitc_likelihood_match_their_dense_definitions(handle, name):
+    """models/sgpr.py:121-155 (SGPR bound) and :229-282 (FITC likelihood) against their DEFINITIONS evaluated densely at 50 digits
+    -- log N(y | 0, Qff + s2 I) - tr(Kff - Qff) / (2 s2) and log N(y | 0, Qff + diag(Kff - Qff) + s2 I), two outputs --, not
+    against a restatement of the reference's Woodbury algebra (tests/golden/mp/svgp.npz)."""
+    import gpflowSlim as gpf
+    mod = _mp_module()
+    g = np.load(os.path.join(MP, "svgp.npz"))
+    X, Y, Z = g[name + "_X"], g[name + "_Y"], g[name + "_Z"]
+    sg = gpf.models.SGPR(X, Y, _build(gpf, mod.SPECS[name]), Z=Z, obs_var=mod.SVGP_NOISE)
+    assert abs(sg.compute_log_likelihood() - float(g[name + "_sgpr_bound"])) <= 1e-8 * abs(float(g[name + "_sgpr_bound"]))
+    fi = gpf.models.GPRFITC(X, Y, _build(gpf, mod.SPECS[name]), Z=Z, obs_var=mod.SVGP_NOISE)
+    assert abs(fi.compute_log_likelihood() - float(g[name + "_fitc_lml"])) <= 1e-8 * abs(float(g[name + "_fitc_lml"]))
+
+
+@pytest.mark.parametrize("name", ["rbf_ard", "matern52", "periodic"])
+def test_lml_gradient_matches_high_precision_differences(handle, name):
+    """gps_gpr_lml_grad (what TF autodiff through tf.cholesky supplies to examples/gpr.py:53-54) against central differences of the
+    60-digit likelihood with a step of 1e-25 (tests/golden/mp/gradient.npz): kernel parameters (constrained values, slot order
+    of the header) and the noise variance, two outputs.  Independent of every derivative formula, the oracle's included."""
+    import gpflowSlim as gpf
+    mod = _mp_module()
+    g = np.load(os.path.join(MP, "gradient.npz"))
+    theta0, fn = mod.GRAD_SPECS[name]
+    kern = _build(gpf, fn(theta0))
+    X, Y = g[name + "_X"], g[name + "_Y"]
+    handle.gpr_set_data(X, ("pins", name))
+    lml, slots, gn, _ = handle.gpr_lml_grad(kern._program(4), mod.NOISE, Y)
+    assert abs(lml - float(g[name + "_lml"])) <= 1e-8 * abs(float(g[name + "_lml"]))
+    slots = np.ravel(slots)
+    got = {"rbf_ard": slots[:5], "matern52": np.array([slots[0], slots[1:5].sum()]), "periodic": slots[:3]}[name]   # (isotropic: one entry per active dim, summed)
+    ref = g[name + "_grad"]
+    assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (got, ref)
+    assert abs(gn - float(g[name + "_grad_noise"])) <= 1e-8 * abs(float(g[name + "_grad_noise"]))
+
+
 # ---------------------------------------------------------------- (c) analytic known answers on the HIP path itself
 def _vals(m):
     return float(np.squeeze(m.kern.variance)), float(np.squeeze(m.likelihood.variance))

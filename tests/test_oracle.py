@@ -209,6 +209,11 @@ def test_oracle_svgp_bound_matches_committed_50_digit_fixtures():
         assert orc.gauss_kl(q_mu, qs, Kp) == pytest.approx(float(g[tag + "_kl"]), rel=1e-8), tag
         el = orc.svgp_elbo(mod.SPECS[name], X, Y, Z, q_mu, qs, mod.SVGP_NOISE, whiten=white, num_data=mod.SVGP_NUM_DATA)
         assert el == pytest.approx(float(g[tag + "_elbo"]), rel=1e-8), tag
+    # the SGPR bound and the FITC likelihood against their dense definitions
+    for name in ("rbf_ard", "matern52"):
+        X, Y, Z = g[name + "_X"], g[name + "_Y"], g[name + "_Z"]
+        assert orc.sgpr_bound(mod.SPECS[name], X, Y, Z, mod.SVGP_NOISE) == pytest.approx(float(g[name + "_sgpr_bound"]), rel=1e-8)
+        assert orc.fitc_lml(mod.SPECS[name], X, Y, Z, mod.SVGP_NOISE) == pytest.approx(float(g[name + "_fitc_lml"]), rel=1e-8)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mp", "*_n*.npz"))))
