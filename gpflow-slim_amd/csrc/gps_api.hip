@@ -1125,6 +1125,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
     double* linv = h->dLinv.d();
     // (the transposed block inverses are not on the path of the likelihood: whoever needs them afterwards -- the gradient,
     // a prediction from this factor -- has them produced by one batched launch then: gpr_ensure_linvT)
+    if (h->plain_linv == linv) h->plain_linv = nullptr;        // (these block inverses are produced anew, not through HipOps::potrf_base)
     rc = gps_launch_small_factor(h, h->dK.d(), np, linv, nullptr, h->dTmp2.d(), n, r, d_info, d_res, h->dAlpha.d(), np, r, &kg);
     h->gpr_linvT_stale = true;
     if (rc == GPS_OK) {

@@ -769,12 +769,8 @@ int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const doubl
     else hipLaunchKernelGGL(sweep_su_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
     GPS_HIP(h, hipGetLastError());
   }
-  static const int dbg_mode = getenv("GPS_STEP_DEBUG") ? atoi(getenv("GPS_STEP_DEBUG")) : 0;
-  if (dbg_mode == 3) {
-    // diagnostics: stamps of every task of this launch (the launch above ran without them: run it again?  no -- this mode
-    // launches WITH stamps: see below)
-  }
-  const bool dbg = dbg_mode == 1;
+  // diagnostics (GPS_STEP_DEBUG): 1 = wait for every launch and compare the counters with the host's books; 3 = in-kernel stamps
+  static const bool dbg = getenv("GPS_STEP_DEBUG") != nullptr && atoi(getenv("GPS_STEP_DEBUG")) == 1;
   if (want_stamps) {
     const int ns1 = nslabs + 1;                       // stamp slots: slab s -> s (top) / s + 1, the chain -> 8
     std::vector<long long> st((size_t)8 * (ntasks + 1));
