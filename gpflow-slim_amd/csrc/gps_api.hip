@@ -685,7 +685,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
-    if (value != 0 && value != 32 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32 or 64");
+    if (value != 0 && value != 32 && value != 33 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32, 33 or 64");
     h->trsm_panel_rows = (int)value; return GPS_OK;
   }
   if (strcmp(key, "trsv_wave_refine") == 0) { h->trsv_wave_refine = (int)value; return GPS_OK; }
@@ -765,8 +765,8 @@ extern "C" int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* us
 // one 128-column leaf  X L11^T = B  (upper: X L11 = B through U = L^T) on m rows, timed over `reps` launches:
 // Diagnostics: the 512-column triangular solve of m rows, launch by launch (panel = 0) or as one launch (panel = 1,
 // trsm_panel.hip); backward: X L = B instead of X L^T = B.  maxdiff_out: largest |difference| between the two on the same input.
-extern "C" int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
-                                double* maxdiff_out) {
+static int diag_trsm512_impl(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
+                             double* maxdiff_out, long long* stamps_out, int64_t cap_blocks) {
   if (!h || m <= 0 || m % GPS_TILE || reps <= 0 || !us_per_solve) return GPS_ERR_ARG;
   GPS_HIP(h, hipSetDevice(h->device));
   const i64 T = GPS_TILE, n = 4 * T;
@@ -808,6 +808,17 @@ extern "C" int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int pan
     GPS_HIP(h, hipStreamSynchronize(h->stream));
     GPS_HIP(h, hipEventElapsedTime(&ms, e0, e1));
   }
+  if (!rc && stamps_out) {                                  // one more launch, every workgroup leaving its phase stamps
+    const i64 nb = std::min<i64>(m / 32, cap_blocks);
+    GPS_HIP(h, h->dGemvWs.ensure((size_t)(m / 32) * 32 * sizeof(long long)));
+    GPS_HIP(h, hipMemsetAsync(h->dGemvWs.p, 0, (size_t)(m / 32) * 32 * sizeof(long long), h->stream));
+    GPS_HIP(h, hipMemcpyAsync(dBm, dB0, (size_t)m * n * 8, hipMemcpyDeviceToDevice, h->stream));
+    h->tp_stamps = (long long*)h->dGemvWs.p;
+    rc = solve(dBm);
+    h->tp_stamps = nullptr;
+    GPS_HIP(h, hipMemcpyAsync(stamps_out, h->dGemvWs.p, (size_t)nb * 32 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    GPS_HIP(h, hipStreamSynchronize(h->stream));
+  }
   if (!rc && maxdiff_out) {
     h->trsm_panel = panel ? 0 : 1;
     GPS_HIP(h, hipMemcpyAsync(dB1, dB0, (size_t)m * n * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -826,6 +837,17 @@ extern "C" int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int pan
   if (rc) return rc;
   *us_per_solve = 1e3 * ms / reps;
   return GPS_OK;
+}
+extern "C" int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
+                                double* maxdiff_out) {
+  return diag_trsm512_impl(h, m, backward, panel, reps, us_per_solve, maxdiff_out, nullptr, 0);
+}
+// the one-launch form once more with phase stamps: stamps_out [min(m / 64, cap_blocks)][32] (trsm_panel.hip: TP_STAMP; m / 64 >= the
+// number of CUs, so that the launch takes 64 rows per workgroup)
+extern "C" int gps_diag_trsm512_stamps(gps_handle_t h, int64_t m, int backward, int reps, double* us_per_solve, long long* stamps_out,
+                                       int64_t cap_blocks) {
+  if (!stamps_out || cap_blocks <= 0) return GPS_ERR_ARG;
+  return diag_trsm512_impl(h, m, backward, 1, reps, us_per_solve, nullptr, stamps_out, cap_blocks);
 }
 
 // mode 0 = product with the block inverse, 1 = refined (trsm_leaf.hip); resid_out = max |X T - B| / (|X| |T|)_max

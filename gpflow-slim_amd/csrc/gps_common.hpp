@@ -194,6 +194,7 @@ struct gps_handle_s {
   int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* leaf_stamps = nullptr;   // phase stamps of one refined leaf launch (gps_diag_trsm_leaf)
+  long long* tp_stamps = nullptr;     // per-workgroup phase stamps of trsm_panel_kernel while gps_diag_trsm512_stamps runs
   long long* gemm_stamps = nullptr;   // per-workgroup timeline buffer while gps_diag_gemm_timeline runs
 
   // profiling

@@ -135,6 +135,7 @@ _SIGNATURES = {
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
     "gps_diag_trsm512": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
+    "gps_diag_trsm512_stamps": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.POINTER(ctypes.c_longlong), _i64],
     "gps_diag_trsm_leaf": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
     "gps_diag_set_cu_mask": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int],
     "gps_diag_gemm_timeline": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, ctypes.c_int,
@@ -495,6 +496,15 @@ class Handle(object):
         self._check(self._lib.gps_diag_trsm512(self._h, int(m), int(bool(backward)), int(bool(panel)), int(reps),
                                                ctypes.byref(us), ctypes.byref(diff)), "gps_diag_trsm512")
         return us.value, diff.value
+
+    def diag_trsm512_stamps(self, m, backward=False, reps=5):
+        """(microseconds per solve, int64 array [m / 64, 32] of phase stamps) of the one-launch 512-column solve."""
+        nb = int(m) // 32                # (64 or 32 rows per workgroup: the unused tail stays 0)
+        buf = np.zeros((nb, 32), dtype=np.int64)
+        us = ctypes.c_double(0)
+        self._check(self._lib.gps_diag_trsm512_stamps(self._h, int(m), int(bool(backward)), int(reps), ctypes.byref(us),
+                                                      buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), nb), "gps_diag_trsm512_stamps")
+        return us.value, buf
 
     def diag_set_cu_mask(self, words):
         arr = (ctypes.c_uint32 * len(words))(*[int(w) & 0xffffffff for w in words])

@@ -493,6 +493,11 @@ int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
  * maxdiff_out (optional): largest |difference| between the two forms on the same input. */
 int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
                      double* maxdiff_out);
+/* the one-launch form with phase stamps of every workgroup: stamps_out [min(m / 64, cap_blocks)][32] 100 MHz ticks --
+ * wave 0 in [0, 14), HW_ID / XCC_ID in [14], [15], wave 7 in [16, 30): 0 start, 1 rows loaded, then per 128-column block j:
+ * 2 + 3 j its product with the block inverse done, 3 + 3 j its rows stored, 4 + 3 j the updates of the later blocks done */
+int gps_diag_trsm512_stamps(gps_handle_t h, int64_t m, int backward, int reps, double* us_per_solve, long long* stamps_out,
+                            int64_t cap_blocks);
 /* one 128-column leaf of the triangular solves on m rows (device-resident synthetic block), average microseconds per
  * launch over `reps`: mode 0 = product with the explicit block inverse, 1 = refined against the factor's diagonal
  * block (what tf.matrix_triangular_solve's substitution delivers, conditionals.py:87,100); upper: the X L = B form;
