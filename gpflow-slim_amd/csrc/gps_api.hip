@@ -685,7 +685,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
-    if (value != 0 && value != 32 && value != 33 && value != 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32, 33 or 64");
+    if (value != 0 && value != 32 && value != 64 && value != 65) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32, 64 or 65");
     h->trsm_panel_rows = (int)value; return GPS_OK;
   }
   if (strcmp(key, "trsv_wave_refine") == 0) { h->trsv_wave_refine = (int)value; return GPS_OK; }

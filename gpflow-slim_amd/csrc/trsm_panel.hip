@@ -13,117 +13,44 @@
 //     for j: X_j = B_j W_j^T ;  B_i -= X_j L_ij^T  (i > j)             (backward: j = 3 .. 0, i < j, with U_ij)
 // B is read once and X written once.  Each product is [R x 128] x [128 x 128]^T on v_mfma_f64_16x16x4_f64, one column
 // tile of the 128 per wave (so a wave needs only ITS 16 rows of the right-hand operand), RT row tiles each:
-//   * left operand (the current B_j, then X_j): accumulators -> LDS image As [R][130] (the accumulator layout is not the
-//     operand layout), read back by conflict-free ds_read_b64 -- shared by the eight waves;
-//   * right operand (rows 16 w .. of W_j / L_ij): streamed through a wave-private LDS region in two chunks of 64 k, the next
-//     chunk loaded into registers (coalesced 16-byte loads, two 512-byte runs per instruction) while the current one feeds
-//     the MFMAs -- private to the wave, so no workgroup barrier in the k loop.  Every workgroup reads the same ten 128 x 128
-//     blocks: L2 hits.
-// W_j is triangular: the k-steps that multiply structural zeros are skipped (the wave's k range is uniform).
-// LDS: As 66.5 KB + 8 x 8.25 KB = 134 KB (RT = 4), one workgroup per CU, two waves per SIMD.
+//   * left operand (the current B_j, then X_j): accumulators -> LDS image [R][130] (the accumulator layout is not the
+//     operand layout), read back by conflict-free ds_read_b128 -- shared by the eight waves;
+//   * right operand (rows 16 w .. of W_j / L_ij): straight from L2 into MFMA operand registers.  The k index of a product is
+//     summed over, so any bijection between (k-step, lane quarter fk) and k will do as long as both operands use the same
+//     one: with k = 16 q + 4 fk + h for k-step 4 q + h, the four values a lane needs of a QUAD q of k-steps are 32 contiguous
+//     bytes of its row (two 16-byte loads; the 16 rows of a wave: half a cache line each) and two ds_read_b128 of its row of
+//     the LDS image.  The prefetch depth is a register ring of TP_NB quads (3 ahead of the MFMAs), carried ACROSS the
+//     products and the barriers between them (the right operands do not depend on anything this kernel computes).  Every
+//     workgroup reads the same ten 128 x 128 blocks: L2 hits.
+// W_j is triangular: the quads that multiply structural zeros are skipped (the wave's range is uniform).
+//
+// Round 5 (tools/tp_stamps.py: phase stamps of every workgroup; docs/LAB_NOTES.md).  The first form staged the right operand
+// through a wave-private LDS region (global -> registers -> LDS -> registers, 134 KB of LDS, one workgroup per CU) and left the
+// fragment reads to the compiler: ds_read, s_waitcnt lgkmcnt(0), one MFMA, again -- 86.9 us per 64 rows at m = 2^20 of which
+// 57.8 are MFMA time (10 % rows not yet loaded, 27 % the four triangular products at two thirds of the pipe, 7 % barriers and
+// stores, updates at 87 %).  Now: fragment reads pinned one k-step pair ahead of their MFMAs (sched_barrier), no LDS staging,
+// and two launch shapes --
+//   * trsm_panel_kernel<RT = 2>: 32 rows per workgroup, 33 KB of LDS and 128 registers: TWO workgroups per CU, one's loads,
+//     barriers, stores and unbalanced triangular products under the other's updates (m < 64 rows x the number of CUs);
+//   * trsm_panel_persistent_kernel (RT = 4): one workgroup per CU walks over its row blocks with the NEXT block's rows
+//     arriving in the accumulator registers of every column block as soon as that block has been solved (larger m).
+// m = 2^20: 5.69 -> 4.80 ms (-16 %); m = 4096: 54 -> 44 us.
 #include "gps_common.hpp"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));      // (HIP's d2 is a struct around a union: arrays of it passed by reference stay in scratch)
 
 #define TP_NT 512
-#define TP_LSA 130                 // As row stride (doubles)
-// the right operand goes through the wave's region in chunks of KC = 64 or 32 k; row stride of the region KC + 2 doubles
-// (132 / 68 dwords = 4 mod 64, as 130 is); 16 (KC + 2) doubles per wave
+#define TP_LSA 130                 // row stride of an LDS image (doubles)
 
 struct TrsmPanelArgs {
   double* B; i64 ldb;              // [m][512] in place
   const double* L; i64 ldl;        // the 512 x 512 diagonal block (lower; or U = L^T upper when backward)
   const double* W;                 // 4 block inverses [128][128] (transposed ones when backward)
-  long long* stamps;               // diagnostics (gps_diag_trsm512_stamps): [workgroup][32] phase stamps of waves 0 and 7 (100 MHz ticks); else null
+  long long* stamps;               // diagnostics (gps_diag_trsm512_stamps): [row block][32] phase stamps of waves 0 and 7 (100 MHz ticks); else null
 };
 
-template <int KC>
-__device__ __forceinline__ void tp_load_chunk(d2 (&v)[KC / 8], const double* rows, i64 ld, int kc, int lane) {
-  // this wave's 16 rows x KC k: 128 / KC rows per instruction
-  constexpr int LPR = KC / 2, RPI = 64 / LPR;          // lanes per row, rows per instruction
-#pragma unroll
-  for (int u = 0; u < KC / 8; ++u) v[u] = *reinterpret_cast<const d2*>(rows + (i64)(RPI * u + lane / LPR) * ld + kc * KC + 2 * (lane % LPR));
-}
-template <int KC>
-__device__ __forceinline__ void tp_put_chunk(double* Bsw, const d2 (&v)[KC / 8], int lane) {
-  constexpr int LPR = KC / 2, RPI = 64 / LPR;
-#pragma unroll
-  for (int u = 0; u < KC / 8; ++u) *reinterpret_cast<d2*>(Bsw + (RPI * u + lane / LPR) * (KC + 2) + 2 * (lane % LPR)) = v[u];
-}
-
-// acc[t] += As[16 t .. ][k] * rows[16 w + .][k]   for the k-steps [ks_lo, ks_hi) of 4 out of 32 (both multiples of 4; FULL: all 32).
-// On entry v holds the first chunk of `rows` (loaded during the previous product); on exit the first chunk of `next_rows`:
-// every load has the k-steps of a chunk to arrive in, across the barriers between the products too (the right operands do
-// not depend on anything this kernel computes).
-//
-// The fragment reads run D k-steps ahead of the MFMAs that use them, in a ring of D + 1 register sets, and the order
-// reads(s + D) -> MFMAs(s) is pinned (left alone the compiler emits read, s_waitcnt lgkmcnt(0), MFMA one by one: the LDS
-// latency of every fragment exposed).  FULL: one pipeline over the 32 k-steps -- the next chunk goes into the wave's region
-// when the reads of the current one have all been ISSUED (LDS operations of one wave execute in order).  Otherwise (the
-// triangular products with the block inverses): groups of four k-steps under a wave-uniform test, a pipeline per group.
-template <int RT, int KC, bool FULL>
-__device__ __forceinline__ void tp_product(v4d (&acc)[RT], const double* As, double* Bsw, d2 (&v)[KC / 8], const double* rows, i64 ld,
-                                           const double* next_rows, i64 next_ld, int ks_lo, int ks_hi, int lane, int fr, int fk) {
-  constexpr int NC = 128 / KC, SPC = KC / 4;           // chunks per product, k-steps per chunk
-  constexpr int D = (RT >= 4) ? 1 : 2;                 // (a k-step is RT MFMAs = RT * 64 cycles of the pipe)
-  const double* pa = As + fr * TP_LSA + fk;
-  const double* pb = Bsw + fr * (KC + 2) + fk;
-  double fa[D + 1][RT], fb[D + 1];
-  auto rd = [&](int set, int ks) {
-    fb[set] = pb[4 * (ks % SPC)];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) fa[set][t] = pa[16 * t * TP_LSA + 4 * ks];
-  };
-  auto mm = [&](int set) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][t], fb[set], acc[t], 0, 0, 0);
-  };
-  auto stage = [&](int c) {                            // chunk c into the wave's region, the one after it into v
-    tp_put_chunk<KC>(Bsw, v, lane);
-    if (c + 1 < NC) tp_load_chunk<KC>(v, rows, ld, c + 1, lane);
-    else tp_load_chunk<KC>(v, next_rows, next_ld, 0, lane);
-  };
-  if (FULL) {
-    stage(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) rd(d, d);
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
-      const int nk = ks + D;
-      if (nk < 32) {
-        if (nk % SPC == 0) stage(nk / SPC);
-        rd(nk % (D + 1), nk);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ks % (D + 1));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      stage(c);
-#pragma unroll
-      for (int q = 0; q < SPC / 4; ++q) {
-        const int k0 = SPC * c + 4 * q;
-        if (k0 >= ks_lo && k0 < ks_hi) {
-#pragma unroll
-          for (int d = 0; d < D; ++d) rd(d, k0 + d);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            if (s + D < 4) rd((s + D) % (D + 1), k0 + s + D);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(s % (D + 1));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-  }
-}
-
-// accumulator tiles -> As (rows 16 t + fk + 4 rg, columns 16 w + fr); NEG: the accumulators of the blocks still to be solved hold
-// -B_i (the updates ADD X_j L_ij^T: no operand is negated in the k loops), the left operand of the next product is B_i
+// accumulator tiles -> an LDS image (rows 16 t + fk + 4 rg, columns 16 w + fr), negated or not
 template <int RT, bool NEG>
 __device__ __forceinline__ void tp_to_lds(double* As, const v4d (&x)[RT], int ct, int fr, int fk) {
 #pragma unroll
@@ -132,34 +59,103 @@ __device__ __forceinline__ void tp_to_lds(double* As, const v4d (&x)[RT], int ct
     for (int rg = 0; rg < 4; ++rg) As[(16 * t + fk + 4 * rg) * TP_LSA + 16 * ct + fr] = NEG ? -x[t][rg] : x[t][rg];
 }
 
-// KC = 64: one workgroup per CU (two waves per SIMD, up to 256 registers); KC = 32 (with RT = 2): 68 KB of LDS and 128 registers,
-// TWO workgroups per CU -- one's loads, stores, barriers and unbalanced inverse products under the other's updates
-template <int RT, bool RN, bool ST = false, int KC = 64>        // ST: the diagnostics build that leaves phase stamps (a few more registers)
-__global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(128 / KC, 128 / KC))) void trsm_panel_kernel(TrsmPanelArgs g) {
+// quads of the right operand in registers (a ring; must divide 8)
+#define TP_NB 4
+
+// per-lane pointer to the wave's rows of a right operand + the quads [lo, hi) of it that are not structurally zero
+// (a wave-uniform base and a 32-bit byte offset of the lane: scalar base + vector offset addressing, no 64-bit pointer per operand)
+struct TpOpnd { const double* base; unsigned off; int lo, hi; };
+__device__ __forceinline__ const double* tp_at(const double* base, unsigned byte_off) {
+  return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+template <int NB>
+__device__ __forceinline__ void tp_ldq(d2 (&bq)[NB][2], int slot, const TpOpnd& o, int q) {
+  const double* p = tp_at(o.base + 16 * q, o.off);
+  bq[slot][0] = *reinterpret_cast<const d2*>(p);
+  bq[slot][1] = *reinterpret_cast<const d2*>(p + 2);
+}
+
+// acc[t] += As[16 t .. ][k] * rows[16 w + .][k] over the quads [cur.lo, cur.hi) (FULL: all eight).  On entry the ring holds
+// the quads 0 .. TP_NB - 1 of `cur` (those in range), on exit those of `nxt`.
+template <int RT, bool FULL, int NB>
+__device__ __forceinline__ void tp_product(v4d (&acc)[RT], const double* pa, d2 (&bq)[NB][2], const TpOpnd cur, const TpOpnd nxt) {
+  d2 fa[2][RT];
+  auto rd = [&](int P) {                          // fragments of the k-step pair P (k-steps 2 P, 2 P + 1) into set P & 1
+#pragma unroll
+    for (int t = 0; t < RT; ++t) fa[P & 1][t] = *reinterpret_cast<const d2*>(pa + 16 * t * TP_LSA + 16 * (P >> 1) + 2 * (P & 1));
+  };
+  auto mm = [&](int P) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[P & 1][t][hh], bq[(P >> 1) % NB][P & 1][hh], acc[t], 0, 0, 0);
+  };
+  auto refill = [&](int q) {                      // quad q is used up: its slot takes the quad NB further on
+    const int n = q + NB;
+    if (n < 8) { if (FULL || (n >= cur.lo && n < cur.hi)) tp_ldq(bq, q % NB, cur, n); }
+    else if (n - 8 >= nxt.lo && n - 8 < nxt.hi) tp_ldq(bq, q % NB, nxt, n - 8);
+  };
+  if (FULL) {
+    rd(0);
+#pragma unroll
+    for (int P = 0; P < 16; ++P) {
+      if (P + 1 < 16) rd(P + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(P);
+      __builtin_amdgcn_sched_barrier(0);
+      if (P & 1) refill(P >> 1);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q >= cur.lo && q < cur.hi) {
+        if (q == 0 || q == cur.lo) rd(2 * q);     // (otherwise read during the quad before)
+        rd(2 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(2 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < 8 && q + 1 < cur.hi) rd(2 * q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(2 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      refill(q);
+    }
+  }
+}
+
+// One row block of R = 16 RT rows per workgroup.  RT = 2: 33 KB of LDS, 128 registers, TWO workgroups per CU -- one's loads,
+// stores, barriers and unbalanced triangular products under the other's updates; RT = 4: one per CU (diagnostics).  The
+// accumulators of the blocks still to be solved hold -B_i (the updates ADD X_j L_ij^T: no operand is negated in the k loops).
+template <int RT, bool RN, bool ST = false>
+__global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(8 / RT, 8 / RT))) void trsm_panel_kernel(TrsmPanelArgs g) {
   extern __shared__ __attribute__((aligned(16))) char tp_smem[];
   constexpr int R = 16 * RT;
   double* As = reinterpret_cast<double*>(tp_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
-  double* Bsw = As + R * TP_LSA + wave * (16 * (KC + 2));
-  // column tile of this wave: waves w and w + 4 share a SIMD, so they take the tiles w and 7 - w -- the triangular products skip
-  // 4 (7 - ct) (forward) / 4 ct (backward) of the 32 k-steps of tile ct, and every SIMD then carries the same 36
-  const int ct = (wave < 4) ? wave : 11 - wave;
+  const int ct = (wave < 4) ? wave : 11 - wave;    // (as in the first form: every SIMD carries the same 36 k-steps of a triangular product)
   double* Brow = g.B + (i64)blockIdx.x * R * g.ldb;
 #define TP_STAMP(q) do { if (ST && lane == 0 && (wave == 0 || wave == 7)) g.stamps[(i64)blockIdx.x * 32 + (wave ? 16 : 0) + (q)] = (long long)wall_clock64(); } while (0)
-  if (KC == 32) __builtin_amdgcn_s_setprio(2);
   TP_STAMP(0);
   if (ST && tid == 0) {
     g.stamps[(i64)blockIdx.x * 32 + 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
     g.stamps[(i64)blockIdx.x * 32 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
   }
-
-  // the right operands in the order they are used: W_j, then the blocks L_ij still to be solved
-  auto w_rows = [&](int j) { return g.W + (i64)j * 128 * 128 + (i64)16 * ct * 128; };
-  // forward: L_ij[c][k] = L[128 i + c][128 j + k] ; backward: U_ij[c][k] = U[128 i + c][128 j + k]  (i < j: above the diagonal)
-  auto l_rows = [&](int i, int j) { return g.L + (i64)(128 * i + 16 * ct) * g.ldl + 128 * j; };
-  d2 v[KC / 8];
-  tp_load_chunk<KC>(v, w_rows(RN ? 3 : 0), 128, 0, lane);
+  // the right operands: W_j (triangular: forward the quads [0, ct + 1), backward [ct, 8)) and the blocks L_ij still to be solved
+  const unsigned w_off = (unsigned)(((16 * ct + fr) * 128 + 4 * fk) * 8), l_off = (unsigned)(((i64)(16 * ct + fr) * g.ldl + 4 * fk) * 8);
+  auto w_op = [&](int j) { return TpOpnd{g.W + (i64)j * 128 * 128, w_off, RN ? ct : 0, RN ? 8 : ct + 1}; };
+  auto l_op = [&](int i, int j) { return TpOpnd{g.L + (i64)(128 * i) * g.ldl + 128 * j, l_off, 0, 8}; };
+  const TpOpnd none{g.W, 0u, 0, 0};
+  d2 bq[TP_NB][2];
+  {
+    const TpOpnd first = w_op(RN ? 3 : 0);
+#pragma unroll
+    for (int q = 0; q < TP_NB; ++q)
+      if (q >= first.lo && q < first.hi) tp_ldq(bq, q, first, q);
+  }
 
   v4d acc[4][RT];
   {
@@ -171,8 +167,6 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(128 / KC,
 #pragma unroll
       for (int u = 0; u < 2 * RT; ++u) *reinterpret_cast<d2*>(As + (2 * RT * wave + u) * TP_LSA + 2 * lane) = t[u];
     };
-    // the block solved first: whole rows (1 KB per instruction) into As, where the solve wants it.  The others straight into
-    // the accumulator layout (128-byte runs): they are not needed before the first update, one product away
     constexpr int o3 = RN ? 3 : 0;
     d2 t0[2 * RT];
     load_rows(t0, o3);
@@ -188,30 +182,23 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(128 / KC,
     __syncthreads();
   }
   TP_STAMP(1);
+  const double* pa = As + fr * TP_LSA + 4 * fk;
 
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     const int j = RN ? 3 - jj : jj;
-    // B_j (updated) as left operand
     if (jj > 0) {
       tp_to_lds<RT, true>(As, acc[j], ct, fr, fk);
       __syncthreads();
     }
-    // X_j = B_j W_j^T.  forward: W_j lower, W[c][k] = 0 for k > c: column tile w needs k <= 16 w + 15.  backward: upper, k >= 16 w.
     v4d x[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) x[t] = v4d{0.0, 0.0, 0.0, 0.0};
-    {
-      // what comes after this product: the first block still to be solved, or (last block) nothing -- any valid address
-      const int i1 = RN ? j - 1 : j + 1;
-      const double* nx = (jj < 3) ? l_rows(i1, j) : w_rows(j);
-      tp_product<RT, KC, false>(x, As, Bsw, v, w_rows(j), 128, nx, (jj < 3) ? g.ldl : 128, RN ? 4 * ct : 0, RN ? 32 : 4 * (ct + 1), lane, fr, fk);
-    }
+    tp_product<RT, false, TP_NB>(x, pa, bq, w_op(j), (jj < 3) ? l_op(RN ? j - 1 : j + 1, j) : none);
     TP_STAMP(2 + 3 * jj);
     __syncthreads();                       // everybody has read B_j
     tp_to_lds<RT, false>(As, x, ct, fr, fk);
     __syncthreads();
-    // X_j is final: whole rows to HBM (wave w: rows 2 RT w ..), 1 KB per instruction
 #pragma unroll
     for (int u = 0; u < 2 * RT; ++u) {
       const int row = 2 * RT * wave + u;
@@ -219,36 +206,146 @@ __global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(128 / KC,
       *reinterpret_cast<d2*>(Brow + (i64)row * g.ldb + 128 * j + 2 * lane) = val;
     }
     TP_STAMP(3 + 3 * jj);
-    // the blocks still to be solved (constant loop bounds: the accumulator array must keep compile-time indices)
-    // two workgroups per CU: the one between its updates (unbalanced product, barriers, stores) goes first on the SIMD -- the
-    // other's updates fill what it leaves
-    if (KC == 32) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int q = 1; q < 4; ++q) {
       if (q < 4 - jj) {
         const int i = RN ? j - q : j + q;
         const bool last = (q == 3 - jj);
-        const int jn = RN ? j - 1 : j + 1;
-        const double* nx = last ? w_rows(jn) : l_rows(RN ? i - 1 : i + 1, j);
-        tp_product<RT, KC, true>(acc[i], As, Bsw, v, l_rows(i, j), g.ldl, nx, last ? 128 : g.ldl, 0, 32, lane, fr, fk);
+        tp_product<RT, true, TP_NB>(acc[i], pa, bq, l_op(i, j), last ? w_op(RN ? j - 1 : j + 1) : l_op(RN ? i - 1 : i + 1, j));
       }
     }
-    if (KC == 32) __builtin_amdgcn_s_setprio(2);
     __syncthreads();                       // As is rewritten by the next block
     TP_STAMP(4 + 3 * jj);
   }
 #undef TP_STAMP
 }
 
-template <int RT, bool RN, bool ST = false, int KC = 64>
+template <int RT, bool RN, bool ST = false>
 static int tp_launch(gps_handle_t h, const TrsmPanelArgs& a, i64 m) {
   constexpr int R = 16 * RT;
-  const size_t lds = (size_t)(R * TP_LSA + 8 * 16 * (KC + 2)) * 8;
-  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_panel_kernel<RT, RN, ST, KC>), (int)lds);
+  const size_t lds = (size_t)(R * TP_LSA) * 8;
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_panel_kernel<RT, RN, ST>), (int)lds);
   if (rc) return rc;
   LaunchScope ls(h, KC_GEMM, 10.0 * 2.0 * (double)m * 128.0 * 128.0, 2.0 * 8.0 * (double)m * 512.0);
   ls.tag[0] = m; ls.tag[1] = 512; ls.tag[2] = 512; ls.tag[3] = 1000 + (RN ? 1 : 0);
-  hipLaunchKernelGGL((trsm_panel_kernel<RT, RN, ST, KC>), dim3((unsigned)(m / R)), dim3(TP_NT), lds, h->stream, a);
+  hipLaunchKernelGGL((trsm_panel_kernel<RT, RN, ST>), dim3((unsigned)(m / R)), dim3(TP_NT), lds, h->stream, a);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+// ---- the same, persistent -------------------------------------------------------------------------------------------------
+// One workgroup per CU walks over row blocks b, b + gridDim.x, ...  LDS holds TWO images [64][130]: A -- the column block being
+// solved (B_j, the left operand of the product with W_j) and X -- the solved one (-X_j, the left operand of the updates, which
+// then ADD: the accumulators hold +B_i and nothing is negated in the k loops).  X_j goes into the other image, so there is no
+// barrier between "everybody has read B_j" and writing it.  The NEXT row block arrives while this one is being solved: the
+// accumulators of a column block are reloaded (plain loads into the registers the block lives in, nothing depends on them
+// until the next row block) as soon as the block has been solved -- the 10 us a workgroup of the kernel above spends waiting
+// for its rows (13 %) are gone, and no extra register is held.  What is left of them: a wave's loads return in order, so the
+// first wait for a right-operand quad issued after these HBM loads waits for them too (~1.5 us per column block).  A start
+// stagger of the workgroups did not change it; issuing them at different times in the two waves of a SIMD, so that the matrix
+// pipe keeps one of them, spilled registers inside the loop (256 are in use) and cost 40 %.
+template <int RT, bool RN, bool ST = false>
+__global__ __launch_bounds__(TP_NT) __attribute__((amdgpu_waves_per_eu(8 / RT, 8 / RT))) void trsm_panel_persistent_kernel(TrsmPanelArgs g, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) char tp_smem[];
+  constexpr int R = 16 * RT, NB = (RT == 2) ? 2 : TP_NB;       // (two workgroups per CU: 128 registers -- a ring of two quads)
+  double* Aimg = reinterpret_cast<double*>(tp_smem);
+  double* Ximg = Aimg + R * TP_LSA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const int ct = (wave < 4) ? wave : 11 - wave;
+  unsigned w_off = (unsigned)(((16 * ct + fr) * 128 + 4 * fk) * 8), l_off = (unsigned)(((i64)(16 * ct + fr) * g.ldl + 4 * fk) * 8);
+  auto w_op = [&](int j) { return TpOpnd{g.W + (i64)j * 128 * 128, w_off, RN ? ct : 0, RN ? 8 : ct + 1}; };
+  auto l_op = [&](int i, int j) { return TpOpnd{g.L + (i64)(128 * i) * g.ldl + 128 * j, l_off, 0, 8}; };
+  constexpr int o3 = RN ? 3 : 0;             // the column block solved first
+  d2 bq[NB][2];
+  {
+    const TpOpnd first = w_op(o3);
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (q >= first.lo && q < first.hi) tp_ldq(bq, q, first, q);
+  }
+  unsigned row_off = (unsigned)(2 * lane * 8);                                            // whole rows: 16 bytes per lane
+  unsigned acc_off = (unsigned)(((i64)fk * g.ldb + 16 * ct + fr) * 8);                    // accumulator layout: 128-byte runs
+  auto load_acc = [&](v4d (&a)[RT], const double* Brow, int i) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) a[t][rg] = *tp_at(Brow + (i64)(16 * t + 4 * rg) * g.ldb + 128 * i, acc_off);
+  };
+  const double* pA = Aimg + fr * TP_LSA + 4 * fk;
+  const double* pX = Ximg + fr * TP_LSA + 4 * fk;
+
+  v4d acc[4][RT];
+  int b = blockIdx.x;
+  {
+    const double* Brow = g.B + (i64)b * R * g.ldb;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) load_acc(acc[RN ? 3 - jj : jj], Brow, RN ? 3 - jj : jj);
+  }
+  for (; b < nblocks; b += gridDim.x) {
+    double* Brow = g.B + (i64)b * R * g.ldb;
+    const int nb = b + gridDim.x;
+    const bool has_next = nb < nblocks;
+    const double* Bnext = g.B + (i64)(has_next ? nb : b) * R * g.ldb;
+    // (the lane offsets are loop invariants: left alone, every base + offset sum of the body is hoisted out of the loop as a
+    // 64-bit register pair per lane -- 13 of them spilled -- instead of scalar base + 32-bit offset addressing at the use)
+    asm volatile("" : "+v"(w_off), "+v"(l_off), "+v"(row_off), "+v"(acc_off));
+#define TP_STAMP(q) do { if (ST && lane == 0 && (wave == 0 || wave == 7)) g.stamps[(i64)b * 32 + (wave ? 16 : 0) + (q)] = (long long)wall_clock64(); } while (0)
+    TP_STAMP(0);
+    if (ST && tid == 0) {
+      g.stamps[(i64)b * 32 + 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+      g.stamps[(i64)b * 32 + 15] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = RN ? 3 - jj : jj;
+      // B_j (updated) as the left operand.  (Everybody is through with the updates of the block before when the barrier
+      // falls, and so with X; with A since the barrier after the product before.)
+      tp_to_lds<RT, false>(Aimg, acc[j], ct, fr, fk);
+      __syncthreads();
+      if (jj == 0) TP_STAMP(1);
+      // X_j = B_j W_j^T in the registers of the block's own accumulators
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[j][t] = v4d{0.0, 0.0, 0.0, 0.0};
+      tp_product<RT, false, NB>(acc[j], pA, bq, w_op(j), (jj < 3) ? l_op(RN ? j - 1 : j + 1, j) : w_op(o3));
+      TP_STAMP(2 + 3 * jj);
+      tp_to_lds<RT, true>(Ximg, acc[j], ct, fr, fk);
+      // the same column block of the next row block
+      if (has_next) load_acc(acc[j], Bnext, j);
+      __syncthreads();
+      // X_j is final: whole rows to HBM (wave w: rows 8 w ..), 1 KB per instruction
+#pragma unroll
+      for (int u = 0; u < 2 * RT; ++u) {
+        const int row = 2 * RT * wave + u;
+        const d2 val = *reinterpret_cast<const d2*>(Ximg + row * TP_LSA + 2 * lane);
+        *reinterpret_cast<d2*>(const_cast<double*>(tp_at(Brow + (i64)row * g.ldb + 128 * j, row_off))) = -val;
+      }
+      TP_STAMP(3 + 3 * jj);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        if (q < 4 - jj) {
+          const int i = RN ? j - q : j + q;
+          const bool last = (q == 3 - jj);
+          tp_product<RT, true, NB>(acc[i], pX, bq, l_op(i, j), last ? w_op(RN ? j - 1 : j + 1) : l_op(RN ? i - 1 : i + 1, j));
+        }
+      }
+      TP_STAMP(4 + 3 * jj);
+    }
+#undef TP_STAMP
+  }
+}
+
+template <int RT, bool RN, bool ST = false>
+static int tp_launch_persistent(gps_handle_t h, const TrsmPanelArgs& a, i64 m) {
+  constexpr int R = 16 * RT;
+  const size_t lds = (size_t)(2 * R * TP_LSA) * 8;
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_panel_persistent_kernel<RT, RN, ST>), (int)lds);
+  if (rc) return rc;
+  LaunchScope ls(h, KC_GEMM, 10.0 * 2.0 * (double)m * 128.0 * 128.0, 2.0 * 8.0 * (double)m * 512.0);
+  ls.tag[0] = m; ls.tag[1] = 512; ls.tag[2] = 512; ls.tag[3] = 1000 + (RN ? 1 : 0);
+  const int nblocks = (int)(m / R);
+  const int grid = std::min(nblocks, h->prop.multiProcessorCount * (4 / RT));
+  hipLaunchKernelGGL((trsm_panel_persistent_kernel<RT, RN, ST>), dim3((unsigned)grid), dim3(TP_NT), lds, h->stream, a, nblocks);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
@@ -259,11 +356,14 @@ int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const doubl
   if (m <= 0) return GPS_OK;
   if (m % 64) return gps_fail(h, GPS_ERR_ARG, "trsm_panel: rows must be a multiple of 64");
   TrsmPanelArgs a{B, ldb, L, ldl, W, h->tp_stamps};
-  // rows per workgroup: 64 unless that leaves CUs idle (one workgroup per CU: LDS)
-  if (h->trsm_panel_rows == 33 && a.stamps) return backward ? tp_launch<2, true, true, 32>(h, a, m) : tp_launch<2, false, true, 32>(h, a, m);
-  if (h->trsm_panel_rows == 33) return backward ? tp_launch<2, true, false, 32>(h, a, m) : tp_launch<2, false, false, 32>(h, a, m);
-  const bool r64 = h->trsm_panel_rows == 64 || (h->trsm_panel_rows == 0 && m / 64 >= (i64)h->prop.multiProcessorCount);
-  if (r64 && a.stamps) return backward ? tp_launch<4, true, true>(h, a, m) : tp_launch<4, false, true>(h, a, m);
-  if (r64) return backward ? tp_launch<4, true>(h, a, m) : tp_launch<4, false>(h, a, m);
+  // the persistent form when every CU gets a block of 64 rows, else 32 rows per workgroup and two workgroups per CU
+  // (trsm_panel_rows: 64 / 32 force one of them, 65 = 64 rows per workgroup, not persistent: diagnostics)
+  const int form = h->trsm_panel_rows ? h->trsm_panel_rows : (m / 64 >= (i64)h->prop.multiProcessorCount ? 64 : 32);
+  if (form == 64) {
+    if (a.stamps) return backward ? tp_launch_persistent<4, true, true>(h, a, m) : tp_launch_persistent<4, false, true>(h, a, m);
+    return backward ? tp_launch_persistent<4, true>(h, a, m) : tp_launch_persistent<4, false>(h, a, m);
+  }
+  if (form == 65) return backward ? tp_launch<4, true>(h, a, m) : tp_launch<4, false>(h, a, m);
+  if (a.stamps) return backward ? tp_launch<2, true, true>(h, a, m) : tp_launch<2, false, true>(h, a, m);
   return backward ? tp_launch<2, true>(h, a, m) : tp_launch<2, false>(h, a, m);
 }

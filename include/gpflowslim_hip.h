@@ -493,7 +493,8 @@ int gps_diag_potrf_base_stamps(gps_handle_t h, int factor, double* out7);
  * maxdiff_out (optional): largest |difference| between the two forms on the same input. */
 int gps_diag_trsm512(gps_handle_t h, int64_t m, int backward, int panel, int reps, double* us_per_solve,
                      double* maxdiff_out);
-/* the one-launch form with phase stamps of every workgroup: stamps_out [min(m / 64, cap_blocks)][32] 100 MHz ticks --
+/* the one-launch form with phase stamps of every row block (32 or 64 rows, as the launcher picks or option trsm_panel_rows
+ * says): stamps_out [min(number of row blocks, cap_blocks)][32] 100 MHz ticks --
  * wave 0 in [0, 14), HW_ID / XCC_ID in [14], [15], wave 7 in [16, 30): 0 start, 1 rows loaded, then per 128-column block j:
  * 2 + 3 j its product with the block inverse done, 3 + 3 j its rows stored, 4 + 3 j the updates of the later blocks done */
 int gps_diag_trsm512_stamps(gps_handle_t h, int64_t m, int backward, int reps, double* us_per_solve, long long* stamps_out,

@@ -190,10 +190,11 @@ def test_trsm_lower(handle, n, nrhs, trans):
 
 @pytest.mark.parametrize("n,nrhs", [(512, 64), (512, 300), (1024, 1000), (1536, 130), (2048, 64)])
 @pytest.mark.parametrize("trans", [False, True])
-@pytest.mark.parametrize("rows", [0, 32, 64])
+@pytest.mark.parametrize("rows", [0, 32, 64, 65])
 def test_trsm_512_column_solve_in_one_launch(handle, n, nrhs, trans, rows):
     """csrc/trsm_panel.hip: every 512-column node of the blocked solve (blocked.hpp::trsm_rec / trsm_rn_rec) as one launch,
-    for both row-tile sizes of the launcher, against scipy; and against the launch-by-launch form of the same solve."""
+    for every form of the launcher (32 rows per workgroup, 64 rows persistent, 64 rows), against scipy; and against the
+    launch-by-launch form of the same solve."""
     rng = np.random.default_rng(n + nrhs)
     G = rng.standard_normal((n, n))
     L = np.linalg.cholesky(G @ G.T + n * np.eye(n))
@@ -217,17 +218,32 @@ def test_trsm_512_column_solve_in_one_launch(handle, n, nrhs, trans, rows):
 
 
 def test_trsm_512_column_solve_many_rows(handle):
-    """The same launch on 128 .. 24576 rows (both row-tile sizes, both directions): identical to rounding with the
-    launch-by-launch solve of the same synthetic block (gps_diag_trsm512)."""
-    for m in (128, 4096, 16384, 24576):
+    """The same launch on 128 .. 64000 rows (every form, both directions; 16384 rows: one row block per workgroup of the
+    persistent form, 24576: one or two, 64000: three or four): identical to rounding with the launch-by-launch solve of the
+    same synthetic block (gps_diag_trsm512)."""
+    for m in (128, 4096, 16384, 24576, 64000):
         for back in (False, True):
-            for rows in (32, 64):
+            for rows in (32, 64, 65):
                 handle.set_option("trsm_panel_rows", rows)
                 try:
                     _, diff = handle.diag_trsm512(m, back, True, reps=1)
                 finally:
                     handle.set_option("trsm_panel_rows", 0)
                 assert diff <= 1e-14, (m, back, rows, diff)
+
+
+def test_trsm_512_column_solve_phase_stamps(handle):
+    """gps_diag_trsm512_stamps: every row block leaves the times of its phases, in order, for both launch shapes."""
+    for m, rows in ((4096, 32), (32768, 64)):
+        handle.set_option("trsm_panel_rows", rows)
+        try:
+            us, st = handle.diag_trsm512_stamps(m, False, reps=1)
+        finally:
+            handle.set_option("trsm_panel_rows", 0)
+        st = st[: m // rows]
+        assert us > 0 and (st[:, 0] > 0).all()
+        for off in (0, 16):
+            assert (np.diff(st[:, off:off + 14], axis=1) >= 0).all()
 
 
 def test_trsm_leaf_refined_residual(handle):

@@ -8,8 +8,8 @@ for m in [int(a) for a in sys.argv[1:]] or [128, 1024, 4096, 8192, 16384, 24576]
     for back in (False, True):
         us0, _ = h.diag_trsm512(m, back, False)
         res = []
-        for rows in (32, 64, 33):
-            if m % (rows & ~1): continue
+        for rows in (32, 64, 65):
+            if m % 64: continue
             h.set_option("trsm_panel_rows", rows)
             us1, diff = h.diag_trsm512(m, back, True)
             res.append("rows %d: %.1f us (%.1f TFLOP/s) diff %.2e" % (rows, us1, 10 * 2 * m * 128 * 128 / us1 / 1e6, diff))
