@@ -705,37 +705,51 @@ int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds_, i64 rows, 
 // capped by the rigorous bound sqrt(||A||_1 ||A||_inf) of each norm (the norm bounds alone are 6 - 50 x too pessimistic on the
 // blocks of an RBF Gram matrix).  One workgroup per block, thread t: row t / column t.  What decides, per leaf, whether the
 // product with the explicit inverse IS the solve or only its preconditioner (gps_api.hip: classify_blocks).
-__device__ __forceinline__ double bc_norm2(const double* __restrict__ A, i64 lda, double* x, double* y, double* red, int t) {
+// (the block sits in LDS, row stride 129: thread t walks row t -- stride 129 across the lanes, conflict-free -- for A x, and
+// column t -- consecutive lanes, consecutive words -- for A^T y.  From global memory, where a row walk is a 1 KB stride across
+// the lanes, the launch took 0.63 ms; round 5)
+#define BC_LS 129
+__device__ __forceinline__ double bc_norm2(const double* __restrict__ A, i64 lda, double* As, double* x, double* y, double* red, int t) {
   // A lower triangular [128][128]; returns min(1.5 * power-iteration estimate of ||A||_2, sqrt(||A||_1 ||A||_inf))
+  __syncthreads();                                        // (the image of the matrix before)
+  for (int r0 = 0; r0 < 128; r0 += 32) {                  // 32 rows in flight (one at a time: 128 memory latencies)
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = A[(i64)(r0 + u) * lda + t];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) As[(r0 + u) * BC_LS + t] = (t <= r0 + u) ? v[u] : 0.0;
+  }
+  __syncthreads();
+  // sums / maxima over the 128 threads: inside the two waves by lane shuffles, across them through red[0 .. 1]
+  auto wave_sum = [](double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
+  auto wave_max = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64)); return v; };
   double cs = 0.0, rs = 0.0;
-  for (int r = t; r < 128; ++r) cs += fabs(A[(i64)r * lda + t]);
-  for (int q = 0; q <= t; ++q) rs += fabs(A[(i64)t * lda + q]);
-  red[t] = cs; red[128 + t] = rs;
+  // (whole rows and columns of the zero-filled image, unrolled: with the triangular trip counts every LDS read waited for the one before)
+#pragma unroll 16
+  for (int r = 0; r < 128; ++r) cs += fabs(As[r * BC_LS + t]);
+#pragma unroll 16
+  for (int q = 0; q < 128; ++q) rs += fabs(As[t * BC_LS + q]);
+  cs = wave_max(cs); rs = wave_max(rs);
+  if ((t & 63) == 0) { red[t >> 6] = cs; red[2 + (t >> 6)] = rs; }
   x[t] = 1.0;
   __syncthreads();
-  for (int off = 64; off > 0; off >>= 1) {
-    if (t < off) { red[t] = fmax(red[t], red[t + off]); red[128 + t] = fmax(red[128 + t], red[128 + t + off]); }
-    __syncthreads();
-  }
-  const double bound = sqrt(red[0] * red[128]);
-  __syncthreads();
-  double est = 0.0;
+  const double bound = sqrt(fmax(red[0], red[1]) * fmax(red[2], red[3]));
+  double est = 0.0, nx = sqrt(128.0);                                             // (||x|| = 1 from the second step on)
   for (int it = 0; it < 16; ++it) {
     double s = 0.0;
-    for (int q = 0; q <= t; ++q) s = fma(A[(i64)t * lda + q], x[q], s);          // y = A x
+#pragma unroll 16
+    for (int q = 0; q < 128; ++q) s = fma(As[t * BC_LS + q], x[q], s);           // y = A x
     y[t] = s;
     __syncthreads();
     double z = 0.0;
-    for (int r = t; r < 128; ++r) z = fma(A[(i64)r * lda + t], y[r], z);         // z = A^T y
-    red[t] = z * z; red[128 + t] = x[t] * x[t];
+#pragma unroll 16
+    for (int r = 0; r < 128; ++r) z = fma(As[r * BC_LS + t], y[r], z);           // z = A^T y
+    const double zz = wave_sum(z * z);
+    if ((t & 63) == 0) red[4 + (it & 1) * 2 + (t >> 6)] = zz;                     // (two slots: the next step's write does not race this step's reads)
     __syncthreads();
-    for (int off = 64; off > 0; off >>= 1) {
-      if (t < off) { red[t] += red[t + off]; red[128 + t] += red[128 + t + off]; }
-      __syncthreads();
-    }
-    const double nz = sqrt(red[0]), nx = sqrt(red[128]);
+    const double nz = sqrt(red[4 + (it & 1) * 2] + red[5 + (it & 1) * 2]);
     est = sqrt(nz / nx);                                                          // ||A^T A x|| / ||x|| -> sigma_max^2
-    __syncthreads();
+    nx = 1.0;
     x[t] = z / nz;
     __syncthreads();
   }
@@ -743,17 +757,22 @@ __device__ __forceinline__ double bc_norm2(const double* __restrict__ A, i64 lda
 }
 
 __global__ __launch_bounds__(128) void block_cond_kernel(const double* __restrict__ L, i64 ldl, const double* __restrict__ W, double* __restrict__ out) {
-  __shared__ double x[128], y[128], red[256];
+  extern __shared__ __attribute__((aligned(16))) char bc_smem[];
+  double* As = reinterpret_cast<double*>(bc_smem);        // [128][BC_LS]
+  double* x = As + 128 * BC_LS; double* y = x + 128; double* red = y + 128;
   const int j = blockIdx.x, t = threadIdx.x;
-  const double nl = bc_norm2(L + (i64)j * 128 * ldl + (i64)j * 128, ldl, x, y, red, t);
-  const double nw = bc_norm2(W + (i64)j * 128 * 128, 128, x, y, red, t);
+  const double nl = bc_norm2(L + (i64)j * 128 * ldl + (i64)j * 128, ldl, As, x, y, red, t);
+  const double nw = bc_norm2(W + (i64)j * 128 * 128, 128, As, x, y, red, t);
   if (t == 0) out[j] = nl * nw;
 }
 
 int gps_launch_block_cond(gps_handle_t h, const double* L, i64 ldl, const double* W, i64 nblk, double* d_out) {
   if (nblk <= 0) return GPS_OK;
+  const size_t lds = (size_t)(128 * BC_LS + 512) * sizeof(double);
+  int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&block_cond_kernel), (int)lds);
+  if (rc) return rc;
   LaunchScope ls(h, KC_OTHER, 0.0, 2.0 * 8.0 * 128 * 128 * nblk);
-  hipLaunchKernelGGL(block_cond_kernel, dim3((unsigned)nblk), dim3(128), 0, h->stream, L, ldl, W, d_out);
+  hipLaunchKernelGGL(block_cond_kernel, dim3((unsigned)nblk), dim3(128), lds, h->stream, L, ldl, W, d_out);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }
