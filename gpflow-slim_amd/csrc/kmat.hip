@@ -181,6 +181,26 @@ __device__ __forceinline__ double gps_sqrt_pos(double x) {
   return sqrt(x);
 #endif
 }
+// The same for the epilogue of kmat_mfma_kernel, where every VALU instruction counts (round 5): the NaN of a NaN argument is
+// handed through by one FMA (x * 0 + result) instead of a compare and two selects.  (An argument of -infinity -- a squared
+// distance that overflowed -- gives NaN instead of 0.)
+__device__ __forceinline__ double gps_exp_nonpos_lean(double x, const ExpTab& t) {
+  const double magic = 6755399441055744.0;
+  const double kd = fma(fmax(x, -1100.0), t.c[13], magic);
+  const int ki = __double2loint(kd);
+  const double k = kd - magic;
+  double r = fma(-k, t.c[14], x);
+  r = fma(-k, t.c[15], r);
+  double p = t.c[0];
+#pragma unroll
+  for (int i = 1; i <= 10; ++i) p = fma(p, r, t.c[i]);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int hi = __double2hiint(p) + (ki << 20);
+  const double v = __hiloint2double(hi, __double2loint(p));
+  return fma(x, 0.0, ki < -1021 ? 0.0 : v);
+}
 __device__ __forceinline__ double gps_exp_nonpos(double x) {        // (kernels that call it a few times only)
   const ExpTab t = gps_exp_load();
   return gps_exp_nonpos(x, t);
@@ -521,25 +541,32 @@ __global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev
 #define KLM 80
 typedef double v4d_k __attribute__((ext_vector_type(4)));
 
+// (no diagonal test per entry: the accumulators of the diagonal entries of a diagonal tile are patched before the epilogue
+// to the dot product that makes r2 -- or the Periodic argument -- exactly 0; see the kernel)
+// The value as TWO factors, pre (variance x polynomial) and e (the exponential): the fold into the running result is then an
+// explicit fma(pre, e, run) / run * (pre * e) -- one instruction less per entry, and no mul + add pair left for the compiler to
+// contract at some unrolled positions and not at others (K[i][j] and K[j][i] are computed at different positions of different
+// lanes: with the contraction left to the compiler a Sum kernel came out 1 ulp asymmetric).
 template <int OP>
-__device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int op, double dot, double ni, double nj, bool on_diag,
-                                                     const ExpTab& et) {
+__device__ __forceinline__ void kmat_prim_from_dot(const KNodeDev& node, int op, double dot, double nsum, const ExpTab& et, double& pre, double& e) {
   const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
   const int o = (OP >= 0) ? OP : op;      // (always a compile-time constant at the call sites)
+  pre = node.variance;
   if (o == GPS_K_PERIODIC) {
     // kernels.py:813-819 in cos / sin feature form: sum_d sin^2(pi (x - x') / p) / l^2 = (D - sum_d cos(a_d - b_d)) / (2 l^2);
     // node.c1 = -1 / (4 l^2), folded on the host (a division per entry is ~12 VALU instructions)
-    const double arg = on_diag ? 0.0 : ((double)(node.nf / 2) - dot) * node.c1;
-    return node.variance * gps_exp_nonpos(arg, et);                             // (no clamp: kernels.py:817-819)
+    e = gps_exp_nonpos_lean(((double)(node.nf / 2) - dot) * node.c1, et);       // (no clamp: kernels.py:817-819)
+    return;
   }
-  double r2 = -2.0 * dot + (ni + nj);                                                    // kernels.py:409-421
-  r2 = on_diag ? r2 * 0.0 : gps_clamp0(r2);      // (exactly 0 on the diagonal -- NaN stays NaN)
-  if (o == GPS_K_RBF) return node.variance * gps_exp_nonpos(-0.5 * r2, et);
+  const double r2 = gps_clamp0(fma(-2.0, dot, nsum));                                    // kernels.py:409-421 (NaN stays NaN)
+  if (o == GPS_K_RBF) { e = gps_exp_nonpos_lean(-0.5 * r2, et); return; }
   const double r = gps_sqrt_pos(r2 + 1e-12);
-  if (o == GPS_K_MATERN12) return node.variance * gps_exp_nonpos(-r, et);
-  if (o == GPS_K_EXPONENTIAL) return node.variance * gps_exp_nonpos(-0.5 * r, et);
-  if (o == GPS_K_MATERN32) return node.variance * (1.0 + sq3 * r) * gps_exp_nonpos(-sq3 * r, et);
-  return node.variance * (1.0 + sq5 * r + 5.0 / 3.0 * (r * r)) * gps_exp_nonpos(-sq5 * r, et);
+  if (o == GPS_K_MATERN12) { e = gps_exp_nonpos_lean(-r, et); return; }
+  if (o == GPS_K_EXPONENTIAL) { e = gps_exp_nonpos_lean(-0.5 * r, et); return; }
+  // variance (1 + sqrt(3) r) and variance (1 + sqrt(5) r + 5/3 r^2) in Horner form on wave-uniform coefficients
+  if (o == GPS_K_MATERN32) { pre = fma(node.variance * sq3, r, node.variance); e = gps_exp_nonpos_lean(-sq3 * r, et); return; }
+  pre = fma(fma(node.variance * (5.0 / 3.0), r, node.variance * sq5), r, node.variance);
+  e = gps_exp_nonpos_lean(-sq5 * r, et);
 }
 
 // OP >= 0: the program is that one stationary primitive (compile-time formulas); OP < 0: a left-deep chain p0 (p_i op_i)*
@@ -551,7 +578,7 @@ __device__ __forceinline__ double kmat_prim_from_dot(const KNodeDev& node, int o
 // lanes of a row cover 128 contiguous bytes (the VALU kernels' store shape; the natural layout -- four ROWS per lane --
 // needs 8-byte stores and measured 8 % slower than the VALU kernel on the store-bound RBF build).
 template <int OP>
-__global__ __launch_bounds__(256, 4) void kmat_mfma_kernel(KmatArgs a, KProgDev P) {
+__global__ __launch_bounds__(256, 3) void kmat_mfma_kernel(KmatArgs a, KProgDev P) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -572,16 +599,21 @@ __global__ __launch_bounds__(256, 4) void kmat_mfma_kernel(KmatArgs a, KProgDev 
   const int n_nodes = (OP >= 0) ? 1 : P.n_nodes;
   for (int nd = 0; nd < n_nodes; nd += (nd == 0 ? 1 : 2)) {
     const KNodeDev node = P.nodes[nd];
-    const int op = (nd == 0) ? -1 : P.nodes[nd + 1].op;
+    // the lane's entry on the diagonal of a diagonal tile, as an index into its 16 (row == 16 j + 4 kq + r: j == w, kq == l15 >> 2,
+    // r == l15 & 3), or -1.  (Opaque to the optimiser per node: sixteen hoisted lane masks cost 32 scalar registers.)
+    int dce = (diag_tile && kq == (l15 >> 2)) ? 4 * w + (l15 & 3) : -1;
+    asm volatile("" : "+v"(dce));
+    // the first value is ADDED to the zeros the running result starts from: two ways to fold, not three
+    const bool mul = (nd > 0) && P.nodes[nd + 1].op == GPS_K_MUL;
     // every value is folded into the running result at once (no 16-entry temporary: the kernel sits at three waves per
     // SIMD because of its registers)
-#define KMAT_FOLD(e, val) run[e] = (op < 0) ? (val) : ((op == GPS_K_ADD) ? (run[e] + (val)) : (run[e] * (val)))
+#define KMAT_FOLD(e, val) run[e] = mul ? (run[e] * (val)) : (run[e] + (val))
     if (OP < 0 && node.op == GPS_K_CONSTANT) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) KMAT_FOLD(e, node.variance);
     } else if (OP < 0 && node.op == GPS_K_WHITE) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) KMAT_FOLD(e, (diag_tile && row == 16 * (e >> 2) + 4 * kq + (e & 3)) ? node.variance : 0.0);
+      for (int e = 0; e < 16; ++e) KMAT_FOLD(e, (e == dce) ? node.variance : 0.0);
     } else {
       const int nf4 = (node.nf + 3) & ~3;
       if (nd > 0) __syncthreads();
@@ -611,22 +643,36 @@ __global__ __launch_bounds__(256, 4) void kmat_mfma_kernel(KmatArgs a, KProgDev 
       }
       const bool has_norm = node.norm_row >= 0;
       const double ni = has_norm ? nr_s[row] : 0.0;
-      // the primitive's formula is chosen ONCE per node, outside the 16 entries: every inner loop is branch-free
-#define KMAT_EVAL(OPC)                                                                                           \
+      if (diag_tile) {
+        // the exact diagonal (x_i == x_j: r2 = 0, Periodic argument 0 -- NaN / infinite coordinates stay NaN).  Stationary:
+        // dot = (n_i + n_i) / 2 makes -2 dot + (n_i + n_j) exactly 0; Periodic: dot = D.  Here, once per node of a diagonal
+        // tile, instead of a test and two selects per entry.
+        const double dv = has_norm ? ni : (double)(node.nf / 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * j + r == dce) acc[j][r] = fma(acc[j][r], 0.0, dv);
+      }
+      // the primitive's formula and the fold are chosen ONCE per node, outside the 16 entries: every inner loop is
+      // branch-free (two independent chains at a time for the scheduler to interleave)
+#define KMAT_EVAL2(OPC, MUL)                                                                                     \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-        double nj[4] = {0.0, 0.0, 0.0, 0.0};                                                                    \
+        double ns[4] = {0.0, 0.0, 0.0, 0.0};                                                                    \
         if (has_norm) {                                                                                         \
           const double2 n01 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq);                        \
           const double2 n23 = *reinterpret_cast<const double2*>(nc_s + 16 * j + 4 * kq + 2);                    \
-          nj[0] = n01.x; nj[1] = n01.y; nj[2] = n23.x; nj[3] = n23.y;                                           \
+          ns[0] = ni + n01.x; ns[1] = ni + n01.y; ns[2] = ni + n23.x; ns[3] = ni + n23.y;                       \
         }                                                                                                       \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                         \
-          const double val = kmat_prim_from_dot<OPC>(node, OPC, acc[j][r], ni, nj[r],                           \
-                                                     diag_tile && row == 16 * j + 4 * kq + r, et);              \
-          KMAT_FOLD(j * 4 + r, val);                                                                            \
+          double pre, ex;                                                                                       \
+          kmat_prim_from_dot<OPC>(node, OPC, acc[j][r], ns[r], et, pre, ex);                                    \
+          run[j * 4 + r] = MUL ? run[j * 4 + r] * (pre * ex) : fma(pre, ex, run[j * 4 + r]);                    \
+          if (r & 1) __builtin_amdgcn_sched_barrier(0);   /* two chains at a time: four or more interleaved spill (128 registers) */ \
         }                                                                                                       \
       }
-      if (OP >= 0) { KMAT_EVAL(OP) }
+#define KMAT_EVAL(OPC) if (mul) { KMAT_EVAL2(OPC, true) } else { KMAT_EVAL2(OPC, false) }
+      if (OP >= 0) { KMAT_EVAL2(OP, false) }
       else switch (node.op) {
         case GPS_K_RBF: KMAT_EVAL(GPS_K_RBF) break;
         case GPS_K_MATERN12: KMAT_EVAL(GPS_K_MATERN12) break;
@@ -636,6 +682,7 @@ __global__ __launch_bounds__(256, 4) void kmat_mfma_kernel(KmatArgs a, KProgDev 
         default: KMAT_EVAL(GPS_K_PERIODIC) break;
       }
 #undef KMAT_EVAL
+#undef KMAT_EVAL2
     }
 #undef KMAT_FOLD
   }
