@@ -44,7 +44,10 @@ if [ "$what" = all ] || [ "$what" = stats ]; then
   done
   echo "timelines done"
   # the 512-column triangular solve: one launch against launch by launch, 128 .. 262144 rows
-  (cd $R && python3 tools/trsm512.py 128 4096 16384 65536 262144 2>&1 | grep -v amdgpu.ids) > $OUT/trsm512.txt || true
+  (cd $R && python3 tools/trsm512.py 128 4096 16384 65536 262144 1048576 2>&1 | grep -v amdgpu.ids) > $OUT/trsm512.txt || true
+  # ... and where a row block of it spends its time (phase stamps of every workgroup; round 5): 32 rows per workgroup and two
+  # workgroups per CU / 64 rows, persistent / 64 rows per workgroup
+  (cd $R && for f in 32 64 65; do python3 tools/tp_stamps.py 1048576 0 $f 2>&1 | grep -v amdgpu.ids; done) > $OUT/trsm512_stamps.txt || true
   (cd $R && python3 tools/kmat_ab.py 2>&1 | grep -v amdgpu.ids) > $OUT/kmat_ab.txt || true
   # the bench line without a profiler around it (kernel tracing costs ~3 %)
   (cd $R && python3 bench.py > $OUT/bench_unprofiled.log 2> $OUT/bench_unprofiled.err) || exit 1

@@ -66,14 +66,15 @@ if kc.get("SQ_INSTS_VALU") and kc.get("SQ_WAVES"):
                            "salu_instructions_per_active_wave": round(kc.get("SQ_INSTS_SALU", 0) / aw),
                            "valu_issue_cycles_per_simd_at_4_per_instruction": round(kc["SQ_INSTS_VALU"] / 1024 * 4),
                            "mfma_busy_cycles_per_simd": round(kc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024)},
-               "reading": "the build is VALU-issue-bound: ~115 VALU instructions per matrix entry (two in-line exponentials, sqrt, folds and selects) plus the fp64 MFMA "
-                          "feature products on the same double-precision pipe; see docs/LAB_NOTES.md (round 4)",
+               "reading": "the build is bound by the double-precision pipe: the VALU instructions of the epilogue (two in-line exponentials, sqrt, polynomial, fold: "
+                          "valu_instructions_per_entry, 4 cycles each) plus the fp64 MFMA feature products (48 per wave and 16 entries, 64 cycles each: the same rate per "
+                          "multiply-add as the VALU on this part) -- at 100 % of the pipe 0.52 ms = 2.07 TB/s; see docs/LAB_NOTES.md (rounds 4 and 5)",
                "kernel_source_sha": sha, "commit": commit}, open(os.path.join(PROF, "%s_kmat_cfg4_counters.json" % tag), "w"), indent=1)
 
 for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("sweep_step_stamps.txt", "sweep_step_stamps.txt"),
                  ("sweep_step_ab.txt", "sweep_step_ab.txt"), ("cross_level_lookahead_ab.txt", "cross_level_lookahead_ab.txt"),
                  ("small_n_stamps.txt", "small_n_stamps.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
-                 ("trsm512.txt", "trsm512.txt"), ("kmat_ab.txt", "kmat_ab.txt")):
+                 ("trsm512.txt", "trsm512.txt"), ("trsm512_stamps.txt", "trsm512_stamps.txt"), ("kmat_ab.txt", "kmat_ab.txt")):
     f = os.path.join(OUT, src)
     if os.path.exists(f):
         if src.endswith(".json"):

@@ -37,6 +37,8 @@ for k, v in per_cu.items():
         gaps.append(b[0] - a[1])
     busy.append(sum(e - s for s, e in v))
 gaps = np.array(gaps)
-print("CUs seen: %d, workgroups per CU %.1f; gap between consecutive workgroups of a CU: mean %.2f us (10 / 50 / 90 %%: %.2f %.2f %.2f); "
+if rows == 32:
+    print("(32 rows per workgroup: two workgroups share a CU, a negative gap is their overlap)")
+print("CUs seen: %d, row blocks per CU %.1f; start of a row block minus end of the one before on the same CU: mean %.2f us (10 / 50 / 90 %%: %.2f %.2f %.2f); "
       "CU busy %.1f %% of the span" % (len(per_cu), len(t) / len(per_cu), gaps.mean() if len(gaps) else 0, *(np.quantile(gaps, [0.1, 0.5, 0.9]) if len(gaps) else (0, 0, 0)),
                                        100 * np.mean(busy) / span))
