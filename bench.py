@@ -650,13 +650,13 @@ def main():
                 with open(pmc) as f:
                     rec = json.load(f)
                 # measured on exactly these device sources, over exactly this launch set (the KC_GEMM class: gemm_nt_f64_kernel<*>
-                # and trsm_panel_kernel<*>): traffic x launches == traffic_total_bytes
+                # and trsm_panel_*kernel<*>): traffic x launches == traffic_total_bytes
                 if rec.get("kernel_source_sha") == kernel_source_sha() and int(rec.get("launches", -1)) == int(g["launches"]):
                     traffic_total, traffic_launches = rec.get("hbm_bytes_total"), int(rec["launches"])
                     traffic, traffic_src = traffic_total / traffic_launches, "profiles/" + os.path.basename(pmc)
                     break
             peak_meas, _ = h.diag_mfma_f64(2)
-            roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (+ trsm_panel_kernel, the 512-column solve built from the same MFMA products: the library's GEMM class)",
+            roofline = {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (+ trsm_panel_kernel / trsm_panel_persistent_kernel, the 512-column solve built from the same MFMA products: the library's GEMM class)",
                         "achieved": round(achieved, 3),
                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                         "traffic": traffic, "traffic_total_bytes": traffic_total, "traffic_launches": traffic_launches,

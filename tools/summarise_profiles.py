@@ -112,13 +112,13 @@ def per_kernel(d, counters):
 fetch, write = per_kernel("prof_pmc_FETCH_SIZE", ["FETCH_SIZE"]), per_kernel("prof_pmc_WRITE_SIZE", ["WRITE_SIZE"])
 if fetch and write:
     # the launch set of bench.py's roofline object: the library's KC_GEMM class = every gemm_nt_f64_kernel<*> launch and the
-    # one-launch 512-column solves (trsm_panel_kernel<*>, trsm_panel.hip), so that traffic x launches = the total below
-    in_class = lambda k: ("gemm_nt_f64_kernel" in k) or ("trsm_panel_kernel" in k)
+    # one-launch 512-column solves (trsm_panel_kernel<*> / trsm_panel_persistent_kernel<*>, trsm_panel.hip), so that traffic x launches = the total below
+    in_class = lambda k: ("gemm_nt_f64_kernel" in k) or ("trsm_panel_" in k)
     gem = lambda acc, c: sum(v.get(c, 0.0) for k, v in acc.items() if in_class(k))
     launches = sum(v["launches"] for k, v in fetch.items() if in_class(k))
     fb, wb = gem(fetch, "FETCH_SIZE") * 1024.0, gem(write, "WRITE_SIZE") * 1024.0          # rocprofv3 reports KB
     rec = {"command": "GPS_LOOKAHEAD=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/one_eval.py 32768 1 (last evaluation only)",
-           "kernel_class": "gemm_nt_f64_kernel<*> + trsm_panel_kernel<*> (the library's KC_GEMM class: what bench.py's roofline.launches counts)", "launches": launches,
+           "kernel_class": "gemm_nt_f64_kernel<*> + trsm_panel_kernel<*> / trsm_panel_persistent_kernel<*> (the library's KC_GEMM class: what bench.py's roofline.launches counts)", "launches": launches,
            "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
            "gfx950_correction": "FETCH_SIZE reports 1/2 of the bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md HBM section): fetch doubled",
            "hbm_bytes_total": 2.0 * fb + wb, "hbm_bytes_per_launch": (2.0 * fb + wb) / max(launches, 1),
