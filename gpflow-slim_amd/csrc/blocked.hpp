@@ -397,11 +397,32 @@ struct Blocked {
     return finish();
   }
 
+  // Many more rows than columns (conditionals.py:87: the [N, M] cross matrix against the M x M factor): 512-column panels left
+  // to right, each updated ONCE with everything solved before it (K = 512 j: long K loops, its columns read and written once)
+  // instead of the recursive halving, whose K = 512 and K = 1024 updates run 7 % / 3 % below the K = 2048 ones (config 5:
+  // 8.1 / 30.7 ms where the long-K rate gives 7.5 / 29.9).  Only when every panel can take the one-launch solve.
+  bool tall_panels(i64 m, i64 n, int transposed, i64 blk0) const {
+    const i64 P = 4 * GPS_TILE;
+    if (!ops.trsm_left_looking(m, n) || n <= P || n % P) return false;
+    for (i64 c = 0; c < n; c += P)
+      if (!ops.leaf512(m, transposed, blk0 + c / GPS_TILE)) return false;
+    return true;
+  }
+
   // solve X L^T = B in place; L [n,n] lower at (L, ldl); B [m,n] at (B, ldb)
   int trsm_rec(const double* L, i64 ldl, i64 n, i64 blk0, double* B, i64 ldb, i64 m) {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 0, B, ldb, m, L, ldl);
     if (n == 4 * GPS_TILE && ops.leaf512(m, 0, blk0)) return ops.trsm_leaf512(blk0, 0, B, ldb, m, L, ldl);
+    if (tall_panels(m, n, 0, blk0)) {
+      const i64 P = 4 * GPS_TILE;
+      for (i64 c = 0; c < n; c += P) {
+        int rc = c ? ops.gemm(0, 0, m, P, c, B, ldb, L + c * ldl, ldl, B + c, ldb) : 0;          // B_c -= X[:, 0:c] L[c:c+P, 0:c]^T
+        if (!rc) rc = ops.trsm_leaf512(blk0 + c / GPS_TILE, 0, B + c, ldb, m, L + c * ldl + c, ldl);
+        if (rc) return rc;
+      }
+      return 0;
+    }
     const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rec(L, ldl, n1, blk0, B, ldb, m);
     if (rc) return rc;
@@ -415,6 +436,16 @@ struct Blocked {
     if (n <= 0 || m <= 0) return 0;
     if (n == GPS_TILE) return ops.trsm_base(blk0, /*transposed inverse*/ 1, B, ldb, m, U, ldu);
     if (n == 4 * GPS_TILE && ops.leaf512(m, 1, blk0)) return ops.trsm_leaf512(blk0, 1, B, ldb, m, U, ldu);
+    if (tall_panels(m, n, 1, blk0)) {                                                              // (right to left)
+      const i64 P = 4 * GPS_TILE;
+      for (i64 c = n - P; c >= 0; c -= P) {
+        // B_c -= X[:, c+P:n] L[c+P:n, c:c+P] = X[:, c+P:n] (U[c:c+P, c+P:n])^T
+        int rc = (c + P < n) ? ops.gemm(0, 0, m, P, n - c - P, B + c + P, ldb, U + c * ldu + c + P, ldu, B + c, ldb) : 0;
+        if (!rc) rc = ops.trsm_leaf512(blk0 + c / GPS_TILE, 1, B + c, ldb, m, U + c * ldu + c, ldu);
+        if (rc) return rc;
+      }
+      return 0;
+    }
     const i64 n1 = split_solve(n), n2 = n - n1;
     int rc = trsm_rn_rec(U + n1 * ldu + n1, ldu, n2, blk0 + n1 / GPS_TILE, B + n1, ldb, m);
     if (rc) return rc;

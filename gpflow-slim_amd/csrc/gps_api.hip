@@ -103,6 +103,8 @@ struct HipOps {
     for (i64 b = blk; b < blk + cnt; ++b) if (!h->plain_flags[(size_t)b]) return false;
     return true;
   }
+  // many rows against few columns: 512-column panels left to right (blocked.hpp::tall_panels)
+  bool trsm_left_looking(i64 m, i64 n) const { return h->trsm_tall_ratio > 0 && m >= (i64)h->trsm_tall_ratio * n; }
   // four leaves and the updates between them as one launch (trsm_panel.hip); not for refined leaves
   bool leaf512(i64 m, int transposed, i64 blk) const {
     return h->trsm_panel > 0 && (!h->refine_now || plain_ok(blk, 4)) && m >= 64 && m % 64 == 0 && (transposed ? linvT != nullptr : true);
@@ -684,6 +686,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
   if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
   if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
+  if (strcmp(key, "trsm_tall_ratio") == 0) { h->trsm_tall_ratio = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
     if (value != 0 && value != 32 && value != 64 && value != 65) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32, 64 or 65");
     h->trsm_panel_rows = (int)value; return GPS_OK;

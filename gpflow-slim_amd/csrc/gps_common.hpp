@@ -267,6 +267,7 @@ struct gps_handle_s {
   DevBuf dTmp3;
   long long resid_ring_max = 1 << 16;   // residuals up to this many bytes are uploaded through a pinned slot (larger ones: the slots would each be re-allocated on first use, 0.3 ms a piece)
   int trsm_panel = 1;         // 512-column triangular solves as one launch (trsm_panel.hip); 0: down to 128 columns launch by launch
+  int trsm_tall_ratio = 16;   // a solve of m rows against n columns goes panel by panel, left-looking, when m >= ratio * n (0: never; blocked.hpp::tall_panels)
   int trsm_panel_rows = 0;    // form of that launch: 32 (rows per workgroup, two workgroups per CU), 64 (persistent), 65 (64 rows, not persistent), 0 = by the number of rows
   DevBuf dSmallOut;           // everything a small-N likelihood + gradient hands back, contiguous (one copy)
   DevBuf dFeatG;              // features of the gradient kernel (its own buffer: they may be prepared before the kernel matrix is built)

@@ -13,6 +13,7 @@ static const i64 T = GPS_TILE;
 
 static i64 g_rl_group = 1;
 static int g_lookahead = 0;
+static int g_tall = 0;        // emul_set_tall: solves of more than 512 columns panel by panel, left-looking (blocked.hpp::tall_panels)
 static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
 static int g_fused = 0;       // emul_set_fused: the sweep's one-launch steps (Ops::step)
@@ -225,6 +226,7 @@ struct CpuOps {
   // the off-diagonal blocks of D (forward: the lower block L; backward: U = L^T, blocks above the diagonal)
   int n_leaf512 = 0;
   bool leaf512(i64 m, int, i64) const { return g_leaf512 != 0 && m % 64 == 0; }
+  bool trsm_left_looking(i64, i64) const { return g_tall != 0; }
   int trsm_leaf512(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
     ++n_leaf512;
     for (int jj = 0; jj < 4; ++jj) {
@@ -261,6 +263,7 @@ struct CpuOps {
 extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_leaf512(int v) { g_leaf512 = v; }
+void emul_set_tall(int v) { g_tall = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
 void emul_set_fused(int v) { g_fused = v; }

@@ -43,15 +43,17 @@ def test_blocked_recursion_matches_lapack(emul, n, m, r, rl_max, group):
     assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
 
 
-@pytest.mark.parametrize("n,m", [(512, 128), (640, 128), (1024, 256), (1536, 128), (1920, 256)])
-@pytest.mark.parametrize("rl_max,la", [(0, 0), (512, 2), (1024, 2)])
-def test_512_column_nodes_of_the_solves(emul, n, m, rl_max, la):
+@pytest.mark.parametrize("n,m", [(512, 128), (640, 128), (1024, 256), (1536, 128), (1920, 256), (2048, 128)])
+@pytest.mark.parametrize("rl_max,la,tall", [(0, 0, 0), (512, 2, 0), (1024, 2, 0), (1024, 2, 1)])
+def test_512_column_nodes_of_the_solves(emul, n, m, rl_max, la, tall):
     """blocked.hpp::split_solve / Ops::trsm_leaf512: with the 512-column node as one operation (emulated the way
-    csrc/trsm_panel.hip does it) every solve of the driver still matches LAPACK, whatever the number of tiles."""
+    csrc/trsm_panel.hip does it) every solve of the driver still matches LAPACK, whatever the number of tiles; tall: the
+    solves of a whole number of 512-column panels go panel by panel, left-looking (blocked.hpp::tall_panels), both directions."""
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))
     emul.emul_set_lookahead(la)
     emul.emul_set_rl_group(ctypes.c_int64(2))
     emul.emul_set_leaf512(1)
+    emul.emul_set_tall(tall)
     try:
         rng = np.random.default_rng(n + m)
         G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
@@ -61,7 +63,7 @@ def test_512_column_nodes_of_the_solves(emul, n, m, rl_max, la):
         p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         rc = emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(m), p(y), ctypes.c_int64(1), ctypes.byref(info))
     finally:
-        emul.emul_set_leaf512(0); emul.emul_set_lookahead(0)
+        emul.emul_set_leaf512(0); emul.emul_set_lookahead(0); emul.emul_set_tall(0)
     assert rc == 0 and info.value == 0
     L = sl.cholesky(A0, lower=True)
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()

@@ -217,6 +217,32 @@ def test_trsm_512_column_solve_in_one_launch(handle, n, nrhs, trans, rows):
     assert (after - mid) - (mid - before) == 6 * (n // 512), (before, mid, after)
 
 
+@pytest.mark.parametrize("trans", [False, True])
+def test_trsm_tall_right_hand_sides_go_panel_by_panel(handle, trans):
+    """blocked.hpp::tall_panels: 16 times more right-hand sides than columns (conditionals.py:87 at config 5's shape) -- the solve
+    goes over 512-column panels left to right (right to left for L^T), one long-K update and one launch each; same result as the
+    recursive halving and as scipy, fewer launches."""
+    n, nrhs = 1024, 16384
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((n, n))
+    L = np.linalg.cholesky(G @ G.T + n * np.eye(n))
+    B = rng.standard_normal((n, nrhs))
+    ref = sl.solve_triangular(L, B, lower=True, trans='T' if trans else 'N')
+    try:
+        handle.set_option("leaf_refine", 0)
+        l0 = handle.profile_get("gemm_f64")["launches"]
+        X = handle.trsm_lower(L, B, trans=trans)
+        l1 = handle.profile_get("gemm_f64")["launches"]
+        handle.set_option("trsm_tall_ratio", 0)
+        X0 = handle.trsm_lower(L, B, trans=trans)
+        l2 = handle.profile_get("gemm_f64")["launches"]
+    finally:
+        handle.set_option("trsm_tall_ratio", 16); handle.set_option("leaf_refine", -1)
+    assert np.abs(X - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(X - X0).max() <= 1e-12 * np.abs(ref).max()
+    assert (l1 - l0, l2 - l1) == (3, 3)          # two panels: one update + two solves either way at 1024 columns
+
+
 def test_trsm_512_column_solve_many_rows(handle):
     """The same launch on 128 .. 64000 rows (every form, both directions; 16384 rows: one row block per workgroup of the
     persistent form, 24576: one or two, 64000: three or four): identical to rounding with the launch-by-launch solve of the
