@@ -1678,7 +1678,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
     if (rc) return rc;
   }
   std::vector<double> extra(sv ? 0 : per);
-  GPS_HIP(h, h->dTmp3.ensure((size_t)nsp * mp * 8));                 // LTA^T [nsp, mp]
+  GPS_HIP(h, h->dTmp3.ensure((size_t)std::max(nsp, q_sqrt_ndim == 3 ? m : (i64)0) * mp * 8));   // LTA^T [nsp, mp] (and, before it, the raw L_q [m, m])
   double* dLTA = h->dTmp3.d();
   bool lta_transposed = false;
   for (i64 q = 0; q < k; ++q) {
@@ -1693,12 +1693,13 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
       if (rc) return rc;
     } else {
       // LTA^T = A^T L_q ; as C = A B^T with B = L_q^T (upper) -> upload tril(L_q) transposed
+      // (the user's row-major L_q goes up as it is -- into the front of dLTA, which the product below overwrites -- and is
+      // transposed, masked and padded on the device)
       GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
-      std::vector<double> LT((size_t)mp * mp, 0.0);
       const double* Lq = q_sqrt + (size_t)q * m * m;
-      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = Lq[a * m + b];
-      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
-      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      GPS_HIP(h, hipMemcpyAsync(dLTA, Lq, (size_t)m * m * 8, hipMemcpyHostToDevice, h->stream));
+      rc = gps_launch_tril_transpose_pad(h, dLTA, m, h->dTmp2.d(), mp);
+      if (rc) return rc;
       if (!full_cov) {
         // only the column sums of squares of L_q^T A are needed: form it as (L_q^T) A^T-transposed, [mp, nsp], with the
         // upper-triangular L_q^T as the A operand -- the GEMM skips its zero half (half the flop of the product below)

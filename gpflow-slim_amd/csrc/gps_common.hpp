@@ -442,6 +442,7 @@ int gps_tri_dot(gps_handle_t h, const double* A, i64 lda, const double* B, i64 l
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64);
+int gps_launch_tril_transpose_pad(gps_handle_t h, const double* src, i64 n, double* dst, i64 np);
 int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                          double* dst, i64 ldd);
 int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
