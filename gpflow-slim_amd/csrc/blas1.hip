@@ -336,16 +336,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   }
 }
 
-// dst [np][np] = tril(src [n][n])^T, zero elsewhere (padding included): the upper-triangular L_q^T the q_sqrt product of the
-// conditional wants (conditionals.py:112-113: tf.matrix_band_part(q_sqrt, -1, 0)), from the user's row-major q_sqrt as
-// uploaded.  (The host loop that did this -- a strided walk over 134 MB at M = 4096 -- was 0.13 s of config 5's 0.70 s bound.)
-__global__ __launch_bounds__(256) void tril_transpose_pad_kernel(const double* __restrict__ src, i64 n, double* __restrict__ dst, i64 np) {
+// dst [np][np] = scale * tril(src [n][n]) (T = false) or its transpose (T = true), zero elsewhere (padding included): the
+// upper-triangular L_q^T the q_sqrt product of the conditional wants (conditionals.py:112-113: tf.matrix_band_part(q_sqrt, -1, 0)),
+// from the user's row-major q_sqrt as uploaded.  (The host loop that did this -- a strided walk over 134 MB at M = 4096 -- was
+// 0.13 s of config 5's 0.70 s bound.)
+template <bool T>
+__global__ __launch_bounds__(256) void tril_pad_kernel(const double* __restrict__ src, i64 n, double* __restrict__ dst, i64 np, double scale) {
   __shared__ double t[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;      // tile of dst: rows r0.., columns c0..
+  if (!T) {
+    for (int j = ty; j < 32; j += 8) {
+      const i64 a = r0 + j, b = c0 + tx;
+      if (a < np && b < np) dst[a * np + b] = (a < n && b <= a) ? scale * src[a * n + b] : 0.0;
+    }
+    return;
+  }
   for (int j = ty; j < 32; j += 8) {
     const i64 a = c0 + j, b = r0 + tx;                       // dst[b][a] = src[a][b] for b <= a < n
-    t[j][tx] = (a < n && b <= a) ? src[a * n + b] : 0.0;
+    t[j][tx] = (a < n && b <= a) ? scale * src[a * n + b] : 0.0;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
@@ -353,11 +362,12 @@ __global__ __launch_bounds__(256) void tril_transpose_pad_kernel(const double* _
     if (b < np && a < np) dst[b * np + a] = t[tx][j];
   }
 }
-int gps_launch_tril_transpose_pad(gps_handle_t h, const double* src, i64 n, double* dst, i64 np) {
+int gps_launch_tril_pad(gps_handle_t h, const double* src, i64 n, double* dst, i64 np, double scale, int transpose) {
   if (np <= 0) return GPS_OK;
   LaunchScope ls(h, KC_OTHER, 0.0, 8.0 * (0.5 * n * n + (double)np * np));
   dim3 grid((unsigned)((np + 31) / 32), (unsigned)((np + 31) / 32));
-  hipLaunchKernelGGL(tril_transpose_pad_kernel, grid, dim3(256), 0, h->stream, src, n, dst, np);
+  if (transpose) hipLaunchKernelGGL(tril_pad_kernel<true>, grid, dim3(256), 0, h->stream, src, n, dst, np, scale);
+  else hipLaunchKernelGGL(tril_pad_kernel<false>, grid, dim3(256), 0, h->stream, src, n, dst, np, scale);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

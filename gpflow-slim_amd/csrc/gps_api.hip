@@ -1586,6 +1586,13 @@ static void kl_host_terms(const double* q_sqrt, int ndim, i64 m, i64 k, double* 
   *logdet_qcov = ld; *trace_white = tw;
 }
 
+// dst [mp, mp] (device) = scale * tril(Lq [m, m] host, row-major), transposed or not, zero elsewhere: through the staging buffer
+static int upload_tril(gps_handle_t h, const double* Lq, i64 m, double* dst, i64 mp, double scale, int transpose) {
+  GPS_HIP(h, h->dStage.ensure((size_t)mp * mp * 8));      // (padded size: the callers that bring a result back through it need that much)
+  GPS_HIP(h, hipMemcpyAsync(h->dStage.p, Lq, (size_t)m * m * 8, hipMemcpyHostToDevice, h->stream));
+  return gps_launch_tril_pad(h, h->dStage.d(), m, dst, mp, scale, transpose);
+}
+
 static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const double* q_sqrt,
                             int q_sqrt_ndim, int white, int full_cov, double* fmean_out,
                             double* fvar_out, int* info, SvgpAcc* sv = nullptr) {
@@ -1698,7 +1705,7 @@ static int conditional_tail(gps_handle_t h, CondIn& c, const double* f, const do
       GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
       const double* Lq = q_sqrt + (size_t)q * m * m;
       GPS_HIP(h, hipMemcpyAsync(dLTA, Lq, (size_t)m * m * 8, hipMemcpyHostToDevice, h->stream));
-      rc = gps_launch_tril_transpose_pad(h, dLTA, m, h->dTmp2.d(), mp);
+      rc = gps_launch_tril_pad(h, dLTA, m, h->dTmp2.d(), mp, 1.0, 1);
       if (rc) return rc;
       if (!full_cov) {
         // only the column sums of squares of L_q^T A are needed: form it as (L_q^T) A^T-transposed, [mp, nsp], with the
@@ -1994,16 +2001,24 @@ static int svgp_whiten(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
   std::vector<double> LT((size_t)mp * mp);
   GPS_HIP(h, h->dTmp2.ensure((size_t)mp * mp * 8));
   for (i64 q = 0; q < k; ++q) {
-    std::fill(LT.begin(), LT.end(), 0.0);
-    if (q_sqrt_ndim == 2) { for (i64 a = 0; a < m; ++a) LT[(size_t)a * mp + a] = q_sqrt[a * k + q]; }
-    else { const double* Lq = q_sqrt + (size_t)q * m * m; for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = Lq[a * m + b]; }
-    GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), LT.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (q_sqrt_ndim == 2) {
+      std::fill(LT.begin(), LT.end(), 0.0);
+      for (i64 a = 0; a < m; ++a) LT[(size_t)a * mp + a] = q_sqrt[a * k + q];
+      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), LT.size() * 8, hipMemcpyHostToDevice, h->stream));
+    } else {
+      rc = upload_tril(h, q_sqrt + (size_t)q * m * m, m, h->dTmp2.d(), mp, 1.0, 1);      // (transposed and padded on the device)
+      if (rc) return rc;
+    }
     rc = bl.trsm_rec(h->dK.d(), mp, mp, 0, h->dTmp2.d(), mp, mp);
     if (rc) return rc;
-    GPS_HIP(h, hipMemcpyAsync(LT.data(), h->dTmp2.p, LT.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    // back as rows of L_w,q: transposed on the device, read back in one sequential pass
+    GPS_HIP(h, h->dStage.ensure((size_t)mp * mp * 8));
+    rc = gps_launch_transpose(h, h->dTmp2.d(), mp, mp, mp, h->dStage.d(), mp);
+    if (rc) return rc;
+    GPS_HIP(h, hipMemcpyAsync(LT.data(), h->dStage.p, LT.size() * 8, hipMemcpyDeviceToHost, h->stream));
     GPS_HIP(h, hipStreamSynchronize(h->stream));
     double* out = Lw.data() + (size_t)q * m * m;
-    for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) out[a * m + b] = LT[(size_t)b * mp + a];
+    for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) out[a * m + b] = LT[(size_t)a * mp + b];
   }
   return GPS_OK;
 }
@@ -2139,14 +2154,13 @@ static int svgp_elbo_grad_body(gps_handle_t h, const gps_kern_node_t* prog, int 
     GPS_HIP(h, h->dG2.ensure((size_t)mp * mp * 8));
     double* Ssum = h->dG2.d();
     const double rs = sqrt(w / s2);
-    std::vector<double> LT((size_t)mp * mp), Ls((size_t)mp * mp), G((size_t)mp * mp);
+    std::vector<double> G((size_t)mp * mp);
     for (i64 q = 0; q < k; ++q) {
       const double* Lq = q_sqrt + (size_t)q * m * m;                  // C-ABI layout [k][m][m]
-      std::fill(LT.begin(), LT.end(), 0.0); std::fill(Ls.begin(), Ls.end(), 0.0);
-      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) { LT[(size_t)b * mp + a] = Lq[a * m + b]; Ls[(size_t)a * mp + b] = rs * Lq[a * m + b]; }
-      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
-      GPS_HIP(h, hipMemcpyAsync(h->dTmp.p, Ls.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
-      GPS_HIP(h, hipStreamSynchronize(h->stream));
+      // L_q^T and sqrt(w / s2) L_q, masked and padded on the device from one upload
+      rc = upload_tril(h, Lq, m, h->dTmp2.d(), mp, 1.0, 1);
+      if (!rc) rc = gps_launch_tril_pad(h, h->dStage.d(), m, h->dTmp.d(), mp, rs, 0);
+      if (rc) return rc;
       rc = gps_launch_gemm_nt(h, q == 0 ? 1 : 2, 0, mp, mp, mp, h->dTmp.d(), mp, h->dTmp.d(), mp, Ssum, mp);    // S (+)= (w/s2) L_q L_q^T
       if (rc) return rc;
       rc = gps_launch_gemm_nt(h, 1, 0, mp, mp, mp, AAT, mp, h->dTmp2.d(), mp, h->dG1.d(), mp);           // (A A^T) L_q
@@ -2387,11 +2401,9 @@ extern "C" int gps_gauss_kl(gps_handle_t h, const double* K, int64_t m, const do
     for (i64 j = 0; j < m; ++j) { double sq = 0.0; for (i64 q = 0; q < k; ++q) sq += q_sqrt[j * k + q] * q_sqrt[j * k + q]; trace += kd[j] * sq; }
   } else {
     trace = 0.0;
-    std::vector<double> LT((size_t)mp * mp);
     for (i64 q = 0; q < k; ++q) {
-      std::fill(LT.begin(), LT.end(), 0.0);
-      for (i64 a = 0; a < m; ++a) for (i64 b = 0; b <= a; ++b) LT[(size_t)b * mp + a] = q_sqrt[((size_t)q * m + a) * m + b];
-      GPS_HIP(h, hipMemcpyAsync(h->dTmp2.p, LT.data(), (size_t)mp * mp * 8, hipMemcpyHostToDevice, h->stream));
+      rc = upload_tril(h, q_sqrt + (size_t)q * m * m, m, h->dTmp2.d(), mp, 1.0, 1);
+      if (rc) return rc;
       double t = 0.0;
       rc = kl_full_one(h, bl, h->dS2.d(), mp, m, h->dTmp2.d(), &t);
       if (rc) return rc;

@@ -217,6 +217,7 @@ struct gps_handle_s {
   void* allreduce_ctx = nullptr;
   double* red_buf = nullptr;                   // caller-owned device buffer the collective library knows
   i64 red_cap = 0;
+  DevBuf dStage;    // a user matrix as uploaded (q_sqrt [m, m]) before a device kernel masks / transposes / pads it
   DevBuf dX;        // [n, d_all]
   DevBuf dK;        // [npad, npad]  K then L (lower, row-major)
   DevBuf dLinv;     // [npad/128][128*128] inverses of the diagonal blocks
@@ -442,7 +443,7 @@ int gps_tri_dot(gps_handle_t h, const double* A, i64 lda, const double* B, i64 l
 int gps_launch_dist_tail(gps_handle_t h, const double* partials64x2, const int* d_info, double* tail_msg, double* tail_own);
 int gps_launch_varexp(gps_handle_t h, const double* fmean, const double* yres, i64 k, int q, const double* base,
                       const double* extra, i64 n, double* partial64);
-int gps_launch_tril_transpose_pad(gps_handle_t h, const double* src, i64 n, double* dst, i64 np);
+int gps_launch_tril_pad(gps_handle_t h, const double* src, i64 n, double* dst, i64 np, double scale, int transpose);
 int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                          double* dst, i64 ldd);
 int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,

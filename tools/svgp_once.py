@@ -17,6 +17,11 @@ sv._q_mu.assign(q_mu); sv._q_sqrt.assign(q_sqrt)
 for i in range(4):
     t0 = time.perf_counter(); v = sv.compute_log_likelihood(); t1 = time.perf_counter()
     print("call %d: %.1f ms elbo %.6f" % (i, 1e3 * (t1 - t0), v))
+if "grad" in sys.argv:
+    for i in range(3):
+        t0 = time.perf_counter(); v, g = sv.compute_log_likelihood_and_gradients(); t1 = time.perf_counter()
+        print("bound + gradient call %d: %.1f ms" % (i, 1e3 * (t1 - t0)))
+    sys.exit(0)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); sv.compute_log_likelihood(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
