@@ -448,6 +448,13 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     inverses; 1: always.  "leaf_plain_kappa" (default 1000): in that mode a leaf whose diagonal block has
  *                     kappa_2 <= this (estimated per block after the factorisation) takes the plain product anyway -- its
  *                     error eps kappa(L_jj) kappa(L) stays a tenth below a backward-stable solve's; 0: refine every leaf
+ *   "trsm_panel"      1 (default): every 512-column node of a plain triangular solve is ONE launch (trsm_panel.hip); 0: down to
+ *                     128 columns launch by launch.  "trsm_panel_rows" 0 (default): 32 rows per workgroup and two workgroups per
+ *                     CU below 64 rows x the number of CUs, one persistent workgroup per CU above; 32 / 64 force one of them,
+ *                     65 = 64 rows per workgroup, not persistent (diagnostics)
+ *   "trsm_tall_ratio" 16 (default): a solve of m rows against n columns with m >= ratio * n (conditionals.py:87 at config 5's
+ *                     shape) goes over its 512-column panels left-looking -- one long-K update and one launch per panel;
+ *                     0: the recursive halving always
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always
