@@ -265,13 +265,27 @@ struct Blocked {
     unsigned long long pending = 0, pending2 = 0;
     bool forked = false, fforked = false;        // a hand-over to the side / follower stream has already happened in this sweep
     i64 fdone = 0;                               // columns of the follower solve issued so far
+    // How a solved piece meets the columns after it (Ops::follower_tail): 0 -- left-looking, every piece first takes one update
+    // with ALL columns before it (K = c_lo: the longest update comes last, and the chain waits for it when the sweep ends);
+    // 1 -- the LAST follower_cols() columns [ts, n) are kept up to date by every earlier piece as soon as it is solved;
+    // 2 -- right-looking throughout: a solved piece is applied to all columns after it at once (K = its width: the updates
+    // SHRINK towards the end of the sweep, and what is left for the chain is one 512-column solve).
+    const int fmode = fol ? ops.follower_tail() : 0;
+    const i64 ts = fmode == 2 ? 0 : ((fmode == 1 && n >= 2 * ops.follower_cols()) ? n - ops.follower_cols() : -1);
     auto follower_piece = [&](i64 c_lo, i64 c_hi) -> int {          // columns [c_lo, c_hi) of  X L^T = FB
       int rc = 0;
-      if (c_lo > 0) rc = ops.gemm(0, 0, fm, c_hi - c_lo, c_lo, FB, ldfb, A + c_lo * lda, lda, FB + c_lo, ldfb);
-      if (rc) return rc;
-      rc = trsm_rec(A + c_lo * lda + c_lo, lda, c_hi - c_lo, blk0 + c_lo / T, FB + c_lo, ldfb, fm);
-      if (rc || TR == nullptr) return rc;
-      return ops.gemm(0, 1, fm, tn, c_hi - c_lo, FB + c_lo, ldfb, FB + c_lo, ldfb, TR, ldt);
+      while (c_lo < c_hi && !rc) {
+        const i64 hi = (ts > c_lo && ts < c_hi) ? ts : c_hi;        // (a piece across the start of the last block: in two)
+        const i64 k0 = fmode == 2 ? c_lo : ((ts >= 0 && c_lo >= ts) ? ts : 0);     // columns [0, k0) have been applied to it already
+        if (c_lo > k0) rc = ops.gemm(0, 0, fm, hi - c_lo, c_lo - k0, FB + k0, ldfb, A + c_lo * lda + k0, lda, FB + c_lo, ldfb);
+        if (!rc) rc = trsm_rec(A + c_lo * lda + c_lo, lda, hi - c_lo, blk0 + c_lo / T, FB + c_lo, ldfb, fm);
+        if (!rc && TR != nullptr) rc = ops.gemm(0, 1, fm, tn, hi - c_lo, FB + c_lo, ldfb, FB + c_lo, ldfb, TR, ldt);
+        const i64 u0 = fmode == 2 ? hi : ((ts >= 0 && hi <= ts) ? ts : n);          // first column it is applied to right away
+        if (!rc && u0 < n)                                          // FB[:, u0:n] -= X[:, c_lo:hi] L[u0:n, c_lo:hi]^T
+          rc = ops.gemm(0, 0, fm, n - u0, hi - c_lo, FB + c_lo, ldfb, A + u0 * lda + c_lo, lda, FB + u0, ldfb);
+        c_lo = hi;
+      }
+      return rc;
     };
     auto finish = [&]() -> int {
       if (pending2) pending = pending2;          // (values grow: the later one covers the earlier)

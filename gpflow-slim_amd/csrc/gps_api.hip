@@ -188,6 +188,7 @@ struct HipOps {
   hipStream_t saved_stream_d = nullptr;
   bool follower() { return h->potrf_follower != 0 && lookahead() && aux_stream(); }
   i64 follower_cols() const { return h->potrf_follower_cols; }
+  int follower_tail() const { return h->potrf_follower_tail; }
   bool trail_follows() const { return h->potrf_trail_follows != 0; }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
@@ -677,6 +678,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
     return GPS_OK;
   }
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
+  if (strcmp(key, "potrf_follower_tail") == 0) { h->potrf_follower_tail = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }

@@ -435,7 +435,11 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "potrf_bulk"      0 (default) / bit 0, bit 1: cross-level look-ahead -- the rest of a trailing update / the first rows of a
  *                     panel solve on a stream of their own beside the sweeps (measured slower on MI355X: DESIGN.md section 0)
  *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
- *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512)
+ *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512); "potrf_follower_tail"
+ *                     2 (default): right-looking -- a solved piece is applied to all columns after it at once, so the
+ *                     updates shrink towards the end of the sweep and one 512-column solve is left for the chain; 1: only
+ *                     the last piece is kept up to date that way; 0: left-looking (every piece first takes one update
+ *                     with all columns before it: the longest update last)
  *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
  *                     child, which runs them on a third stream beside its second sweep
  *   "leaf_refine"     -1 (default): the 128-column leaves of the triangular solves are refined once against the factor's

@@ -13,6 +13,7 @@ static const i64 T = GPS_TILE;
 
 static i64 g_rl_group = 1;
 static int g_lookahead = 0;
+static int g_follower_tail = 2;   // emul_set_follower_tail: the follower's last block right-looking (blocked.hpp::potrf_rl_groups)
 static int g_tall = 0;        // emul_set_tall: solves of more than 512 columns panel by panel, left-looking (blocked.hpp::tall_panels)
 static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
@@ -137,6 +138,7 @@ struct CpuOps {
   int deferred_close() { if (!def_open) return -14; def_open = 0; def_unjoined = 1; return 0; }
   int deferred_join() { if (!def_unjoined) return -15; def_unjoined = 0; return 0; }
   i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
+  int follower_tail() const { return g_follower_tail; }
   bool trail_follows() const { return g_lookahead == 2; }        // (both forms of the trailing update are emulated)
   unsigned long long fol_pub = 0;
   // side sections: what they write stays "in flight" until the chain has joined the join value published after it (values
@@ -264,6 +266,7 @@ extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_leaf512(int v) { g_leaf512 = v; }
 void emul_set_tall(int v) { g_tall = v; }
+void emul_set_follower_tail(int v) { g_follower_tail = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
 void emul_set_fused(int v) { g_fused = v; }

@@ -120,6 +120,31 @@ def test_panel_sweep_matches_lapack(emul, n, nb, rl_max):
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,rl_max,la", [(1024, 512, 1), (1536, 512, 2), (2048, 1024, 1), (2048, 1024, 2), (2560, 1024, 2), (2048, 512, 2)])
+def test_follower_solve_left_or_right_looking(emul, n, rl_max, la, mode):
+    """blocked.hpp::potrf_rl_groups, Ops::follower_tail: the solve of the block below a swept diagonal block follows the sweep
+    piece by piece -- left-looking (0), with its last block kept up to date by every earlier piece (1), or right-looking
+    throughout (2).  Same factor in every mode (the block below IS part of it)."""
+    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
+    emul.emul_set_lookahead(la)
+    emul.emul_set_rl_group(ctypes.c_int64(2))
+    emul.emul_set_follower_tail(mode)
+    try:
+        rng = np.random.default_rng(n + mode)
+        G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
+        B = rng.standard_normal((128, n)); B2 = B.copy(); y = rng.standard_normal((1, n))
+        A0 = A.copy()
+        info = ctypes.c_int(0)
+        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        rc = emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
+    finally:
+        emul.emul_set_lookahead(0); emul.emul_set_follower_tail(2)
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A0, lower=True)
+    assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
+
+
 @pytest.mark.parametrize("n,rl_max", [(1536, 384), (1280, 256), (2048, 512)])
 def test_deferred_piece_of_the_parent_solve(emul, n, rl_max):
     """Nodes whose first half is itself a node with a swept first half hand the first part of their panel solve down
