@@ -116,6 +116,22 @@ struct HipOps {
   }
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B,
            i64 ldb, double* C, i64 ldc) {
+    // Beside a latency chain (the follower / deferred stream) a rectangular update goes out in launches of at most
+    // follower_max_wgs 128 x 128 tiles: a launch with more workgroups than the GPU holds keeps handing freed slots to its own
+    // waiting workgroups, and the chain's launches -- a few hundred short workgroups each -- queue behind them (measured,
+    // N = 8192: chain steps of 49 - 218 us beside the follower, 41 - 58 us without one).  With every workgroup of a launch
+    // resident at once the CUs drain towards its end and the chain gets them.
+    if (h->follower_max_wgs > 0 && op == 0 && !lower && h->def_stream && h->stream == h->def_stream && M >= 128 && N > 128) {
+      const i64 rows = (M + 127) / 128;
+      const i64 w = std::max<i64>(1, h->follower_max_wgs / rows) * 128;
+      if (w < N) {
+        for (i64 u = 0; u < N; u += w) {
+          const int rc = gps_launch_gemm_nt(h, op, lower, M, std::min(w, N - u), K, A, lda, B + u * ldb, ldb, C + u, ldc);
+          if (rc) return rc;
+        }
+        return GPS_OK;
+      }
+    }
     return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
   }
   int trsv_base(i64 blk, double* y, i64 ldy, i64 r, const double* D, i64 ldd) {
@@ -189,6 +205,7 @@ struct HipOps {
   bool follower() { return h->potrf_follower != 0 && lookahead() && aux_stream(); }
   i64 follower_cols() const { return h->potrf_follower_cols; }
   int follower_tail() const { return h->potrf_follower_tail; }
+
   bool trail_follows() const { return h->potrf_trail_follows != 0; }
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
@@ -679,6 +696,7 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   }
   if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_follower_tail") == 0) { h->potrf_follower_tail = (int)value; return GPS_OK; }
+  if (strcmp(key, "follower_max_wgs") == 0) { h->follower_max_wgs = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }

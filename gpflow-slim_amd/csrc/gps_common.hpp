@@ -160,6 +160,7 @@ struct gps_handle_s {
   long long la_retries = 0;                    // evaluations re-run that way (gps_profile_get "lookahead_retries")
   PinnedRing ring;
   int potrf_follower_cols = 512;               // ... in pieces of at least this many columns
+  int follower_max_wgs = 256;   // rectangular updates on the follower / deferred stream go out in launches of at most this many 128 x 128 tiles (0: whole): every workgroup resident at once, so the CUs drain towards the launch's end and the latency chain beside it gets them
   int potrf_follower_tail = 2; // how a solved piece of the follower meets the columns after it: 0 left-looking, 1 the last follower_cols columns kept up to date by every earlier piece, 2 right-looking throughout (blocked.hpp::potrf_rl_groups)
   int potrf_follower = 1;                      // the parent's panel solve follows the sweep on the side stream (blocked.hpp)
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt

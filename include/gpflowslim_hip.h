@@ -440,6 +440,9 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *                     updates shrink towards the end of the sweep and one 512-column solve is left for the chain; 1: only
  *                     the last piece is kept up to date that way; 0: left-looking (every piece first takes one update
  *                     with all columns before it: the longest update last)
+ *   "follower_max_wgs" 256 (default): rectangular updates on that second / third stream are launched in column chunks of at
+ *                     most this many 128 x 128 tiles, so that a launch never has workgroups waiting for a slot (which would
+ *                     keep taking the slots the chain's short launches need); 0: one launch per update
  *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
  *                     child, which runs them on a third stream beside its second sweep
  *   "leaf_refine"     -1 (default): the 128-column leaves of the triangular solves are refined once against the factor's
