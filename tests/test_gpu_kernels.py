@@ -675,6 +675,33 @@ def test_sweep_step_modes_agree_with_the_three_launch_sweep(handle, n, mode):
     assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(1.0, np.abs(a[1]).max()) and np.abs(a[2] - b[2]).max() <= 1e-10 * np.abs(a[2]).max()
 
 
+@pytest.mark.parametrize("n", [8192, 9000, 12288])
+def test_follower_solve_modes_agree(handle, n):
+    """The solve that follows a sweep on the second stream (blocked.hpp::potrf_rl_groups): left-looking, last block right-looking,
+    right-looking throughout (option "potrf_follower_tail" 0 / 1 / 2), and its updates whole or in launches of at most 256 / 64
+    tiles (option "follower_max_wgs"): same likelihood and predictions (the pieces are summed in another order: 1e-11), no
+    evaluation re-run without look-ahead -- sizes with one (8192), with a ragged (9000) and with two (12288) followed sweeps."""
+    import gpflowSlim as gpf
+    import oracle.gp_oracle as orc
+    X, Y, Xs = orc.synthetic_gpr_data(n, 6, 64, seed=n)
+    m = gpf.models.GPR(X, Y, gpf.kernels.RBF(6, lengthscales=2.0) + gpf.kernels.Matern32(6, variance=0.3, lengthscales=1.1), obs_var=0.07)
+    res = {}
+    try:
+        for tail, cap in ((0, 0), (1, 0), (2, 0), (2, 256), (2, 64), (0, 256)):
+            handle.set_option("potrf_follower_tail", tail); handle.set_option("follower_max_wgs", cap)
+            before = handle.profile_get("lookahead_retries")["launches"]
+            lml = m.compute_log_likelihood()
+            mu, var = m.predict_f(Xs)
+            res[(tail, cap)] = (lml, mu, var)
+            assert handle.profile_get("lookahead_retries")["launches"] == before
+    finally:
+        handle.set_option("potrf_follower_tail", 2); handle.set_option("follower_max_wgs", 256)
+    a = res[(0, 0)]
+    for key, b in res.items():
+        assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0]), key
+        assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(1.0, np.abs(a[1]).max()) and np.abs(a[2] - b[2]).max() <= 1e-10 * np.abs(a[2]).max(), key
+
+
 @pytest.mark.parametrize("n,mode", [(3000, 2), (5200, 2), (5200, 3)])
 def test_concurrent_sweep_step_launches(n, mode):
     """The one-launch sweep steps (option "potrf_fused_step"; csrc/small_n.hip::sweep_step_kernel: workgroups synchronised through
