@@ -60,10 +60,6 @@ struct GemmArgs {
   // Look-ahead hand-over (blocked.hpp::potrf_rl_groups): the first workgroup publishes sig_val at sig_ptr when the
   // kernel STARTS -- on an in-order stream that means "everything launched before this kernel has completed".
   unsigned long long* sig_ptr; unsigned long long sig_val;
-  // ... and the join the other way round: every workgroup waits (bounded; a time-out is counted at wait_timeouts and rejects
-  // the evaluation, as in la_wait_kernel) until *wait_ptr >= wait_val before it touches its operands -- the chain's wait for
-  // the side stream's remainder update without a launch of its own between two launches of the chain
-  const unsigned long long* wait_ptr; unsigned long long wait_val; unsigned long long* wait_timeouts;
   long long* stamps;  // diagnostics (gps_diag_gemm_timeline): [blockIdx][6] = start, end, HW_ID, XCC_ID, K loop start, K loop end (100 MHz ticks); else null
 };
 
@@ -178,21 +174,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   }
   if (g.sig_ptr && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(g.sig_ptr, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (g.wait_ptr) {
-    if (threadIdx.x == 0) {
-      const unsigned long long t0 = wall_clock64();
-      for (;;) {
-        if (__hip_atomic_load(g.wait_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= g.wait_val) break;
-        if (wall_clock64() - t0 > 100000000ull) {                     // 1 s at 100 MHz
-          if (blockIdx.x == 0) atomicAdd(g.wait_timeouts, 1ull);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-  }
   if (g.stamps && threadIdx.x == 0) {
     long long* st = g.stamps + 6 * (long long)blockIdx.x;
     st[0] = (long long)wall_clock64();
@@ -490,10 +471,8 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     if (ns > h->gemm_tail_max_slices) ns = h->gemm_tail_max_slices;
     while (ns > 1 && (g.K / BK_MIN) / ns < 8) --ns;           // at least 8 slabs (K = 128) per slice
     if (nfull >= slots && ns > 1) {
-      // (the bulk stream's GEMMs run beside the main stream's: a work space of their own)
-      const bool on_bulk = h->bulk_stream != nullptr && h->stream == h->bulk_stream;
-      DevBuf& ws = on_bulk ? h->dGemmWsB : h->dGemmWs;
-      DevBuf& cnt = on_bulk ? h->dGemmCntB : h->dGemmCnt;
+      DevBuf& ws = h->dGemmWs;
+      DevBuf& cnt = h->dGemmCnt;
       GPS_HIP(h, ws.ensure((size_t)r * ns * BM * BN * sizeof(double)));
       if (cnt.cap == 0) {
         GPS_HIP(h, cnt.ensure(512 * sizeof(unsigned)));
@@ -502,12 +481,12 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
       g.nfull = nfull; g.nsplit = ns; g.ws = ws.d(); g.cnt = (unsigned*)cnt.p;
     }
   }
-  // scheduled K loop (see the kernel) for the square 128x128 and 64x64 tiles; "gemm_pipe" = 0 keeps the compiler's order
+  // scheduled K loop (see the kernel) for the square 128x128 and 64x64 tiles
   constexpr int P = ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) ? 2 : 0;
-  if (P && h->gemm_pipe) return dispatch_ops<BM, BN, WGM, P>(h, op, lower, g);
-  // deeper K slabs for the latency-bound small tiles (when K allows it)
+  if (P) return dispatch_ops<BM, BN, WGM, P>(h, op, lower, g);
+  // deeper K slabs for the latency-bound small tiles (when K allows it): 32x32 tiles 64-deep, the 16/32 x 128 row panels 32-deep
   constexpr int DEEP = (BM == 32 && BN == 32) ? 64 : ((BN == 128 && BM <= 32) ? 32 : 16);
-  if (DEEP > 16 && h->gemm_deep_slabs && g.K % DEEP == 0) return dispatch_ops<BM, BN, WGM, 0, DEEP>(h, op, lower, g);
+  if (DEEP > 16 && g.K % DEEP == 0) return dispatch_ops<BM, BN, WGM, 0, DEEP>(h, op, lower, g);
   return dispatch_ops<BM, BN, WGM, 0>(h, op, lower, g);
 }
 
@@ -536,7 +515,6 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
   g.stamps = h->gemm_stamps;
   g.sig_ptr = h->next_sig_ptr; g.sig_val = h->next_sig_val; h->next_sig_ptr = nullptr;      // consumed by this launch
-  g.wait_ptr = h->next_wait_ptr; g.wait_val = h->next_wait_val; g.wait_timeouts = h->next_wait_timeouts; h->next_wait_ptr = nullptr;
   g.cb_tiles = 0; g.cb_stride = 0;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
@@ -585,7 +563,6 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
   GemmArgs g;
   g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;
   g.sig_ptr = nullptr; g.sig_val = 0;
-  g.wait_ptr = nullptr; g.wait_val = 0; g.wait_timeouts = nullptr;
   g.stamps = h->gemm_stamps;
   // needed 128x128 tiles: block b uses rows >= b*stride
   double t128 = 0.0;

@@ -20,75 +20,6 @@ struct HipOps {
                                  (linvT && store_T) ? linvT + blk * GPS_TILE * GPS_TILE : nullptr, d_info, row0,
                                  factor);
   }
-  // ---- one launch per 128 columns of the sweep (small_n.hip: sweep_step_kernel): the solve of the rows below block `blk`, the
-  // update of the next block column with the group's panels, and the next diagonal block's potrf_base
-  bool fused_step() { return h->potrf_fused_step != 0 && !h->refine_now && factor == 1 && h->prop.multiProcessorCount >= 160 && lookahead(); }
-  int step(i64 blk, double* B, i64 ldb, i64 m, i64 kprev, i64 row0_next) {
-    if (h->plain_linv == linv) h->plain_linv = nullptr;
-    double* ln = linv + (blk + 1) * GPS_TILE * GPS_TILE;
-    double* lt = (linvT && store_T) ? linvT + (blk + 1) * GPS_TILE * GPS_TILE : nullptr;
-    // "potrf_fused_step" = 3: solve + update as one lean launch (its workgroups share their CUs with the side streams' GEMMs),
-    // the next diagonal block by a potrf_base launch behind it; 1 / 2: all three in one launch of whole-CU workgroups
-    if (h->potrf_fused_step != 3) return gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, ln, lt, d_info, row0_next, factor, 1);
-    int rc = gps_launch_sweep_step(h, B, ldb, m, linv + blk * GPS_TILE * GPS_TILE, kprev, nullptr, nullptr, d_info, row0_next, factor, 0);
-    if (rc) return rc;
-    return gps_launch_potrf_base(h, B + GPS_TILE, ldb, ln, lt, d_info, row0_next, factor);
-  }
-  // The join with the side stream before a step whose next block column the side stream's last remainder update wrote: a wait
-  // launch in front of the step.  (Awaited INSIDE the step launch -- built, round 5 -- it deadlocks: the step's workgroups
-  // hold one CU each (150 KB of LDS) while they wait, and the update they wait for needs CUs to finish.)
-  int step_join(unsigned long long t) { return chain_join(t); }
-  // ... or carried by the step launched BEFORE the one that needs it: its chain workgroup awaits the value before it leaves
-  // (blocked.hpp: exit_join), so that no wait launch sits between two steps
-  bool step_exit_join() const { return h->potrf_fused_step == 2; }
-  int step_carry_join(unsigned long long v) {
-    if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) v = ~0ull;
-    h->next_wait_ptr = la_flags() + 1; h->next_wait_val = v; h->next_wait_timeouts = la_flags() + 2;
-    return GPS_OK;
-  }
-  bool two_stage_join() const { return h->potrf_two_stage_join != 0; }
-  // ---- forward substitution following the factorisation (blocked.hpp: YFollow): its own stream, ordered behind the
-  // calling stream by one event per section
-  hipStream_t saved_stream_y = nullptr;
-  bool y_follow() {
-    if (!h->trsv_follow || !lookahead()) return false;
-    if (!h->y_stream) {
-      hipError_t e;
-      if (h->prop.multiProcessorCount == 256) {
-        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        e = hipExtStreamCreateWithCUMask(&h->y_stream, 8, mask);
-      } else {
-        e = hipStreamCreateWithFlags(&h->y_stream, hipStreamNonBlocking);
-      }
-      if (e != hipSuccess) { h->y_stream = nullptr; return false; }
-      if (!h->ev_y_join && hipEventCreateWithFlags(&h->ev_y_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(h->y_stream); h->y_stream = nullptr; return false;
-      }
-    }
-    return true;
-  }
-  int y_open() {
-    if (h->y_event_next >= h->y_events.size()) {
-      hipEvent_t ev;
-      GPS_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      h->y_events.push_back(ev);
-    }
-    hipEvent_t ev = h->y_events[h->y_event_next++];
-    GPS_HIP(h, hipEventRecord(ev, h->stream));
-    GPS_HIP(h, hipStreamWaitEvent(h->y_stream, ev, 0));
-    saved_stream_y = h->stream; h->stream = h->y_stream;
-    return GPS_OK;
-  }
-  int y_close() { h->stream = saved_stream_y; saved_stream_y = nullptr; return GPS_OK; }
-  int y_prepare(i64 blk0, i64 nblk) {         // the vector leaves read the transposed block inverses
-    if (store_T || !linvT) return GPS_OK;
-    return gps_launch_transpose_blocks(h, linv + blk0 * GPS_TILE * GPS_TILE, linvT + blk0 * GPS_TILE * GPS_TILE, nblk);
-  }
-  int y_join() {                              // the calling stream waits for everything issued on the y stream
-    GPS_HIP(h, hipEventRecord(h->ev_y_join, h->y_stream));
-    GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_y_join, 0));
-    return GPS_OK;
-  }
   // B[m,128] = B * Linv[blk]^T  (transposed == 0)   or   B * Linv[blk]  (transposed == 1)
   // D: the diagonal block the leaf solves against (lower block of L, or the upper block of U = L^T when transposed)
   int trsm_base(i64 blk, int transposed, double* B, i64 ldb, i64 m, const double* D, i64 ldd) {
@@ -160,7 +91,7 @@ struct HipOps {
   i64 rl_max() const { return h->potrf_rl_max; }   // diagonal blocks up to this size: right-looking panel sweep
   i64 rl_group() const { return h->potrf_rl_group; }
   // ---- look-ahead of the sweep (see blocked.hpp::potrf_rl_groups)
-  i64 lookahead_min_rows() const { return h->potrf_lookahead_min; }
+  i64 lookahead_min_rows() const { return 1024; }   // rows of the remainder from which the hand-over pays
   bool lookahead() {
     // never on an external stream (gps_set_stream): that may be the legacy default stream, which synchronises
     // implicitly with a blocking side stream -- the hand-over would wait on itself
@@ -170,7 +101,7 @@ struct HipOps {
       // CU's LDS, and a GEMM that keeps refilling every CU with small workgroups would starve it until its own tail.
       hipError_t e;
       if (h->prop.multiProcessorCount == 256) {
-        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const uint32_t mask[8] = {GPS_LA_MASK_WORD0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         e = hipExtStreamCreateWithCUMask(&h->side_stream, 8, mask);
       } else {
         e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
@@ -202,11 +133,8 @@ struct HipOps {
   }
   hipStream_t saved_stream = nullptr;
   hipStream_t saved_stream_d = nullptr;
-  bool follower() { return h->potrf_follower != 0 && lookahead() && aux_stream(); }
-  i64 follower_cols() const { return h->potrf_follower_cols; }
-  int follower_tail() const { return h->potrf_follower_tail; }
-
-  bool trail_follows() const { return h->potrf_trail_follows != 0; }
+  bool follower() { return lookahead() && aux_stream(); }
+  i64 follower_cols() const { return 512; }         // the follower solve goes out in pieces of at least this many columns
   // `first`: first hand-over of a sweep.  The side stream is then idle and its wait kernel would start at once and spin
   // until the chain gets here -- through whole big GEMMs of the level above, where one extra resident wave costs a CU
   // its second GEMM workgroup (measured: every big launch 4-10 % slower).  An event keeps the queue parked instead;
@@ -245,12 +173,12 @@ struct HipOps {
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 3, h->fol_ticket, la_flags() + 2);
   }
   // ---- deferred stream: big pieces of a parent's panel solve that run beside a child's sweep (coarse: events)
-  bool deferred() { return h->potrf_deferred != 0 && lookahead() && aux_stream(); }
+  bool deferred() { return lookahead() && aux_stream(); }
   bool aux_stream() {
     if (!h->def_stream) {
       hipError_t e;
       if (h->prop.multiProcessorCount == 256) {
-        const uint32_t mask[8] = {h->la_mask_word0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const uint32_t mask[8] = {GPS_LA_MASK_WORD0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         e = hipExtStreamCreateWithCUMask(&h->def_stream, 8, mask);
       } else {
         e = hipStreamCreateWithFlags(&h->def_stream, hipStreamNonBlocking);
@@ -282,80 +210,11 @@ struct HipOps {
     GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_def_join, 0));
     return GPS_OK;
   }
-  // ---- bulk stream: cross-level look-ahead (blocked.hpp: pieces (a) and (b)); coarse (milliseconds of GEMM work): events
-  bool bulk_busy = false;
-  hipStream_t saved_stream_b = nullptr;
-  bool bulk() {
-    if (!h->potrf_bulk || bulk_busy || !lookahead()) return false;
-    if (!h->bulk_stream) {
-      hipError_t e;
-      if (h->potrf_bulk_prio) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // (lo: numerically greatest = least urgent)
-        e = hipStreamCreateWithPriority(&h->bulk_stream, hipStreamNonBlocking, lo);
-      } else if (h->prop.multiProcessorCount == 256) {
-        // (mask word w = CUs 4 w .. 4 w + 3 of every XCD, one per shader engine: the chain's kernels are dealt out over all XCDs
-        // and must find free CUs in each of them)
-        uint32_t mask[8];
-        for (int w = 0; w < 8; ++w) mask[w] = (w < h->potrf_bulk_reserve) ? 0u : 0xffffffffu;
-        e = hipExtStreamCreateWithCUMask(&h->bulk_stream, 8, mask);
-      } else {
-        e = hipStreamCreateWithFlags(&h->bulk_stream, hipStreamNonBlocking);
-      }
-      if (e != hipSuccess) { h->bulk_stream = nullptr; return false; }
-      if ((!h->ev_bulk_fork && hipEventCreateWithFlags(&h->ev_bulk_fork, hipEventDisableTiming) != hipSuccess) ||
-          (!h->ev_bulk_join && hipEventCreateWithFlags(&h->ev_bulk_join, hipEventDisableTiming) != hipSuccess)) {
-        (void)hipStreamDestroy(h->bulk_stream);
-        h->bulk_stream = nullptr;
-        return false;
-      }
-    }
-    if (h->bulk_pending) {
-      // a piece an earlier call left behind (it returned early with an error): nothing of this call may overtake it
-      if (hipStreamSynchronize(h->bulk_stream) != hipSuccess) return false;
-      h->bulk_pending = false;
-    }
-    return true;
-  }
-  bool bulk_rest() { return (h->potrf_bulk & 1) && bulk(); }     // piece (a)
-  i64 bulk_chunk(i64 k) const { return (h->potrf_bulk_kc >= 128 && h->potrf_bulk_kc < k) ? (i64)h->potrf_bulk_kc : k; }
-  i64 bulk_rows(i64 n1a, i64 m) {            // rows of a (b) piece: potrf_bulk_flop of GEMM work, whole tiles
-    if (!(h->potrf_bulk & 2) || !bulk()) return 0;
-    i64 rows = (i64)(h->potrf_bulk_flop / ((double)n1a * (double)n1a)) / GPS_TILE * GPS_TILE;
-    if (rows < 4 * GPS_TILE) rows = 4 * GPS_TILE;
-    return rows < m ? rows : m;
-  }
-  int bulk_open() {
-    GPS_HIP(h, hipEventRecord(h->ev_bulk_fork, h->stream));
-    GPS_HIP(h, hipStreamWaitEvent(h->bulk_stream, h->ev_bulk_fork, 0));
-    saved_stream_b = h->stream; h->stream = h->bulk_stream;
-    bulk_busy = true; h->bulk_pending = true;
-    return GPS_OK;
-  }
-  int bulk_close() {
-    hipError_t e = hipEventRecord(h->ev_bulk_join, h->bulk_stream);
-    h->stream = saved_stream_b; saved_stream_b = nullptr;
-    GPS_HIP(h, e);
-    return GPS_OK;
-  }
-  int bulk_join() {
-    GPS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_bulk_join, 0));
-    bulk_busy = false; h->bulk_pending = false;
-    return GPS_OK;
-  }
   int chain_join(unsigned long long t) {
     // diagnostics ("la_fault_inject" = k): the k-th join from now waits for a ticket that never comes, i.e. takes the
     // time-out path of a missed hand-over (tests/test_gpu_kernels.py::test_lookahead_timeout_is_retried)
     if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) t = ~0ull;
     return gps_launch_la_wait(h, h->stream, nullptr, 0, la_flags() + 1, t, la_flags() + 2);
-  }
-  // the same join carried by the GEMM launched next on the chain (the caller guarantees that the next launch IS one): its
-  // workgroups wait for the ticket themselves -- one launch less between two potrf_base calls on every other step
-  int chain_join_next_gemm(unsigned long long t) {
-    if (!h->la_fused_join) return chain_join(t);
-    if (h->la_fault_inject > 0 && --h->la_fault_inject == 0) t = ~0ull;
-    h->next_wait_ptr = la_flags() + 1; h->next_wait_val = t; h->next_wait_timeouts = la_flags() + 2;
-    return GPS_OK;
   }
   bool fill_zeros() const { return false; }     // nothing on the device path reads L^-T below its diagonal blocks
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
@@ -400,20 +259,10 @@ static int read_info(gps_handle_t h, int* d_info, int* info) {
     return gps_fail(h, GPS_ERR_STATE, "trsv wavefront timed out (result invalid)");
   }
   if (la_timeouts) {
-    if (getenv("GPS_STEP_DEBUG") && h->dStepSync.p) {      // diagnostics: where the one-launch sweep steps stand
-      unsigned long long c[40];
-      (void)hipDeviceSynchronize();
-      (void)hipMemcpy(c, h->dStepSync.p, sizeof(c), hipMemcpyDeviceToHost);
-      unsigned long long f[4] = {0, 0, 0, 0};
-      (void)hipMemcpy(f, h->dLaFlags.p, sizeof(f), hipMemcpyDeviceToHost);
-      fprintf(stderr, "time-outs %llu | step counters: abort %llu  Q %llu (%llu)  XN %llu (%llu)  DN %llu (%llu)  SD %llu (%llu) | la flags: fork %llu (host %llu) join %llu follower %llu (host %llu)\n",
-              la_timeouts, c[0], c[8], h->step_q, c[16], h->step_xn, c[24], h->step_dn, c[32], h->step_sd, f[0], h->la_ticket, f[1], f[3], h->fol_ticket);
-    }
     // not sticky: the counter is cleared (stream-ordered) so that the handle is usable again; the entry point re-runs
     // the evaluation once without look-ahead (with_la_retry)
     (void)hipMemsetAsync((unsigned long long*)h->dLaFlags.p + 2, 0, 8, h->stream);
     h->la_timed_out = true;
-    h->step_dirty = true;               // (the one-launch sweep steps count their time-outs there too: their counters start over)
     return gps_fail(h, GPS_ERR_STATE, "look-ahead hand-over timed out (result invalid)");
   }
   return GPS_OK;
@@ -462,7 +311,7 @@ static int classify_blocks(gps_handle_t h, const HipOps& ops, const double* L, i
 static int gpr_lml_finish(gps_handle_t h, i64 r, double* lml);
 // a cooperative launch of the small-N path gave up: counted; the fourth in a row sends the handle's next 256 evaluations of
 // that size launch by launch (a GPU shared with something that holds its CUs must not cost a bounded wait per optimiser step;
-// option "small_cooldown" reads / sets what is left of the back-off)
+// gps_profile_get "small_n_cooldown" reads what is left of the back-off)
 static void small_gave_up(gps_handle_t h) {
   h->small_fallbacks++;
   if (++h->small_consec >= 4) { h->small_cooldown = 256; h->small_consec = 0; }
@@ -491,17 +340,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   for (int i = 0; i < 8; ++i) {
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   }
-  if (const char* m0 = getenv("GPS_LA_MASK0")) h->la_mask_word0 = (uint32_t)strtoul(m0, nullptr, 0);     // diagnostics
-  if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);                           // diagnostics
-  if (const char* v = getenv("GPS_BULK")) h->potrf_bulk = atoi(v);                                       // diagnostics
-  if (const char* v = getenv("GPS_FUSED_STEP")) h->potrf_fused_step = atoi(v);                           // diagnostics
-  if (const char* v = getenv("GPS_BULK_RESERVE")) h->potrf_bulk_reserve = atoi(v);                       // diagnostics
-  if (const char* v = getenv("GPS_BULK_KC")) h->potrf_bulk_kc = atoi(v);                                 // diagnostics
-  if (const char* v = getenv("GPS_BULK_PRIO")) h->potrf_bulk_prio = atoi(v);                             // diagnostics
-  if (const char* v = getenv("GPS_TRSV_WAVE")) h->trsv_wave = atoi(v);                                   // (same switches as
-  if (const char* v = getenv("GPS_LEAF_PERSISTENT")) h->leaf_persistent = atoi(v);                       //  gps_set_option,
-  if (const char* v = getenv("GPS_SMALL_N")) h->small_n = atoi(v);
-  if (const char* v = getenv("GPS_KMAT_FAST")) h->kmat_fast = atoi(v);                                   //  for a whole run)
+  if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);     // diagnostics: counter collection serialises the dispatches (tools/collect_profiles.sh)
   if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   *out = h;
   return GPS_OK;
@@ -511,7 +350,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
 static void release_work_buffers(gps_handle_t h, bool all) {
   DevBuf* bufs[] = {&h->dX, &h->dK, &h->dLinv, &h->dAlpha, &h->dFeat, &h->dFeat2, &h->dProg,
                     &h->dXnew, &h->dB, &h->dMean, &h->dVar, &h->dTmp, &h->dTmp2, &h->dTmp3, &h->dA, &h->dY,
-                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dGemmWsB, &h->dGemmCntB, &h->dStepSync, &h->dStepScratch, &h->dBlkCond,
+                    &h->dKinv, &h->dNkn, &h->dS1, &h->dS2, &h->dS3, &h->dS4, &h->dGemvWs, &h->dGemvCnt, &h->dGemmWs, &h->dGemmCnt, &h->dBlkCond, &h->dStage,
                     &h->dDistScal, &h->dGradSums, &h->dSmallOut, &h->dFeatG, &h->dG1, &h->dG2, &h->dG3, &h->dG4, &h->dWave, &h->dDistComm[0], &h->dDistComm[1], &h->dDistComm[2]};
   for (DevBuf* b : bufs) b->release();
   if (all) h->dSmallSync.release();
@@ -527,8 +366,6 @@ extern "C" int gps_release_buffers(gps_handle_t h) {
   GPS_HIP(h, hipStreamSynchronize(h->stream));
   if (h->side_stream) GPS_HIP(h, hipStreamSynchronize(h->side_stream));
   if (h->def_stream) GPS_HIP(h, hipStreamSynchronize(h->def_stream));
-  if (h->bulk_stream) GPS_HIP(h, hipStreamSynchronize(h->bulk_stream));
-  if (h->y_stream) GPS_HIP(h, hipStreamSynchronize(h->y_stream));
   gps_profile_collect(h);
   release_work_buffers(h, false);
   h->have_factor = false; h->dist_have_part_factor = false; h->n = 0; h->npad = 0; h->r = 0;
@@ -548,17 +385,11 @@ extern "C" int gps_destroy(gps_handle_t h) {
   (void)hipStreamDestroy(h->ext_stream ? h->own_stream : h->stream);
   if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
   if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); }
-  if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); }
-  if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); }
   if (h->dist_chain) { (void)hipStreamSynchronize(h->dist_chain); (void)hipStreamDestroy(h->dist_chain); }
   if (h->dist_bulk_own) { (void)hipStreamSynchronize(h->dist_bulk_own); (void)hipStreamDestroy(h->dist_bulk_own); }
   for (auto e : h->dist_events) (void)hipEventDestroy(e);
-  for (auto e : h->y_events) (void)hipEventDestroy(e);
-  if (h->ev_y_join) (void)hipEventDestroy(h->ev_y_join);
   if (h->ev_def_fork) (void)hipEventDestroy(h->ev_def_fork);
   if (h->ev_def_join) (void)hipEventDestroy(h->ev_def_join);
-  if (h->ev_bulk_fork) (void)hipEventDestroy(h->ev_bulk_fork);
-  if (h->ev_bulk_join) (void)hipEventDestroy(h->ev_bulk_join);
   h->dLaFlags.release();
   h->ring.release();
   if (h->hRes) (void)hipHostFree(h->hRes);
@@ -648,21 +479,13 @@ extern "C" int gps_last_stage_ms(gps_handle_t h, double* out5) {
 
 extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (!h || !key) return GPS_ERR_ARG;
-  if (strcmp(key, "gemm_min_tiles") == 0) { h->gemm_min_tiles = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_force_tile") == 0) { h->gemm_force_tb = (int)value; return GPS_OK; }
-  if (strcmp(key, "gemm_deep_slabs") == 0) { h->gemm_deep_slabs = (int)value; return GPS_OK; }
-  if (strcmp(key, "gemm_pipe") == 0) { h->gemm_pipe = (int)value; return GPS_OK; }
   if (strcmp(key, "gemm_tail_split") == 0) { h->gemm_tail_split = (int)value; return GPS_OK; }
-  if (strcmp(key, "gemm_tail_max_slices") == 0) { h->gemm_tail_max_slices = (int)value < 1 ? 1 : ((int)value > 64 ? 64 : (int)value); return GPS_OK; }
   if (strcmp(key, "kmat_fast") == 0) { h->kmat_fast = (int)value; return GPS_OK; }
   if (strcmp(key, "kmat_mfma") == 0) { h->kmat_mfma = (int)value; return GPS_OK; }
-  if (strcmp(key, "trsv_follow") == 0) { h->trsv_follow = (int)value; return GPS_OK; }
   if (strcmp(key, "trsv_wave") == 0) { h->trsv_wave = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_trail_follows") == 0) { h->potrf_trail_follows = (int)value; return GPS_OK; }
-  if (strcmp(key, "leaf_persistent") == 0) { h->leaf_persistent = (int)value; return GPS_OK; }
   if (strcmp(key, "gpr_aug_rows") == 0) { h->gpr_aug_rows = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_refine") == 0) { h->leaf_refine = (int)value; return GPS_OK; }
-  if (strcmp(key, "leaf_refine_cond") == 0) { h->leaf_refine_cond = value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_max") == 0) { h->potrf_rl_max = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_lookahead") == 0) { h->potrf_lookahead = (int)value; return GPS_OK; }
   if (strcmp(key, "la_fault_inject") == 0) { h->la_fault_inject = (int)value; return GPS_OK; }
@@ -670,42 +493,11 @@ extern "C" int gps_set_option(gps_handle_t h, const char* key, double value) {
   if (strcmp(key, "small_fault_inject") == 0) { h->small_fault_inject = (int)value; return GPS_OK; }
   if (strcmp(key, "svgp_kl_weight") == 0) { h->svgp_kl_weight = value; return GPS_OK; }
   if (strcmp(key, "dist_partitioned") == 0) { h->dist_partitioned = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_follower") == 0) { h->potrf_follower = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_deferred") == 0) { h->potrf_deferred = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_bulk") == 0) { h->potrf_bulk = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_fused_step") == 0) { h->potrf_fused_step = (int)value; return GPS_OK; }
   if (strcmp(key, "leaf_plain_kappa") == 0) { h->leaf_plain_kappa = value; h->plain_linv = nullptr; return GPS_OK; }
-  if (strcmp(key, "potrf_step_helpers") == 0) { h->potrf_step_helpers = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_two_stage_join") == 0) { h->potrf_two_stage_join = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_bulk_flop") == 0) { h->potrf_bulk_flop = value; return GPS_OK; }
-  if (strcmp(key, "potrf_bulk_reserve") == 0) {   // takes effect when the bulk stream is (re)created
-    const int v = (int)value < 1 ? 1 : ((int)value > 6 ? 6 : (int)value);
-    if (v == h->potrf_bulk_reserve) return GPS_OK;
-    h->potrf_bulk_reserve = v;
-    if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; h->bulk_pending = false; }
-    return GPS_OK;
-  }
-  if (strcmp(key, "la_mask_word0") == 0) {        // diagnostics: takes effect when the side / deferred streams are (re)created
-    if (h->la_mask_word0 == (uint32_t)value) return GPS_OK;
-    h->la_mask_word0 = (uint32_t)value;
-    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
-    if (h->def_stream) { (void)hipStreamSynchronize(h->def_stream); (void)hipStreamDestroy(h->def_stream); h->def_stream = nullptr; }
-    if (h->bulk_stream) { (void)hipStreamSynchronize(h->bulk_stream); (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; h->bulk_pending = false; }
-    if (h->y_stream) { (void)hipStreamSynchronize(h->y_stream); (void)hipStreamDestroy(h->y_stream); h->y_stream = nullptr; }
-    return GPS_OK;
-  }
-  if (strcmp(key, "potrf_follower_cols") == 0) { h->potrf_follower_cols = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_follower_tail") == 0) { h->potrf_follower_tail = (int)value; return GPS_OK; }
   if (strcmp(key, "follower_max_wgs") == 0) { h->follower_max_wgs = (int)value; return GPS_OK; }
-  if (strcmp(key, "potrf_lookahead_min") == 0) { h->potrf_lookahead_min = (int)value; return GPS_OK; }
   if (strcmp(key, "potrf_rl_group") == 0) { h->potrf_rl_group = (int)value < 1 ? 1 : (int)value; return GPS_OK; }
   if (strcmp(key, "small_n") == 0) { h->small_n = (int)value; return GPS_OK; }
-  if (strcmp(key, "small_cooldown") == 0) { h->small_cooldown = (int)value; h->small_consec = 0; return GPS_OK; }
-  if (strcmp(key, "small_kgen") == 0) { h->small_kgen = (int)value; return GPS_OK; }
-  if (strcmp(key, "small_n_max") == 0) { h->small_n_max = (i64)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel") == 0) { h->trsm_panel = (int)value; return GPS_OK; }
-  if (strcmp(key, "resid_ring_max") == 0) { h->resid_ring_max = (long long)value; return GPS_OK; }
-  if (strcmp(key, "la_fused_join") == 0) { h->la_fused_join = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_tall_ratio") == 0) { h->trsm_tall_ratio = (int)value; return GPS_OK; }
   if (strcmp(key, "trsm_panel_rows") == 0) {
     if (value != 0 && value != 32 && value != 64 && value != 65) return gps_fail(h, GPS_ERR_ARG, "trsm_panel_rows: 0, 32, 64 or 65");
@@ -1114,8 +906,8 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // of trsv.  Against the one-launch wavefront substitution (trsv_wave.hip: 0.28 ms at N = 8192, 1.2 ms at 32768, where the
   // recursive one took 0.62 / 3.2 ms) the augmented rows still win up to N = 4096 (-3 %), lose from 8192 on (+1.5 %) and
   // tie at 12288.  Hence automatic (-1): on below 6200 points.  (The block-column multi-GPU path always uses it.)
-  // "trsv_follow" (also off): the recursive substitution issued block by block behind the factorisation on a stream of
-  // its own -- measured far worse still (see gps_common.hpp).
+  // (The recursive substitution issued block by block behind the factorisation on a stream of its own was measured far worse
+  // still -- round 2, docs/LAB_NOTES.md -- and is gone.)
   const bool aug = r > 0 && r <= GPS_TILE && (h->gpr_aug_rows > 0 || (h->gpr_aug_rows < 0 && np < 6200));
   GPS_HIP(h, h->dK.ensure((size_t)(np + GPS_TILE) * np * 8));
   double* const dAug = h->dK.d() + np * np;
@@ -1144,7 +936,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   // (small path, one stationary primitive: the cooperative launch generates K itself -- no kernel-matrix launches at all)
   SmallKgen kg;
   const int op0 = n_nodes == 1 ? prog[0].op : -1;
-  if (small && h->small_n >= 1 && h->small_kgen && (op0 == GPS_K_RBF || op0 == GPS_K_MATERN12 || op0 == GPS_K_MATERN32 || op0 == GPS_K_MATERN52 ||
+  if (small && h->small_n >= 1 && (op0 == GPS_K_RBF || op0 == GPS_K_MATERN12 || op0 == GPS_K_MATERN32 || op0 == GPS_K_MATERN52 ||
       op0 == GPS_K_EXPONENTIAL) && prog[0].n_dims >= 1 && prog[0].n_dims <= 16 && prog[0].variance > 0.0) {
     kg.on = 1; kg.op = op0; kg.X = h->dX.d(); kg.d_all = (int)h->d_all; kg.nd = prog[0].n_dims; kg.variance = prog[0].variance; kg.noise = noise_var;
     for (int d = 0; d < 16; ++d) { kg.dims[d] = 0; kg.inv_ls[d] = 0.0; }
@@ -1220,21 +1012,15 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   rc = gps_launch_fill_info(h, d_info, INT_MAX);
   if (rc) return rc;
   HipOps ops{h, h->dLinv.d(), h->dLinv.d() + (np / GPS_TILE) * GPS_TILE * GPS_TILE, d_info};
-  bool followed = false;
   {
     // the factorisation itself only needs the block inverses; their transposes (for the vector solves) are produced
     // by batched launches off the critical path rather than by 128 KB of extra stores in every potrf_base.
-    // (Option "trsv_follow": alpha = L^-1 (Y - m) follows the factorisation block by block on a stream of its own.)
     HipOps fops = ops;
     fops.store_T = false;
     Blocked<HipOps> fbl(fops);
-    followed = !aug && r > 0 && fops.y_follow();
-    Blocked<HipOps>::YFollow yf{h->dAlpha.d(), np, r};
-    h->y_event_next = 0;
-    rc = fbl.potrf_rec(h->dK.d(), np, np, 0, 0, nullptr, aug ? (i64)GPS_TILE : 0, followed ? &yf : nullptr);
+    rc = fbl.potrf_rec(h->dK.d(), np, np, 0, 0, nullptr, aug ? (i64)GPS_TILE : 0);
     if (rc) return rc;
-    if (followed) rc = fops.y_join();
-    else rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
+    rc = gps_launch_transpose_blocks(h, ops.linv, ops.linvT, np / GPS_TILE);
     if (rc) return rc;
     if (h->refine_now) { rc = classify_blocks(h, ops, h->dK.d(), np, np); if (rc) return rc; }      // (low noise: the predictions' solves)
   }
@@ -1242,7 +1028,7 @@ static int gpr_factor(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes, 
   GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   if (aug) {
     GPS_HIP(h, hipMemcpyAsync(h->dAlpha.p, dAug, (size_t)r * np * 8, hipMemcpyDeviceToDevice, h->stream));
-  } else if (r > 0 && !followed) {
+  } else if (r > 0) {
     rc = trsv_forward(h, ops, h->dK.d(), np, np, h->dAlpha.d(), np, r);
     if (rc) return rc;
   }
@@ -2483,16 +2269,6 @@ extern "C" int gps_set_stream(gps_handle_t h, void* hip_stream, int external) {
       (void)hipStreamSynchronize(h->def_stream);
       (void)hipStreamDestroy(h->def_stream);
       h->def_stream = nullptr;
-    }
-    if (h->y_stream) {
-      (void)hipStreamSynchronize(h->y_stream);
-      (void)hipStreamDestroy(h->y_stream);
-      h->y_stream = nullptr;
-    }
-    if (h->bulk_stream) {
-      (void)hipStreamSynchronize(h->bulk_stream);
-      (void)hipStreamDestroy(h->bulk_stream);
-      h->bulk_stream = nullptr; h->bulk_pending = false;
     }
   } else if (h->ext_stream) {
     h->stream = h->own_stream; h->ext_stream = false;

@@ -96,55 +96,22 @@ struct gps_handle_s {
 
   // GEMM tile selection (gemm_f64.hip): use the next smaller tile while the grid would have
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
-  int gemm_min_tiles = 512;
+  int gemm_min_tiles = 512;    // (constant)
   int gemm_force_tb = 0;
-  int gemm_deep_slabs = 1;     // 32x32 tiles use 64-deep K slabs, the 16/32 x 128 row panels 32-deep ones
-  int gemm_pipe = 1;           // scheduled K loop of the square 128x128 / 64x64 tiles (0: the compiler's order)
   // look-ahead of the sweep (potrf_rl_groups): the remainder update of a pair of panels runs on side_stream (one CU per
   // XCD left free for potrf_base) and is handed over through two monotone device counters instead of events
   int potrf_lookahead = 1;
-  int potrf_lookahead_min = 1024;              // rows of that remainder from which the hand-over pays
   hipStream_t side_stream = nullptr;
   hipStream_t def_stream = nullptr;            // deferred pieces of a parent's panel solve (blocked.hpp: Deferred)
   hipEvent_t ev_def_fork = nullptr, ev_def_join = nullptr;
-  int potrf_deferred = 1;
-  // cross-level look-ahead (blocked.hpp: "bulk" pieces (a) and (b)): a CU-masked, event-ordered stream of its own; one piece
-  // in flight at a time.  potrf_bulk: bit 0 = (a) the rest of a trailing update beside the child's first half, bit 1 = (b) the
-  // first rows of a panel solve beside the last sweep of the first half; potrf_bulk_flop: GEMM work of a (b) piece.
-  // OFF: built, correct (CPU emulation with a region race detector, same LML on the GPU) and measured slower in every form
-  // tried on MI355X -- N = 32768, same-process A/B, potrf stage: 180.2 -> 183.3 (a) / 181.5 (b) / 184.5 ms (both); with 8 / 12 /
-  // 16 / 24 CUs of every XCD kept from the bulk stream: +2.2 .. +43 ms; pieces cut into K = 256 .. 2048 launches on a
-  // lowest-priority un-masked stream: +1.5 .. +4.5 ms.  The kernel trace shows why: the chain's own launches keep their pace
-  // beside a resident GEMM (potrf_base 30 us, panel solve 19, block column 24 against 18), but every launch of the sweep's
-  // side and follower streams waits for workgroups of the bulk GEMM to retire (they live 3.5 ms at K = 16384) or shares its
-  // CUs: remainder updates 65 -> 480 us, follower pieces 2 x; and a potrf(8192) window already holds 4.5 ms of GEMM work in
-  // its 8.4 ms, so a static split of the CUs cannot pay either (docs/LAB_NOTES.md, round 5).
-  hipStream_t bulk_stream = nullptr;
-  hipEvent_t ev_bulk_fork = nullptr, ev_bulk_join = nullptr;
-  bool bulk_pending = false;                   // a piece has been issued and not yet joined
-  int potrf_bulk = 0;
-  int potrf_bulk_kc = 0;                       // K chunk of a piece (a)'s launches (0: one launch)
-  int potrf_bulk_prio = 0;                     // 1: the bulk stream is an un-masked stream of the lowest priority instead of a CU-masked one
-  int potrf_bulk_reserve = 2;                  // CU-mask words (4 CUs of every XCD each) the bulk stream leaves to the chain
-  double potrf_bulk_flop = 1.2e11;
-  DevBuf dGemmWsB, dGemmCntB;                  // the tail split's work space of GEMMs on the bulk stream (they run beside the main stream's)
-  // forward substitution of gps_gpr_lml following the factorisation on a stream of its own (blocked.hpp: YFollow).
-  // Off: measured on MI355X, ~500 small kernels dribbling in beside the 128x128 GEMM rounds (which own every register of
-  // a CU) cost the factorisation far more than the 3 ms they hide (N = 32768: 189 -> 231 ms, N = 8192: 6.4 -> 8.4 ms).
-  int potrf_trail_follows = 0;   // the trailing update behind a swept first half applied piece by piece behind the sweep (blocked.hpp): measured, loses
-  int leaf_persistent = 1;       // refined solve leaves: resident workgroups walk the row tiles (trsm_leaf.hip)
-  int trsv_follow = 0;
   int trsv_wave = 1;             // vector solves as one wavefront launch (trsv_wave.hip); 0: recursive trsv of blocked.hpp
   int trsv_wave_refine = 1;      // ... also where the leaves are refined (one refinement step per block inside the wavefront); 0: the recursion with refined leaves
   unsigned long long wave_fallbacks = 0;
-  hipStream_t y_stream = nullptr;
-  std::vector<hipEvent_t> y_events; size_t y_event_next = 0;
-  hipEvent_t ev_y_join = nullptr;
   // CU mask word 0 of the side / deferred streams (bit i = CU i/8 of XCD i%8; CU c sits in shader engine c%4): 0 keeps
   // one CU per shader engine per XCD free (32 CUs).  With only one per XCD (0xffffff00) a potrf_base workgroup that the
   // dispatcher steers to another shader engine waits there for resident GEMM workgroups to finish (60-110 us, about
   // one call in ten); N = 8192: 5.90 -> 5.77 ms, N = 16384: 29.2 -> 28.8 ms, N = 32768 unchanged.
-  uint32_t la_mask_word0 = 0x00000000u;
+#define GPS_LA_MASK_WORD0 0x00000000u
   hipEvent_t ev_la = nullptr;
   DevBuf dLaFlags;                             // [0] fork ticket (chain -> side), [1] join ticket (side -> chain), [2] spin time-outs
   unsigned long long la_ticket = 0, fol_ticket = 0;
@@ -152,24 +119,14 @@ struct gps_handle_s {
   // padded points up to which the factorisation is one cooperative launch (as many workgroups as pairs up to 896, everything
   // drawn from a queue above; against launch by launch: N = 1024 / 1536 / 2048: -17 / -14 / -11 % per likelihood, 3072: -2 %,
   // 4096: +35 % -- the 16-row-slab products are no match for the GEMM kernel once the bulk outweighs the chain)
-  i64 small_n_max = 2048;
-  int small_kgen = 1;                          // the one-launch small-N path generates the kernel matrix of a single RBF primitive itself
+  static constexpr i64 small_n_max = 2048;
   int small_fault_inject = 0;                  // diagnostics: the k-th cooperative small-N launch from now starts aborted
   int wave_fault_inject = 0;                   // diagnostics: the k-th wavefront substitution from now reports "gave up"
   bool la_timed_out = false;                   // set by read_info when a hand-over wait gave up: the entry point re-runs without look-ahead
   long long la_retries = 0;                    // evaluations re-run that way (gps_profile_get "lookahead_retries")
   PinnedRing ring;
-  int potrf_follower_cols = 512;               // ... in pieces of at least this many columns
   int follower_max_wgs = 256;   // rectangular updates on the follower / deferred stream go out in launches of at most this many 128 x 128 tiles (0: whole): every workgroup resident at once, so the CUs drain towards the launch's end and the latency chain beside it gets them
-  int potrf_follower_tail = 2; // how a solved piece of the follower meets the columns after it: 0 left-looking, 1 the last follower_cols columns kept up to date by every earlier piece, 2 right-looking throughout (blocked.hpp::potrf_rl_groups)
-  int potrf_follower = 1;                      // the parent's panel solve follows the sweep on the side stream (blocked.hpp)
   unsigned long long* next_sig_ptr = nullptr; unsigned long long next_sig_val = 0;      // carried by the next gps_launch_gemm_nt
-  const unsigned long long* next_wait_ptr = nullptr; unsigned long long next_wait_val = 0;      // ... which first waits for this ticket
-  unsigned long long* next_wait_timeouts = nullptr;
-  // the chain's join with the side stream inside the GEMM that follows it instead of a la_wait launch of its own.  Off: measured
-  // SLOWER (N = 8192: 5.20 -> 5.29 ms, N = 32768: 180.2 -> 181.2 ms) -- the GEMM's waiting workgroups hold the slots the side
-  // stream's remainder update, which they are waiting for, needs to finish.
-  int la_fused_join = 0;
   int potrf_rl_group = 2;      // ... with the remainder updated once per group of this many panels (K = 128 * group)
   int potrf_rl_max = 4096;        // potrf_rec: diagonal blocks of at most this many columns use the right-looking sweep (blocked.hpp)
   // 128-column leaves of the triangular solves (trsm_leaf.hip): -1 = refine where the matrix may be ill conditioned
@@ -178,7 +135,7 @@ struct gps_handle_s {
   // 0 = plain product with the block inverse, 1 = always refine
   int gpr_aug_rows = -1;         // gps_gpr_lml / predict: (Y - m)^T as augmented rows of the factorisation instead of a trsv pass (-1: below 6200 points)
   int leaf_refine = -1;
-  double leaf_refine_cond = 2e6;
+  static constexpr double leaf_refine_cond = 2e6;
   bool refine_now = false;       // resolved at every API entry
   // Per-block refinement (round 5): where leaves are to be refined, a leaf whose diagonal block is well conditioned
   // (kappa_2(L_jj) = ||L_jj||_2 ||W_j||_2, by power iteration with a safety factor, capped by the 1- / inf-norm bound; <= leaf_plain_kappa) takes the plain product with the explicit inverse anyway: its
@@ -193,7 +150,7 @@ struct gps_handle_s {
   bool factor_refine = false;    // what the resident GPR factor was built with (warm predict_f keeps it)
   int kmat_fast = 1;             // one-primitive stationary programs: the stack-free kernel-matrix kernel (kmat.hip)
   int kmat_mfma = 1;             // chains of primitives (Sum / Product): the feature dot products on the matrix pipe (kmat_mfma_kernel); 2: one-primitive programs too
-  int gemm_tail_max_slices = 16;
+  static constexpr int gemm_tail_max_slices = 16;
   int gemm_tail_split = 1;     // split the K range of the tiles of a partial last round (gemm_f64.hip)
   long long* leaf_stamps = nullptr;   // phase stamps of one refined leaf launch (gps_diag_trsm_leaf)
   long long* tp_stamps = nullptr;     // per-workgroup phase stamps of trsm_panel_kernel while gps_diag_trsm512_stamps runs
@@ -268,7 +225,7 @@ struct gps_handle_s {
   DevBuf dTmp;      // generic scratch (host-matrix entry points)
   DevBuf dTmp2;
   DevBuf dTmp3;
-  long long resid_ring_max = 1 << 16;   // residuals up to this many bytes are uploaded through a pinned slot (larger ones: the slots would each be re-allocated on first use, 0.3 ms a piece)
+  static constexpr long long resid_ring_max = 1 << 16;   // residuals up to this many bytes are uploaded through a pinned slot (larger ones: the slots would each be re-allocated on first use, 0.3 ms a piece)
   int trsm_panel = 1;         // 512-column triangular solves as one launch (trsm_panel.hip); 0: down to 128 columns launch by launch
   int trsm_tall_ratio = 16;   // a solve of m rows against n columns goes panel by panel, left-looking, when m >= ratio * n (0: never; blocked.hpp::tall_panels)
   int trsm_panel_rows = 0;    // form of that launch: 32 (rows per workgroup, two workgroups per CU), 64 (persistent), 65 (64 rows, not persistent), 0 = by the number of rows
@@ -277,28 +234,11 @@ struct gps_handle_s {
   DevBuf dGradSums;           // reduced sums of the gradient kernel (grad.hip)
   void* hRes = nullptr;       // pinned host landing area of small read-backs (GPS_HRES_BYTES)
   bool small_defer = false, small_pending = false;   // gps_gpr_lml_grad: the small launch's results are read back later, with the gradient's
-  DevBuf dStepSync;           // counters of the one-launch sweep step (small_n.hip: sweep_step_kernel); monotone, their host-side values below
-  unsigned long long step_q = 0, step_xn = 0, step_dn = 0, step_sd = 0, step_tp = 0;
   DevBuf dBlkCond;            // kappa_1 of the diagonal blocks (classify_blocks)
-  DevBuf dStepScratch;        // [128][128]: the helper tasks' product for the top tile
-  int potrf_step_helpers = 1; // option: the earlier panels' product of the top tile by eight more workgroups of the step launch
-  bool step_dirty = false;    // a bounded wait of such a launch ran out: the area is cleared before the next one
-  // One launch per 128 columns of the sweep (small_n.hip: sweep_step_kernel), round 5 -- BUILT, TESTED, OFF: in isolation the
-  // launch replaces 52.7 us of launches by 44.8, but what the sweep gains depends on the box: same-process A/B of the final
-  // form against the round-4 schedule on six MI355X boxes: N = 4096 -4 / -1 / +4 / +3.5 / +3.5 / +3 %, N = 8192 -2.3 / -1.5 /
-  // 0 / +1.5 / +1.3 %, N = 32768 -0.4 ... +0.4 % (docs/LAB_NOTES.md).  The chain and the side stream's remainder updates
-  // form a cycle; shortening one of them moves the wait, not the sweep.
-  //   potrf_fused_step  1: solve + next block column + next potrf_base as one launch; 2: ... whose chain workgroup also awaits the
-  //                     NEXT step's join with the side stream before it leaves; 3: solve + update as one LEAN launch (51 KB of
-  //                     LDS instead of 150: shares its CUs), potrf_base launched behind it; 0 (default): three launches
-  //   potrf_two_stage_join  the side stream publishes the first block column of its remainder update before the rest
-  //   potrf_step_helpers    the earlier panel's share of the next diagonal tile's update by eight more workgroups of the launch
-  int potrf_two_stage_join = 0;
-  int potrf_fused_step = 0;
   DevBuf dSmallSync;          // counters of the one-launch factorisation of small problems (small_n.hip), zero between calls
   int small_n = 1;            // option "small_n": GPR problems of up to 512 padded rows (and 16 outputs) are factored by one cooperative launch
   long long small_fallbacks = 0;   // such launches that gave up (a bounded wait ran out): the evaluation was redone launch by launch
-  int small_consec = 0;            // give-ups in a row; two of them send the next small_cooldown evaluations launch by launch
+  int small_consec = 0;            // give-ups in a row; the fourth sends the next 256 evaluations (small_cooldown) launch by launch
   int small_cooldown = 0;          // (back-off: a device that something else keeps busy must not cost a bounded wait per step)
   bool small_valid = false; double small_slog = 0.0, small_ssq = 0.0;   // reductions the last small launch produced
   bool ev3_is_ev2 = false;
@@ -408,8 +348,6 @@ struct SmallKgen { int on = 0; int op = 0; const double* X = nullptr; int d_all 
 int gps_launch_small_factor(gps_handle_t h, double* dK, i64 np, double* linv, double* linvT, const double* d_resid, i64 n, i64 r,
                             int* d_info, double* d_res4, double* d_alpha, i64 ld_alpha, i64 alpha_rows, const SmallKgen* kgen = nullptr);
 int gps_small_factor_reset(gps_handle_t h);
-int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const double* W, i64 kprev, double* Linv_next, double* LinvT_next,
-                          int* d_info, i64 row0_next, int factor, int chain);
 // trsm_panel.hip
 int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const double* L, i64 ldl, const double* W, int backward);
 int gps_launch_small_inverse(gps_handle_t h, const double* dK, i64 np, const double* linv, const double* d_alpha, i64 r,

@@ -196,82 +196,6 @@ __device__ __forceinline__ void sn_product(SnOwn<SH, SOLVE>& o, char* smem, cons
   sn_store_tile<SH, SOLVE>(o, smem, C, ldc, C2, ldc2, c2_rows, wave, lane, fr, fk);
 }
 
-// LEAN variants of the above for launches whose workgroups must leave room on their CU (sweep_step_kernel without the chain):
-// the B operand is staged in K-quarters -- each wave its 16 rows x 32 columns, 4.3 KB instead of 16.6 -- into a region only that
-// wave reads (no workgroup barrier between quarters, the next quarter's rows are fetched behind the current one's MFMAs); 51 KB of
-// LDS per workgroup instead of 150: three workgroups per CU, and GEMM workgroups of the side streams beside them.
-#define LN_BS 34                                       // row stride of a wave's quarter region (doubles)
-#define LN_AS_OFF (8 * 16 * LN_BS)
-#define LN_LDS_BYTES ((LN_AS_OFF + 16 * SN_LS) * 8)
-
-// this wave's two of the slab's 16 rows of A -> As[row][SN_LS]
-__device__ __forceinline__ void ln_stage_a(double* As, const double* g, i64 ldg, int wave, int lane) {
-  const double2 v0 = *reinterpret_cast<const double2*>(g + (i64)(2 * wave) * ldg + 2 * lane);
-  const double2 v1 = *reinterpret_cast<const double2*>(g + (i64)(2 * wave + 1) * ldg + 2 * lane);
-  *reinterpret_cast<double2*>(As + (2 * wave) * SN_LS + 2 * lane) = v0;
-  *reinterpret_cast<double2*>(As + (2 * wave + 1) * SN_LS + 2 * lane) = v1;
-}
-
-template <int SH, bool SOLVE>
-__device__ __forceinline__ void ln_own(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* C, i64 ldc,
-                                       int wave, int lane, int fr, int fk) {
-  double* As = reinterpret_cast<double*>(smem) + LN_AS_OFF;
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) o.acc[0][rg] = SOLVE ? 0.0 : C[(i64)(fk + 4 * rg) * ldc + 16 * wave + fr];
-  if (SOLVE) ln_stage_a(As, A, lda, wave, lane);
-}
-
-template <int SH, bool SOLVE>
-__device__ __forceinline__ void ln_mma(SnOwn<SH, SOLVE>& o, char* smem, const double* A, i64 lda, const double* __restrict__ Bm,
-                                       i64 ldb, int wave, int lane, int fr, int fk) {
-  static_assert(SH == 16, "lean products: 16-row slabs");
-  double* Bs = reinterpret_cast<double*>(smem) + wave * 16 * LN_BS;
-  double* As = reinterpret_cast<double*>(smem) + LN_AS_OFF;
-  if (!SOLVE) ln_stage_a(As, A, lda, wave, lane);
-  const int nq = SOLVE ? (16 * (wave + 1) + 31) / 32 : 4;       // (W lower triangular: columns beyond the tile's last are zero)
-  const int r = lane >> 2, c0 = (lane & 3) * 8;                 // this lane's 64 bytes of the quarter: row r, columns c0 .. c0 + 7
-  const double* src = Bm + (i64)(16 * wave + r) * ldb + c0;
-  double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2),
-          v2 = *reinterpret_cast<const double2*>(src + 4), v3 = *reinterpret_cast<const double2*>(src + 6);
-  __syncthreads();                                              // the rows of A are in LDS
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (q < nq) {
-      *reinterpret_cast<double2*>(Bs + r * LN_BS + c0) = v0; *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 2) = v1;
-      *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 4) = v2; *reinterpret_cast<double2*>(Bs + r * LN_BS + c0 + 6) = v3;
-      if (q < 3) {            // (the next quarter's rows, unconditionally: named registers, not an array the compiler parks in scratch)
-        const double* nx = src + 32 * (q + 1);
-        v0 = *reinterpret_cast<const double2*>(nx); v1 = *reinterpret_cast<const double2*>(nx + 2);
-        v2 = *reinterpret_cast<const double2*>(nx + 4); v3 = *reinterpret_cast<const double2*>(nx + 6);
-      }
-      // (the region belongs to this wave alone and a wave's LDS operations complete in order: no barrier)
-#pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) {
-        const double b = Bs[fr * LN_BS + 4 * s2 + fk];
-        const double a = As[fr * SN_LS + 32 * q + 4 * s2 + fk];
-        if (!SOLVE || 32 * q + 4 * s2 < 16 * (wave + 1))
-          o.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SOLVE ? a : -a, b, o.acc[0], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this quarter's fragment reads are done before the region is overwritten
-    }
-  }
-}
-
-template <int SH, bool SOLVE>
-__device__ __forceinline__ void ln_store_tile(SnOwn<SH, SOLVE>& o, char* smem, double* C, i64 ldc, int wave, int lane, int fr, int fk) {
-  double* Bs = reinterpret_cast<double*>(smem) + wave * 16 * LN_BS;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) Bs[(fk + 4 * rg) * LN_BS + fr] = o.acc[0][rg];
-#pragma unroll
-  for (int hlf = 0; hlf < 2; ++hlf) {
-    const int row = 8 * hlf + (lane >> 3), col = 2 * (lane & 7);
-    const double2 v = *reinterpret_cast<const double2*>(Bs + row * LN_BS + col);
-    pb_store16(&C[(i64)row * ldc + 16 * wave + col], v);
-  }
-  __syncthreads();                                               // (the rows of A may be restaged)
-}
-
 // One pair = one 16-row slab of block row bi (bi == nblk: the augmented rows) x block column k: generate (K inside the launch), update
 // with the columns j < k as they appear, solve against block k.
 template <int SH>
@@ -501,307 +425,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
   __syncthreads();
   if (s_flag_p[2]) for (int w = tid; w < SN_USED_WORDS(nblk); w += NT) sync[w] = 0u;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// ONE LAUNCH PER 128 COLUMNS of the right-looking sweep (blocked.hpp::potrf_rl_groups, Ops::step; round 5).  Launch by launch a
-// step of the sweep is three dependent launches -- potrf_base of the diagonal block, the solve of every row below against
-// its inverse, the update of the next block column -- and the next potrf_base can only start when the third has drained:
-// 52.7 us per 128 columns at N = 8192 (30.5 + 12.4 + 9.8, each with its launch ramp), of which the next diagonal block needs
-// only the TOP tile of the solve and of the update.  Here the solve (S), the update (U) and the NEXT block's factorisation (P)
-// are one launch, synchronised like the small-N launch above (tasks drawn from a counter, monotone counters in HBM,
-// write-through hand-overs, bounded waits):
-//   tasks 0 .. 7   the slabs (16 rows) of the top tile = the rows of the next diagonal block: S, count XN; once all eight have
-//                  solved (XN) U of their slab of the diagonal tile; count DN
-//   task 8         the CHAIN: waits for DN = 8, then potrf_base_body on the next diagonal block (factor + inverse)
-//   tasks 9 ..     the other slabs of the rows below: S, then U once XN = 8
-// Every slab counts SD when its S has left; whoever completes the count publishes the sweep's fork ticket (the side stream's
-// remainder update and the follower wait for it: blocked.hpp) -- what the panel solve's completion used to signal.  The counters only grow (the launch gets their values at launch time): nothing
-// to zero, no last-to-leave protocol.  A wait that runs out sets the abort word and the look-ahead's time-out counter: the
-// evaluation is re-run launch by launch (gps_api.hip: with_la_retry) and the next launch of this kind starts from a clean area.
-typedef unsigned long long u64;
-#define ST_ABORT 0
-#define ST_Q 8
-#define ST_XN 16
-#define ST_DN 24
-#define ST_SD 32
-#define ST_TP 40
-#define ST_WORDS 48
-
-struct StepArgs {
-  double* B; i64 lda; int m;          // the rows below the block just factored, its 128 columns: solved in place.  m: multiple of 16, >= 128
-  const double* W;                    // that block's inverse [128][128]
-  int kprev;                          // columns of the group's earlier panels directly left of B (their update of the next block column is due too)
-  double* Linv_next; double* LinvT_next; int* info; int row0_next; int factor;       // potrf_base of the next diagonal block (B's rows 0 .. 127, columns 128 .. 255)
-  u64* sync; u64 q0, xn0, dn0, sd0, tp0;   // the counters and their values at launch
-  double* scratch;                    // [128][128]: the earlier panels' product for the top tile, by helper tasks (or null: the top slabs do it themselves)
-  u64* sig; u64 sig_val;              // fork ticket to publish when every slab is solved (or null)
-  const u64* exit_wait; u64 exit_val; // join value of the side stream the NEXT step needs: awaited by the chain workgroup before it leaves (or null)
-  u64* timeouts;
-  long long* stamps;                  // diagnostics (GPS_STEP_DEBUG=3): 100 MHz wall-clock stamps, 8 per task
-};
-
-__device__ __forceinline__ u64 st_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ bool st_wait(const StepArgs& g, const u64* c, u64 target, int* s_flag) {
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-      if (st_load(c) >= target) break;
-      if (st_load(g.sync + ST_ABORT) != 0ull) { ok = 0; break; }
-      if (wall_clock64() - t0 > 100000000ull) {                    // 1 s at 100 MHz: an error, not a hang
-        __hip_atomic_store(g.sync + ST_ABORT, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(g.timeouts, 1ull);
-        ok = 0; break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *s_flag = ok;
-  }
-  __syncthreads();
-  const int ok = *s_flag;
-  __syncthreads();
-  return ok != 0;
-}
-
-// Helper task hs (second panel of a group onwards, 8 of them): - P_prev[slab hs] Pn_prev^T of the TOP tile into the scratch tile,
-// beside the top slabs' own solve -- the next diagonal block waits for the top tile's update, and this half of it needs
-// nothing of this launch (3.5 us off the chain on those steps).
-template <int SH, bool LEAN>
-__device__ __forceinline__ void st_helper_task(const StepArgs& g, char* smem, int hs) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fk = lane >> 4;
-  const i64 ld = g.lda;
-  SnOwn<SH, false> own;
-#pragma unroll
-  for (int t = 0; t < SH / 16; ++t)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] = 0.0;
-  const double* Pslab = g.B + (i64)hs * SH * ld - g.kprev;
-  for (int kb = 0; kb < g.kprev; kb += 128) {
-    if (LEAN) ln_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
-    else sn_mma<SH, false>(own, smem, Pslab + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
-    __syncthreads();
-  }
-  if (LEAN) ln_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, wave, lane, fr, fk);
-  else sn_store_tile<SH, false>(own, smem, g.scratch + (i64)hs * SH * 128, 128, nullptr, 0, 0, wave, lane, fr, fk);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(g.sync + ST_TP, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int SH, bool LEAN>
-__device__ __forceinline__ void st_slab_task(const StepArgs& g, char* smem, int* s_flag_p, int s, int nslabs) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fk = lane >> 4;
-  const bool top = s < 128 / SH;
-  const i64 ld = g.lda;
-  double* X = g.B + (i64)s * SH * ld;                 // this slab's rows of the column block being solved
-  double* Cn = X + 128;                               // ... of the next block column
-  long long* stp = g.stamps ? g.stamps + 8 * (s < 128 / SH ? s : s + 1) : nullptr;
-#define ST_STAMP(q) do { if (stp && tid == 0) stp[q] = (long long)wall_clock64(); } while (0)
-  ST_STAMP(0);
-  // ---- S: X <- X W^T (W lower triangular: k-steps beyond the tile's last column are skipped)
-  {
-    SnOwn<SH, true> own;
-    if (LEAN) {
-      ln_own<SH, true>(own, smem, X, ld, X, ld, wave, lane, fr, fk);
-      ln_mma<SH, true>(own, smem, X, ld, g.W, 128, wave, lane, fr, fk);
-      __syncthreads();                                // (everybody has read the rows about to be overwritten)
-      ln_store_tile<SH, true>(own, smem, X, ld, wave, lane, fr, fk);
-    } else {
-      sn_own<SH, true>(own, smem, X, ld, X, ld, wave, lane, fr, fk);
-      sn_product<SH, true>(own, smem, X, ld, g.W, 128, X, ld, nullptr, 0, 0, wave, lane, fr, fk);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    if (top) __hip_atomic_fetch_add(g.sync + ST_XN, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 before = __hip_atomic_fetch_add(g.sync + ST_SD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every slab's solved rows are in memory (write-through stores, drained before each count): the panel is complete
-    if (g.sig && before + 1 == g.sd0 + (u64)nslabs) __hip_atomic_store(g.sig, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  ST_STAMP(1);
-  // ---- U: Cn -= [P_prev | X] [Pn_prev | Xn]^T  (Pn, Xn: the top tile's rows of the same columns)
-  SnOwn<SH, false> own;
-  if (LEAN) ln_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
-  else sn_own<SH, false>(own, smem, nullptr, 0, Cn, ld, wave, lane, fr, fk);
-  const bool helped = top && g.scratch != nullptr && g.kprev > 0;
-  if (helped) {
-    // (the top tile's share of the earlier panels' product comes from the helper tasks)
-    if (!st_wait(g, g.sync + ST_TP, g.tp0 + (u64)(128 / SH), s_flag_p)) return;
-    const double* T = g.scratch + (i64)s * SH * 128;
-#pragma unroll
-    for (int t = 0; t < SH / 16; ++t)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) own.acc[t][rg] += T[(16 * t + fk + 4 * rg) * 128 + 16 * wave + fr];
-  } else {
-    for (int kb = 0; kb < g.kprev; kb += 128) {       // the group's earlier panels: final since the previous launches, no wait
-      if (LEAN) ln_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
-      else sn_mma<SH, false>(own, smem, X - g.kprev + kb, ld, g.B - g.kprev + kb, ld, wave, lane, fr, fk);
-      __syncthreads();                                // (everybody has read the staged rows: the next product restages them)
-    }
-  }
-  ST_STAMP(2);
-  if (!st_wait(g, g.sync + ST_XN, g.xn0 + (u64)(128 / SH), s_flag_p)) return;
-  ST_STAMP(3);
-  if (LEAN) { ln_mma<SH, false>(own, smem, X, ld, g.B, ld, wave, lane, fr, fk); ln_store_tile<SH, false>(own, smem, Cn, ld, wave, lane, fr, fk); }
-  else { sn_mma<SH, false>(own, smem, X, ld, g.B, ld, wave, lane, fr, fk); sn_store_tile<SH, false>(own, smem, Cn, ld, nullptr, 0, 0, wave, lane, fr, fk); }
-  ST_STAMP(4);
-  if (top) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(g.sync + ST_DN, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ST_STAMP(5);
-  }
-}
-
-// CHAIN = true: the launch described above (150 KB of LDS per workgroup: one per CU).  CHAIN = false: S and U only, with the lean
-// products (51 KB: the workgroups share their CUs with each other and with the side streams' GEMMs); the next diagonal block is
-// factored by a potrf_base launch behind it ("potrf_fused_step" = 3).
-template <int SH, bool CHAIN>
-__device__ __forceinline__ void sweep_step_body(const StepArgs& g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int LDS_MAIN = CHAIN ? ((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) : LN_LDS_BYTES;
-  int* const s_flag_p = reinterpret_cast<int*>(smem_raw + LDS_MAIN);        // [0] waits  [1] ticket  [3] aborted
-  const int tid = threadIdx.x;
-  // tasks: 0 .. 7 the top slabs, [8 the chain,] then (with helpers) 8 helper tasks, then the other slabs
-  const int nslabs = g.m / SH, top = 128 / SH, nh = (g.scratch && g.kprev > 0) ? top : 0, nc = CHAIN ? 1 : 0, ntasks = nslabs + nc + nh;
-  const bool one_each = (int)gridDim.x >= ntasks;     // as many workgroups as tasks: one draw each
-  auto draw = [&]() -> int {                          // next task, -1: nothing left / aborted
-    __syncthreads();
-    if (tid == 0) {
-      s_flag_p[1] = (int)(__hip_atomic_fetch_add(g.sync + ST_Q, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.q0);
-      s_flag_p[3] = (st_load(g.sync + ST_ABORT) != 0ull) ? 1 : 0;
-    }
-    __syncthreads();
-    const int t = s_flag_p[1];
-    // (an aborted launch -- this one, or an earlier one of the evaluation: the abort word stays until the host clears it --
-    // still hands the fork ticket on: the evaluation is void anyway, and the side streams must not sit out their own bounds
-    // one after the other)
-    if (s_flag_p[3] && t == 0 && tid == 0 && g.sig) __hip_atomic_store(g.sig, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    return (s_flag_p[3] || t >= ntasks) ? -1 : t;
-  };
-  auto slab_or_helper = [&](int t) {
-    if (t >= top + nc && t < top + nc + nh) st_helper_task<SH, !CHAIN>(g, smem_raw, t - top - nc);
-    else st_slab_task<SH, !CHAIN>(g, smem_raw, s_flag_p, t < top ? t : t - nc - nh, nslabs);
-  };
-  // (the chain is straight-line code between two copies of the slab loop: inside ONE loop with it the compiler spills)
-  int t = draw();
-  while (t >= 0 && (!CHAIN || t != top)) {
-    slab_or_helper(t);
-    if (one_each) return;
-    t = draw();
-  }
-  if (!CHAIN || t != top) return;
-  // ---- the chain: the next diagonal block, as soon as its eight slabs have taken this panel
-  if (g.stamps && tid == 0) g.stamps[8 * top] = (long long)wall_clock64();
-  if (!st_wait(g, g.sync + ST_DN, g.dn0 + (u64)top, s_flag_p)) return;
-  if (g.stamps && tid == 0) g.stamps[8 * top + 1] = (long long)wall_clock64();
-  potrf_base_body(smem_raw, g.B + 128, g.lda, g.Linv_next, g.LinvT_next, g.info, g.row0_next, g.factor, nullptr);
-  if (g.stamps && tid == 0) g.stamps[8 * top + 2] = (long long)wall_clock64();
-  // The next step's join with the side stream, here: the launch ends when what the next launch will read has been written --
-  // no wait launch between two steps, and only this workgroup (one CU) waits; the slabs have left, their CUs are free for the
-  // update that is being waited for.  (All slabs of a step waiting INSIDE the step for such a join deadlocks: 240 CUs held.)
-  if (g.exit_wait && !st_wait(g, g.exit_wait, g.exit_val, s_flag_p)) return;
-  if (g.stamps && tid == 0) g.stamps[8 * top + 3] = (long long)wall_clock64();
-  if (one_each) return;
-  for (t = draw(); t >= 0; t = draw()) slab_or_helper(t);
-}
-
-template <int SH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void sweep_step_kernel(StepArgs g) { sweep_step_body<SH, true>(g); }
-template <int SH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 4))) void sweep_su_kernel(StepArgs g) { sweep_step_body<SH, false>(g); }
-
-// S + U + the next block's potrf_base of one step of the sweep (see above).  B: rows below the factored block, its columns
-// (m rows, m >= 128: there is a next block); W: the block's inverse; kprev: columns of earlier panels of the group left of B.
-// GPS_ERR_UNSUPPORTED: not a shape / device for this path (the caller launches the three kernels).
-int gps_launch_sweep_step(gps_handle_t h, double* B, i64 lda, i64 m, const double* W, i64 kprev, double* Linv_next, double* LinvT_next,
-                          int* d_info, i64 row0_next, int factor, int chain) {
-  if (m < 128 || m % 16 || kprev % 128 || kprev < 0 || h->prop.multiProcessorCount < 160) return GPS_ERR_UNSUPPORTED;
-  const int SH = 16;
-  const bool helpers = kprev > 0 && h->potrf_step_helpers != 0;
-  const int nslabs = (int)(m / SH), ntasks = nslabs + (chain ? 1 : 0) + (helpers ? 128 / SH : 0);
-  const int slots = chain ? h->prop.multiProcessorCount - 8 : 2 * h->prop.multiProcessorCount;      // one workgroup per CU (LDS) / three fit
-  const int grid = ntasks < slots ? ntasks : slots;
-  if (!h->dStepSync.p || h->step_dirty) {
-    GPS_HIP(h, h->dStepSync.ensure((size_t)ST_WORDS * 8));
-    GPS_HIP(h, hipMemsetAsync(h->dStepSync.p, 0, (size_t)ST_WORDS * 8, h->stream));
-    h->step_q = h->step_xn = h->step_dn = h->step_sd = h->step_tp = 0;
-    h->step_dirty = false;
-  }
-  StepArgs a;
-  a.B = B; a.lda = lda; a.m = (int)m; a.W = W; a.kprev = (int)kprev;
-  a.Linv_next = Linv_next; a.LinvT_next = LinvT_next; a.info = d_info; a.row0_next = (int)row0_next; a.factor = factor;
-  a.sync = (u64*)h->dStepSync.p; a.q0 = h->step_q; a.xn0 = h->step_xn; a.dn0 = h->step_dn; a.sd0 = h->step_sd; a.tp0 = h->step_tp;
-  a.scratch = nullptr;
-  if (helpers) {
-    GPS_HIP(h, h->dStepScratch.ensure((size_t)128 * 128 * 8));
-    a.scratch = h->dStepScratch.d();
-    h->step_tp += 128 / SH;
-  }
-  a.sig = h->next_sig_ptr; a.sig_val = h->next_sig_val; h->next_sig_ptr = nullptr;         // consumed by this launch
-  a.exit_wait = h->next_wait_ptr; a.exit_val = h->next_wait_val; h->next_wait_ptr = nullptr;
-  a.timeouts = h->dLaFlags.p ? (u64*)h->dLaFlags.p + 2 : nullptr;
-  if (!a.timeouts) return GPS_ERR_UNSUPPORTED;
-  // what the launch will add to the counters: every workgroup draws until it sees a ticket >= ntasks
-  h->step_q += (u64)ntasks + (u64)(grid >= ntasks ? 0 : grid);
-  h->step_xn += 128 / SH; h->step_dn += 128 / SH; h->step_sd += (u64)nslabs;        // (the top slabs count DN in either form)
-  a.stamps = nullptr;
-  static const bool want_stamps = getenv("GPS_STEP_DEBUG") && atoi(getenv("GPS_STEP_DEBUG")) == 3;
-  if (want_stamps) {
-    GPS_HIP(h, h->dTmp3.ensure((size_t)8 * (ntasks + 1) * 8));
-    GPS_HIP(h, hipMemsetAsync(h->dTmp3.p, 0, (size_t)8 * (ntasks + 1) * 8, h->stream));
-    a.stamps = (long long*)h->dTmp3.p;
-  }
-  const size_t lds = (chain ? (size_t)((PB_LDS_BYTES > SN_LDS_BYTES) ? PB_LDS_BYTES : SN_LDS_BYTES) : (size_t)LN_LDS_BYTES) + 128;
-  int rc0 = chain ? gps_dyn_lds(h, reinterpret_cast<const void*>(&sweep_step_kernel<16>), (int)lds)
-                  : gps_dyn_lds(h, reinterpret_cast<const void*>(&sweep_su_kernel<16>), (int)lds);
-  if (rc0) return rc0;
-  {
-    LaunchScope ls(h, chain ? KC_POTRF_BASE : KC_GEMM, (chain ? 2.0 * 128 * 128 * 128 / 3.0 : 0.0) + 2.0 * (double)m * 128.0 * (128.0 + (double)kprev), 3.0 * 8.0 * (double)m * 128.0);
-    if (chain) hipLaunchKernelGGL(sweep_step_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
-    else hipLaunchKernelGGL(sweep_su_kernel<16>, dim3(grid), dim3(NT), lds, h->stream, a);
-    GPS_HIP(h, hipGetLastError());
-  }
-  // diagnostics (GPS_STEP_DEBUG): 1 = wait for every launch and compare the counters with the host's books; 3 = in-kernel stamps
-  static const bool dbg = getenv("GPS_STEP_DEBUG") != nullptr && atoi(getenv("GPS_STEP_DEBUG")) == 1;
-  if (want_stamps) {
-    const int ns1 = nslabs + 1;                       // stamp slots: slab s -> s (top) / s + 1, the chain -> 8
-    std::vector<long long> st((size_t)8 * (ntasks + 1));
-    GPS_HIP(h, hipMemcpyAsync(st.data(), h->dTmp3.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    GPS_HIP(h, hipStreamSynchronize(h->stream));
-    long long t0 = LLONG_MAX;
-    for (int t = 0; t < ns1; ++t) if (st[8 * t] && st[8 * t] < t0) t0 = st[8 * t];
-    auto us = [&](long long v) { return v ? (v - t0) * 0.01 : -1.0; };
-    double s_done = 0, u_done = 0, start_max = 0;
-    for (int t = 0; t < ns1; ++t) {
-      if (t == 8) continue;
-      if (us(st[8 * t]) > start_max) start_max = us(st[8 * t]);
-      if (us(st[8 * t + 1]) > s_done) s_done = us(st[8 * t + 1]);
-      if (us(st[8 * t + 4]) > u_done) u_done = us(st[8 * t + 4]);
-    }
-    fprintf(stderr, "step m=%lld kprev=%lld tasks=%d grid=%d | top slab 0: start %.1f S done %.1f prev-U done %.1f XN seen %.1f U done %.1f DN counted %.1f | slab %d: start %.1f S %.1f XN %.1f U %.1f | "
-                    "all slabs: last start %.1f last S %.1f last U %.1f | chain: start %.1f DN seen %.1f factored %.1f next join seen %.1f\n",
-            (long long)m, (long long)kprev, ntasks, grid, us(st[0]), us(st[1]), us(st[2]), us(st[3]), us(st[4]), us(st[5]),
-            nslabs - 1, us(st[8 * (ns1 - 1)]), us(st[8 * (ns1 - 1) + 1]), us(st[8 * (ns1 - 1) + 3]), us(st[8 * (ns1 - 1) + 4]),
-            start_max, s_done, u_done, us(st[64]), us(st[65]), us(st[66]), us(st[67]));
-  }
-  if (dbg) {
-    // diagnostics: wait for the launch and compare the counters with what the host expects them to be now
-    u64 c[ST_WORDS];
-    const hipError_t e = hipStreamSynchronize(h->stream);
-    (void)hipMemcpy(c, h->dStepSync.p, sizeof(c), hipMemcpyDeviceToHost);
-    fprintf(stderr, "step m=%lld kprev=%lld grid=%d ntasks=%d sync=%s | abort %llu  Q %llu (%llu)  XN %llu (%llu)  DN %llu (%llu)  SD %llu (%llu)  sig %p\n",
-            (long long)m, (long long)kprev, grid, ntasks, hipGetErrorString(e), c[ST_ABORT], c[ST_Q], h->step_q, c[ST_XN], h->step_xn,
-            c[ST_DN], h->step_dn, c[ST_SD], h->step_sd, (void*)a.sig);
-  }
-  return GPS_OK;
 }
 
 // K (lower, + noise, identity padded) is in dK [np + 128][np]; resid [n][r] on the device.  On success dK holds L and the

@@ -281,7 +281,7 @@ static int launch_leaf_u(gps_handle_t h, double* B, i64 ldb, i64 m, const double
   // one workgroup per CU fits (140 KB of LDS at BM = 64): more tiles than CUs are walked by the resident workgroups
   const i64 ntiles = m / BM;
   const i64 cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
-  if (h->leaf_persistent && ntiles > cus) {
+  if (ntiles > cus) {
     int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&trsm_leaf_refine_kernel<BM, NT, UPPER, true>), (int)lds);
     if (rc) return rc;
     hipLaunchKernelGGL((trsm_leaf_refine_kernel<BM, NT, UPPER, true>), dim3((unsigned)cus), dim3(NT), lds, h->stream, B, ldb, m, W, D, ldd, stamps);
@@ -312,7 +312,7 @@ int gps_launch_trsm_leaf_refine(gps_handle_t h, double* B, i64 ldb, i64 m, const
   // beyond, the 64-row tile has the densest MFMA stream (and its resident workgroups walk the tiles)
   const i64 cus = h->prop.multiProcessorCount > 0 ? h->prop.multiProcessorCount : 256;
   if (m / 16 <= cus) return launch_leaf<16, 256>(h, B, ldb, m, W, D, ldd, upper);
-  if (m / 32 <= cus || h->leaf_persistent == 2) return launch_leaf<32, 256>(h, B, ldb, m, W, D, ldd, upper);
+  if (m / 32 <= cus) return launch_leaf<32, 256>(h, B, ldb, m, W, D, ldd, upper);
   return launch_leaf<64, 512>(h, B, ldb, m, W, D, ldd, upper);
 }
 

@@ -409,73 +409,61 @@ int gps_dist_unpack(gps_handle_t h, int64_t j, int buf);
 int gps_dist_update(gps_handle_t h, int64_t j, int64_t c_lo, int64_t c_hi, int lane);
 int gps_dist_finish(gps_handle_t h, double* lml, int* info);
 
-/* tuning knobs (diagnostics; defaults are what bench.py measures):
- *   "gemm_min_tiles"  workgroups a GEMM launch should have before a larger tile is chosen
- *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic)
- *   "gemm_pipe"       1 (default): hand-scheduled K loop (sched_group_barrier) of the 128x128 and 64x64 tiles;
- *                     0: the compiler's instruction order
+/* options (diagnostics and A/B switches; the defaults are what bench.py measures).  Round 6 removed every switch of a
+ * design that was measured and rejected (one launch per 128 columns of a sweep, cross-level look-ahead, trailing update
+ * behind a sweep, joins carried by GEMMs, the substitution following the factorisation, left-looking follower solve) together
+ * with its device code: docs/LAB_NOTES.md keeps the measurements and the commits that hold the code.
+ *   "gemm_force_tile" pin the GEMM tile edge to 128 / 64 / 32 (0 = automatic: the largest tile that still gives 512 workgroups)
  *   "gemm_tail_split" 1 (default): the tiles of a partial last round of a 128x128 launch are cut into
  *                     K-slices over the idle workgroup slots; 0: one workgroup per tile
- *   "gemm_tail_max_slices"  most K-slices per tile of that tail (default 16)
- *   "gemm_deep_slabs" 1 (default): deeper K slabs for the latency-bound small tiles
  *   "potrf_rl_max"    diagonal blocks of at most this many columns (default 4096) are factored by a right-looking
  *                     sweep over 128-column panels instead of the recursion (tf.cholesky, models/gpr.py:70); 0: recursion only
  *   "potrf_rl_group"  panels per remainder update of that sweep (default 2: K = 256)
  *   "potrf_lookahead" 1 (default): that remainder update runs on a second stream beside the next potrf_base, handed over
- *                     through device counters (never on an external stream); "potrf_lookahead_min": remainder rows
- *                     from which it is used (default 1024)
- *   "potrf_fused_step" 0 (default): three launches per 128 columns of that sweep; 1: ONE launch -- the solve of the rows below, the
- *                     update of the next block column and the NEXT diagonal block's factorisation (small_n.hip:
- *                     sweep_step_kernel); 2: ... whose chain workgroup also awaits, before it leaves, the join with the second
- *                     stream that the next step needs; 3: solve + update as one lean launch, potrf_base behind it.  Measured on
- *                     six MI355X boxes: -4 ... +4 % at N = 4096, +-0.4 % at N = 32768 -- off
- *   "potrf_two_stage_join" 0 (default) / 1: the second stream publishes the FIRST block column of its remainder update before
- *                     the rest (which nothing touches for one more step); "potrf_step_helpers" 1: the earlier panel's share
- *                     of the next diagonal tile's update by eight more workgroups of the step launch
- *   "potrf_bulk"      0 (default) / bit 0, bit 1: cross-level look-ahead -- the rest of a trailing update / the first rows of a
- *                     panel solve on a stream of their own beside the sweeps (measured slower on MI355X: DESIGN.md section 0)
- *   "potrf_follower"  1 (default): the panel solve of the block below a swept diagonal block follows the sweep on
- *                     that second stream, in pieces of "potrf_follower_cols" columns (default 512); "potrf_follower_tail"
- *                     2 (default): right-looking -- a solved piece is applied to all columns after it at once, so the
- *                     updates shrink towards the end of the sweep and one 512-column solve is left for the chain; 1: only
- *                     the last piece is kept up to date that way; 0: left-looking (every piece first takes one update
- *                     with all columns before it: the longest update last)
- *   "follower_max_wgs" 256 (default): rectangular updates on that second / third stream are launched in column chunks of at
+ *                     through device counters (never on an external stream; remainders of at least 1024 rows); the panel
+ *                     solve of the block below a swept diagonal block follows the sweep on a third stream, right-looking, in
+ *                     pieces of 512 columns; a 16384-column node hands the first 4096 columns of its panel solve to its child,
+ *                     which runs them beside its second sweep.  0: everything on the handle's stream
+ *   "follower_max_wgs" 256 (default): rectangular updates on that third stream are launched in column chunks of at
  *                     most this many 128 x 128 tiles, so that a launch never has workgroups waiting for a slot (which would
  *                     keep taking the slots the chain's short launches need); 0: one launch per update
- *   "potrf_deferred"  1 (default): a 16384-column node hands the first 4096 columns of its panel solve to its
- *                     child, which runs them on a third stream beside its second sweep
  *   "leaf_refine"     -1 (default): the 128-column leaves of the triangular solves are refined once against the factor's
  *                     diagonal block (X0 = B W^T; R = B - X0 L11^T; X = X0 + R W^T, W = inv(L11): the accuracy of
  *                     tf.matrix_triangular_solve's substitution, conditionals.py:87,100) wherever the matrix may be ill
  *                     conditioned: gps_conditional / gps_base_conditional / gps_svgp_elbo / gps_gauss_kl / gps_sgpr /
  *                     gps_fitc / gps_potrf / gps_trsm_lower, and the GPR entry points when the bound
- *                     cond_2(K + noise I) <= (N Kdiag + noise) / noise exceeds "leaf_refine_cond" (default 2e6: the plain
- *                     products are ~7 u cond from exact, 1e-8 holds up to cond 1.3e7); 0: plain products with the block
- *                     inverses; 1: always.  "leaf_plain_kappa" (default 1000): in that mode a leaf whose diagonal block has
- *                     kappa_2 <= this (estimated per block after the factorisation) takes the plain product anyway -- its
- *                     error eps kappa(L_jj) kappa(L) stays a tenth below a backward-stable solve's; 0: refine every leaf
+ *                     cond_2(K + noise I) <= (N Kdiag + noise) / noise exceeds 2e6 (the plain products are ~7 u cond from
+ *                     exact, 1e-8 holds up to cond 1.3e7); 0: plain products with the block inverses; 1: always
+ *   "leaf_plain_kappa" (default 1000): in refine mode a leaf whose diagonal block has kappa_2 <= this (estimated per block
+ *                     after the factorisation) takes the plain product anyway -- its error eps kappa(L_jj) kappa(L) stays a
+ *                     tenth below a backward-stable solve's; 0: refine every leaf
  *   "trsm_panel"      1 (default): every 512-column node of a plain triangular solve is ONE launch (trsm_panel.hip); 0: down to
- *                     128 columns launch by launch.  "trsm_panel_rows" 0 (default): 32 rows per workgroup and two workgroups per
- *                     CU below 64 rows x the number of CUs, one persistent workgroup per CU above; 32 / 64 force one of them,
- *                     65 = 64 rows per workgroup, not persistent (diagnostics)
+ *                     128 columns launch by launch
+ *   "trsm_panel_rows" 0 (default): 32 rows per workgroup and two workgroups per CU below 64 rows x the number of CUs, one
+ *                     persistent workgroup per CU above; 32 / 64 force one of them, 65 = 64 rows per workgroup, not persistent
  *   "trsm_tall_ratio" 16 (default): a solve of m rows against n columns with m >= ratio * n (conditionals.py:87 at config 5's
  *                     shape) goes over its 512-column panels left-looking -- one long-K update and one launch per panel;
  *                     0: the recursive halving always
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always
- *   "leaf_persistent" 1 (default): the refined solve leaves run as resident workgroups that walk the row tiles (long panels:
- *                     -14 %); 0: one workgroup per 64-row tile
+ *   "small_n"         1 (default): GPR problems of up to 2048 padded points (16 outputs) are factored by ONE cooperative launch
+ *                     (small_n.hip; one stationary primitive: the launch builds K itself); 0: launch by launch.  After four
+ *                     give-ups in a row the handle sends its next 256 evaluations launch by launch (gps_profile_get
+ *                     "small_n_cooldown" reads what is left of that back-off)
  *   "trsv_wave"       1 (default): L a = y and L^T a = y of the GPR entry points run as ONE wavefront launch over the
- *                     128-row blocks (trsv_wave.hip: 1.2 ms at N = 32768); 0: recursive substitution (4 N / 128 launches,
- *                     3.2 ms).  Refined leaves (jittered factors) always take the recursive one.
- *   "trsv_follow"     0 (default) / 1: the forward substitution is issued block by block behind the factorisation on a
- *                     stream of its own (measured slower: DESIGN.md section 6)
+ *                     128-row blocks (trsv_wave.hip: 1.2 ms at N = 32768); 0: recursive substitution (4 N / 128 launches)
+ *   "trsv_wave_refine" 1 (default): also where the leaves are refined (one refinement step per block inside the wavefront)
  *   "kmat_fast"       1 (default): one-primitive stationary programs and Sum / Product chains of primitives (programs
  *                     "p0 p1 op p2 op ...") use the stack-free kernel-matrix kernels; 0: the stack interpreter for all
- *   "la_fault_inject" diagnostics: the k-th look-ahead join from now takes the time-out path (the evaluation is then
- *                     re-run once without look-ahead; gps_profile_get(h, "lookahead_retries", &count, ...) counts it)  */
+ *   "kmat_mfma"       1 (default): chains of primitives compute their feature products on the matrix pipe; 2: one-primitive
+ *                     programs too; 0: never
+ *   "svgp_kl_weight"  weight of the KL term of gps_svgp_elbo(_grad) (default 1; 1 / P on every rank of a data-sharded run)
+ *   "dist_partitioned" 1 (default): a rank of the block-column factorisation stores only its own block columns (8 N^2 / P bytes)
+ *   "la_fault_inject" / "wave_fault_inject" / "small_fault_inject"  test hooks: the k-th look-ahead join / wavefront substitution /
+ *                     cooperative small-N launch from now takes its give-up path (the evaluation is then re-run once through the
+ *                     launch-by-launch forms; gps_profile_get(h, "lookahead_retries" | "trsv_wave_fallbacks" | "small_n_fallbacks",
+ *                     &count, ...) counts it)  */
 int gps_set_option(gps_handle_t h, const char* key, double value);
 
 /* ---- diagnostics ---------------------------------------------------------

@@ -13,15 +13,11 @@ static const i64 T = GPS_TILE;
 
 static i64 g_rl_group = 1;
 static int g_lookahead = 0;
-static int g_follower_tail = 2;   // emul_set_follower_tail: the follower's last block right-looking (blocked.hpp::potrf_rl_groups)
 static int g_tall = 0;        // emul_set_tall: solves of more than 512 columns panel by panel, left-looking (blocked.hpp::tall_panels)
 static int g_leaf512 = 0;     // emul_set_leaf512: 512-column nodes of the triangular solves as one operation (Ops::trsm_leaf512)
 static i64 g_rl_max = 0;      // emul_set_rl_max: size up to which potrf_rec takes the right-looking sweep
-static int g_fused = 0;       // emul_set_fused: the sweep's one-launch steps (Ops::step)
-static int g_bulk = 0;        // emul_set_bulk: cross-level look-ahead -- bit 0: piece (a), bit 1: piece (b); rows of a (b) piece below
-static i64 g_bulk_rows = 256;
 static int g_side_bad = 0;    // operations of the chain that touched what a side section had written and the chain had not joined yet
-static int g_bulk_pieces = 0, g_bulk_bad = 0;      // pieces issued / pairing or race violations seen (read by the tests)
+static int g_forget_join = 0; // emul_set_forget_join: self-test of the race detector -- an Ops whose chain_join does nothing
 
 struct CpuOps {
   std::vector<double> linv, linvT;
@@ -30,7 +26,6 @@ struct CpuOps {
   explicit CpuOps(i64 nblk) : linv(nblk * T * T, 0.0), linvT(nblk * T * T, 0.0) {}
 
   int potrf_base(double* A, i64 lda, i64 blk, i64 row0) {
-    if (join_armed) return -31;                 // a join handed to "the next GEMM" must be followed by one
     ++n_base;
     touch(A, lda, T, T, true);
     for (i64 j = 0; j < T; ++j) {
@@ -60,7 +55,6 @@ struct CpuOps {
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb,
            double* C, i64 ldc) {
     ++n_gemm;
-    join_armed = false;                         // (a pending fused join is consumed by this launch)
     if (M % T || N % T || K % 16) return -1;
     touch(A, lda, M, K, false); touch(B, ldb, N, K, false); touch(C, ldc, M, N, true);
     if (op != 1 && op != 3) touch(C, ldc, M, N, false);
@@ -102,28 +96,6 @@ struct CpuOps {
     for (i64 i = 0; i < T; ++i) for (i64 c = 0; c < T; ++c) Y[i * ldy + c] = W[i * T + c];
     return 0;
   }
-  // one launch per 128 columns (blocked.hpp: Ops::step): here the three operations it stands for, in order
-  int n_step = 0;
-  bool fused_step() { return (g_fused & 1) != 0; }
-  bool two_stage_join() const { return (g_fused & 2) != 0; }
-  int step_join(unsigned long long t) { return chain_join(t); }
-  // a join value the NEXT step needs, awaited by this step before it ends (after its own work): it takes effect when the
-  // step has run AND the value has been published, whichever comes last
-  unsigned long long carry = 0;
-  bool carry_armed = false;                                     // step_carry_join must be followed by the step that carries it
-  bool step_exit_join() const { return (g_fused & 8) != 0; }
-  int step_carry_join(unsigned long long v) { if (carry || v <= joined) return -52; carry = v; carry_armed = true; return 0; }
-  void apply_carry() { if (carry && !carry_armed && published >= carry) { (void)chain_join(carry); carry = 0; } }
-  int step(i64 blk, double* B, i64 ldb, i64 m, i64 kprev, i64 row0_next) {
-    if (m < T || open_side || fol_open || def_open) return -51;
-    ++n_step;
-    int rc = trsm_base(blk, 0, B, ldb, m);
-    if (!rc) rc = gemm(0, 0, m, T, kprev + T, B - kprev, ldb, B - kprev, ldb, B + T, ldb);
-    if (!rc) rc = potrf_base(B + T, ldb, blk + 1, row0_next);
-    carry_armed = false;
-    apply_carry();
-    return rc;
-  }
   i64 rl_max() const { return g_rl_max; }
   i64 rl_group() const { return g_rl_group; }
   // look-ahead hooks: the host emulation is sequential; the hooks check that forks, side sections and joins pair up
@@ -138,8 +110,6 @@ struct CpuOps {
   int deferred_close() { if (!def_open) return -14; def_open = 0; def_unjoined = 1; return 0; }
   int deferred_join() { if (!def_unjoined) return -15; def_unjoined = 0; return 0; }
   i64 follower_cols() const { return g_lookahead == 2 ? 512 : 256; }
-  int follower_tail() const { return g_follower_tail; }
-  bool trail_follows() const { return g_lookahead == 2; }        // (both forms of the trailing update are emulated)
   unsigned long long fol_pub = 0;
   // side sections: what they write stays "in flight" until the chain has joined the join value published after it (values
   // grow: a section may publish several, e.g. after the first block column of a remainder update and after the rest); until
@@ -153,7 +123,6 @@ struct CpuOps {
     if (!open_side || v <= published) return -8;
     published = v;
     for (auto& q : side_pending) if (q.v == 0) q.v = v;
-    apply_carry();
     return 0;
   }
   int side_close() {
@@ -166,40 +135,17 @@ struct CpuOps {
   int follower_close() { if (!fol_open) return -17; fol_open = 0; return 0; }
   int follower_publish() { if (!fol_open) return -11; ++fol_pub; return 0; }
   int follower_join() { if (open_side || fol_open || fol_pub == 0) return -12; return 0; }
-  // cross-level look-ahead (blocked.hpp: pieces (a) and (b)).  Sequential here -- a piece is executed when it is issued --, so
-  // what the hooks check is (i) the pairing: one piece in flight at a time, every piece joined, and (ii) a race detector by
-  // regions: every rectangle of the matrix a piece reads or writes is recorded, and until the join no operation of the
-  // calling stream may write a rectangle the piece touches or read one it writes (touch()).
-  int bulk_state = 0;            // 0 idle, 1 open (launches go to the bulk stream), 2 in flight (closed, not joined)
-  std::vector<Rect> bulk_reads, bulk_writes;
   const double* base = nullptr; i64 base_ld = 0, base_rows = 0;        // the matrix being factored (set by the entry points below)
   static bool overlap(const Rect& a, const Rect& b) { return a.r0 < b.r0 + b.nr && b.r0 < a.r0 + a.nr && a.c0 < b.c0 + b.nc && b.c0 < a.c0 + a.nc; }
   void touch(const double* p, i64 ld, i64 nr, i64 nc, bool write) {
     if (!base || ld != base_ld || p < base || p >= base + base_rows * base_ld) return;      // (block inverses etc.: not in the matrix)
     const Rect r{(i64)((p - base) / base_ld), (i64)((p - base) % base_ld), nr, nc};
     if (open_side) { side_pending.push_back(SideRect{r, 0, !write}); return; }
-    if (!fol_open && !def_open && bulk_state != 1)             // an operation of the chain
+    if (!fol_open && !def_open)                                // an operation of the chain
       for (const SideRect& q : side_pending) if ((write || !q.rd) && overlap(r, q.r)) ++g_side_bad;
-    if (bulk_state == 1) { (write ? bulk_writes : bulk_reads).push_back(r); return; }
-    if (bulk_state != 2) return;
-    for (const Rect& w : bulk_writes) if (overlap(r, w)) ++g_bulk_bad;
-    if (write) for (const Rect& q : bulk_reads) if (overlap(r, q)) ++g_bulk_bad;
-  }
-  bool bulk() { return g_bulk != 0 && bulk_state == 0; }
-  bool bulk_rest() { return (g_bulk & 1) && bulk(); }
-  i64 bulk_chunk(i64 k) const { return k > 256 ? 256 : k; }
-  i64 bulk_rows(i64, i64 m) { if (!(g_bulk & 2) || !bulk()) return 0; return g_bulk_rows < m ? g_bulk_rows : m; }
-  int n_bulk_open = 0;
-  int bulk_open() { if (bulk_state != 0 || open_side || def_open || fol_open) { ++g_bulk_bad; return -41; } bulk_state = 1; ++n_bulk_open; return 0; }
-  int bulk_close() { if (bulk_state != 1) { ++g_bulk_bad; return -42; } bulk_state = 2; return 0; }
-  int bulk_join() {
-    if (bulk_state != 2) { ++g_bulk_bad; return -43; }
-    bulk_reads.clear(); bulk_writes.clear();
-    bulk_state = 0;
-    return 0;
   }
   int chain_join(unsigned long long v) {
-    if (g_fused & 4) return 0;                                  // (self-test of the race detector: an Ops that forgets to join)
+    if (g_forget_join) return 0;                                // (self-test of the race detector: an Ops that forgets to join)
     if (v > published || v <= joined) return -9;              // a join for something that was never published / joined twice
     joined = v;
     std::vector<SideRect> keep;
@@ -207,14 +153,6 @@ struct CpuOps {
     side_pending.swap(keep);
     return 0;
   }
-  // (the join carried by the next GEMM: that launch must follow at once)
-  bool join_armed = false;
-  int chain_join_next_gemm(unsigned long long t) { int rc = chain_join(t); join_armed = (rc == 0); return rc; }
-  // forward substitution following the factorisation: sequential here; the hooks check pairing
-  int y_opened = 0, y_sections = 0;
-  int y_open() { if (y_opened || open_side || def_open || fol_open) return -21; y_opened = 1; ++y_sections; return 0; }
-  int y_close() { if (!y_opened) return -22; y_opened = 0; return 0; }
-  int y_prepare(i64, i64) { return y_opened ? 0 : -23; }
   bool fill_zeros() const { return true; }
   int zero_block(double* Y, i64 ldy, i64 rows, i64 cols) {
     for (i64 i = 0; i < rows; ++i) for (i64 c = 0; c < cols; ++c) Y[i * ldy + c] = 0.0;
@@ -266,42 +204,10 @@ extern "C" {
 void emul_set_rl_max(i64 v) { g_rl_max = v; }
 void emul_set_leaf512(int v) { g_leaf512 = v; }
 void emul_set_tall(int v) { g_tall = v; }
-void emul_set_follower_tail(int v) { g_follower_tail = v; }
 void emul_set_rl_group(i64 v) { g_rl_group = v; }
 void emul_set_lookahead(int v) { g_lookahead = v; }
-void emul_set_fused(int v) { g_fused = v; }
+void emul_set_forget_join(int v) { g_forget_join = v; }
 int emul_side_bad(int reset) { const int v = g_side_bad; if (reset) g_side_bad = 0; return v; }
-void emul_set_bulk(int v, i64 rows) { g_bulk = v; g_bulk_rows = rows; g_bulk_pieces = g_bulk_bad = 0; }
-void emul_bulk_counts(int* pieces, int* bad) { *pieces = g_bulk_pieces; *bad = g_bulk_bad; }
-// the race detector itself: a piece that writes a block the calling stream then reads before the join must be flagged (1),
-// the same with the join in between must not (0)
-int emul_bulk_selftest(int with_join) {
-  const i64 n = 3 * T;
-  std::vector<double> A((size_t)n * n, 1.0);
-  CpuOps ops(n / T);
-  ops.base = A.data(); ops.base_ld = n; ops.base_rows = n;
-  g_bulk_bad = 0;
-  const int saved = g_bulk; g_bulk = 3;
-  int rc = ops.bulk_open();
-  if (!rc) rc = ops.gemm(0, 0, T, T, T, A.data() + T * n, n, A.data() + T * n, n, A.data() + 2 * T * n + 2 * T, n);     // piece writes block (2, 2)
-  if (!rc) rc = ops.bulk_close();
-  if (!rc && with_join) rc = ops.bulk_join();
-  if (!rc) rc = ops.gemm(0, 0, T, T, T, A.data() + 2 * T * n + 2 * T, n, A.data(), n, A.data() + T * n, n);               // calling stream reads block (2, 2)
-  g_bulk = saved;
-  return rc ? -1 : (g_bulk_bad > 0 ? 1 : 0);
-}
-// A [(n + e), n] in place with the cross-level look-ahead hooks armed: factor (+ augmented rows), count the bulk pieces and
-// the violations of the race detector; a piece still in flight at the end is a violation
-int emul_potrf_bulk(double* A, i64 n, i64 e, int* info) {
-  CpuOps ops(n / T);
-  ops.base = A; ops.base_ld = n; ops.base_rows = n + e;
-  Blocked<CpuOps> bl(ops);
-  int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, e);
-  *info = ops.info;
-  g_bulk_pieces += ops.n_bulk_open;
-  if (ops.bulk_state != 0) ++g_bulk_bad;
-  return rc;
-}
 // the general panel sweep (panels of nb columns factored by potrf_rec, solved by trsm_rec): index check only
 int emul_potrf_rl(double* A, i64 n, i64 nb, int* info) {
   CpuOps ops(n / T);
@@ -333,15 +239,6 @@ int emul_potrf_aug(double* A, i64 n, i64 e, int* info) {
   Blocked<CpuOps> bl(ops);
   int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, e);
   *info = ops.info;
-  return rc;
-}
-// A [n, n] in place -> L, with y [r][n] -> L^-1 y issued block by block behind the factorisation (YFollow)
-int emul_potrf_yfollow(double* A, i64 n, double* y, i64 r, int* info, int* sections) {
-  CpuOps ops(n / T);
-  Blocked<CpuOps> bl(ops);
-  Blocked<CpuOps>::YFollow yf{y, n, r};
-  int rc = bl.potrf_rec(A, n, n, 0, 0, nullptr, 0, &yf);
-  *info = ops.info; *sections = ops.y_sections;
   return rc;
 }
 // A [n,n] SPD in place -> L ; yt [r][n]: L^T a = yt ; Kinv [n,n] (lower valid) = A^-1 ; Yout = L^-T

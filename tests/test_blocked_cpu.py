@@ -120,18 +120,15 @@ def test_panel_sweep_matches_lapack(emul, n, nb, rl_max):
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("n,rl_max,la", [(1024, 512, 1), (1536, 512, 2), (2048, 1024, 1), (2048, 1024, 2), (2560, 1024, 2), (2048, 512, 2)])
-def test_follower_solve_left_or_right_looking(emul, n, rl_max, la, mode):
-    """blocked.hpp::potrf_rl_groups, Ops::follower_tail: the solve of the block below a swept diagonal block follows the sweep
-    piece by piece -- left-looking (0), with its last block kept up to date by every earlier piece (1), or right-looking
-    throughout (2).  Same factor in every mode (the block below IS part of it)."""
+def test_follower_solve_right_looking(emul, n, rl_max, la):
+    """blocked.hpp::potrf_rl_groups: the solve of the block below a swept diagonal block follows the sweep piece by piece,
+    right-looking (a solved piece is applied to all the columns after it).  Same factor as LAPACK's (the block below IS part of it)."""
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))
     emul.emul_set_lookahead(la)
     emul.emul_set_rl_group(ctypes.c_int64(2))
-    emul.emul_set_follower_tail(mode)
     try:
-        rng = np.random.default_rng(n + mode)
+        rng = np.random.default_rng(n + 2)
         G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n)
         B = rng.standard_normal((128, n)); B2 = B.copy(); y = rng.standard_normal((1, n))
         A0 = A.copy()
@@ -139,7 +136,7 @@ def test_follower_solve_left_or_right_looking(emul, n, rl_max, la, mode):
         p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         rc = emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
     finally:
-        emul.emul_set_lookahead(0); emul.emul_set_follower_tail(2)
+        emul.emul_set_lookahead(0)
     assert rc == 0 and info.value == 0
     L = sl.cholesky(A0, lower=True)
     assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
@@ -190,80 +187,15 @@ def test_augmented_rows_ride_through_the_factorisation(emul, n, e, rl_max, group
     assert np.abs(M[n:] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("rl_max,group,la", [(0, 1, 0), (256, 1, 0), (512, 2, 0), (512, 2, 1), (256, 2, 2), (384, 2, 1)])
-@pytest.mark.parametrize("n,r", [(128, 1), (256, 2), (640, 1), (1152, 3), (1536, 1), (2048, 2)])
-def test_forward_substitution_follows_the_factorisation(emul, n, r, rl_max, group, la):
-    """potrf_rec with a YFollow: the solves L a = y are issued block by block as the factor becomes final (trsv_rec of a
-    finished diagonal block, gemv of a finished block below it) -- same result as a forward substitution afterwards."""
-    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
-    emul.emul_set_lookahead(la)
-    emul.emul_set_rl_group(ctypes.c_int64(group))
-    rng = np.random.default_rng(n + r + rl_max)
-    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n); A0 = A.copy()
-    y = rng.standard_normal((r, n)); y0 = y.copy()
-    info, sections = ctypes.c_int(0), ctypes.c_int(0)
-    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    rc = emul.emul_potrf_yfollow(p(A), ctypes.c_int64(n), p(y), ctypes.c_int64(r), ctypes.byref(info), ctypes.byref(sections))
-    emul.emul_set_lookahead(0)
-    assert rc == 0 and info.value == 0
-    L = sl.cholesky(A0, lower=True)
-    assert np.abs(np.tril(A) - L).max() <= 1e-12 * np.abs(L).max()
-    assert np.abs(y - sl.solve_triangular(L, y0.T, lower=True).T).max() <= 1e-12
-    assert sections.value >= 1
-
-
-@pytest.mark.parametrize("n,e,rl_max,bulk,expect", [(1024, 0, 256, 1, 1), (1536, 128, 256, 1, 3), (1280, 0, 256, 3, 3), (2048, 0, 256, 1, 3), (2048, 0, 256, 2, 1),
-                                                    (2048, 128, 256, 3, 4), (2304, 0, 256, 3, 6), (1024, 0, 512, 3, 0)])
-def test_cross_level_lookahead_schedule(emul, n, e, rl_max, bulk, expect):
-    """blocked.hpp, round 5: (a) the rest of a trailing update and (b) the first rows of a panel solve leave the calling stream's
-    order (Ops::bulk_*) to run beside the sweeps.  As index logic on the CPU: the factor (and the augmented rows) still match
-    LAPACK; the expected number of pieces was issued, every one joined; and the emulation's region race detector saw no
-    operation of the calling stream touch what a piece in flight reads or writes."""
-    emul.emul_set_rl_max(ctypes.c_int64(rl_max))
-    emul.emul_set_lookahead(1)
-    emul.emul_set_rl_group(ctypes.c_int64(2))
-    emul.emul_set_bulk(bulk, ctypes.c_int64(256))
-    try:
-        rng = np.random.default_rng(n + e + bulk)
-        G = rng.standard_normal((n, n)); K = G @ G.T + n * np.eye(n)
-        E = rng.standard_normal((e, n))
-        A = np.ascontiguousarray(np.vstack([K, E]))
-        info = ctypes.c_int(0)
-        p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-        rc = emul.emul_potrf_bulk(p(A), ctypes.c_int64(n), ctypes.c_int64(e), ctypes.byref(info))
-        pieces, bad = ctypes.c_int(0), ctypes.c_int(0)
-        emul.emul_bulk_counts(ctypes.byref(pieces), ctypes.byref(bad))
-    finally:
-        emul.emul_set_bulk(0, ctypes.c_int64(256)); emul.emul_set_lookahead(0)
-    assert rc == 0 and info.value == 0
-    L = sl.cholesky(K, lower=True)
-    assert np.abs(np.tril(A[:n]) - L).max() <= 1e-12 * np.abs(L).max()
-    if e:
-        assert np.abs(A[n:] - sl.solve_triangular(L, E.T, lower=True).T).max() <= 1e-11
-    assert bad.value == 0
-    # (n = 2048 with 256-column sweeps is N = 32768 with 4096-column sweeps in small: three rests (a) and one row piece (b))
-    assert pieces.value == expect, pieces.value
-
-
-def test_cross_level_lookahead_race_detector_detects(emul):
-    assert emul.emul_bulk_selftest(0) == 1 and emul.emul_bulk_selftest(1) == 0
-
-
 @pytest.mark.parametrize("n,m,e", [(256, 128, 0), (640, 128, 128), (1024, 256, 0), (1408, 128, 128)])
-@pytest.mark.parametrize("fused", [1, 2, 3, 9, 11])
 @pytest.mark.parametrize("rl_max,group,la", [(256, 2, 1), (512, 2, 1), (1024, 2, 2), (1024, 3, 1), (2048, 4, 2)])
-def test_one_launch_sweep_steps_as_index_logic(emul, n, m, e, rl_max, group, la, fused):
-    """blocked.hpp::potrf_rl_groups with Ops::step (round 5: panel solve + next block column + next potrf_base as ONE launch per
-    128 columns, csrc/small_n.hip::sweep_step_kernel; fused & 1) and with the side stream's remainder update joined in two
-    stages (first block column, then the rest one step later; fused & 2), the joins carried by the step before the one that needs
-    them (fused & 8): which rows, which earlier panels of the group, which
-    block is factored next, where the fork ticket and the joins go -- against LAPACK, with and without augmented rows,
-    followers on; the emulation's race detector checks that the chain touches nothing a side section wrote (or writes what it
-    read) before the matching join."""
+def test_sweep_look_ahead_as_index_logic(emul, n, m, e, rl_max, group, la):
+    """blocked.hpp::potrf_rl_groups with the look-ahead on: which rows, which earlier panels of the group, where the fork ticket
+    and the joins go -- against LAPACK, with and without augmented rows, followers on; the emulation's race detector checks that
+    the chain touches nothing a side section wrote (or writes what it read) before the matching join."""
     emul.emul_set_rl_max(ctypes.c_int64(rl_max))
     emul.emul_set_lookahead(la)
     emul.emul_set_rl_group(ctypes.c_int64(group))
-    emul.emul_set_fused(fused)
     emul.emul_side_bad(1)
     try:
         rng = np.random.default_rng(n + m + e)
@@ -288,14 +220,14 @@ def test_one_launch_sweep_steps_as_index_logic(emul, n, m, e, rl_max, group, la,
             assert np.abs(B - sl.solve_triangular(L, B0.T, lower=True).T).max() <= 1e-12
         assert emul.emul_side_bad(0) == 0
     finally:
-        emul.emul_set_fused(0); emul.emul_set_lookahead(0)
+        emul.emul_set_lookahead(0)
 
 
 def test_side_stream_race_detector_detects(emul):
     """The detector behind the test above, firing: with the lookahead_min threshold of the emulation every group forks a side
-    section; an Ops that "forgets" the joins (emul_set_fused bit 2) must be flagged."""
+    section; an Ops that "forgets" the joins (emul_set_forget_join) must be flagged."""
     emul.emul_set_rl_max(ctypes.c_int64(1024)); emul.emul_set_lookahead(1); emul.emul_set_rl_group(ctypes.c_int64(2))
-    emul.emul_set_fused(4)
+    emul.emul_set_forget_join(1)
     emul.emul_side_bad(1)
     try:
         n = 1024
@@ -307,4 +239,4 @@ def test_side_stream_race_detector_detects(emul):
         emul.emul_all(p(A), ctypes.c_int64(n), p(B), p(B2), ctypes.c_int64(128), p(y), ctypes.c_int64(1), ctypes.byref(info))
         assert emul.emul_side_bad(0) > 0
     finally:
-        emul.emul_set_fused(0); emul.emul_set_lookahead(0)
+        emul.emul_set_forget_join(0); emul.emul_set_lookahead(0)

@@ -648,115 +648,28 @@ def test_concurrent_small_launches(n, threads):
         assert out[t][0][0] == out[0][0][0] and np.array_equal(out[t][0][1], out[0][0][1])
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
-@pytest.mark.parametrize("n", [2304, 4096, 5000, 8192])
-def test_sweep_step_modes_agree_with_the_three_launch_sweep(handle, n, mode):
-    """Option "potrf_fused_step" (csrc/small_n.hip::sweep_step_kernel; off by default -- its gain depends on the box): every 128
-    columns of a sweep as ONE launch (1), with the next step's join carried by its chain workgroup (2), or solve + update as one
-    lean launch and potrf_base behind it (3), with the side stream's two-stage join: same likelihood, predictions and gradient
-    as the three-launch sweep -- with and without augmented rows (5000 < 6200 <= 8192), queued (4096) and one task per workgroup."""
-    import gpflowSlim as gpf
-    import oracle.gp_oracle as orc
-    X, Y, Xs = orc.synthetic_gpr_data(n, 5, 64, seed=n)
-    m = gpf.models.GPR(X, Y, gpf.kernels.Matern52(5, lengthscales=1.7) + gpf.kernels.RBF(5, variance=0.4, lengthscales=0.9), obs_var=0.05)
-    res = {}
-    try:
-        for md in (0, mode):
-            handle.set_option("potrf_fused_step", md); handle.set_option("potrf_two_stage_join", 1 if md else 0)
-            before = handle.profile_get("lookahead_retries")["launches"]
-            lml = m.compute_log_likelihood()
-            mu, var = m.predict_f(Xs)
-            res[md] = (lml, mu, var)
-            assert handle.profile_get("lookahead_retries")["launches"] == before
-    finally:
-        handle.set_option("potrf_fused_step", 0); handle.set_option("potrf_two_stage_join", 0)
-    a, b = res[0], res[mode]
-    assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0])
-    assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(1.0, np.abs(a[1]).max()) and np.abs(a[2] - b[2]).max() <= 1e-10 * np.abs(a[2]).max()
-
-
 @pytest.mark.parametrize("n", [8192, 9000, 12288])
-def test_follower_solve_modes_agree(handle, n):
-    """The solve that follows a sweep on the second stream (blocked.hpp::potrf_rl_groups): left-looking, last block right-looking,
-    right-looking throughout (option "potrf_follower_tail" 0 / 1 / 2), and its updates whole or in launches of at most 256 / 64
-    tiles (option "follower_max_wgs"): same likelihood and predictions (the pieces are summed in another order: 1e-11), no
-    evaluation re-run without look-ahead -- sizes with one (8192), with a ragged (9000) and with two (12288) followed sweeps."""
+def test_follower_solve_launch_caps_agree(handle, n):
+    """The solve that follows a sweep on the second stream (blocked.hpp::potrf_rl_groups, right-looking): its updates whole or in
+    launches of at most 256 / 64 tiles (option "follower_max_wgs"), and the sweep without any look-ahead: same likelihood and
+    predictions (the pieces are summed in another order: 1e-11), no evaluation re-run without look-ahead -- sizes with one (8192),
+    with a ragged (9000) and with two (12288) followed sweeps."""
     import gpflowSlim as gpf
     import oracle.gp_oracle as orc
     X, Y, Xs = orc.synthetic_gpr_data(n, 6, 64, seed=n)
     m = gpf.models.GPR(X, Y, gpf.kernels.RBF(6, lengthscales=2.0) + gpf.kernels.Matern32(6, variance=0.3, lengthscales=1.1), obs_var=0.07)
     res = {}
     try:
-        for tail, cap in ((0, 0), (1, 0), (2, 0), (2, 256), (2, 64), (0, 256)):
-            handle.set_option("potrf_follower_tail", tail); handle.set_option("follower_max_wgs", cap)
+        for la, cap in ((0, 0), (1, 0), (1, 256), (1, 64)):
+            handle.set_option("potrf_lookahead", la); handle.set_option("follower_max_wgs", cap)
             before = handle.profile_get("lookahead_retries")["launches"]
             lml = m.compute_log_likelihood()
             mu, var = m.predict_f(Xs)
-            res[(tail, cap)] = (lml, mu, var)
+            res[(la, cap)] = (lml, mu, var)
             assert handle.profile_get("lookahead_retries")["launches"] == before
     finally:
-        handle.set_option("potrf_follower_tail", 2); handle.set_option("follower_max_wgs", 256)
+        handle.set_option("potrf_lookahead", 1); handle.set_option("follower_max_wgs", 256)
     a = res[(0, 0)]
     for key, b in res.items():
         assert abs(a[0] - b[0]) <= 1e-11 * abs(a[0]), key
         assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(1.0, np.abs(a[1]).max()) and np.abs(a[2] - b[2]).max() <= 1e-10 * np.abs(a[2]).max(), key
-
-
-@pytest.mark.parametrize("n,mode", [(3000, 2), (5200, 2), (5200, 3)])
-def test_concurrent_sweep_step_launches(n, mode):
-    """The one-launch sweep steps (option "potrf_fused_step"; csrc/small_n.hip::sweep_step_kernel: workgroups synchronised through
-    counters in HBM, mode 2: whole-CU workgroups and a chain workgroup that awaits the side stream's join before it leaves) with
-    four factorisations in flight at once: four handles in four host threads, 25 likelihood evaluations each at a size that takes
-    the sweep (N > 2048).  Every thread: bit-identical results step after step and across threads, equal to LAPACK on the
-    oracle's kernel matrix to 1e-8, no evaluation re-run without look-ahead (a bounded wait that ran out), no stalled step."""
-    import os
-    import threading
-    import time
-    import gpflowSlim as gpf
-    import oracle.gp_oracle as orc
-    from gpflowSlim import _backend as be
-    if mode == 2 and os.environ.get("GPS_POISON_ALLOC") == "2":
-        pytest.skip("GPS_POISON_ALLOC=2 synchronises the device inside buffer requests: a step launch that awaits work the host issues "
-                    "right behind it (mode 2) then waits for itself until its bound -- every evaluation is re-run (correct, 1 s late)")
-    d, steps, threads = 6, 25, 4
-    rng = np.random.default_rng(n)
-    X = rng.standard_normal((n, d)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((n, 1))
-    ls = np.sqrt(d) * np.linspace(0.8, 1.2, d)
-    prog = gpf.kernels.RBF(d, variance=1.1, lengthscales=ls, ARD=True)._program(d)
-    ref = orc.gpr_lml({"type": "rbf", "variance": 1.1, "lengthscales": ls, "input_dim": d}, X, Y, 0.1)
-    out, errors = {}, []
-
-    def run(t):
-        try:
-            h = be.Handle(0)
-            h.set_option("potrf_fused_step", mode); h.set_option("potrf_two_stage_join", 1)
-            h.gpr_set_data(X, X)
-            vals, t_max = [], 0.0
-            for i in range(steps):
-                t0 = time.perf_counter()
-                vals.append(h.gpr_lml(prog, 0.1, Y))
-                if i >= 2:
-                    t_max = max(t_max, time.perf_counter() - t0)
-            out[t] = (vals, t_max, h.profile_get("lookahead_retries")["launches"])
-            h.close()
-        except Exception as e:
-            errors.append((t, repr(e)))
-
-    ths = [threading.Thread(target=run, args=(t,)) for t in range(threads)]
-    for t in ths: t.start()
-    for t in ths: t.join()
-    assert not errors, errors
-    for t in range(threads):
-        vals, t_max, retries = out[t]
-        # every value right, whatever happened; bit-identical unless an evaluation was re-run without look-ahead (a bounded wait
-        # that ran out: the launch-by-launch path sums in another order) -- seen once in some thirty runs of this test, under
-        # GPS_POISON_ALLOC=1 in a shuffled suite, not reproduced since: at most one such re-run is tolerated here, and reported
-        assert all(abs(v - ref) <= 1e-8 * abs(ref) for v in vals), (t, sorted(set(vals)), ref)
-        if retries == 0:
-            assert all(v == vals[0] for v in vals), "thread %d: the likelihood changed between steps: %r" % (t, sorted(set(vals)))
-            assert t_max < 0.5, (t, t_max)
-        else:
-            print("thread %d: %d evaluation(s) re-run without look-ahead, slowest step %.3f s, values %r" % (t, retries, t_max, sorted(set(vals))))
-    assert sum(out[t][2] for t in out) <= 1, [out[t][2] for t in out]
-    clean = [out[t][0][0] for t in out if out[t][2] == 0]
-    assert all(v == clean[0] for v in clean)
