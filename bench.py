@@ -545,11 +545,12 @@ def main():
         # predict_f latency (reference semantics = cold: re-factorises, models/gpr.py:119-121)
         # five calls each, median reported with min / max beside it: one slow call (a clock ramp, a page fault of a fresh
         # box) then shows up as an outlier instead of as the number
-        def latency(reps=5):
+        def latency(reps=5, Xq=None):
+            Xq = Xnew if Xq is None else Xq
             ts = []
             for _ in range(reps):
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-                model.predict_f(Xnew)
+                model.predict_f(Xq)
                 torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t1))
             ts.sort()
             return {"median": round(ts[len(ts) // 2], 2), "min": round(ts[0], 2), "max": round(ts[-1], 2), "calls": reps}
@@ -560,6 +561,25 @@ def main():
         model.predict_f(Xnew)
         warm = latency()
         cold_ms, warm_ms = cold["median"], warm["median"]
+        # latency table (examples/gpr.py:56,60-68 predicts on ~51 points every 10 steps): N* = 64 / 256 / n_new on the resident
+        # factor, and the FIRST such call after a new factor -- it builds the factor's 2048-column inverse blocks
+        # (csrc/gps_gpr.hip: gpr_wide_inverse), every later call on that factor reuses them
+        table = {}
+        for ns_t in sorted(set([64, 256, args.n_new])):
+            Xq = np.ascontiguousarray(Xnew[:ns_t]) if ns_t <= Xnew.shape[0] else rng.standard_normal((ns_t, d))
+            model.predict_f(Xq)
+            w = latency(Xq=Xq)
+            set_step(args.steps + 1 + len(table), False); model.compute_log_likelihood()      # a new factor: no wide blocks yet
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            model.predict_f(Xq)
+            torch.cuda.synchronize(); first_ms = 1e3 * (time.perf_counter() - t1)
+            table["n_new=%d" % ns_t] = {"warm_ms": w["median"], "warm_min_ms": w["min"], "warm_max_ms": w["max"],
+                                        "first_call_after_new_factor_ms": round(first_ms, 2),
+                                        "trsm_frac_of_peak": round(float(n) * n * max(ns_t, 128) / (w["median"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+        table["note"] = ("warm: median of 5 predict_f calls on the resident factor (wall time incl. the host round trip of mean and "
+                         "variance); first_call_after_new_factor: one call right after a likelihood evaluation with new "
+                         "hyper-parameters -- includes building the factor's wide inverse blocks once; trsm_frac_of_peak = N^2 max(N*, 128) "
+                         "flop (test points padded to one 128-row tile) / warm time / 78.6 TFLOP/s")
         progress("predict_latency_done")
         # predict_f throughput at N* = 8192 on the resident factor: trsm N^2 N* flop on the MFMA, then one
         # HBM pass over A^T for the mean and the variance
@@ -759,6 +779,7 @@ def main():
                "config": {"workload": workload, "n": n, "d": d, "n_new": args.n_new, "parallelism": parallelism},
                "predict_f_latency_ms": {"cold_refactor": round(cold_ms, 2), "warm_resident_factor": round(warm_ms, 2), "n_new": args.n_new,
                                         "statistic": "median of 5 calls", "cold_calls": cold, "warm_calls": warm},
+               "predict_f_latency_table": table,
                "fallback_counters": {"lookahead_retries": int(h.profile_get("lookahead_retries")["launches"]),
                                      "trsv_wave_fallbacks": int(h.profile_get("trsv_wave_fallbacks")["launches"]),
                                      "small_n_fallbacks": int(h.profile_get("small_n_fallbacks")["launches"]),

@@ -384,6 +384,15 @@ __global__ __launch_bounds__(256) void transpose_blocks_kernel(const double* __r
   for (int j = ty; j < 32; j += 8) dst[base + (i64)(c0 + j) * 128 + r0 + tx] = t[tx][j];
 }
 
+// The 128 x 128 blocks src[b] laid out along the diagonals of wide blocks: dst is [nblk * 128, wb] (diagonal blocks of wb columns
+// stacked), block b goes to rows 128 b .., columns (128 b) % wb ..  (level 0 of the wide inverse blocks: gps_gpr.hip)
+__global__ __launch_bounds__(256) void blocks_to_diag_kernel(const double* __restrict__ src, double* __restrict__ dst, i64 wb) {
+  const i64 b = blockIdx.y;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), c = (threadIdx.x & 63) * 2;
+  const double2 v = *reinterpret_cast<const double2*>(src + b * 128 * 128 + (i64)r * 128 + c);
+  *reinterpret_cast<double2*>(dst + (b * 128 + r) * wb + (b * 128) % wb + c) = v;
+}
+
 // dst [prow, pcol] <- src [rows, cols] zero padded; identity_pad: dst[i][i] = 1 for i >= rows;
 // diag_add added on the real diagonal.
 __global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict__ src, i64 lds_,
@@ -809,6 +818,15 @@ int gps_launch_block_cond(gps_handle_t h, const double* L, i64 ldl, const double
   if (rc) return rc;
   LaunchScope ls(h, KC_OTHER, 0.0, 2.0 * 8.0 * 128 * 128 * nblk);
   hipLaunchKernelGGL(block_cond_kernel, dim3((unsigned)nblk), dim3(128), lds, h->stream, L, ldl, W, d_out);
+  GPS_HIP(h, hipGetLastError());
+  return GPS_OK;
+}
+
+int gps_launch_blocks_to_diag(gps_handle_t h, const double* src, double* dst, i64 nblk, i64 wb) {
+  if (nblk <= 0) return GPS_OK;
+  if (wb % 128 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return gps_fail(h, GPS_ERR_ARG, "blocks_to_diag: bad layout");
+  LaunchScope ls(h, KC_OTHER, 0.0, (double)nblk * 128 * 128 * 16);
+  hipLaunchKernelGGL(blocks_to_diag_kernel, dim3(32, (unsigned)nblk), dim3(256), 0, h->stream, src, dst, wb);
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

@@ -46,7 +46,16 @@ struct GemmArgs {
   int Tm, Tn;       // tiles
   int K;
   int ntiles;
-  int triA;         // A is upper triangular (A[i][k] == 0 for k < i): tile row tm starts its K loop at tm*BM
+  // Triangular operands (the zero part is never read; K loop cut to the non-zero range of the tile):
+  //   1: A upper triangular (M == K; A[i][k] == 0 for k < i): tile row tm starts at k = tm*BM
+  //   2: A lower triangular (M == K; k > i zero): tile row tm ends at k = (tm+1)*BM
+  //   3: B lower triangular (N == K; B[n][k] == 0 for k > n): tile column tn ends at k = (tn+1)*BN
+  int triA;
+  // Batch (batch > 1; round 6: the 2048-column inverse blocks of a factor are built by batched products over all diagonal
+  // blocks at once): problem p reads / writes its operands at  base + (p * rs) * ld + (p * cs) % cm  (cm == 0: no wrap) --
+  // blocks that step along a diagonal, possibly inside a buffer that stacks wide diagonal blocks (column offset modulo the width).
+  int batch, tpb;   // problems ; tiles per problem (ntiles = batch * tpb)
+  i64 a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, a_cm, b_cm, c_cm;
   // Block-cyclic columns (cb_tiles > 0; the multi-GPU trailing update): tile column tn lies in owned block
   // tn / cb_tiles, whose rows of B and columns of C start cb_stride elements after those of the previous owned
   // block; tiles entirely above a block's first row are skipped (the update is lower-trapezoidal).
@@ -154,6 +163,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   }
   int tm, tn;
   i64 bcol;                              // first row of B / first column of C of this tile
+  const double* gA = g.A; const double* gB = g.B; double* gC = g.C;
+  if (g.batch > 1) {
+    const int p = tile_id / g.tpb;
+    tile_id -= p * g.tpb;
+    gA += (i64)p * g.a_rs * g.lda + (g.a_cm ? ((i64)p * g.a_cs) % g.a_cm : (i64)p * g.a_cs);
+    gB += (i64)p * g.b_rs * g.ldb + (g.b_cm ? ((i64)p * g.b_cs) % g.b_cm : (i64)p * g.b_cs);
+    gC += (i64)p * g.c_rs * g.ldc + (g.c_cm ? ((i64)p * g.c_cs) % g.c_cm : (i64)p * g.c_cs);
+  }
   if (g.cb_tiles > 0) {
     // only the needed tiles are enumerated (so that the XCD chunks carry equal work): owned block ob holds
     // (Tm - ob * q) tile rows x cb_tiles tile columns, q = cb_stride / BM
@@ -190,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
   // global -> register staging map: 8 threads cover one 16-double (128 B) row slab
   const int lrow = tid / TPR;         // 0..RPP-1
   const int lk = (tid % TPR) * 2;     // 0,2,..,BKT-2
-  const double* Ag = g.A + (i64)(tm * BM + lrow) * g.lda + lk;
-  const double* Bg = g.B + (bcol + lrow) * g.ldb + lk;
+  const double* Ag = gA + (i64)(tm * BM + lrow) * g.lda + lk;
+  const double* Bg = gB + (bcol + lrow) * g.ldb + lk;
   const bool a_ld = (BM >= RPP) || (lrow < BM);         // BM < RPP: only some of the threads stage A
 
   v2d ra[LPA], rb[LPB];
@@ -204,7 +221,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       for (int j = 0; j < NI; ++j) acc[q][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   int nk = g.K / BK;
-  int kt0 = g.triA ? (tm * BM) / BK : 0;
+  int kt0 = g.triA == 1 ? (tm * BM) / BK : 0;
+  if (g.triA == 2) nk = ((tm + 1) * BM) / BK;
+  if (g.triA == 3) nk = ((tn + 1) * BN) / BK;
   if (slice >= 0) {                      // slabs [kt0, nk) of this slice: an even split of K / BK, remainder to the first slices
     const int per = nk / g.nsplit, rem = nk - per * g.nsplit;
     kt0 = slice * per + min(slice, rem);
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
-            cv[ii][j][rg] = g.C[(row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16];
+            cv[ii][j][rg] = gC[(row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16];
     }
 #pragma unroll
     for (int ii = 0; ii < IB; ++ii)
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          double* cp = g.C + (row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16;
+          double* cp = gC + (row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16;
           const double av = acc[0][i0 + ii][j][rg];
           if (OP == 0) *cp = cv[ii][j][rg] - av;
           else if (OP == 2) *cp = cv[ii][j][rg] + av;
@@ -458,12 +477,14 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     nt = 0;
     for (i64 ob = 0; ob < nblocks; ++ob) nt += ((i64)g.Tm - ob * q) * g.cb_tiles;
   }
+  g.tpb = (int)nt;
+  if (g.batch > 1) nt *= g.batch;
   if (nt > 0x7fffffff) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: too many tiles");
   g.ntiles = (int)nt;
   // tail split: 128x128 tiles only (512 resident slots on 256 CUs), never for the in-place or triangular-A forms
   g.nfull = g.ntiles; g.nsplit = 1; g.ws = nullptr; g.cnt = nullptr;
   // (not on the look-ahead side stream either: the slice work space is shared by all launches of the handle)
-  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256 &&
+  if (BM == 128 && BN == 128 && h->gemm_tail_split && !g.triA && g.batch <= 1 && g.cb_tiles == 0 && g.C != g.A && h->prop.multiProcessorCount == 256 &&
       (h->side_stream == nullptr || h->stream != h->side_stream) && (h->def_stream == nullptr || h->stream != h->def_stream)) {
     const int slots = 512;
     const int nfull = (g.ntiles / slots) * slots, r = g.ntiles - nfull;
@@ -498,34 +519,53 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc) {
+  return gps_launch_gemm_nt_ex(h, op, lower == 2 ? 0 : lower, lower == 2 ? 1 : 0, M, N, K, A, lda, B, ldb, C, ldc, nullptr);
+}
+
+// tri: 0 none, 1 A upper triangular, 2 A lower triangular (both M == K), 3 B lower triangular (N == K): GemmArgs::triA.
+// bt: batch of equal problems whose operands step along diagonals (GemmBatch, gps_common.hpp) or nullptr.
+int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64 N, i64 K,
+                          const double* A, i64 lda, const double* B, i64 ldb,
+                          double* C, i64 ldc, const GemmBatch* bt) {
   if (M <= 0 || N <= 0 || K <= 0) return GPS_OK;
-  const int triA = (lower == 2);
+  const int triA = tri;
   if (triA) {
-    if (M != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: triangular A must be square");
-    lower = 0;
+    if (triA < 0 || triA > 3 || lower) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: bad triangular mode");
+    if ((triA == 3 ? N : M) != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: a triangular operand must be square");
   }
+  const i64 nbatch = (bt && bt->batch > 1) ? bt->batch : 1;
   if (M % 128 || N % 128 || K % BK_MIN || (lower && M < N))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16 (lower: M >= N)");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: operands must be 16-byte aligned with even leading dimension");
   const bool rowpanel = (C == A);
-  if (rowpanel && (N != 128 || lower))
-    return gps_fail(h, GPS_ERR_ARG, "gemm_nt: in-place form needs N == 128");
+  if (rowpanel && (N != 128 || lower || triA || nbatch > 1))
+    return gps_fail(h, GPS_ERR_ARG, "gemm_nt: in-place form needs N == 128 (no batch, no triangular operand)");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = (int)K; g.triA = triA;
+  g.batch = (int)nbatch; g.tpb = 0;
+  g.a_rs = g.a_cs = g.b_rs = g.b_cs = g.c_rs = g.c_cs = g.a_cm = g.b_cm = g.c_cm = 0;
+  if (nbatch > 1) {
+    if (lower) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: no batched lower-triangle form");
+    g.a_rs = bt->a_rs; g.a_cs = bt->a_cs; g.a_cm = bt->a_cm; g.b_rs = bt->b_rs; g.b_cs = bt->b_cs; g.b_cm = bt->b_cm;
+    g.c_rs = bt->c_rs; g.c_cs = bt->c_cs; g.c_cm = bt->c_cm;
+    if ((g.a_cs & 1) || (g.b_cs & 1) || (g.a_cm & 1) || (g.b_cm & 1)) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: batch column steps must be even");
+  }
   g.stamps = h->gemm_stamps;
   g.sig_ptr = h->next_sig_ptr; g.sig_val = h->next_sig_val; h->next_sig_ptr = nullptr;      // consumed by this launch
   g.cb_tiles = 0; g.cb_stride = 0;
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
-  const double t128 = lower ? 0.5 * (double)(N / 128) * (double)(N / 128 + 1) + (double)((M - N) / 128) * (double)(N / 128)
-                            : (double)(M / 128) * (double)(N / 128);
-  const double flops = triA ? 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)   // sum_i 2 (K - 128 i)
-                            : 2.0 * t128 * 128.0 * 128.0 * (double)K;
+  const double t128 = (double)nbatch * (lower ? 0.5 * (double)(N / 128) * (double)(N / 128 + 1) + (double)((M - N) / 128) * (double)(N / 128)
+                                             : (double)(M / 128) * (double)(N / 128));
+  // (triangular operand: sum over the tiles of 2 x their non-zero K range, counted in 128-blocks)
+  const double flops = triA == 3 ? (double)nbatch * 128.0 * 128.0 * (double)(M / 128) * (double)(N / 128) * (double)(N + 128)
+                     : triA      ? (double)nbatch * 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)
+                                 : 2.0 * t128 * 128.0 * 128.0 * (double)K;
   const double bytes = t128 * (((op == 0 || op == 2) ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
                        8.0 * (double)K * (double)(M + N);   // compulsory traffic: C rmw + each panel once
   LaunchScope ls(h, KC_GEMM, flops, bytes);
-  ls.tag[0] = M; ls.tag[1] = N; ls.tag[2] = K; ls.tag[3] = op + 10 * lower + 20 * triA + 100 * (rowpanel ? 1 : 0);
+  ls.tag[0] = M; ls.tag[1] = N; ls.tag[2] = K; ls.tag[3] = op + 10 * lower + 20 * triA + 100 * (rowpanel ? 1 : 0) + 1000 * (nbatch > 1 ? nbatch : 0);
   const double target = (double)h->gemm_min_tiles;   // workgroups wanted before a larger tile is used
   const int force = h->gemm_force_tb;
   if (rowpanel) {
@@ -562,6 +602,7 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
   GemmArgs g;
   g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;
+  g.batch = 1; g.tpb = 0; g.a_rs = g.a_cs = g.b_rs = g.b_cs = g.c_rs = g.c_cs = g.a_cm = g.b_cm = g.c_cm = 0;
   g.sig_ptr = nullptr; g.sig_val = 0;
   g.stamps = h->gemm_stamps;
   // needed 128x128 tiles: block b uses rows >= b*stride

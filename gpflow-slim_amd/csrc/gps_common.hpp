@@ -11,6 +11,7 @@
 #include "../../include/gpflowslim_hip.h"
 
 #define GPS_TILE 128            // base block of the factorisation = GEMM tile edge
+#define GPS_WB 2048             // columns of the wide inverse blocks of predict_f (gps_gpr.hip)
 
 typedef int64_t i64;
 
@@ -191,6 +192,13 @@ struct gps_handle_s {
   DevBuf dInfo;     // int info word
   DevBuf dXnew;     // [n_new, d_all]
   DevBuf dB;        // [nspad, npad]   K(Xnew, X) then A^T
+  // predict_f on few test points (round 6): wide inverse blocks of the resident factor, built once per factor.  dWbig / dWtbig:
+  // [nf, GPS_WB] = the inverses of the GPS_WB-column diagonal blocks of L (lower) / their transposes, stacked; nf = whole blocks
+  // of npad.  dBigT: scratch of the level-by-level build.  dB2: the solution (the wide leaves are out-of-place products).
+  DevBuf dWbig, dWtbig, dBigT, dB2;
+  unsigned long long factor_gen = 0, big_inv_gen = ~0ull;   // the factor the wide blocks belong to (factor_gen: bumped whenever dK / dLinv change)
+  i64 big_inv_nf = 0;
+  int predict_inv_blocks = 1;   // option "predict_inverse_blocks"
   DevBuf dMean;     // [n_new, r]
   DevBuf dVar;      // [n_new] or [nspad, nspad]
   // ---- block-column distributed factorisation (gps_dist_*) ----
@@ -318,6 +326,12 @@ static inline int gps_dyn_lds(gps_handle_t h, const void* fn, int bytes) {
 int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        const double* A, i64 lda, const double* B, i64 ldb,
                        double* C, i64 ldc);
+// ... with a triangular operand (tri: 1 A upper, 2 A lower, 3 B lower) and / or as a batch of equal problems whose operands
+// step along diagonals: problem p at  base + (p * rs) * ld + (p * cs) % cm  (cm == 0: no wrap)
+struct GemmBatch { i64 batch = 1; i64 a_rs = 0, a_cs = 0, a_cm = 0, b_rs = 0, b_cs = 0, b_cm = 0, c_rs = 0, c_cs = 0, c_cm = 0; };
+int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64 N, i64 K,
+                          const double* A, i64 lda, const double* B, i64 ldb,
+                          double* C, i64 ldc, const GemmBatch* bt);
 int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 stride, i64 K, const double* A, i64 lda,
                               double* C, i64 ldc, int c_packed = 0);
 // potrf_base.hip : factor one 128x128 diagonal block in place (lower), write its
@@ -392,6 +406,7 @@ int gps_launch_pad_copy(gps_handle_t h, const double* src, i64 lds, i64 rows, i6
 int gps_launch_extract(gps_handle_t h, const double* src, i64 lds, i64 rows, i64 cols,
                        double* dst, i64 ldd, int lower_only);
 int gps_launch_transpose_blocks(gps_handle_t h, const double* src, double* dst, i64 nblk);
+int gps_launch_blocks_to_diag(gps_handle_t h, const double* src, double* dst, i64 nblk, i64 wb);
 int gps_launch_block_cond(gps_handle_t h, const double* L, i64 ldl, const double* W, i64 nblk, double* d_out);
 int gps_launch_scale_rows(gps_handle_t h, double* A, i64 lda, i64 rows, i64 cols, const double* sc);
 int gps_launch_scale_cols(gps_handle_t h, const double* src, i64 lds_, i64 rows, i64 cols, const double* sc,

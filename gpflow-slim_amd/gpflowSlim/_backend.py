@@ -134,6 +134,8 @@ _SIGNATURES = {
     "gps_diag_mfma_f64": [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_int_p],
     "gps_diag_gemm_nt": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _c_double_p, _c_double_p,
                          _c_double_p],
+    "gps_diag_gemm_nt_batched": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i64, _i64, _i64, _i64, _c_double_p, _c_double_p,
+                                 _c_double_p],
     "gps_diag_trsm512": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
     "gps_diag_trsm512_stamps": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.POINTER(ctypes.c_longlong), _i64],
     "gps_diag_trsm_leaf": [ctypes.c_void_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
@@ -481,6 +483,17 @@ class Handle(object):
         assert B.shape[1] == k and C.shape == (m, n)
         self._check(self._lib.gps_diag_gemm_nt(self._h, op, int(lower), m, n, k, _ptr(A), _ptr(B), _ptr(C)),
                     "gps_diag_gemm_nt")
+        return C
+
+    def diag_gemm_nt_batched(self, op, tri, A, B, C):
+        """A [batch, m, k], B [batch, n, k], C [batch, m, n]; tri: 0 none, 1 A upper, 2 A lower, 3 B lower triangular."""
+        A, B = _f64(A), _f64(B)
+        C = np.array(C, dtype=np.float64, order="C", copy=True)
+        batch, m, k = A.shape
+        n = B.shape[1]
+        assert B.shape == (batch, n, k) and C.shape == (batch, m, n)
+        self._check(self._lib.gps_diag_gemm_nt_batched(self._h, op, int(tri), batch, m, n, k, _ptr(A), _ptr(B), _ptr(C)),
+                    "gps_diag_gemm_nt_batched")
         return C
 
     def diag_trsm_leaf(self, m, mode, upper=False, reps=50):

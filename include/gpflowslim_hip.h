@@ -474,10 +474,15 @@ int gps_diag_mfma_f64(gps_handle_t h, int waves_per_simd, double* tflops,
                       int* layout_ok);
 /* raw device GEMM on host matrices, for unit tests:
  * C[m,n] (op)= A[m,k] * B[n,k]^T ; op: 0 -> C -= A B^T, 1 -> C = A B^T, 2 -> C += A B^T, 3 -> C = -A B^T.
- * lower == 1: only tiles on/below the diagonal are computed (m == n); lower == 2: A (m == k) is upper
- * triangular and its zero part is skipped.                                   */
+ * lower == 1: only tiles on/below the diagonal are computed (m == n); lower == 2 / 3: A (m == k) is upper / lower
+ * triangular, lower == 4: B (n == k) is lower triangular -- the zero part of a triangular operand is never read.   */
 int gps_diag_gemm_nt(gps_handle_t h, int op, int lower, int64_t m, int64_t n,
                      int64_t k, const double* A, const double* B, double* C);
+/* ... as ONE launch over a batch of equal problems stacked row-wise: A [batch * m, k], B [batch * n, k], C [batch * m, n];
+ * tri: 0 none, 1 A upper, 2 A lower, 3 B lower triangular (the form that builds the wide inverse blocks of predict_f from
+ * the 128-column ones: gps_gpr_predict)                                                                             */
+int gps_diag_gemm_nt_batched(gps_handle_t h, int op, int tri, int64_t batch, int64_t m, int64_t n, int64_t k,
+                             const double* A, const double* B, double* C);
 /* device-resident GEMM of the given shape on pseudo-random operands (lower == 1: syrk form, B = A): average
  * launch time over `reps`, plus one instrumented launch whose workgroups record
  * stamps_out[6*b + {0..5}] = start, end (100 MHz ticks), HW_ID, XCC_ID, K-loop start, K-loop end.               */

@@ -58,6 +58,51 @@ def test_gemm_nt_triangular_a(handle, m, n, op, tile):
     assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("m,n", [(128, 256), (512, 384), (1024, 1024), (2048, 128)])
+@pytest.mark.parametrize("op", [1, 3])
+@pytest.mark.parametrize("tile", [0, 128, 64, 32])
+def test_gemm_nt_lower_triangular_operands(handle, m, n, op, tile):
+    """Round 6 (the wide inverse blocks of predict_f): lower == 3: A [m, m] lower triangular, the kernel stops at the last
+    column of the tile's rows; lower == 4: B [n, n] lower triangular (C [m, n] = A B^T with k <= column).  Whatever sits in
+    the zero part of the triangular operand beyond its diagonal blocks must not be read (NaN there)."""
+    rng = np.random.default_rng(m + n + op + tile)
+    handle.set_option("gemm_force_tile", tile)
+    try:
+        A = np.tril(rng.standard_normal((m, m))); Ap = A.copy()
+        for ti in range(m // 128):
+            Ap[ti * 128:(ti + 1) * 128, (ti + 1) * 128:] = np.nan
+        B = rng.standard_normal((n, m)); C = rng.standard_normal((m, n))
+        out = handle.diag_gemm_nt(op, 3, Ap, B, C)
+        ref = A @ B.T if op == 1 else -(A @ B.T)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        Bt = np.tril(rng.standard_normal((n, n))); Bp = Bt.copy()
+        for ti in range(n // 128):
+            Bp[ti * 128:(ti + 1) * 128, (ti + 1) * 128:] = np.nan
+        A2 = rng.standard_normal((m, n)); C2 = rng.standard_normal((m, n))
+        out = handle.diag_gemm_nt(op, 4, A2, Bp, C2)
+        ref = A2 @ Bt.T if op == 1 else -(A2 @ Bt.T)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    finally:
+        handle.set_option("gemm_force_tile", 0)
+
+
+@pytest.mark.parametrize("batch,m,n,k,tri", [(1, 128, 128, 128, 0), (5, 128, 256, 128, 0), (16, 256, 256, 256, 1), (7, 512, 512, 512, 2),
+                                            (3, 1024, 1024, 1024, 3), (64, 128, 128, 128, 3), (9, 384, 128, 384, 2)])
+@pytest.mark.parametrize("op", [0, 1, 3])
+def test_gemm_nt_batched(handle, batch, m, n, k, tri, op):
+    """One launch over a batch of equal problems (what builds the 2048-column inverse blocks level by level), with and without a
+    triangular operand: every problem equals its own numpy product."""
+    rng = np.random.default_rng(batch + m + n + k + tri + op)
+    A = rng.standard_normal((batch, m, k)); B = rng.standard_normal((batch, n, k)); C = rng.standard_normal((batch, m, n))
+    if tri == 1: A = np.triu(A)
+    if tri == 2: A = np.tril(A)
+    if tri == 3: B = np.tril(B)
+    out = handle.diag_gemm_nt_batched(op, tri, A, B, C)
+    prod = np.einsum("pmk,pnk->pmn", A, B)
+    ref = {0: C - prod, 1: prod, 3: -prod}[op]
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("op,lower,m,n,k", [(0, 0, 8192, 1152, 1024), (1, 0, 8192, 1152, 512), (2, 0, 9216, 1024, 256),
                                              (3, 0, 8192, 1152, 384), (0, 1, 4224, 4224, 256), (2, 1, 4480, 4480, 1024)])
 def test_gemm_nt_tail_split(handle, op, lower, m, n, k):

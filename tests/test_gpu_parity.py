@@ -122,6 +122,50 @@ def test_gpr_parity(handle, kind, n, d, r, ns):
     assert rel(dens, orc.gaussian_density(np.zeros((ns, r)), rmu, rvar + noise)) <= 1e-7
 
 
+@pytest.mark.parametrize("n,ns,kind", [(4096, 64, "rbf_ard"), (4500, 200, "matern52"), (5000, 1, "rbf_ard"), (6144, 1024, "rbf_ard"),
+                                       (8192, 300, "m52_plus_periodic"), (9000, 2048, "rbf_ard")])
+def test_predict_f_wide_inverse_blocks(handle, n, ns, kind):
+    """predict_f on at most 2048 test points (round 6; csrc/gps_gpr.hip: gpr_wide_inverse, trsm_wide_rec): 2048-column nodes of
+    A^T = Kx^T L^-T as ONE product with the inverse of the factor's 2048-column diagonal block, built once per factor by
+    batched triangular products from the 128-column inverses.  Same mean / variance / full covariance as the recursive solve
+    (option "predict_inverse_blocks" = 0) to 1e-11 and as the oracle to 1e-8 (models/gpr.py:119-131); a call that re-factors and
+    a call on the resident factor give the same bits; a new factor gets new blocks.  Sizes: whole blocks only (4096, 6144,
+    8192) and columns behind the last whole block (4500 -> 4608, 5000 -> 5120, 9000 -> 9088)."""
+    import gpflowSlim as gpf
+    d = 5
+    rng = np.random.default_rng(n + ns)
+    X = rng.standard_normal((n, d)); Y = np.sin(X @ rng.standard_normal((d, 2))) + 0.1 * rng.standard_normal((n, 2))
+    Xs = rng.standard_normal((ns, d))
+    kern, spec = make_kernel(gpf, kind, d)
+    m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+    noise = orc.constrained(0.1)
+    try:
+        mu, var = m.predict_f(Xs)                           # re-factors; builds the wide blocks
+        m.reuse_factor = True
+        mu2, var2 = m.predict_f(Xs)                         # resident factor, cached blocks
+        assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+        handle.set_option("predict_inverse_blocks", 0)
+        mu0, var0 = m.predict_f(Xs)
+        assert rel(mu, mu0) <= 1e-11 and rel(var, var0) <= 1e-11
+        nsf = min(ns, 300)
+        _, cov0 = m.predict_f_full_cov(Xs[:nsf])
+        handle.set_option("predict_inverse_blocks", 1)
+        _, cov = m.predict_f_full_cov(Xs[:nsf])
+        assert rel(cov, cov0) <= 1e-11
+        if n <= 6144:
+            rmu, rvar = orc.gpr_predict(spec, X, Y, noise, Xs)
+            assert rel(mu, rmu) <= RTOL and rel(var, rvar) <= RTOL
+        # new hyper-parameters: the blocks of the old factor must not be used
+        m.likelihood._variance.assign(0.3)
+        lml = m.compute_log_likelihood()
+        mu3, var3 = m.predict_f(Xs)
+        handle.set_option("predict_inverse_blocks", 0)
+        mu4, var4 = m.predict_f(Xs)
+        assert rel(mu3, mu4) <= 1e-11 and rel(var3, var4) <= 1e-11 and rel(var3, var) > 1e-3
+    finally:
+        handle.set_option("predict_inverse_blocks", 1)
+
+
 EPS = np.finfo(np.float64).eps
 
 
