@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
 
   int nk = g.K / BK;
   int kt0 = g.triA == 1 ? (tm * BM) / BK : 0;
-  if (g.triA == 2) nk = ((tm + 1) * BM) / BK;
-  if (g.triA == 3) nk = ((tn + 1) * BN) / BK;
+  // (rounded up to whole slabs: a slab deeper than the tile -- 32 x 32 tiles, 64-deep -- ends inside the same diagonal 128-block,
+  // whose part beyond the diagonal is stored as zeros)
+  if (g.triA == 2) nk = ((tm + 1) * BM + BK - 1) / BK;
+  if (g.triA == 3) nk = ((tn + 1) * BN + BK - 1) / BK;
   if (slice >= 0) {                      // slabs [kt0, nk) of this slice: an even split of K / BK, remainder to the first slices
     const int per = nk / g.nsplit, rem = nk - per * g.nsplit;
     kt0 = slice * per + min(slice, rem);
