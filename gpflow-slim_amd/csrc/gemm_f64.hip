@@ -55,6 +55,7 @@ struct GemmArgs {
   // blocks at once): problem p reads / writes its operands at  base + (p * rs) * ld + (p * cs) % cm  (cm == 0: no wrap) --
   // blocks that step along a diagonal, possibly inside a buffer that stacks wide diagonal blocks (column offset modulo the width).
   int batch, tpb;   // problems ; tiles per problem (ntiles = batch * tpb)
+  int pair;         // workgroups take two mirror tiles (kernel template PAIR): 1 tile columns, 2 tile rows; ntiles / tpb count the PAIRS
   i64 a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, a_cm, b_cm, c_cm;
   // Block-cyclic columns (cb_tiles > 0; the multi-GPU trailing update): tile column tn lies in owned block
   // tn / cb_tiles, whose rows of B and columns of C start cb_stride elements after those of the previous owned
@@ -128,326 +129,37 @@ __device__ __forceinline__ void decode_tile(int id, int Tm, int Tn, int& tm, int
 // (BM/WGM) x (BN/WGN) sub-tile = MI x NI accumulators of 16x16.
 // BKT: K-slab depth.  The per-slab cost of the staging and the barrier (~0.3 us) is fixed, so the small tiles, whose
 // slab holds only 4-16 MFMAs per wave, use deeper slabs (fewer of them); the square MFMA-bound tiles keep 16.
-template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0, int BKT = 16>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(GemmArgs g) {
-  constexpr int BK = BKT, LS = BKT + 2;           // (shadow the file-level defaults)
-  constexpr int TPR = BKT / 2, RPP = 256 / TPR;   // threads per staged row (16 bytes each), rows per pass
-  constexpr int WGN = 4 / WGM;
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile
-  constexpr int MI = WTM / 16, NI = WTN / 16;          // 16x16 MFMA tiles per wave
-  constexpr int LPA = (BM + RPP - 1) / RPP, LPB = (BN + RPP - 1) / RPP;   // 16-byte loads per thread per K-slab
-  static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one MFMA tile");
-  // Small tiles split K over KS accumulator sets (k-step kk of a slab goes to set kk % KS), summed in the
-  // epilogue.  (Measured: a dependent v_mfma_f64_16x16x4_f64 chain already issues every ~67 cycles, so this
-  // is neutral for throughput; it only shortens the dependency chain seen by the scheduler.)
-  constexpr int KS = (MI * NI >= 4) ? 1 : (MI * NI == 2 ? 2 : 4);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* As = reinterpret_cast<double*>(smem_raw);       // [2][BM][LS]
-  double* Bs = As + 2 * BM * LS;                          // [2][BN][LS]
-
-  // Tail split.  Tiles of one launch are equal, so a launch whose tile count is slightly above a multiple of the
-  // resident workgroup slots (512 at 128x128: e.g. the 2080 tiles of a lower-triangular 8192 update) ends with a
-  // round in which a few tiles run for a whole tile time while the rest of the GPU idles.  The first
-  // nfull = multiple-of-512 tiles run as usual; each of the remaining tiles is cut into nsplit K-slices handled by
-  // different workgroups, whose partial sums go to `ws`; the slice that arrives last at the tile's counter adds
-  // them in slice order and applies the result to C (deterministic: no floating-point atomics, and the split is
-  // a function of the launch shape only).
-  int tile_id, slice = -1, tail = 0;
-  if ((int)blockIdx.x < g.nfull || g.nsplit <= 1) {
-    tile_id = xcd_remap((int)blockIdx.x, g.nsplit > 1 ? g.nfull : g.ntiles);
-  } else {
-    const int q = (int)blockIdx.x - g.nfull;
-    tail = q / g.nsplit;
-    slice = q - tail * g.nsplit;
-    tile_id = g.nfull + tail;
-  }
-  int tm, tn;
-  i64 bcol;                              // first row of B / first column of C of this tile
-  const double* gA = g.A; const double* gB = g.B; double* gC = g.C;
-  if (g.batch > 1) {
-    const int p = tile_id / g.tpb;
-    tile_id -= p * g.tpb;
-    gA += (i64)p * g.a_rs * g.lda + (g.a_cm ? ((i64)p * g.a_cs) % g.a_cm : (i64)p * g.a_cs);
-    gB += (i64)p * g.b_rs * g.ldb + (g.b_cm ? ((i64)p * g.b_cs) % g.b_cm : (i64)p * g.b_cs);
-    gC += (i64)p * g.c_rs * g.ldc + (g.c_cm ? ((i64)p * g.c_cs) % g.c_cm : (i64)p * g.c_cs);
-  }
-  if (g.cb_tiles > 0) {
-    // only the needed tiles are enumerated (so that the XCD chunks carry equal work): owned block ob holds
-    // (Tm - ob * q) tile rows x cb_tiles tile columns, q = cb_stride / BM
-    const int q = (int)(g.cb_stride / BM);
-    int ob = 0, rem = tile_id;
-    for (;;) {
-      const int cnt = (g.Tm - ob * q) * g.cb_tiles;
-      if (rem < cnt) break;
-      rem -= cnt; ++ob;
-    }
-    tm = ob * q + rem / g.cb_tiles;
-    const int wi = rem % g.cb_tiles;
-    tn = ob * g.cb_tiles + wi;
-    bcol = (i64)ob * g.cb_stride + (i64)wi * BN;
-  } else {
-    decode_tile<LOWER>(tile_id, g.Tm, g.Tn, tm, tn);
-    bcol = (i64)tn * BN;
-  }
-  if (g.sig_ptr && blockIdx.x == 0 && threadIdx.x == 0)
-    __hip_atomic_store(g.sig_ptr, g.sig_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (g.stamps && threadIdx.x == 0) {
-    long long* st = g.stamps + 6 * (long long)blockIdx.x;
-    st[0] = (long long)wall_clock64();
-    st[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-    st[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-  }
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wr = wave / WGN, wc = wave % WGN;
-  const int fr = lane & 15, fk = lane >> 4;
-
-  // global -> register staging map: 8 threads cover one 16-double (128 B) row slab
-  const int lrow = tid / TPR;         // 0..RPP-1
-  const int lk = (tid % TPR) * 2;     // 0,2,..,BKT-2
-  const double* Ag = gA + (i64)(tm * BM + lrow) * g.lda + lk;
-  const double* Bg = gB + (bcol + lrow) * g.ldb + lk;
-  const bool a_ld = (BM >= RPP) || (lrow < BM);         // BM < RPP: only some of the threads stage A
-
-  v2d ra[LPA], rb[LPB];
-  v4d acc[KS][MI][NI];
-#pragma unroll
-  for (int q = 0; q < KS; ++q)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[q][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  int nk = g.K / BK;
-  int kt0 = g.triA == 1 ? (tm * BM) / BK : 0;
-  // (rounded up to whole slabs: a slab deeper than the tile -- 32 x 32 tiles, 64-deep -- ends inside the same diagonal 128-block,
-  // whose part beyond the diagonal is stored as zeros)
-  if (g.triA == 2) nk = ((tm + 1) * BM + BK - 1) / BK;
-  if (g.triA == 3) nk = ((tn + 1) * BN + BK - 1) / BK;
-  if (slice >= 0) {                      // slabs [kt0, nk) of this slice: an even split of K / BK, remainder to the first slices
-    const int per = nk / g.nsplit, rem = nk - per * g.nsplit;
-    kt0 = slice * per + min(slice, rem);
-    nk = kt0 + per + (slice < rem ? 1 : 0);
-  }
-
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < LPA; ++i)
-      if (a_ld) ra[i] = *reinterpret_cast<const v2d*>(Ag + (i64)(i * RPP) * g.lda + (i64)kt * BK);
-#pragma unroll
-    for (int i = 0; i < LPB; ++i)
-      rb[i] = *reinterpret_cast<const v2d*>(Bg + (i64)(i * RPP) * g.ldb + (i64)kt * BK);
-  };
-  auto lstore = [&](int buf) {
-    double* a = As + buf * BM * LS + lrow * LS + lk;
-    double* b = Bs + buf * BN * LS + lrow * LS + lk;
-#pragma unroll
-    for (int i = 0; i < LPA; ++i)
-      if (a_ld) *reinterpret_cast<v2d*>(a + i * RPP * LS) = ra[i];
-#pragma unroll
-    for (int i = 0; i < LPB; ++i)
-      *reinterpret_cast<v2d*>(b + i * RPP * LS) = rb[i];
-  };
-
-  gload(kt0);
-  lstore(kt0 & 1);
-  __syncthreads();
-
-  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 4] = (long long)wall_clock64();
-  if (PIPE == 2) {
-    // Scheduled K loop with the slab's last 8 MFMAs deferred across the barrier: they only need registers, so they
-    // run while the next slab's first fragments are being read.  Two fragment sets F0 / F1 (one k-step each).
-    double fa[2][MI], fb[2][NI];
-    auto rd = [&](int set, int buf, int kk) {
-      const double* a_base = As + buf * BM * LS + (wr * WTM + fr) * LS + fk + kk * 4;
-      const double* b_base = Bs + buf * BN * LS + (wc * WTN + fr) * LS + fk + kk * 4;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[set][i] = a_base[i * 16 * LS];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) fb[set][j] = b_base[j * 16 * LS];
-    };
-    auto mm = [&](int set, int i0, int i1) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        if (i >= i0 && i < i1) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[0][i][j], 0, 0, 0);
-        }
-    };
-    int kt = kt0;
-    if (kt + 1 < nk) {
-      // first slab: nothing deferred yet
-      gload(kt + 1);
-      rd(0, kt & 1, 0);
-      rd(1, kt & 1, 1); mm(0, 0, MI);
-      rd(0, kt & 1, 2); mm(1, 0, MI);
-      rd(1, kt & 1, 3); mm(0, 0, MI);
-      mm(1, 0, MI / 2);
-      lstore((kt & 1) ^ 1);
-      __syncthreads();
-      ++kt;
-      for (; kt + 1 < nk; ++kt) {
-        const int buf = kt & 1;
-        gload(kt + 1);
-        rd(0, buf, 0);
-        mm(1, MI / 2, MI);               // deferred from the previous slab (F1 still holds its k-step 3)
-        rd(1, buf, 1); mm(0, 0, MI);
-        rd(0, buf, 2); mm(1, 0, MI);
-        rd(1, buf, 3); mm(0, 0, MI);
-        mm(1, 0, MI / 2);
-        lstore(buf ^ 1);
-        // order of the block (counts for a BM x BN tile: NLD 16-byte global loads / LDS writes per thread, MI + NI
-        // fragment reads per k-step pair -- the compiler pairs k-steps into ds_read2_b64 --, MI * NI MFMAs per k-step)
-        constexpr int NLD = LPA + LPB, NFR = MI + NI, NMM = MI * NI;
-        __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);   // global loads of the next slab
-        __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);   // fragments of k-steps 0, 1
-        __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2, 0);   // deferred MFMAs of the previous slab
-#pragma unroll
-        for (int q = 0; q < 3 * NMM / 2; ++q) {                // k-steps 0..2 with the remaining fragment reads
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {                        // first half of k-step 3 + the next slab's LDS writes
-          __builtin_amdgcn_sched_group_barrier(0x008, (NMM / 2 + NLD - 1) / NLD, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        __syncthreads();
-      }
-      // last slab (in LDS since the barrier), then everything that is still deferred
-      rd(0, kt & 1, 0);
-      mm(1, MI / 2, MI);
-      rd(1, kt & 1, 1); mm(0, 0, MI);
-      rd(0, kt & 1, 2); mm(1, 0, MI);
-      rd(1, kt & 1, 3); mm(0, 0, MI);
-      mm(1, 0, MI);
-    } else {
-      rd(0, kt & 1, 0);
-      rd(1, kt & 1, 1); mm(0, 0, MI);
-      rd(0, kt & 1, 2); mm(1, 0, MI);
-      rd(1, kt & 1, 3); mm(0, 0, MI);
-      mm(1, 0, MI);
-    }
-    __syncthreads();
-  } else
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-
-    const double* a_base = As + buf * BM * LS + (wr * WTM + fr) * LS + fk;
-    const double* b_base = Bs + buf * BN * LS + (wc * WTN + fr) * LS + fk;
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = a_base[i * 16 * LS + kk * 4];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = b_base[j * 16 * LS + kk * 4];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[kk % KS][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[kk % KS][i][j], 0, 0, 0);
-    }
-
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 5] = (long long)wall_clock64();
-  // epilogue.  f64 accumulator map (differs from every other dtype on gfx950):
-  //   col = lane & 15, row = (lane >> 4) + 4 * reg.
-#pragma unroll
-  for (int q = 1; q < KS; ++q)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[0][i][j] += acc[q][i][j];
-  if (slice >= 0) {
-    __shared__ unsigned s_ticket;
-    double* mine = g.ws + ((i64)tail * g.nsplit + slice) * (BM * BN) + tid;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) mine[((i * NI + j) * 4 + rg) * 256] = acc[0][i][j][rg];
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(&g.cnt[tail], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != (unsigned)(g.nsplit - 1)) {
-      if (g.stamps && tid == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
-      return;
-    }
-    __threadfence();
-    // slice order outermost: all MI*NI*4 loads of one slice are in flight together (element by element, each sum
-    // was a chain of nsplit dependent loads: 365 us for 16 slices); per element the order of the additions is the same
-    const double* all = g.ws + (i64)tail * g.nsplit * (BM * BN) + tid;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[0][i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    for (int sl = 0; sl < g.nsplit; ++sl) {
-      const double* src = all + (i64)sl * (BM * BN);
-      double v[MI][NI][4];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) v[i][j][rg] = __builtin_nontemporal_load(src + ((i * NI + j) * 4 + rg) * 256);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) acc[0][i][j][rg] += v[i][j][rg];
-    }
-    if (tid == 0) g.cnt[tail] = 0;       // ready for the next launch on this stream
-  }
-  const i64 row0 = (i64)tm * BM + wr * WTM + (lane >> 4);
-  const i64 col0 = (g.cb_cpack ? (i64)tn * BN : bcol) + wc * WTN + (lane & 15);
-  // C read-modify-write in batches: all loads of a batch are issued before the first store.  (Written as
-  // `*cp = *cp - acc` per element the compiler has to assume that a store may alias the next load -- ldc is a
-  // run-time value -- and emits load / wait / store one element at a time: 64 memory round trips per thread,
-  // 96 us per tile when every workgroup of a round does it at the same moment.)
-  constexpr int IB = (MI >= 2) ? 2 : 1;                 // tile rows of 16 per batch
-#pragma unroll
-  for (int i0 = 0; i0 < MI; i0 += IB) {
-    double cv[IB][NI][4];
-    if (OP == 0 || OP == 2) {
-#pragma unroll
-      for (int ii = 0; ii < IB; ++ii)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            cv[ii][j][rg] = gC[(row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16];
-    }
-#pragma unroll
-    for (int ii = 0; ii < IB; ++ii)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          double* cp = gC + (row0 + (i0 + ii) * 16 + 4 * rg) * g.ldc + col0 + j * 16;
-          const double av = acc[0][i0 + ii][j][rg];
-          if (OP == 0) *cp = cv[ii][j][rg] - av;
-          else if (OP == 2) *cp = cv[ii][j][rg] + av;
-          else if (OP == 3) *cp = -av;
-          else *cp = av;
-        }
-  }
-  if (g.stamps && threadIdx.x == 0) g.stamps[6 * (long long)blockIdx.x + 1] = (long long)wall_clock64();
-}
+#define GEMM_KERNEL_NAME gemm_nt_f64_kernel
+#define GEMM_PAIR_TPARAM
+#include "gemm_f64_kernel.inc"
+#undef GEMM_KERNEL_NAME
+#undef GEMM_PAIR_TPARAM
+#define GEMM_PAIRED
+#define GEMM_KERNEL_NAME gemm_nt_f64_pair_kernel
+#define GEMM_PAIR_TPARAM , int PAIR = 1
+#include "gemm_f64_kernel.inc"
+#undef GEMM_PAIRED
+#undef GEMM_KERNEL_NAME
+#undef GEMM_PAIR_TPARAM
 
 template <int BM, int BN, int WGM, bool LOWER, int OP, int PIPE = 0, int BKT = 16>
 static int launch_variant(gps_handle_t h, const GemmArgs& g) {
   const size_t lds = (size_t)(2 * (BM + BN) * (BKT + 2)) * sizeof(double);
+  // paired tiles: the square scheduled tiles with a triangular operand, plain C = +- A B^T (what the wide inverse blocks use)
+  if (g.pair && BM == BN && PIPE == 2 && !LOWER && (OP == 1 || OP == 3)) {
+    const int grid = g.ntiles;          // (already halved: launch_cfg)
+    if (g.pair == 1) {
+      int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_pair_kernel<BM, BN, WGM, false, OP, PIPE, BKT, 1>), (int)lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((gemm_nt_f64_pair_kernel<BM, BN, WGM, false, OP, PIPE, BKT, 1>), dim3(grid), dim3(256), lds, h->stream, g);
+    } else {
+      int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_pair_kernel<BM, BN, WGM, false, OP, PIPE, BKT, 2>), (int)lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((gemm_nt_f64_pair_kernel<BM, BN, WGM, false, OP, PIPE, BKT, 2>), dim3(grid), dim3(256), lds, h->stream, g);
+    }
+    GPS_HIP(h, hipGetLastError());
+    return GPS_OK;
+  }
   int rc = gps_dyn_lds(h, reinterpret_cast<const void*>(&gemm_nt_f64_kernel<BM, BN, WGM, LOWER, OP, PIPE, BKT>), (int)lds);
   if (rc) return rc;
   const int grid = g.nsplit > 1 ? g.nfull + (g.ntiles - g.nfull) * g.nsplit : g.ntiles;
@@ -478,6 +190,13 @@ static int launch_cfg(gps_handle_t h, int op, int lower, GemmArgs& g, i64 M, i64
     const i64 q = g.cb_stride / BM, nblocks = g.Tn / g.cb_tiles;
     nt = 0;
     for (i64 ob = 0; ob < nblocks; ++ob) nt += ((i64)g.Tm - ob * q) * g.cb_tiles;
+  }
+  // a triangular operand on the square scheduled tiles (C = +- A B^T): mirror tiles in pairs when the tile count allows it
+  g.pair = 0;
+  if (g.triA && !lower && g.cb_tiles == 0 && BM == BN && (BM == 128 || BM == 64) && (op == 1 || op == 3) && g.C != g.A && h->gemm_pair) {
+    if (g.triA == 3 && g.Tn % 2 == 0) g.pair = 1;
+    if (g.triA != 3 && g.Tm % 2 == 0) g.pair = 2;
+    if (g.pair) nt /= 2;
   }
   g.tpb = (int)nt;
   if (g.batch > 1) nt *= g.batch;
@@ -604,7 +323,7 @@ int gps_launch_gemm_nt_cyclic(gps_handle_t h, i64 M, i64 nblocks, i64 nb, i64 st
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt_cyclic: sizes must be multiples of 128 and the blocks must lie inside the panel");
   GemmArgs g;
   g.A = A; g.B = A; g.C = C; g.lda = lda; g.ldb = lda; g.ldc = ldc; g.K = (int)K; g.triA = 0;
-  g.batch = 1; g.tpb = 0; g.a_rs = g.a_cs = g.b_rs = g.b_cs = g.c_rs = g.c_cs = g.a_cm = g.b_cm = g.c_cm = 0;
+  g.batch = 1; g.tpb = 0; g.pair = 0; g.a_rs = g.a_cs = g.b_rs = g.b_cs = g.c_rs = g.c_cs = g.a_cm = g.b_cm = g.c_cm = 0;
   g.sig_ptr = nullptr; g.sig_val = 0;
   g.stamps = h->gemm_stamps;
   // needed 128x128 tiles: block b uses rows >= b*stride

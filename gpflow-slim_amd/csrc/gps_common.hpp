@@ -99,6 +99,7 @@ struct gps_handle_s {
   // fewer workgroups than this; gemm_force_tb != 0 pins the tile edge (diagnostics)
   int gemm_min_tiles = 512;    // (constant)
   int gemm_force_tb = 0;
+  int gemm_pair = 1;           // (diagnostics, GPS_GEMM_PAIR) products with a triangular operand: mirror tiles in pairs
   // look-ahead of the sweep (potrf_rl_groups): the remainder update of a pair of panels runs on side_stream (one CU per
   // XCD left free for potrf_base) and is handed over through two monotone device counters instead of events
   int potrf_lookahead = 1;

@@ -18,6 +18,7 @@ extern "C" int gps_create(int device_id, gps_handle_t* out) {
   for (int i = 0; i < 8; ++i) {
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   }
+  if (const char* v = getenv("GPS_GEMM_PAIR")) h->gemm_pair = atoi(v);               // diagnostics: A/B of the paired triangular tiles
   if (const char* la = getenv("GPS_LOOKAHEAD")) h->potrf_lookahead = atoi(la);     // diagnostics: counter collection serialises the dispatches (tools/collect_profiles.sh)
   if (h->dInfo.ensure(64) != hipSuccess || h->dScal.ensure(4096) != hipSuccess) { delete h; return GPS_ERR_HIP; }
   *out = h;

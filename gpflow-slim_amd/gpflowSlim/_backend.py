@@ -184,7 +184,12 @@ def load_library():
         _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(path)
         for name, argtypes in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if os.environ.get("GPFLOWSLIM_HIP_LIB"):      # (an older build named for an A/B: entry points added since are simply absent)
+                    continue
+                raise
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         lib.gps_last_error.argtypes = [ctypes.c_void_p]
