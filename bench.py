@@ -41,7 +41,7 @@ def kernel_source_sha():
     hsh = hashlib.sha1()
     src = os.path.join(ROOT, "gpflow-slim_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp", ".inc")):
             with open(os.path.join(src, name), "rb") as f:
                 hsh.update(name.encode()); hsh.update(f.read())
     return hsh.hexdigest()[:16]

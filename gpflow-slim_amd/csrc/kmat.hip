@@ -44,6 +44,7 @@ struct KmatArgs {
   double* K; i64 ldk;
   i64 n, m;                               // real extents
   int sym; int lower_only; int identity_pad; int maxnf;
+  int tri_grid = 0;   // (kmat_single_kernel) 1-D grid over the tiles of the lower triangle only
   i64 row_off, col_off;                   // global index of local row / column 0 (sub-block builds)
   double diag_add;
 };
@@ -347,8 +348,21 @@ __global__ __launch_bounds__(256) void kmat_tile_kernel(KmatArgs a, KProgDev P) 
 // which brings the kernel under 128 VGPRs (four waves per SIMD).
 template <int OP>
 __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDev node) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;   // 128-granular: diagonal blocks stay full
+  int ti, tj;
+  if (a.tri_grid) {
+    // lower triangle of a square matrix: only the needed tiles are launched (round 6; the rectangular grid started as many
+    // workgroups again that returned at once).  128-granular (diagonal blocks stay full): block q of the row-major lower
+    // triangle of 128-blocks, 64 x 64 tile s of it.
+    const unsigned q = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    unsigned bi = (unsigned)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+    while (bi * (bi + 1) / 2 > q) --bi;
+    const unsigned bj = q - bi * (bi + 1) / 2;
+    ti = (int)(2 * bi + (sub >> 1)); tj = (int)(2 * bj + (sub & 1));
+  } else {
+    ti = blockIdx.y; tj = blockIdx.x;
+    if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;   // 128-granular: diagonal blocks stay full
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* nr_s = reinterpret_cast<double*>(smem_raw);      // [KT]
   double* nc_s = nr_s + KT;                                // [KT]
@@ -367,16 +381,22 @@ __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDe
     nc_s[tid] = a.Fc[(i64)node.norm_row * a.ldfc + gj0 + tid];
   }
   __syncthreads();
+  // the thread's 4 x 4 patch: rows 4 ty .. 4 ty + 3, columns {2 tx, 2 tx + 1, 32 + 2 tx, 33 + 2 tx} -- the sixteen lanes of a
+  // row then store 256 contiguous bytes per instruction (whole 128-byte lines; columns 4 tx .. 4 tx + 3 made every store
+  // instruction write every other 16 bytes of a row: round 6)
+  const int c_lo = 2 * tx, c_hi = 32 + 2 * tx;
   double dot[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) dot[e] = 0.0;
   for (int f = 0; f < node.nf; ++f) {
     const double2 r01 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4), r23 = *reinterpret_cast<const double2*>(Fr_s + f * KLS + ty * 4 + 2);
-    const double2 c01 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4), c23 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + tx * 4 + 2);
+    const double2 c01 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + c_lo), c23 = *reinterpret_cast<const double2*>(Fc_s + f * KLS + c_hi);
     const double fr[4] = {r01.x, r01.y, r23.x, r23.y}, fc[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
     for (int e = 0; e < 16; ++e) dot[e] = fma(fr[e >> 2], fc[e & 3], dot[e]);
   }
+  const double2 n01 = *reinterpret_cast<const double2*>(nc_s + c_lo), n23 = *reinterpret_cast<const double2*>(nc_s + c_hi);
+  const double ncol[4] = {n01.x, n01.y, n23.x, n23.y};
   const double sq3 = 1.7320508075688772, sq5 = 2.23606797749979;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -386,8 +406,8 @@ __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDe
     double o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const i64 gj = a.col_off + gj0 + tx * 4 + c;
-      double r2 = -2.0 * dot[q * 4 + c] + (ni + nc_s[tx * 4 + c]);        // kernels.py:409-421, same op order as the interpreter
+      const i64 gj = a.col_off + gj0 + (c < 2 ? c_lo + c : c_hi + c - 2);
+      double r2 = -2.0 * dot[q * 4 + c] + (ni + ncol[c]);        // kernels.py:409-421, same op order as the interpreter
       r2 = gps_clamp0(r2);
       double val;
       if (OP == GPS_K_RBF) {
@@ -403,9 +423,9 @@ __global__ __launch_bounds__(256, 4) void kmat_single_kernel(KmatArgs a, KNodeDe
       else if (a.sym && gi == gj) val += a.diag_add;
       o[c] = val;
     }
-    double* dst = a.K + li * a.ldk + gj0 + tx * 4;
-    *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+    double* dst = a.K + li * a.ldk + gj0;
+    *reinterpret_cast<double2*>(dst + c_lo) = make_double2(o[0], o[1]);
+    *reinterpret_cast<double2*>(dst + c_hi) = make_double2(o[2], o[3]);
   }
 }
 
@@ -415,7 +435,14 @@ static int launch_single(gps_handle_t h, const KmatArgs& a, const KNodeDev& node
   int rcl = gps_dyn_lds(h, reinterpret_cast<const void*>(&kmat_single_kernel<OP>), (int)((2 * KT + 2 * KMAXF * KLS) * sizeof(double)));
   if (rcl) return rcl;
   LaunchScope ls(h, KC_KMAT, tiles * KT * KT * (2.0 * node.nf + 30.0), tiles * KT * KT * 8.0);
-  hipLaunchKernelGGL(kmat_single_kernel<OP>, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream, a, node);
+  KmatArgs at = a;
+  at.tri_grid = (a.lower_only && a.row_off == 0 && a.col_off == 0 && prow == pcol && prow % 128 == 0 && prow / 128 < 40000) ? 1 : 0;
+  if (at.tri_grid) {
+    const i64 nb = prow / 128;
+    hipLaunchKernelGGL(kmat_single_kernel<OP>, dim3((unsigned)(2 * nb * (nb + 1))), dim3(256), lds, h->stream, at, node);
+  } else {
+    hipLaunchKernelGGL(kmat_single_kernel<OP>, dim3((unsigned)(pcol / KT), (unsigned)(prow / KT)), dim3(256), lds, h->stream, at, node);
+  }
   GPS_HIP(h, hipGetLastError());
   return GPS_OK;
 }

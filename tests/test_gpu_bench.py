@@ -39,6 +39,9 @@ def test_bench_one_gpu_line():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample_parity_rel_err"] <= 1e-8
     assert out["predict_f_throughput"]["points_per_s"] > 0
+    tab = out["predict_f_latency_table"]                # N* = 64 / 256 / n_new on the resident factor + the first call after a new factor
+    for k in ("n_new=64", "n_new=256", "n_new=%d" % out["config"]["n_new"]):
+        assert 0 < tab[k]["warm_ms"] <= tab[k]["warm_max_ms"] and tab[k]["first_call_after_new_factor_ms"] > 0 and 0 < tab[k]["trsm_frac_of_peak"] < 1
 
 
 def test_bench_two_ranks_block_column_gloo():

@@ -12,6 +12,8 @@ for r in range(rounds):
         env = dict(os.environ, GPFLOWSLIM_HIP_LIB=os.path.join(ROOT, "gpflow-slim_amd", v, "libgpflowslim_hip.so"))
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "one_eval.py"), str(n), str(evals)], env=env, capture_output=True, text=True).stdout
         tot = [float(l.split("'total': ")[1].split("}")[0]) for l in out.splitlines() if "'total'" in l][1:]
+        km = [float(l.split("'kmat': ")[1].split(",")[0]) for l in out.splitlines() if "'kmat'" in l][1:]
+        tv = [float(l.split("'trsv': ")[1].split(",")[0]) for l in out.splitlines() if "'trsv'" in l][1:]
         res[v].append(min(tot))
-        print(v, ["%.3f" % t for t in tot], flush=True)
+        print(v, ["%.3f" % t for t in tot], "kmat", ["%.3f" % t for t in km], "trsv", ["%.3f" % t for t in tv], flush=True)
 print(json.dumps({k: {"best_ms": round(min(v), 3), "all": [round(x, 3) for x in v]} for k, v in res.items()}))
