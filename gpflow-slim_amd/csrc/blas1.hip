@@ -746,7 +746,9 @@ int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds_, i64 rows, 
 }
 
 // kappa_2 of every 128 x 128 diagonal block of a factor, from the block and its explicit inverse W_j: ||L_jj||_2 ||W_j||_2 with both
-// norms by 16 steps of power iteration on A^T A (from the all-ones vector; it converges from below, hence the factor 1.5),
+// norms by 16 steps of power iteration on A^T A (it converges from below, hence the factor 1.5; the start vector mixes a constant,
+// an alternating and a pseudo-random part -- round 6, ADVICE: from the all-ones vector alone the iteration starts nearly orthogonal
+// to the oscillatory dominant singular vectors of W_j = L_jj^-1 of a smooth Gram block and could under-estimate a small spectral gap),
 // capped by the rigorous bound sqrt(||A||_1 ||A||_inf) of each norm (the norm bounds alone are 6 - 50 x too pessimistic on the
 // blocks of an RBF Gram matrix).  One workgroup per block, thread t: row t / column t.  What decides, per leaf, whether the
 // product with the explicit inverse IS the solve or only its preconditioner (gps_api.hip: classify_blocks).
@@ -776,10 +778,14 @@ __device__ __forceinline__ double bc_norm2(const double* __restrict__ A, i64 lda
   for (int q = 0; q < 128; ++q) rs += fabs(As[t * BC_LS + q]);
   cs = wave_max(cs); rs = wave_max(rs);
   if ((t & 63) == 0) { red[t >> 6] = cs; red[2 + (t >> 6)] = rs; }
-  x[t] = 1.0;
+  // start vector: constant + alternating + pseudo-random (a fixed integer hash of t): components along smooth AND oscillatory directions
+  const double x0 = 1.0 + ((t & 1) ? -0.75 : 0.75) + 0.25 * ((double)((((unsigned)t * 2654435761u) >> 16) & 0xffu) / 127.5 - 1.0);
+  x[t] = x0;
+  const double xx = wave_sum(x0 * x0);
+  if ((t & 63) == 0) red[8 + (t >> 6)] = xx;
   __syncthreads();
   const double bound = sqrt(fmax(red[0], red[1]) * fmax(red[2], red[3]));
-  double est = 0.0, nx = sqrt(128.0);                                             // (||x|| = 1 from the second step on)
+  double est = 0.0, nx = sqrt(red[8] + red[9]);                                   // (||x|| = 1 from the second step on)
   for (int it = 0; it < 16; ++it) {
     double s = 0.0;
 #pragma unroll 16

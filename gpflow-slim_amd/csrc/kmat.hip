@@ -182,9 +182,10 @@ __device__ __forceinline__ double gps_sqrt_pos(double x) {
   return sqrt(x);
 #endif
 }
-// The same for the epilogue of kmat_mfma_kernel, where every VALU instruction counts (round 5): the NaN of a NaN argument is
-// handed through by one FMA (x * 0 + result) instead of a compare and two selects.  (An argument of -infinity -- a squared
-// distance that overflowed -- gives NaN instead of 0.)
+// The same for the epilogue of kmat_mfma_kernel, where every VALU instruction counts (round 5).  A NaN argument is handed
+// through by a compare and a select on the result (round 6: the round-5 form, one FMA x * 0 + result, also turned an
+// argument of -infinity -- a squared distance that overflowed -- into NaN where tf.exp and the other kernel-matrix kernels
+// give 0: tests/test_gpu_parity.py::test_overflowed_distances_give_zero_not_nan).
 __device__ __forceinline__ double gps_exp_nonpos_lean(double x, const ExpTab& t) {
   const double magic = 6755399441055744.0;
   const double kd = fma(fmax(x, -1100.0), t.c[13], magic);
@@ -200,7 +201,8 @@ __device__ __forceinline__ double gps_exp_nonpos_lean(double x, const ExpTab& t)
   p = fma(p, r, 1.0);
   const int hi = __double2hiint(p) + (ki << 20);
   const double v = __hiloint2double(hi, __double2loint(p));
-  return fma(x, 0.0, ki < -1021 ? 0.0 : v);
+  const double z = ki < -1021 ? 0.0 : v;
+  return x != x ? x : z;
 }
 __device__ __forceinline__ double gps_exp_nonpos(double x) {        // (kernels that call it a few times only)
   const ExpTab t = gps_exp_load();

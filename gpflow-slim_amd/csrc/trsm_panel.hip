@@ -363,7 +363,10 @@ int gps_launch_trsm_panel(gps_handle_t h, double* B, i64 ldb, i64 m, const doubl
     if (a.stamps) return backward ? tp_launch_persistent<4, true, true>(h, a, m) : tp_launch_persistent<4, false, true>(h, a, m);
     return backward ? tp_launch_persistent<4, true>(h, a, m) : tp_launch_persistent<4, false>(h, a, m);
   }
-  if (form == 65) return backward ? tp_launch<4, true>(h, a, m) : tp_launch<4, false>(h, a, m);
+  if (form == 65) {
+    if (a.stamps) return backward ? tp_launch<4, true, true>(h, a, m) : tp_launch<4, false, true>(h, a, m);
+    return backward ? tp_launch<4, true>(h, a, m) : tp_launch<4, false>(h, a, m);
+  }
   if (a.stamps) return backward ? tp_launch<2, true, true>(h, a, m) : tp_launch<2, false, true>(h, a, m);
   return backward ? tp_launch<2, true>(h, a, m) : tp_launch<2, false>(h, a, m);
 }

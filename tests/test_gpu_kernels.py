@@ -521,6 +521,26 @@ def test_nan_inputs_propagate_through_the_kernel_matrix(handle):
             handle.set_option("small_n", 1)
 
 
+def test_overflowed_distances_give_zero_not_nan(handle):
+    """tf.exp(-inf) = 0 (kernels.py:439, 576-610): points so far apart that their squared distance overflows have covariance 0
+    on every build path -- the one-primitive kernel, the chains on the matrix pipe (its lean exponential gave
+    NaN there) and the interpreter."""
+    import gpflowSlim as gpf
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((200, 3)); X[11] = 1e160; X[12] = -1e160
+    for opt, kern in ((None, gpf.kernels.RBF(3, lengthscales=1.1)), (None, gpf.kernels.Matern32(3) + gpf.kernels.RBF(3, variance=0.5)),
+                      (("kmat_mfma", 0), gpf.kernels.Matern32(3) + gpf.kernels.RBF(3, variance=0.5)),
+                      (("kmat_fast", 0), gpf.kernels.Matern52(3) * gpf.kernels.RBF(3, variance=0.5))):
+        if opt: handle.set_option(opt[0], opt[1])
+        try:
+            K = kern.K(X)
+        finally:
+            handle.set_option("kmat_mfma", 1); handle.set_option("kmat_fast", 1)
+        far = np.zeros(200, dtype=bool); far[[11, 12]] = True
+        assert np.isfinite(K).all(), (opt, np.argwhere(~np.isfinite(K))[:5])
+        assert (K[far][:, ~far] == 0).all() and K[11, 12] == 0 and (np.diag(K) > 0).all()
+
+
 @pytest.mark.parametrize("n,r", [(1, 1), (2, 1), (50, 1), (128, 2), (129, 1), (300, 3), (455, 1), (512, 1), (640, 2), (768, 1), (896, 1), (1000, 1), (1300, 2), (2048, 1), (2100, 1)])
 def test_one_launch_factorisation_of_small_problems(handle, n, r):
     """Problems of up to 2048 padded rows (the reference's own example is N ~ 455, examples/gpr.py:36) are factored by ONE

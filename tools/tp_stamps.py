@@ -11,6 +11,8 @@ rows = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 h.set_option("trsm_panel_rows", rows)
 us, st = h.diag_trsm512_stamps(m, back)
 st = st[st[:, 0] != 0]
+if len(st) == 0:
+    print("rows option %d: no stamps recorded (%.1f us per solve)" % (rows, us)); sys.exit(0)
 t = st.astype(np.float64) / 100.0            # microseconds
 t0 = t[:, 0].min()
 span = max(t[:, 13].max(), t[:, 29].max()) - t0
