@@ -456,7 +456,7 @@ static int launch_single(gps_handle_t h, const KmatArgs& a, const KNodeDev& node
 // running value is an accumulator, the primitives use the in-line exponential of the single-primitive kernel (every
 // argument is <= 0 up to rounding), and the kernel fits four waves per SIMD.  Same tile, staging, formulas and operand
 // order (older op newer) as kmat_tile_kernel.
-__global__ __launch_bounds__(256, 3) void kmat_chain_kernel(KmatArgs a, KProgDev P) {
+__global__ __launch_bounds__(256, 2) void kmat_chain_kernel(KmatArgs a, KProgDev P) {      // (2: no scratch; with 3 the kernel spilled 20 VGPRs -- it is the fall-back behind kmat_mfma_kernel)
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (a.lower_only && ((a.col_off >> 6) + tj) >> 1 > ((a.row_off >> 6) + ti) >> 1) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

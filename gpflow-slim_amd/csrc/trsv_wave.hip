@@ -67,12 +67,9 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
     for (int k = 0; k < 32; ++k) wr[k] = Wp[k * 128];
   }
   // (REFINE) this thread's 32 entries of the diagonal block: row oc of L_ii (forward) / column oc (backward), k = 32 part ..
+  // (fetched right BEHIND the panel loop -- the first product with W and two barriers lie between the loads and their use --:
+  // held from the start they cost the forward two-right-hand-side form 124 bytes of scratch; round 6)
   double lr[REFINE ? 32 : 1];
-  if (REFINE) {
-    const double* Dp = L + (i64)i * 128 * ldl + (i64)i * 128;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) lr[k] = TRANS ? Dp[(i64)(32 * part + k) * ldl + oc] : Dp[(i64)oc * ldl + 32 * part + k];
-  }
   // first block of the panel:  forward j = 0..i-1 (block column j of block row i);  backward j = nblk-1..i+1 (block row j
   // of block column i).  Step s of the loop is block jj(s).
   const int steps = t;
@@ -154,6 +151,11 @@ __global__ __launch_bounds__(512) void trsv_wave_kernel(const double* __restrict
     for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
   }
 
+  if (REFINE) {
+    const double* Dp = L + (i64)i * 128 * ldl + (i64)i * 128;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lr[k] = TRANS ? Dp[(i64)(32 * part + k) * ldl + oc] : Dp[(i64)oc * ldl + 32 * part + k];
+  }
   // ---- t = y_i - (sum over the panel)
   if (!TRANS) {
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
