@@ -522,15 +522,18 @@ def test_nan_inputs_propagate_through_the_kernel_matrix(handle):
 
 
 def test_overflowed_distances_give_zero_not_nan(handle):
-    """tf.exp(-inf) = 0 (kernels.py:439, 576-610): points so far apart that their squared distance overflows have covariance 0
+    """tf.exp(-inf) = 0 (kernels.py:439): points so far apart that their squared distance overflows have covariance 0 under RBF
     on every build path -- the one-primitive kernel, the chains on the matrix pipe (its lean exponential gave
-    NaN there) and the interpreter."""
+    NaN there), the chain kernel and the interpreter.  (Matern-3/2 and -5/2 give NaN there in the reference too:
+    (1 + sqrt(3) inf) * exp(-inf) = inf * 0, kernels.py:592-594, 608-610.)"""
     import gpflowSlim as gpf
     rng = np.random.default_rng(5)
-    X = rng.standard_normal((200, 3)); X[11] = 1e160; X[12] = -1e160
-    for opt, kern in ((None, gpf.kernels.RBF(3, lengthscales=1.1)), (None, gpf.kernels.Matern32(3) + gpf.kernels.RBF(3, variance=0.5)),
-                      (("kmat_mfma", 0), gpf.kernels.Matern32(3) + gpf.kernels.RBF(3, variance=0.5)),
-                      (("kmat_fast", 0), gpf.kernels.Matern52(3) * gpf.kernels.RBF(3, variance=0.5))):
+    # (|x|^2 = 6e307 .. 7e307 is finite and so is the sum of two of them; the squared distance between the two far points, 4 |x|^2,
+    # overflows: r^2 = +inf, exp(-inf) = 0.  Larger coordinates would make the DIAGONAL inf - inf = NaN in the reference's formula too.)
+    X = rng.standard_normal((200, 3)); X[11] = 4.9e153; X[12] = -4.9e153
+    for opt, kern in ((None, gpf.kernels.RBF(3, lengthscales=1.1)), (None, gpf.kernels.RBF(3, lengthscales=0.9) + gpf.kernels.RBF(3, variance=0.5)),
+                      (("kmat_mfma", 0), gpf.kernels.RBF(3, lengthscales=0.9) + gpf.kernels.RBF(3, variance=0.5)),
+                      (("kmat_fast", 0), gpf.kernels.RBF(3, lengthscales=0.9) * gpf.kernels.RBF(3, variance=0.5))):
         if opt: handle.set_option(opt[0], opt[1])
         try:
             K = kern.K(X)
