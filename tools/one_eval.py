@@ -11,6 +11,8 @@ d = 8
 X, Y, _ = orc.synthetic_gpr_data(n, d, 0)
 kern = gpf.kernels.RBF(d, variance=1.0, lengthscales=np.sqrt(d) * np.ones(d), ARD=True)
 m = gpf.models.GPR(X, Y, kern, obs_var=0.1)
+for k, v in [a.split("=") for a in os.environ.get("GPS_OPTS", "").split(",") if a]:       # e.g. GPS_OPTS=potrf_rl_max=2048,potrf_rl_group=3
+    gpf.get_handle().set_option(k, float(v))
 for i in range(reps + 1):
     t0 = time.perf_counter(); lml = m.compute_log_likelihood(); t1 = time.perf_counter()
     print(i, lml, 1e3 * (t1 - t0), gpf.get_handle().last_stage_ms())
