@@ -8,7 +8,7 @@ OUT=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 what=${1:-all}
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 if [ "$what" = all ] || [ "$what" = pmc ]; then
   # counter collection serialises the dispatches: a look-ahead hand-over could only time out (and the evaluation would
   # be re-run without it) -- switch it off up front
@@ -31,12 +31,13 @@ if [ "$what" = all ] || [ "$what" = stats ]; then
   echo "small-N stats done"
   # potrf_base phase stamps (with and without the transposed inverse) and the DPP / SIMD-sharing probe behind its design
   (cd $R && python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids; GPS_PB_NO_T=1 python3 tools/pb_stamps.py 2>&1 | grep -v amdgpu.ids) > $OUT/potrf_base_stamps.txt || true
-  # the one-launch sweep step (round 5): in-kernel stamps of every launch of an N = 4096 sweep, and the same-process A/B of the
-  # round's sweep changes against the round-4 schedule (potrf stage, ms)
-  (cd $R && GPS_STEP_DEBUG=3 timeout -k 5 120 python3 tools/step_debug.py 4096 1 2>&1 | grep -E "^step|^fused" | sed -n "1,12p;28,32p") > $OUT/sweep_step_stamps.txt || true
-  (cd $R && for n in 4096 8192 16384 32768; do echo "N = $n"; timeout -k 5 300 python3 tools/ab_multi.py "potrf_fused_step=0,potrf_two_stage_join=0,potrf_lookahead_min=1024;potrf_fused_step=1,potrf_two_stage_join=0,potrf_step_helpers=0,potrf_lookahead_min=1024;potrf_fused_step=1,potrf_two_stage_join=1,potrf_step_helpers=0,potrf_lookahead_min=1024;potrf_fused_step=2,potrf_two_stage_join=1,potrf_step_helpers=0,potrf_lookahead_min=1024;potrf_fused_step=2,potrf_two_stage_join=1,potrf_step_helpers=1,potrf_lookahead_min=1024;potrf_fused_step=2,potrf_two_stage_join=1,potrf_step_helpers=1,potrf_lookahead_min=256" $n 5 2>&1 | grep -v amdgpu.ids; done) > $OUT/sweep_step_ab.txt || true
-  (cd $R && for n in 16384 32768; do echo "N = $n (potrf_bulk: 1 = the rest of a trailing update, 2 = the first rows of a panel solve, beside the sweeps)"; timeout -k 5 300 python3 tools/ab_multi.py "potrf_bulk=0;potrf_bulk=1;potrf_bulk=2;potrf_bulk=3" $n 4 2>&1 | grep -v amdgpu.ids; done) > $OUT/cross_level_lookahead_ab.txt || true
-  (cd $R && GPS_SMALL_STAMPS=1 python3 tools/sn_once.py 2>&1 | grep -v amdgpu.ids | tail -16) > $OUT/small_n_stamps.txt || true
+  # predict_f on few test points (round 6): kernel trace of a warm call at N* = 1024 (tools/trace_tail.py: from its cross kernel matrix
+  # on, and the build of the 2048-column inverse blocks), the latency table with and without the wide blocks
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_pred -- python3 $R/tools/predict_once.py 32768 1024 > $OUT/prof_pred.log 2>&1 || exit 1
+  python3 $R/tools/trace_tail.py $(find $OUT/prof_pred -name "*kernel_trace.csv" | head -1) kmat_prep > $OUT/predict_timeline_1024.txt || true
+  python3 $R/tools/trace_tail.py $(find $OUT/prof_pred -name "*kernel_trace.csv" | head -1) blocks_to_diag 2> /dev/null | sed -n "1,14p" > $OUT/predict_wide_build.txt || true
+  (cd $R && echo "wide inverse blocks (default)"; python3 tools/predict_once.py 32768 64 256 1024 2048 2>&1 | grep n_new | cut -c1-90; echo "predict_inverse_blocks=0 (the recursive solve down to 512-column launches)"; GPS_OPTS=predict_inverse_blocks=0 python3 tools/predict_once.py 32768 64 256 1024 2048 2>&1 | grep n_new | cut -c1-90; echo "GPS_GEMM_PAIR=0 (one tile per workgroup in the triangular products)"; GPS_GEMM_PAIR=0 python3 tools/predict_once.py 32768 64 256 1024 2>&1 | grep n_new | cut -c1-90) > $OUT/predict_ab.txt || true
+  echo "predict done"
   # timelines of one evaluation (kernel trace -> tools/eval_timeline.py): where the time of the chain and of the bulk goes
   for n in 8192 32768; do
     rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tl$n -- python3 $R/tools/one_eval.py $n 1 > $OUT/prof_tl$n.log 2>&1 || exit 1

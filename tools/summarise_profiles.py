@@ -1,10 +1,10 @@
-"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/<tag>_* (tag = argv[1], default r05)."""
+"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/prof_*) into the tracked summaries profiles/<tag>_* (tag = argv[1], default r06)."""
 import csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out"); PROF = os.path.join(ROOT, "profiles")
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -71,9 +71,8 @@ if kc.get("SQ_INSTS_VALU") and kc.get("SQ_WAVES"):
                           "multiply-add as the VALU on this part) -- at 100 % of the pipe 0.52 ms = 2.07 TB/s; see docs/LAB_NOTES.md (rounds 4 and 5)",
                "kernel_source_sha": sha, "commit": commit}, open(os.path.join(PROF, "%s_kmat_cfg4_counters.json" % tag), "w"), indent=1)
 
-for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("sweep_step_stamps.txt", "sweep_step_stamps.txt"),
-                 ("sweep_step_ab.txt", "sweep_step_ab.txt"), ("cross_level_lookahead_ab.txt", "cross_level_lookahead_ab.txt"),
-                 ("small_n_stamps.txt", "small_n_stamps.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
+for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("predict_timeline_1024.txt", "predict_timeline_1024.txt"),
+                 ("predict_wide_build.txt", "predict_wide_build.txt"), ("predict_ab.txt", "predict_ab.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
                  ("trsm512.txt", "trsm512.txt"), ("trsm512_stamps.txt", "trsm512_stamps.txt"), ("kmat_ab.txt", "kmat_ab.txt")):
     f = os.path.join(OUT, src)
     if os.path.exists(f):

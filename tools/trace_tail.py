@@ -12,7 +12,7 @@ def short(n):
     n = n.replace("void ", "").replace("gemm_nt_f64_kernel", "gemm")
     n = re.sub(r"\(.*", "", n)
     return n[:60]
-prev_end = t0
+prev_end = 0.0
 for r in rows:
     s = (int(r["Start_Timestamp"]) - t0) / 1e3; e = (int(r["End_Timestamp"]) - t0) / 1e3
     g = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", "1")) or 1))
