@@ -43,6 +43,9 @@ if [ "$what" = all ] || [ "$what" = stats ]; then
     rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tl$n -- python3 $R/tools/one_eval.py $n 1 > $OUT/prof_tl$n.log 2>&1 || exit 1
     python3 $R/tools/eval_timeline.py $(find $OUT/prof_tl$n -name "*kernel_trace.csv" | head -1) $([ $n = 8192 ] && echo 60 || echo 400) > $OUT/timeline_$n.txt || true
   done
+  # the per-step budget of a sweep (what the chain of 128-column steps spends where): N = 4096 (one sweep, nothing beside it) and N = 8192
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tl4096 -- python3 $R/tools/one_eval.py 4096 2 > $OUT/prof_tl4096.log 2>&1 || exit 1
+  (python3 $R/tools/sweep_budget.py $(find $OUT/prof_tl4096 -name "*kernel_trace.csv" | head -1); python3 $R/tools/sweep_budget.py $(find $OUT/prof_tl8192 -name "*kernel_trace.csv" | head -1) | sed -n "1,2p;\$p") > $OUT/sweep_step_budget.txt || true
   echo "timelines done"
   # the 512-column triangular solve: one launch against launch by launch, 128 .. 262144 rows
   (cd $R && python3 tools/trsm512.py 128 4096 16384 65536 262144 1048576 2>&1 | grep -v amdgpu.ids) > $OUT/trsm512.txt || true

@@ -72,7 +72,7 @@ if kc.get("SQ_INSTS_VALU") and kc.get("SQ_WAVES"):
                "kernel_source_sha": sha, "commit": commit}, open(os.path.join(PROF, "%s_kmat_cfg4_counters.json" % tag), "w"), indent=1)
 
 for src, dst in (("soak.json", "soak.json"), ("potrf_base_stamps.txt", "potrf_base_stamps.txt"), ("predict_timeline_1024.txt", "predict_timeline_1024.txt"),
-                 ("predict_wide_build.txt", "predict_wide_build.txt"), ("predict_ab.txt", "predict_ab.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
+                 ("predict_wide_build.txt", "predict_wide_build.txt"), ("predict_ab.txt", "predict_ab.txt"), ("sweep_step_budget.txt", "sweep_step_budget.txt"), ("timeline_8192.txt", "timeline_8192.txt"), ("timeline_32768.txt", "timeline_32768.txt"),
                  ("trsm512.txt", "trsm512.txt"), ("trsm512_stamps.txt", "trsm512_stamps.txt"), ("kmat_ab.txt", "kmat_ab.txt")):
     f = os.path.join(OUT, src)
     if os.path.exists(f):
