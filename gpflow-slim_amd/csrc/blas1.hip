@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void la_wait_kernel(unsigned long long* sig, un
   if (sig) __hip_atomic_store(sig, sval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (!flag) return;
   // bounded by the 100 MHz wall clock: 1 s is four orders of magnitude beyond any legitimate hand-over wait (tens of
-  // microseconds), still not a hang; the evaluation is then re-run without look-ahead (gps_api.hip: with_la_retry)
+  // microseconds), still not a hang; the evaluation is then re-run without look-ahead (gps_ops.hpp: with_la_retry)
   const unsigned long long t0 = wall_clock64();
   for (;;) {
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= val) return;
@@ -751,7 +751,7 @@ int gps_launch_transpose(gps_handle_t h, const double* src, i64 lds_, i64 rows, 
 // to the oscillatory dominant singular vectors of W_j = L_jj^-1 of a smooth Gram block and could under-estimate a small spectral gap),
 // capped by the rigorous bound sqrt(||A||_1 ||A||_inf) of each norm (the norm bounds alone are 6 - 50 x too pessimistic on the
 // blocks of an RBF Gram matrix).  One workgroup per block, thread t: row t / column t.  What decides, per leaf, whether the
-// product with the explicit inverse IS the solve or only its preconditioner (gps_api.hip: classify_blocks).
+// product with the explicit inverse IS the solve or only its preconditioner (gps_ops.hpp: classify_blocks).
 // (the block sits in LDS, row stride 129: thread t walks row t -- stride 129 across the lanes, conflict-free -- for A x, and
 // column t -- consecutive lanes, consecutive words -- for A^T y.  From global memory, where a row walk is a 1 KB stride across
 // the lanes, the launch took 0.63 ms; round 5)

@@ -1,6 +1,6 @@
 // Recursive blocked factorisation / triangular solves, written once over an "Ops" policy.
 //
-// The product instantiates it with HipOps (gps_api.hip: every op is a HIP kernel launch on the
+// The product instantiates it with HipOps (gps_ops.hpp: every op is a HIP kernel launch on the
 // handle's stream).  tests/cpu_blocked/ instantiates the same template with naive host loops so
 // the index arithmetic of the recursion can be checked without a GPU -- that emulation is test
 // infrastructure only and is never linked into libgpflowslim_hip.so.

@@ -9,7 +9,7 @@ idx = max(i for i, r in enumerate(rows) if "kmat_prep" in r["Kernel_Name"])
 rows = rows[idx:]
 t0 = int(rows[0]["Start_Timestamp"])
 def short(n):
-    n = re.sub(r"\(.*", "", n); n = n.replace("void ", "").replace("gemm_nt_f64_kernel", "gemm")
+    n = re.sub(r"\(.*", "", n); n = n.replace("void ", "").replace("gemm_nt_f64_kernel", "gemm").replace("gemm_nt_f64_pair_kernel", "gemm_pair")
     return n[:44]
 tot = 0
 for r in rows:

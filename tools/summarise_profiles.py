@@ -112,7 +112,7 @@ fetch, write = per_kernel("prof_pmc_FETCH_SIZE", ["FETCH_SIZE"]), per_kernel("pr
 if fetch and write:
     # the launch set of bench.py's roofline object: the library's KC_GEMM class = every gemm_nt_f64_kernel<*> launch and the
     # one-launch 512-column solves (trsm_panel_kernel<*> / trsm_panel_persistent_kernel<*>, trsm_panel.hip), so that traffic x launches = the total below
-    in_class = lambda k: ("gemm_nt_f64_kernel" in k) or ("trsm_panel_" in k)
+    in_class = lambda k: ("gemm_nt_f64_kernel" in k) or ("gemm_nt_f64_pair_kernel" in k) or ("trsm_panel_" in k)
     gem = lambda acc, c: sum(v.get(c, 0.0) for k, v in acc.items() if in_class(k))
     launches = sum(v["launches"] for k, v in fetch.items() if in_class(k))
     fb, wb = gem(fetch, "FETCH_SIZE") * 1024.0, gem(write, "WRITE_SIZE") * 1024.0          # rocprofv3 reports KB
@@ -129,7 +129,7 @@ if fetch and write:
 mf = per_kernel("prof_pmc_mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
 if mf:
     tot_b = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for v in mf.values()); tot_a = sum(v.get("GRBM_GUI_ACTIVE", 0) for v in mf.values())
-    gb = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for k, v in mf.items() if "gemm_nt_f64_kernel" in k); ga = sum(v.get("GRBM_GUI_ACTIVE", 0) for k, v in mf.items() if "gemm_nt_f64_kernel" in k)
+    gb = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for k, v in mf.items() if "gemm_nt_f64_" in k); ga = sum(v.get("GRBM_GUI_ACTIVE", 0) for k, v in mf.items() if "gemm_nt_f64_" in k)
     # the CSV sums GRBM_GUI_ACTIVE over its 8 XCD instances: per-XCD cycles = value / 8
     rec = {"definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), last evaluation of tools/one_eval.py 32768 1 (GPS_LOOKAHEAD=0: counter collection serialises the dispatches)",
            "whole_evaluation": tot_b / (tot_a / 8.0 * 1024.0) if tot_a else None, "gemm_class": gb / (ga / 8.0 * 1024.0) if ga else None,

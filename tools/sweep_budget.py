@@ -10,7 +10,7 @@ idx = max(i for i, r in enumerate(rows) if "kmat_prep" in r["Kernel_Name"])
 rows = rows[idx:]
 t0 = int(rows[0]["Start_Timestamp"])
 K = [((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"),
-      re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("gemm_nt_f64_kernel", "gemm"))) for r in rows]
+      re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("gemm_nt_f64_kernel", "gemm").replace("gemm_nt_f64_pair_kernel", "gemm_pair"))) for r in rows]
 pb = [k for k in K if k[3].startswith("potrf_base")]
 chain_q = pb[0][2]
 print("%d potrf_base launches on queue %s; evaluation span %.1f us" % (len(pb), chain_q, max(k[1] for k in K)))
