@@ -12,6 +12,7 @@
 
 #define GPS_TILE 128            // base block of the factorisation = GEMM tile edge
 #define GPS_WB 2048             // columns of the wide inverse blocks of predict_f (gps_gpr.hip)
+#define GPS_WIDE_MAX_ROWS 8192  // ... used for predictions on at most this many (padded) test points
 
 typedef int64_t i64;
 

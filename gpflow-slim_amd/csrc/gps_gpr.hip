@@ -504,7 +504,7 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
 }
 
 // ---- predict_f on few test points: wide inverse blocks of the resident factor ------------------------------------------------
-// A^T = Kx^T L^-T for m <= 2048 rows (models/gpr.py:122) is a chain of launches that cannot fill the GPU below the 4096-column
+// A^T = Kx^T L^-T for few rows (models/gpr.py:122; used up to GPS_WIDE_MAX_ROWS = 8192 test points) is a chain of launches that cannot fill the GPU below the 4096-column
 // level of trsm_rec: measured at N = 32768, m = 1024 (rocprofv3, round 6): the 64 one-launch 512-column leaves 43 us each on
 // 32 workgroups, the K = 512 / 1024 updates at 32 / 40 TFLOP/s -- 4.2 of the call's 19.5 ms for 5 % of its flop.  With the
 // explicit inverses W_c of the GPS_WB = 2048-column diagonal blocks of L the 2048-column node is ONE product
@@ -605,9 +605,10 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
   Blocked<HipOps> bl(ops);
   const double* dAt = h->dB.d();                  // where A^T ends up
   const i64 nf = (np / GPS_WB) * GPS_WB;
-  if (h->predict_inv_blocks && !h->refine_now && nsp <= 2048 && nf >= 2 * GPS_WB) {
-    // few test points: 2048-column nodes as one product with the wide inverse blocks (the choice depends on the shapes only:
-    // a call that re-factors and a call on the resident factor give the same bits)
+  if (h->predict_inv_blocks && !h->refine_now && nsp <= GPS_WIDE_MAX_ROWS && nf >= 2 * GPS_WB) {
+    // up to 8192 test points: 2048-column nodes as one product with the wide inverse blocks (the choice depends on the shapes
+    // only: a call that re-factors and a call on the resident factor give the same bits).  What it buys shrinks with the rows:
+    // N = 32768: N* = 64 -48 %, 1024 -15 %, 4096 -2.6 %, 8192 -0.6 %
     rc = gpr_wide_inverse(h);
     if (rc) return rc;
     GPS_HIP(h, h->dB2.ensure((size_t)nsp * np * 8));

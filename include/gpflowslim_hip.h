@@ -444,6 +444,10 @@ int gps_dist_finish(gps_handle_t h, double* lml, int* info);
  *   "trsm_tall_ratio" 16 (default): a solve of m rows against n columns with m >= ratio * n (conditionals.py:87 at config 5's
  *                     shape) goes over its 512-column panels left-looking -- one long-K update and one launch per panel;
  *                     0: the recursive halving always
+ *   "predict_inverse_blocks" 1 (default): gps_gpr_predict on at most 8192 test points (N >= 4096 padded, plain leaves) solves
+ *                     A^T = Kx^T L^-T (models/gpr.py:122) against the inverses of the factor's 2048-column diagonal blocks -- every
+ *                     2048-column node ONE product; the blocks are built once per factor (11 batched launches with triangular
+ *                     operands, 1.3 ms at N = 32768) by the first such call; 0: the recursive solve down to 512-column launches
  *   "gpr_aug_rows"    -1 (default): below 6200 points gps_gpr_lml / _predict / _lml_grad store (Y - m)^T as augmented
  *                     rows under K and get alpha = L^-1 (Y - m) (densities.py:82) out of the factorisation itself;
  *                     0 / 1: never / always

@@ -123,9 +123,9 @@ def test_gpr_parity(handle, kind, n, d, r, ns):
 
 
 @pytest.mark.parametrize("n,ns,kind", [(4096, 64, "rbf_ard"), (4500, 200, "matern52"), (5000, 1, "rbf_ard"), (6144, 1024, "rbf_ard"),
-                                       (8192, 300, "m52_plus_periodic"), (9000, 2048, "rbf_ard")])
+                                       (8192, 300, "m52_plus_periodic"), (9000, 2048, "rbf_ard"), (4224, 5000, "rbf_ard")])
 def test_predict_f_wide_inverse_blocks(handle, n, ns, kind):
-    """predict_f on at most 2048 test points (round 6; csrc/gps_gpr.hip: gpr_wide_inverse, trsm_wide_rec): 2048-column nodes of
+    """predict_f on at most 8192 test points (round 6; csrc/gps_gpr.hip: gpr_wide_inverse, trsm_wide_rec): 2048-column nodes of
     A^T = Kx^T L^-T as ONE product with the inverse of the factor's 2048-column diagonal block, built once per factor by
     batched triangular products from the 128-column inverses.  Same mean / variance / full covariance as the recursive solve
     (option "predict_inverse_blocks" = 0) to 1e-11 and as the oracle to 1e-8 (models/gpr.py:119-131); a call that re-factors and
