@@ -575,11 +575,11 @@ def main():
             torch.cuda.synchronize(); first_ms = 1e3 * (time.perf_counter() - t1)
             table["n_new=%d" % ns_t] = {"warm_ms": w["median"], "warm_min_ms": w["min"], "warm_max_ms": w["max"],
                                         "first_call_after_new_factor_ms": round(first_ms, 2),
-                                        "trsm_frac_of_peak": round(float(n) * n * max(ns_t, 128) / (w["median"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+                                        "trsm_frac_of_peak": round(float(n) * n * (64 if ns_t <= 64 else h_npad(ns_t)) / (w["median"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
         table["note"] = ("warm: median of 5 predict_f calls on the resident factor (wall time incl. the host round trip of mean and "
                          "variance); first_call_after_new_factor: one call right after a likelihood evaluation with new "
-                         "hyper-parameters -- includes building the factor's wide inverse blocks once; trsm_frac_of_peak = N^2 max(N*, 128) "
-                         "flop (test points padded to one 128-row tile) / warm time / 78.6 TFLOP/s")
+                         "hyper-parameters -- includes building the factor's wide inverse blocks once; trsm_frac_of_peak = N^2 x padded N* "
+                         "flop (test points padded to whole 128-row tiles, to half a tile up to 64 points) / warm time / 78.6 TFLOP/s")
         progress("predict_latency_done")
         # predict_f throughput at N* = 8192 on the resident factor: trsm N^2 N* flop on the MFMA, then one
         # HBM pass over A^T for the mean and the variance

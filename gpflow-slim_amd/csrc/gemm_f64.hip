@@ -255,7 +255,10 @@ int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64
     if ((triA == 3 ? N : M) != K) return gps_fail(h, GPS_ERR_ARG, "gemm_nt: a triangular operand must be square");
   }
   const i64 nbatch = (bt && bt->batch > 1) ? bt->batch : 1;
-  if (M % 128 || N % 128 || K % BK_MIN || (lower && M < N))
+  // (M a multiple of 64 only: half a tile row of right-hand sides -- predict_f on at most 64 test points, round 6 --, with the
+  // 64 x 64 / 32 x 32 tiles or the 16-row in-place panels; not for the lower-triangle form or a triangular A)
+  const bool half_rows = (M % 128 == 64) && !lower && triA != 1 && triA != 2 && nbatch == 1;
+  if ((M % 128 && !half_rows) || N % 128 || K % BK_MIN || (lower && M < N))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: M,N must be multiples of 128 and K of 16 (lower: M >= N)");
   if ((lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return gps_fail(h, GPS_ERR_ARG, "gemm_nt: operands must be 16-byte aligned with even leading dimension");
@@ -278,9 +281,9 @@ int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64
   // lower: the triangle is counted at the granularity of the chosen tile; with a tile < 128 the
   // part of a diagonal 128-block above the diagonal tiles is simply not touched (never read).
   const double t128 = (double)nbatch * (lower ? 0.5 * (double)(N / 128) * (double)(N / 128 + 1) + (double)((M - N) / 128) * (double)(N / 128)
-                                             : (double)(M / 128) * (double)(N / 128));
+                                             : ((double)M / 128.0) * (double)(N / 128));
   // (triangular operand: sum over the tiles of 2 x their non-zero K range, counted in 128-blocks)
-  const double flops = triA == 3 ? (double)nbatch * 128.0 * 128.0 * (double)(M / 128) * (double)(N / 128) * (double)(N + 128)
+  const double flops = triA == 3 ? (double)nbatch * 128.0 * 128.0 * ((double)M / 128.0) * (double)(N / 128) * (double)(N + 128)
                      : triA      ? (double)nbatch * 128.0 * 128.0 * (double)(N / 128) * (double)(M / 128) * (double)(M + 128)
                                  : 2.0 * t128 * 128.0 * 128.0 * (double)K;
   const double bytes = t128 * (((op == 0 || op == 2) ? 2.0 : 1.0) * 128.0 * 128.0 * 8.0) +
@@ -292,8 +295,8 @@ int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64
   if (rowpanel) {
     // leaves are latency-bound: aim at ~256 workgroups (one per CU), never fewer rows than 16
     int bm = 16;
-    if (force) bm = force;
-    else if (M / 128 >= 256) bm = 128;
+    if (force) bm = (half_rows && force > 64) ? 64 : force;
+    else if (M / 128 >= 256 && !half_rows) bm = 128;
     else if (M / 64 >= 256) bm = 64;
     else if (M / 32 >= 256) bm = 32;
     if (bm == 128) return launch_cfg<128, 128, 2>(h, op, 0, g, M, N);
@@ -303,8 +306,9 @@ int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64
   }
   int tb = 32;
   if (force) tb = force < 32 ? 32 : force;
-  else if (t128 >= target) tb = 128;
+  else if (t128 >= target && !half_rows) tb = 128;
   else if (4.0 * t128 >= target) tb = 64;
+  if (half_rows && tb > 64) tb = 64;
   if (tb == 128) return launch_cfg<128, 128, 2>(h, op, lower, g, M, N);
   if (tb == 64) return launch_cfg<64, 64, 2>(h, op, lower, g, M, N);
   return launch_cfg<32, 32, 2>(h, op, lower, g, M, N);

@@ -592,7 +592,9 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
     GPS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   }
   const i64 n = h->n, np = h->npad, d = h->d_all;
-  const i64 nsp = gps_pad(n_new);
+  // (up to 64 test points, wide path: half a tile row of right-hand sides -- examples/gpr.py predicts on ~51 points)
+  const bool wide = h->predict_inv_blocks && !h->refine_now && gps_pad(n_new) <= GPS_WIDE_MAX_ROWS && (np / GPS_WB) * GPS_WB >= 2 * GPS_WB;
+  const i64 nsp = (wide && !full_cov && n_new <= 64) ? 64 : gps_pad(n_new);
   GPS_HIP(h, hipEventRecord(h->ev[3], h->stream));
   GPS_HIP(h, h->dXnew.ensure((size_t)n_new * d * 8));
   GPS_HIP(h, hipMemcpyAsync(h->dXnew.p, Xnew, (size_t)n_new * d * 8, hipMemcpyHostToDevice, h->stream));
@@ -605,7 +607,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
   Blocked<HipOps> bl(ops);
   const double* dAt = h->dB.d();                  // where A^T ends up
   const i64 nf = (np / GPS_WB) * GPS_WB;
-  if (h->predict_inv_blocks && !h->refine_now && nsp <= GPS_WIDE_MAX_ROWS && nf >= 2 * GPS_WB) {
+  if (wide) {
     // up to 8192 test points: 2048-column nodes as one product with the wide inverse blocks (the choice depends on the shapes
     // only: a call that re-factors and a call on the resident factor give the same bits).  What it buys shrinks with the rows:
     // N = 32768: N* = 64 -48 %, 1024 -15 %, 4096 -2.6 %, 8192 -0.6 %

@@ -86,6 +86,22 @@ def test_gemm_nt_lower_triangular_operands(handle, m, n, op, tile):
         handle.set_option("gemm_force_tile", 0)
 
 
+@pytest.mark.parametrize("m,n,k", [(64, 128, 128), (64, 2048, 2048), (192, 384, 4096), (64, 16384, 256)])
+@pytest.mark.parametrize("op", [0, 1])
+@pytest.mark.parametrize("tri", [0, 4])
+def test_gemm_nt_half_tile_row(handle, m, n, k, op, tri):
+    """M a multiple of 64 only (predict_f on at most 64 test points pads its right-hand sides to half a tile row): the 64 x 64 /
+    32 x 32 tiles, with and without a lower-triangular B."""
+    if tri == 4 and n != k:
+        pytest.skip("a triangular B is square")
+    rng = np.random.default_rng(m + n + k + op + tri)
+    A = rng.standard_normal((m, k)); B = rng.standard_normal((n, k)); C = rng.standard_normal((m, n))
+    if tri == 4: B = np.tril(B)
+    out = handle.diag_gemm_nt(op, tri, A, B, C)
+    ref = C - A @ B.T if op == 0 else A @ B.T
+    assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("batch,m,n,k,tri", [(1, 128, 128, 128, 0), (5, 128, 256, 128, 0), (16, 256, 256, 256, 1), (7, 512, 512, 512, 2),
                                             (3, 1024, 1024, 1024, 3), (64, 128, 128, 128, 3), (9, 384, 128, 384, 2)])
 @pytest.mark.parametrize("op", [0, 1, 3])
