@@ -86,14 +86,11 @@ def test_gemm_nt_lower_triangular_operands(handle, m, n, op, tile):
         handle.set_option("gemm_force_tile", 0)
 
 
-@pytest.mark.parametrize("m,n,k", [(64, 128, 128), (64, 2048, 2048), (192, 384, 4096), (64, 16384, 256)])
+@pytest.mark.parametrize("m,n,k,tri", [(64, 128, 128, 0), (64, 128, 128, 4), (64, 2048, 2048, 0), (64, 2048, 2048, 4), (192, 384, 4096, 0), (64, 16384, 256, 0)])
 @pytest.mark.parametrize("op", [0, 1])
-@pytest.mark.parametrize("tri", [0, 4])
-def test_gemm_nt_half_tile_row(handle, m, n, k, op, tri):
+def test_gemm_nt_half_tile_row(handle, m, n, k, tri, op):
     """M a multiple of 64 only (predict_f on at most 64 test points pads its right-hand sides to half a tile row): the 64 x 64 /
     32 x 32 tiles, with and without a lower-triangular B."""
-    if tri == 4 and n != k:
-        pytest.skip("a triangular B is square")
     rng = np.random.default_rng(m + n + k + op + tri)
     A = rng.standard_normal((m, k)); B = rng.standard_normal((n, k)); C = rng.standard_normal((m, n))
     if tri == 4: B = np.tril(B)
