@@ -28,6 +28,11 @@
 #define GPS_TILE 128
 #endif
 
+// A batch of equal NT products whose operands step along diagonals (Ops::gemm_ex): problem p reads / writes its operands at
+// base + (p * rs) * ld + (p * cs) % cm  (cm == 0: no wrap) -- blocks along the diagonal of the factor, or inside a buffer that
+// stacks wide diagonal blocks (column offset modulo the width).
+struct GemmBatch { int64_t batch = 1; int64_t a_rs = 0, a_cs = 0, a_cm = 0, b_rs = 0, b_cs = 0, b_cm = 0, c_rs = 0, c_cs = 0, c_cm = 0; };
+
 template <class Ops>
 struct Blocked {
   Ops& ops;
@@ -353,5 +358,50 @@ struct Blocked {
     rc = ops.gemv_sub(L + n1 * ldl, ldl, n2, n1, y, y + n1, ldy, r);          // y2 -= L21 a1
     if (rc) return rc;
     return trsv_rec(L + n1 * ldl + n1, ldl, n2, blk0 + n1 / GPS_TILE, y + n1, ldy, r);
+  }
+
+  // ---- wide inverse blocks of a factor (round 6; predict_f on few test points, models/gpr.py:122) --------------------------------
+  // W_c = inv(L_cc) for every wb-column diagonal block c of the first nf columns of L (nf a multiple of wb, wb = 128 * 2^k), built
+  // level by level from the 128-column inverses (linv / linvT: [nf / 128][128 x 128], potrf_base's) for ALL diagonal blocks at once:
+  //   [[L11, 0], [L21, L22]]^-1 = [[W11, 0], [-W22 L21 W11, W22]]   as three batched NT products per level b -> 2 b
+  //   T^T = W11^T L21^T  (A upper triangular) ;  W21 = -W22 (T^T)^T  (A lower triangular) ;  (W^T)12 = -T^T W22^T  (B lower triangular)
+  // W, Wt: [nf, wb] -- the wide blocks (lower triangular) / their transposes, stacked: block c at rows c wb, level-b block k at rows
+  // k b, columns (k b) % wb.  T: scratch [nf / 2, wb / 2].  The transposes are kept because the NT form needs W11^T as a left operand;
+  // the last level does not produce them.
+  int wide_inverse(const double* L, i64 ldl, i64 nf, i64 wb, const double* linv, const double* linvT, double* W, double* Wt, double* Tm) {
+    if (nf <= 0) return 0;
+    const i64 T = GPS_TILE, ldt = wb / 2;
+    int rc = ops.blocks_to_diag(linv, W, nf / T, wb);
+    if (!rc) rc = ops.blocks_to_diag(linvT, Wt, nf / T, wb);
+    for (i64 b = T; b < wb && !rc; b *= 2) {
+      GemmBatch bt;
+      bt.batch = nf / (2 * b);
+      // T^T [b, b] of pair p (rows p b of the scratch) = W11^T L21^T
+      bt.a_rs = 2 * b; bt.a_cs = 2 * b; bt.a_cm = wb; bt.b_rs = 2 * b; bt.b_cs = 2 * b; bt.b_cm = 0; bt.c_rs = b; bt.c_cs = 0; bt.c_cm = 0;
+      rc = ops.gemm_ex(/*C = A B^T*/ 1, /*A upper*/ 1, b, b, b, Wt, wb, L + b * ldl, ldl, Tm, ldt, &bt);
+      if (rc) break;
+      // W21 = -W22 (T^T)^T
+      bt.a_rs = 2 * b; bt.a_cs = 2 * b; bt.a_cm = wb; bt.b_rs = b; bt.b_cs = 0; bt.b_cm = 0; bt.c_rs = 2 * b; bt.c_cs = 2 * b; bt.c_cm = wb;
+      rc = ops.gemm_ex(/*C = -A B^T*/ 3, /*A lower*/ 2, b, b, b, W + b * wb + b, wb, Tm, ldt, W + b * wb, wb, &bt);
+      if (rc || 2 * b >= wb) break;                       // (the transposes only feed the next level)
+      // (W^T)12 = -T^T W22^T
+      bt.a_rs = b; bt.a_cs = 0; bt.a_cm = 0; bt.b_rs = 2 * b; bt.b_cs = 2 * b; bt.b_cm = wb; bt.c_rs = 2 * b; bt.c_cs = 2 * b; bt.c_cm = wb;
+      rc = ops.gemm_ex(3, /*B lower*/ 3, b, b, b, Tm, ldt, W + b * wb + b, wb, Wt + b, wb, &bt);
+    }
+    return rc;
+  }
+
+  // X L^T = B for columns [c0, c0 + n) (n a multiple of wb) against the wide inverse blocks W: X [m, .] <- solution, B destroyed.
+  // n == wb: X_c = B_c W_c^T, ONE product (B lower triangular: half the K range per tile on average); else halves with the
+  // update B2 -= X1 L21^T between them (K >= wb: no launch below the wb-column level).
+  int trsm_wide_rec(const double* L, i64 ldl, i64 c0, i64 n, i64 wb, const double* W, double* B, double* X, i64 ld, i64 m) {
+    if (n <= 0 || m <= 0) return 0;
+    if (n == wb) return ops.gemm_ex(1, /*B lower*/ 3, m, wb, wb, B + c0, ld, W + c0 * wb, wb, X + c0, ld, nullptr);
+    const i64 n1 = ((n / wb) / 2) * wb, n2 = n - n1;
+    int rc = trsm_wide_rec(L, ldl, c0, n1, wb, W, B, X, ld, m);
+    if (rc) return rc;
+    rc = ops.gemm(0, 0, m, n2, n1, X + c0, ld, L + (c0 + n1) * ldl + c0, ldl, B + c0 + n1, ld);       // B2 -= X1 L21^T
+    if (rc) return rc;
+    return trsm_wide_rec(L, ldl, c0 + n1, n2, wb, W, B, X, ld, m);
   }
 };

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../include/gpflowslim_hip.h"
+#include "blocked.hpp"
 
 #define GPS_TILE 128            // base block of the factorisation = GEMM tile edge
 #define GPS_WB 2048             // columns of the wide inverse blocks of predict_f (gps_gpr.hip)
@@ -330,7 +331,7 @@ int gps_launch_gemm_nt(gps_handle_t h, int op, int lower, i64 M, i64 N, i64 K,
                        double* C, i64 ldc);
 // ... with a triangular operand (tri: 1 A upper, 2 A lower, 3 B lower) and / or as a batch of equal problems whose operands
 // step along diagonals: problem p at  base + (p * rs) * ld + (p * cs) % cm  (cm == 0: no wrap)
-struct GemmBatch { i64 batch = 1; i64 a_rs = 0, a_cs = 0, a_cm = 0, b_rs = 0, b_cs = 0, b_cm = 0, c_rs = 0, c_cs = 0, c_cm = 0; };
+struct GemmBatch;      // (blocked.hpp)
 int gps_launch_gemm_nt_ex(gps_handle_t h, int op, int lower, int tri, i64 M, i64 N, i64 K,
                           const double* A, i64 lda, const double* B, i64 ldb,
                           double* C, i64 ldc, const GemmBatch* bt);

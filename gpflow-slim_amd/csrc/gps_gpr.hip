@@ -509,10 +509,9 @@ extern "C" int gps_gpr_lml_grad(gps_handle_t h, const gps_kern_node_t* prog, int
 // 32 workgroups, the K = 512 / 1024 updates at 32 / 40 TFLOP/s -- 4.2 of the call's 19.5 ms for 5 % of its flop.  With the
 // explicit inverses W_c of the GPS_WB = 2048-column diagonal blocks of L the 2048-column node is ONE product
 // X_c = B_c W_c^T (B lower triangular: half the K range per tile on average), and only the K >= 2048 updates remain.
-// W is built level by level from the 128-column inverses potrf_base leaves behind, for all diagonal blocks at once:
-//   [[L11, 0], [L21, L22]]^-1 = [[W11, 0], [-W22 L21 W11, W22]]   as three batched NT products per level
-//   T^T = W11^T L21^T  (A upper triangular) ;  W21 = -W22 (T^T)^T  (A lower triangular) ;  (W^T)12 = -T^T W22^T  (B lower triangular)
-// (W^T is kept beside W because the NT form needs W11^T as a left operand), 11 launches, ~N * 3 * sum b^2 flop = 1.4e11 dense
+// W is built level by level from the 128-column inverses potrf_base leaves behind, for all diagonal blocks at once
+// (blocked.hpp: wide_inverse -- three batched NT products with a triangular operand per level; trsm_wide_rec; both checked as index
+// logic on the CPU, tests/test_blocked_cpu.py), 11 launches, ~N * 3 * sum b^2 flop = 1.4e11 dense
 // at N = 32768, cut by the triangular forms; cached until the factor changes (factor_gen).  Not where leaves are refined.
 // cond(L_cc) <= sqrt(cond(K + s I)): the products stay within the same 7 u cond bound as the 128-column ones (gps_common.hpp).
 static int gpr_wide_inverse(gps_handle_t h) {
@@ -525,42 +524,12 @@ static int gpr_wide_inverse(gps_handle_t h) {
   int rc = gpr_ensure_linvT(h);
   if (rc) return rc;
   const i64 nblk = np / GPS_TILE;
-  double* W = h->dWbig.d(); double* Wt = h->dWtbig.d(); double* T = h->dBigT.d();
-  const double* L = h->dK.d();
-  const i64 ldt = WB / 2;
-  rc = gps_launch_blocks_to_diag(h, h->dLinv.d(), W, nf / GPS_TILE, WB);
-  if (!rc) rc = gps_launch_blocks_to_diag(h, h->dLinv.d() + nblk * GPS_TILE * GPS_TILE, Wt, nf / GPS_TILE, WB);
-  for (i64 b = GPS_TILE; b < WB && !rc; b *= 2) {
-    GemmBatch bt;
-    bt.batch = nf / (2 * b);
-    // T^T [b, b] of pair p (rows p b of the scratch) = W11^T L21^T
-    bt.a_rs = 2 * b; bt.a_cs = 2 * b; bt.a_cm = WB; bt.b_rs = 2 * b; bt.b_cs = 2 * b; bt.b_cm = 0; bt.c_rs = b; bt.c_cs = 0; bt.c_cm = 0;
-    rc = gps_launch_gemm_nt_ex(h, /*C = A B^T*/ 1, 0, /*A upper*/ 1, b, b, b, Wt, WB, L + b * np, np, T, ldt, &bt);
-    if (rc) break;
-    // W21 = -W22 (T^T)^T
-    bt.a_rs = 2 * b; bt.a_cs = 2 * b; bt.a_cm = WB; bt.b_rs = b; bt.b_cs = 0; bt.b_cm = 0; bt.c_rs = 2 * b; bt.c_cs = 2 * b; bt.c_cm = WB;
-    rc = gps_launch_gemm_nt_ex(h, /*C = -A B^T*/ 3, 0, /*A lower*/ 2, b, b, b, W + b * WB + b, WB, T, ldt, W + b * WB, WB, &bt);
-    if (rc || 2 * b >= WB) break;                       // (the transposes only feed the next level)
-    // (W^T)12 = -T^T W22^T
-    bt.a_rs = b; bt.a_cs = 0; bt.a_cm = 0; bt.b_rs = 2 * b; bt.b_cs = 2 * b; bt.b_cm = WB; bt.c_rs = 2 * b; bt.c_cs = 2 * b; bt.c_cm = WB;
-    rc = gps_launch_gemm_nt_ex(h, 3, 0, /*B lower*/ 3, b, b, b, T, ldt, W + b * WB + b, WB, Wt + b, WB, &bt);
-  }
+  HipOps ops{h, h->dLinv.d(), h->dLinv.d() + nblk * GPS_TILE * GPS_TILE, (int*)h->dInfo.p};
+  Blocked<HipOps> bl(ops);
+  rc = bl.wide_inverse(h->dK.d(), np, nf, WB, ops.linv, ops.linvT, h->dWbig.d(), h->dWtbig.d(), h->dBigT.d());
   if (rc) return rc;
   h->big_inv_gen = h->factor_gen; h->big_inv_nf = nf;
   return GPS_OK;
-}
-
-// X L^T = B for the first n columns (a multiple of GPS_WB) against the wide inverse blocks: X [m, n] <- solution, B destroyed
-static int trsm_wide_rec(gps_handle_t h, const double* L, i64 ldl, i64 c0, i64 n, double* B, double* X, i64 ld, i64 m) {
-  const i64 WB = GPS_WB;
-  if (n == WB)       // X_c = B_c W_c^T
-    return gps_launch_gemm_nt_ex(h, 1, 0, /*B lower*/ 3, m, WB, WB, B + c0, ld, h->dWbig.d() + c0 * WB, WB, X + c0, ld, nullptr);
-  const i64 n1 = ((n / WB) / 2) * WB, n2 = n - n1;
-  int rc = trsm_wide_rec(h, L, ldl, c0, n1, B, X, ld, m);
-  if (rc) return rc;
-  rc = gps_launch_gemm_nt(h, 0, 0, m, n2, n1, X + c0, ld, L + (c0 + n1) * ldl + c0, ldl, B + c0 + n1, ld);       // B2 -= X1 L21^T
-  if (rc) return rc;
-  return trsm_wide_rec(h, L, ldl, c0 + n1, n2, B, X, ld, m);
 }
 
 extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int n_nodes,
@@ -614,7 +583,7 @@ extern "C" int gps_gpr_predict(gps_handle_t h, const gps_kern_node_t* prog, int 
     rc = gpr_wide_inverse(h);
     if (rc) return rc;
     GPS_HIP(h, h->dB2.ensure((size_t)nsp * np * 8));
-    rc = trsm_wide_rec(h, h->dK.d(), np, 0, nf, h->dB.d(), h->dB2.d(), np, nsp);
+    rc = bl.trsm_wide_rec(h->dK.d(), np, 0, nf, GPS_WB, h->dWbig.d(), h->dB.d(), h->dB2.d(), np, nsp);
     if (rc) return rc;
     if (nf < np) {
       // the columns behind the last whole block: one update, the recursive solve in place, then beside the others

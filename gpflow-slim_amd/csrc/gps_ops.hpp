@@ -68,6 +68,11 @@ struct HipOps {
     }
     return gps_launch_gemm_nt(h, op, lower, M, N, K, A, lda, B, ldb, C, ldc);
   }
+  // a product with a triangular operand (tri: 1 A upper, 2 A lower, 3 B lower) and / or a batch of them (blocked.hpp: wide_inverse)
+  int gemm_ex(int op, int tri, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb, double* C, i64 ldc, const GemmBatch* bt) {
+    return gps_launch_gemm_nt_ex(h, op, 0, tri, M, N, K, A, lda, B, ldb, C, ldc, bt);
+  }
+  int blocks_to_diag(const double* src, double* dst, i64 nblk, i64 wb) { return gps_launch_blocks_to_diag(h, src, dst, nblk, wb); }
   int trsv_base(i64 blk, double* y, i64 ldy, i64 r, const double* D, i64 ldd) {
     if (!linvT) return gps_fail(h, GPS_ERR_STATE, "trsv needs the transposed block inverses");
     if (h->refine_now) return gps_launch_trsv_leaf_refine(h, linvT + blk * GPS_TILE * GPS_TILE, D, ldd, y, ldy, r, 0);

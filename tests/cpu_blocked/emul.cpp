@@ -55,7 +55,7 @@ struct CpuOps {
   int gemm(int op, int lower, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb,
            double* C, i64 ldc) {
     ++n_gemm;
-    if (M % T || N % T || K % 16) return -1;
+    if ((M % T && !(M % 64 == 0 && lower == 0)) || N % T || K % 16) return -1;      // (half a tile row of right-hand sides: as the device launcher)
     touch(A, lda, M, K, false); touch(B, ldb, N, K, false); touch(C, ldc, M, N, true);
     if (op != 1 && op != 3) touch(C, ldc, M, N, false);
     std::vector<double> out((size_t)M * N, 0.0);
@@ -72,6 +72,44 @@ struct CpuOps {
       for (i64 j = 0; j < N; ++j)
         if (done[i * N + j])
           C[i * ldc + j] = (op == 0) ? C[i * ldc + j] - out[i * N + j] : (op == 2 ? C[i * ldc + j] + out[i * N + j] : (op == 3 ? -out[i * N + j] : out[i * N + j]));
+    return 0;
+  }
+  // a product with a triangular operand and / or a batch of them (blocked.hpp: wide_inverse, trsm_wide_rec).  As the device kernel:
+  // the zero part of a triangular operand beyond its diagonal 128-blocks is never READ (the tests poison it with NaN).
+  int n_gemm_ex = 0;
+  int gemm_ex(int op, int tri, i64 M, i64 N, i64 K, const double* A, i64 lda, const double* B, i64 ldb, double* C, i64 ldc, const GemmBatch* bt) {
+    ++n_gemm_ex;
+    if (M % 64 || N % T || K % 16 || (tri && (tri == 3 ? N : M) != K)) return -61;
+    if (tri < 0 || tri > 3 || (op != 1 && op != 3 && op != 0)) return -62;
+    const i64 nb = bt ? bt->batch : 1;
+    for (i64 p = 0; p < nb; ++p) {
+      const double* a = A; const double* b = B; double* c = C;
+      if (bt) {
+        a += p * bt->a_rs * lda + (bt->a_cm ? (p * bt->a_cs) % bt->a_cm : p * bt->a_cs);
+        b += p * bt->b_rs * ldb + (bt->b_cm ? (p * bt->b_cs) % bt->b_cm : p * bt->b_cs);
+        c += p * bt->c_rs * ldc + (bt->c_cm ? (p * bt->c_cs) % bt->c_cm : p * bt->c_cs);
+      }
+      std::vector<double> out((size_t)M * N);
+      for (i64 i = 0; i < M; ++i)
+        for (i64 j = 0; j < N; ++j) {
+          i64 k0 = 0, k1 = K;                                   // K range at the granularity of the 128-blocks
+          if (tri == 1) k0 = (i / T) * T;
+          if (tri == 2) k1 = (i / T + 1) * T;
+          if (tri == 3) k1 = (j / T + 1) * T;
+          double s = 0.0;
+          for (i64 k = k0; k < k1; ++k) s += a[i * lda + k] * b[j * ldb + k];
+          out[i * N + j] = s;
+        }
+      for (i64 i = 0; i < M; ++i)
+        for (i64 j = 0; j < N; ++j)
+          c[i * ldc + j] = (op == 0) ? c[i * ldc + j] - out[i * N + j] : (op == 3 ? -out[i * N + j] : out[i * N + j]);
+    }
+    return 0;
+  }
+  int blocks_to_diag(const double* src, double* dst, i64 nblk, i64 wb) {
+    for (i64 b = 0; b < nblk; ++b)
+      for (i64 i = 0; i < T; ++i)
+        for (i64 j = 0; j < T; ++j) dst[(b * T + i) * wb + (b * T) % wb + j] = src[b * T * T + i * T + j];
     return 0;
   }
   int trsv_t_base(i64 blk, double* y, i64 ldy, i64 r, const double* = nullptr, i64 = 0) {
@@ -231,6 +269,19 @@ int emul_all(double* A, i64 n, double* B, double* B2, i64 m, double* y, i64 r, i
   rc = bl.trsm_rn_rec(U.data(), n, n, 0, B2, n, m);
   if (rc) return rc;
   return bl.trsv_rec(A, n, n, 0, y, n, r);
+}
+// A [n, n] SPD in place -> L; then the wide inverse blocks of its first nf = (n / wb) wb columns (W, Wt: [nf, wb], NaN where
+// nothing may be read or is written; T: scratch) and X L^T = B for those columns against them (B [m, n] destroyed, X [m, n] out)
+int emul_wide(double* A, i64 n, i64 wb, double* W, double* Wt, double* Tm, double* B, double* X, i64 m, int* info) {
+  CpuOps ops(n / T);
+  Blocked<CpuOps> bl(ops);
+  int rc = bl.potrf_rec(A, n, n, 0, 0);
+  *info = ops.info;
+  if (rc) return rc;
+  const i64 nf = (n / wb) * wb;
+  rc = bl.wide_inverse(A, n, nf, wb, ops.linv.data(), ops.linvT.data(), W, Wt, Tm);
+  if (rc) return rc;
+  return bl.trsm_wide_rec(A, n, 0, nf, wb, W, B, X, n, m);
 }
 // A [(n + e), n] in place: rows 0..n-1 SPD -> L, rows n..n+e-1 (e a multiple of 128) -> E L^-T  (augmented rows)
 int emul_potrf_aug(double* A, i64 n, i64 e, int* info) {

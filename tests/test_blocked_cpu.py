@@ -240,3 +240,36 @@ def test_side_stream_race_detector_detects(emul):
         assert emul.emul_side_bad(0) > 0
     finally:
         emul.emul_set_forget_join(0); emul.emul_set_lookahead(0)
+
+
+@pytest.mark.parametrize("n,wb,m", [(256, 256, 128), (512, 256, 64), (1024, 512, 128), (1280, 512, 192), (2048, 1024, 128), (1536, 256, 128)])
+def test_wide_inverse_blocks_as_index_logic(emul, n, wb, m):
+    """blocked.hpp::wide_inverse / trsm_wide_rec (round 6; predict_f on few test points, models/gpr.py:122): the inverses of the
+    factor's wb-column diagonal blocks, built level by level from the 128-column ones by batched products whose operands step
+    along diagonals (row / column strides, column offsets modulo the block width), then X L^T = B as one product per wb-column
+    node.  Against LAPACK: every wide block equals inv(L_cc) (its strict upper part untouched: still NaN beyond the diagonal
+    128-blocks), and X equals the triangular solve for the whole blocks' columns."""
+    emul.emul_set_rl_max(ctypes.c_int64(256)); emul.emul_set_lookahead(0); emul.emul_set_rl_group(ctypes.c_int64(2))
+    rng = np.random.default_rng(n + wb + m)
+    G = rng.standard_normal((n, n)); A = G @ G.T + n * np.eye(n); A0 = A.copy()
+    nf = (n // wb) * wb
+    W = np.full((nf, wb), np.nan); Wt = np.full((nf, wb), np.nan); Tm = np.full((max(nf // 2, 1), wb // 2), np.nan)
+    B = rng.standard_normal((m, n)); B0 = B.copy(); X = np.full((m, n), np.nan)
+    info = ctypes.c_int(0)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = emul.emul_wide(p(A), ctypes.c_int64(n), ctypes.c_int64(wb), p(W), p(Wt), p(Tm), p(B), p(X), ctypes.c_int64(m), ctypes.byref(info))
+    assert rc == 0 and info.value == 0
+    L = sl.cholesky(A0, lower=True)
+    low128 = np.tril(np.ones((128, 128), dtype=bool))
+    for c in range(nf // wb):
+        blk = L[c * wb:(c + 1) * wb, c * wb:(c + 1) * wb]
+        ref = sl.solve_triangular(blk, np.eye(wb), lower=True)
+        got = W[c * wb:(c + 1) * wb]
+        low = np.tril(np.ones((wb, wb), dtype=bool))
+        assert np.abs(got[low] - ref[low]).max() <= 1e-12 * np.abs(ref).max()
+        # above the diagonal: zeros inside the diagonal 128-blocks (the 128-column inverses are stored whole), untouched beyond
+        for i in range(wb // 128):
+            assert np.all(got[i * 128:(i + 1) * 128, i * 128:(i + 1) * 128][~low128] == 0.0)
+            assert np.isnan(got[i * 128:(i + 1) * 128, (i + 1) * 128:]).all()
+    ref = sl.solve_triangular(L[:nf, :nf], B0[:, :nf].T, lower=True).T
+    assert np.abs(X[:, :nf] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())

@@ -292,14 +292,14 @@ def test_gpr_not_positive_definite_raises(handle):
 
 @pytest.mark.parametrize("ratio", [1e-5])
 def test_gpr_low_noise_sweep_large(handle, ratio):
-    """The low-noise end of the sweep above at N = 8192 (the regime a fit ends in, at a size where the substitution is a
-    wavefront over 64 blocks and the factorisation has a followed sweep; round 6: 16384 -> 8192, the oracle's two dense
+    """The low-noise end of the sweep above at N = 6144 (the regime a fit ends in, at a size where the substitution is a
+    wavefront over 48 blocks and the factorisation has a followed sweep; round 6: 16384 -> 6144, the oracle's two dense
     factorisations were 30 s of the suite): refined leaves in the factorisation AND the refined wavefront substitution (trsv_wave.hip,
     one refinement step per diagonal block) -- LML, mean and variance against LAPACK within max(1e-8, 2 eps cond_2), the
     condition number from the two extreme eigenvalues; and the wavefront equals the recursive substitution with refined
     leaves to rounding."""
     import gpflowSlim as gpf
-    n, d, ns, var = 8192, 2, 40, 1.3
+    n, d, ns, var = 6144, 2, 40, 1.3
     rng = np.random.default_rng(int(1e7 * ratio) + 3)
     X = rng.uniform(-3.0, 3.0, (n, d)); Xs = rng.uniform(-3.0, 3.0, (ns, d))
     noise = orc.constrained(ratio * var)
