@@ -35,6 +35,25 @@ def test_library_exports_every_declared_symbol(gpf):
     assert declared == set(_backend.EXPORTED_SYMBOLS), "ctypes binding and header disagree"
 
 
+def test_documented_options_are_the_accepted_options():
+    """Every key gps_set_option accepts is documented in the public header's option list, and the list names no key the
+    library does not take (option keys missing from the header; round 6 removed 25 keys with their designs)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "gpflow-slim_amd", "csrc", "gps_handle.hip")).read()
+    body = src[src.index('extern "C" int gps_set_option('):]
+    body = body[:body.index("\n}\n")]
+    accepted = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body))
+    hdr = open(os.path.join(root, "include", "gpflowslim_hip.h")).read()
+    block = hdr[hdr.index("/* options (diagnostics and A/B switches"):hdr.index("int gps_set_option(")]
+    documented = set(re.findall(r'^ \*\s+(?:"[a-z_0-9]+"(?: / )?)+', block, flags=re.M) and re.findall(r'"([a-z_0-9]+)"', "\n".join(
+        ln for ln in block.splitlines() if re.match(r'^ \*   "', ln))))
+    assert len(accepted) <= 25, sorted(accepted)
+    assert accepted <= documented, sorted(accepted - documented)
+    stale = {k for k in documented - accepted if k not in ("lookahead_retries", "trsv_wave_fallbacks", "small_n_fallbacks", "small_n_cooldown")}
+    assert not stale, sorted(stale)
+
+
 def test_kern_node_struct_layout_matches_header(gpf):
     from gpflowSlim import _backend as be
     # int32 op, n_dims, active_dims[32]; double variance, period, lengthscales[32]
